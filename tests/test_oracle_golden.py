@@ -1,0 +1,254 @@
+"""Pin the CPU oracle to outputs of the reference itself (tests/golden, produced by
+tests/golden/make_golden.py importing /root/reference).  CPU only."""
+import numpy as np
+import pytest
+
+TRELLIS_NAMES = ["SOQPSKTrellis8x1", "SOQPSKTrellis4x2", "SOQPSKTrellis4x2DiffEncoded",
+                 "SimpleTrellis2", "SimpleTrellis4"]
+
+
+def pn_padded(oracle, degree):
+    return np.unpackbits(np.packbits(oracle.pn_sequence(degree)))
+
+
+# ------------------------------------------------------------------ a1
+@pytest.mark.parametrize("deg", [2, 3, 7, 9, 15, 16])
+def test_glfsr_full_period(oracle, golden, deg):
+    g = golden("glfsr")
+    bits = oracle.pn_sequence(deg)
+    assert np.array_equal(np.packbits(bits), g[f"pn{deg}_packed"])
+    # reference tests/test_glfsr.py:6-25 — the second period repeats the first
+    two, state = oracle.glfsr_bits(oracle.lfsr_mask(deg), (1 << deg) - 1, 2 * ((1 << deg) - 1))
+    assert np.array_equal(two[: bits.size], two[bits.size:]) and state == (1 << deg) - 1
+
+
+def test_glfsr_masks_and_long_registers(oracle, golden):
+    g = golden("glfsr")
+    assert [oracle.lfsr_mask(k) for k in range(2, 65)] == [int(m) for m in g["masks"]]
+    assert oracle.lfsr_mask(15) == 0x6000 and oracle.lfsr_mask(23) == 0x420000
+    for deg in (23, 31, 47, 64):
+        bits, st = oracle.glfsr_bits(oracle.lfsr_mask(deg), (1 << deg) - 1, 200)
+        assert np.array_equal(bits, g[f"pn{deg}_first200"])
+        assert st == int(g[f"pn{deg}_state200"][0])
+    with pytest.raises(KeyError):
+        oracle.lfsr_mask(1)
+    with pytest.raises(KeyError):
+        oracle.lfsr_mask(65)
+
+
+# ------------------------------------------------------------------ a2 / a2'
+@pytest.mark.parametrize("name", TRELLIS_NAMES)
+def test_trellis_tables_and_encoder(oracle, golden, name):
+    g = golden("encode")
+    t = oracle.trellis_tables(name)
+    cols, states, card, ocard, bpc = (int(v) for v in g[f"{name}__dims"])
+    assert (t["columns"], t["states"], t["card"], len(t["alphabet"]), t["bpc"]) == \
+        (cols, states, card, ocard, bpc)
+    flat = np.stack([t["br_inp"], t["br_out"], t["br_start"].astype(np.int8),
+                     t["br_end"].astype(np.int8)], axis=1)
+    assert np.array_equal(flat, g[f"{name}__branches"])
+    rand = g["rand_bits"]
+    sym, i, st = oracle.fsm_encode(name, rand)
+    assert sym.dtype == np.int8 and np.array_equal(sym, g[f"{name}__rand"])
+    assert [i, st] == [int(v) for v in g[f"{name}__final_i_state"]]
+    a, i1, s1 = oracle.fsm_encode(name, rand[:1002])
+    b, _, _ = oracle.fsm_encode(name, rand[1002:], i1, s1)
+    assert np.array_equal(np.concatenate((a, b)), g[f"{name}__rand_chunked"])
+    for deg in (9, 15):
+        assert np.array_equal(oracle.fsm_encode(name, pn_padded(oracle, deg))[0],
+                              g[f"{name}__pn{deg}"])
+
+
+def test_encoder_rejects_ragged_input(oracle):
+    with pytest.raises(ValueError):
+        oracle.fsm_encode("SimpleTrellis4", np.zeros(5, dtype=np.uint8))
+    assert oracle.fsm_encode("SimpleTrellis4", np.zeros(0, dtype=np.uint8))[0].size == 0
+
+
+def test_precoder_and_mappers(oracle, golden):
+    g = golden("encode")
+    rand = g["rand_bits"]
+    assert np.array_equal(oracle.soqpsk_precoder(rand)[0], g["precoder__rand"])
+    a, i, mem = oracle.soqpsk_precoder(rand[:1001])
+    b, _, _ = oracle.soqpsk_precoder(rand[1001:], i, mem)
+    assert np.array_equal(np.concatenate((a, b)), g["precoder__rand_chunked"])
+    assert np.array_equal(oracle.multih_mapper(rand)[0], g["multih__rand"])
+    assert np.array_equal(oracle.pcmfm_mapper(rand), g["pcmfm__rand"])
+    with pytest.raises(ValueError):
+        oracle.multih_mapper(rand[:7])
+    # closed forms — trellis encoders are the precoder in disguise
+    assert np.array_equal(g["SOQPSKTrellis4x2__rand"], -2 * g["precoder__rand"])
+    assert np.array_equal(g["SOQPSKTrellis8x1__rand"], -2 * g["precoder__rand"])
+
+
+# ------------------------------------------------------------------ a3
+def test_pulses(oracle, golden):
+    g = golden("pulses")
+    for sps in (4, 8, 10):
+        np.testing.assert_array_equal(oracle.freq_pulse_soqpsk_tg(sps), g[f"tg_{sps}"])
+        np.testing.assert_array_equal(oracle.freq_pulse_soqpsk_mil(sps), g[f"mil_{sps}"])
+        np.testing.assert_array_equal(oracle.freq_pulse_soqpsk_a(sps), g[f"a_{sps}"])
+        np.testing.assert_array_equal(oracle.freq_pulse_soqpsk_b(sps), g[f"b_{sps}"])
+        np.testing.assert_array_equal(oracle.freq_pulse_multih_irig(sps), g[f"multih_{sps}"])
+        for w, f in (("tg", oracle.freq_pulse_soqpsk_tg), ("mil", oracle.freq_pulse_soqpsk_mil)):
+            rho = oracle.rho_pulses(f(sps), 0.25, sps, 2)
+            for k in range(2):
+                assert rho[k].shape == g[f"rho{k}_{w}_{sps}"].shape
+                np.testing.assert_allclose(rho[k], g[f"rho{k}_{w}_{sps}"], rtol=0, atol=1e-15)
+    for sps, order in ((8, 4), (8, 6), (20, 4), (20, 8)):
+        np.testing.assert_array_equal(oracle.freq_pulse_pcmfm(sps, order), g[f"pcmfm_{sps}_{order}"])
+    np.testing.assert_array_equal(oracle.kaiser_fir_lpf(8, 0.5), g["kaiser_8_0p5"])
+    np.testing.assert_array_equal(oracle.kaiser_fir_lpf(10, 0.7, 0.2, 60.0), g["kaiser_10_0p7_w0p2_r60"])
+    q = np.cumsum(oracle.freq_pulse_soqpsk_tg(8)) / 8
+    np.testing.assert_array_equal(oracle.pam_unit_pulse(q, 0.25), g["unit_pulse_tg_8"])
+    np.testing.assert_array_equal(oracle.pam_unit_pulse2(q, 0.25), g["unit_pulse2_tg_8"])
+    np.testing.assert_array_equal(oracle.normalize_cpm_filter(8, g["normalize_in"]), g["normalize_out"])
+    assert g["tg_8"].size == 65 and g["tg_10"].size == 81 and g["kaiser_8_0p5"].size == 82
+    assert abs(g["tg_8"].sum() / 8 - 0.5) < 1e-15
+
+
+# ------------------------------------------------------------------ a4 / a5
+CASES = ["tg8", "tg10", "mil8", "mh8", "pcm8", "pcm5", "tiny", "one"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cpm_modulate(oracle, golden, case):
+    g = golden("modulate")
+    sym, h, pulse, sps = (g[f"{case}__symbols"], g[f"{case}__h"], g[f"{case}__pulse"],
+                          int(g[f"{case}__sps"][0]))
+    t, s = oracle.cpm_modulate(sym, h if h.size > 1 else float(h[0]), pulse, sps)
+    np.testing.assert_array_equal(t, g[f"{case}__time"])
+    assert s.dtype == np.complex128 and s.shape == g[f"{case}__signal"].shape
+    # same libm cos/sin, same op order -> bit-identical here; allow 2 ulp for other hosts
+    np.testing.assert_allclose(s, g[f"{case}__signal"], rtol=0, atol=5e-16)
+
+
+def test_fir_stage_and_direct_form(oracle, golden):
+    g = golden("modulate")
+    sym, pulse = g["tg8__symbols"], g["tg8__pulse"]
+    fp = oracle.upsample_fir(sym, 0.25, pulse, 8)
+    np.testing.assert_array_equal(fp, g["tg8__freq_pulses"])
+    np.testing.assert_allclose(oracle.upsample_fir_direct(sym, 0.25, pulse, 8), fp, rtol=0, atol=1e-15)
+    for case in ("mh8", "pcm5", "tiny", "one", "tg10"):
+        sym, h, pulse, sps = (g[f"{case}__symbols"], g[f"{case}__h"], g[f"{case}__pulse"],
+                              int(g[f"{case}__sps"][0]))
+        np.testing.assert_allclose(oracle.upsample_fir_direct(sym, h, pulse, sps),
+                                   oracle.upsample_fir(sym, h, pulse, sps), rtol=0, atol=1e-15)
+
+
+def test_frequency_and_phase_modulate(oracle, golden):
+    g = golden("modulate")
+    np.testing.assert_allclose(oracle.frequency_modulate(g["fm_in"], 8, 0.25), g["fm_out_sps8"],
+                               rtol=0, atol=5e-16)
+    np.testing.assert_allclose(oracle.frequency_modulate(g["fm_in"], 5), g["fm_out_sps5"],
+                               rtol=0, atol=5e-16)
+    np.testing.assert_array_equal(oracle.phase_modulate(g["fm_in"], 1.7), g["pm_out"])
+
+
+def test_pn15_checksums(oracle, golden):
+    g = golden("modulate")
+    sym = oracle.fsm_encode("SOQPSKTrellis4x2DiffEncoded", pn_padded(oracle, 15))[0]
+    _t, s = oracle.cpm_modulate(sym, 0.25, oracle.freq_pulse_soqpsk_tg(8), 8)
+    assert s.size == 262152
+    np.testing.assert_allclose(s[::997], g["pn15_tg8_every997"], rtol=0, atol=5e-16)
+    assert abs(s.sum() - g["pn15_tg8_sum"][0]) < 1e-9
+    # the figures recorded in SURVEY 8(c)-4
+    assert abs(s.sum() - (1973.1487909793555 + 2104.360125442322j)) < 1e-9
+    assert np.histogram(sym, bins=[-3, -1, 1, 3])[0].tolist() == [8343, 16384, 8041]
+
+
+# ------------------------------------------------------------------ a6
+def test_numpy_awgn(oracle, golden):
+    g = golden("awgn")
+    rng = np.random.Generator(np.random.PCG64(seed=1))
+    n = oracle.numpy_awgn(np.sqrt(2) / 2, 4104, rng)
+    np.testing.assert_array_equal(n, g["seed1_sigma_sqrt_half_4104"])
+    assert abs(n[0] - (0.24436493 + 0.58097176j)) < 1e-8
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors, philox4x32-10
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+    ]
+    for ctr, key, want in kat:
+        assert oracle.philox4x32_10(ctr, key).tolist() == want
+    n = oracle.philox_awgn(0.5, seed=7, stream=3, first_index=0, n=200000)
+    assert abs(n.real.std() - 0.5) < 5e-3 and abs(n.imag.std() - 0.5) < 5e-3
+    assert abs(n.mean()) < 5e-3 and abs(np.mean(n.real * n.imag)) < 5e-3
+    # counter-based: any sub-range reproduces
+    np.testing.assert_array_equal(oracle.philox_awgn(0.5, 7, 3, 1000, 50), n[1000:1050])
+
+
+# ------------------------------------------------------------------ a7-a11
+def test_mf_banks_and_detector_on_pn9(oracle, golden):
+    g = golden("detect")
+    bits, sigma = g["pn9_bits"], float(g["pn9_sigma"][0])
+    pulse = oracle.freq_pulse_soqpsk_tg(8)
+    for kind, off in (("PT", -1), ("PAM", 0)):
+        res = oracle.detection_run(bits, pulse, 0.25, 8, sigma, noise=g["pn9_tg8__noise"],
+                                   detector=kind, timing_offset=off)
+        assert np.array_equal(res["symbols"], g["pn9_tg8__symbols"])
+        np.testing.assert_allclose(res["received"], g["pn9_tg8__received"], rtol=0, atol=1e-15)
+        full = g["pn9_tg8__pt_full"] if kind == "PT" else g["pn9_tg8__pam_full"]
+        cols = g[f"pn9_tg8__{kind}_cols"]
+        assert np.array_equal(oracle.decimate_columns(res["received"].size, 8, 2, off), cols)
+        np.testing.assert_allclose(res["mf_rows"], full[:, cols].T, rtol=0, atol=1e-13)
+        assert np.array_equal(res["det_bits"], g[f"pn9_tg8__{kind}_det_bits"])
+        assert np.array_equal(res["det_syms"], g[f"pn9_tg8__{kind}_det_syms"])
+        assert [res["sym_errors"], res["bit_errors"], res["compared"]] == \
+            [int(v) for v in g[f"pn9_tg8__{kind}_errors"]]
+    assert int(g["pn9_tg8__PT_errors"][1]) > 0  # the fixture does contain detector errors
+
+
+def test_decimating_bank_matches_full_rate(oracle, golden):
+    g = golden("detect")
+    r = g["pn9_tg8__received"]
+    taps = oracle.pt_taps(oracle.freq_pulse_soqpsk_tg(8), 0.25, 8)
+    assert taps.shape == (3, 9)
+    cols = g["pn9_tg8__PT_cols"]
+    rows = oracle.mf_bank_decim_direct(r, taps, int(cols[0]), 8, cols.size)
+    np.testing.assert_allclose(rows, g["pn9_tg8__pt_full"][:, cols].T, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("length", [2, 4, 6])
+@pytest.mark.parametrize("diff", [True, False])
+def test_detector_on_random_triplets(oracle, golden, length, diff):
+    g = golden("detect")
+    fb, fs = oracle.ViterbiOracle(length, diff).run(g["triplets"], full=True)
+    assert np.array_equal(fb, g[f"trip_L{length}_diff{int(diff)}_bits"])
+    assert np.array_equal(fs, g[f"trip_L{length}_diff{int(diff)}_syms"])
+    # streaming: state carried across two calls
+    v = oracle.ViterbiOracle(length, diff)
+    a = v.run(g["triplets"][:1777])[0]
+    b = v.run(g["triplets"][1777:])[0]
+    assert np.array_equal(np.concatenate((a, b)), fb[:, 0])
+
+
+def test_end_to_end_error_counts(oracle, golden):
+    """The reference's published result (images/soqpsk_pam.png) and the
+    sps-8 operating point of BASELINE.md §2, reproduced by the oracle."""
+    e = golden("e2e.json")
+    bits = pn_padded(oracle, 15)
+    assert e["example_sps10_MIL_PT"] == [73, 61, 32765] and e["example_sps10_MIL_PAM"] == [0, 0, 32765]
+    assert e["example_sps10_TG_PT"] == [14, 14, 32765] and e["example_sps10_TG_PAM"] == [11, 11, 32765]
+    rng = np.random.Generator(np.random.PCG64(seed=1))
+    for label, pulse, offs in (("MIL", oracle.freq_pulse_soqpsk_mil(10), {"PT": -1, "PAM": -3}),
+                               ("TG", oracle.freq_pulse_soqpsk_tg(10), {"PT": -1, "PAM": 0})):
+        sym = oracle.fsm_encode("SOQPSKTrellis4x2DiffEncoded", bits)[0]
+        noise = oracle.numpy_awgn(np.sqrt(2) / 2, (sym.size + 1) * 10, rng)
+        for kind in ("PT", "PAM"):
+            res = oracle.detection_run(bits, pulse, 0.25, 10, None, noise=noise, detector=kind,
+                                       timing_offset=offs[kind])
+            assert [res["sym_errors"], res["bit_errors"], res["compared"]] == \
+                e[f"example_sps10_{label}_{kind}"]
+    rng = np.random.Generator(np.random.PCG64(seed=1))
+    noise = oracle.numpy_awgn(float(np.sqrt(0.4)), (bits.size + 1) * 8, rng)
+    for kind, off in (("PT", -1), ("PAM", 0)):
+        res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise,
+                                   detector=kind, timing_offset=off)
+        assert [res["sym_errors"], res["bit_errors"], res["compared"]] == e[f"sps8_10dB_TG_{kind}"]
+    assert e["sps8_10dB_TG_PT"][1] == 16 and e["sps8_10dB_TG_PAM"][1] == 2

@@ -1,0 +1,170 @@
+"""Benchmark: SOQPSK-TG modulate + AWGN + matched filter + 4-state Viterbi detect @ 8 sps.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one block of synthetic PN23 bits, entirely in HBM
+(`wf_link_run`: PRBS -> encode -> upsample+FIR -> phase scan+cexp -> derotate+AWGN ->
+decimating PT bank -> Viterbi -> error count).  N > 1: one process per GPU under torchrun,
+every rank runs its own independent trial blocks (weak scaling, no data-path collective);
+the only exchange is the final all-reduce of the error counters (RCCL over xGMI).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+# algorithmic HBM bytes per symbol of each materialising stage at sps = 8, fp64 / complex128
+# (DESIGN.md "Kernels"): what the stage must read + write at minimum.
+def stage_bytes_per_symbol(sps: int, nfilt: int = 3) -> dict:
+    return {
+        "prbs": 1, "encode": 2,
+        "fir": 1 + 8 * sps,                 # i8 symbol in, sps f64 out
+        "phase": 8 * sps + 16 * sps,        # f64 in, c128 out
+        "awgn": 16 * sps + 16 * sps,        # c128 in, c128 out
+        "mfbank": 16 * sps + 16 * nfilt,    # c128 in, nfilt c128 per symbol out
+        "viterbi": 16 * nfilt + 2,          # 3 c128 in, bit + symbol out
+        "count": 4,
+    }
+
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+
+
+def cpu_baseline(sps: int, ebn0: float, nsym: int) -> dict:
+    """The oracle (CPU port of the reference algorithm: C loops + numpy) timed on one host
+    core over a bounded sample of the same workload."""
+    import numpy as np
+
+    import oracle
+
+    oracle.build_c_oracle()
+    t0 = time.perf_counter()
+    bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, nsym)
+    rng = np.random.Generator(np.random.PCG64(seed=1))
+    res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(sps), 0.25, sps,
+                               oracle.sigma_for_ebn0(ebn0, sps), rng=rng)
+    dt = time.perf_counter() - t0
+    return {"value": round(nsym / dt / 1e6, 4), "unit": "Msym/s", "cores": 1, "kind": "port",
+            "sample": f"{nsym} PN23 symbols of the same SOQPSK-TG @{sps}sps chain (oracle: C loops + numpy, "
+                      f"PCG64 noise), {dt:.1f} s, bit errors {res['bit_errors']}/{res['compared']}"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nsym", type=int, default=10_000_000)
+    ap.add_argument("--sps", type=int, default=8)
+    ap.add_argument("--ebn0", type=float, default=10.0)
+    ap.add_argument("--detector", default="PT")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 22)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from waveforms_amd import _hip
+    from waveforms_amd.link import SOQPSKLink
+
+    link = SOQPSKLink(args.nsym, args.sps, detector=args.detector)
+    slots = 64
+    assert args.steps >= 1
+
+    def step(k: int, timed: bool) -> None:
+        # every (rank, step) is its own trial block: distinct PRBS segment and Philox subsequence
+        block = k * world + rank
+        link.run_block(args.ebn0, seed=1, stream_id=block, skip_bits=block * args.nsym,
+                       event_slot=(k % slots) if timed else -1)
+
+    def fence() -> None:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(-1 - k, False)
+    link.reset_counts() if args.warmup else None
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    se, be, compared = link.result()
+    counts = torch.tensor([se, be, compared], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)     # the one collective of the job
+    se, be, compared = (int(v) for v in counts.cpu().tolist())
+
+    # per-stage kernel time from the HIP events recorded inside the timed region
+    n_ev = min(args.steps, slots)
+    acc = {}
+    for k in range(args.steps - n_ev, args.steps):
+        for name, ms in link.stage_ms(k % slots).items():
+            acc[name] = acc.get(name, 0.0) + ms / n_ev
+    bps = stage_bytes_per_symbol(args.sps)
+    stages = {}
+    for name, ms in acc.items():
+        gb = bps[name] * args.nsym / 1e9
+        stages[name] = {"ms": round(ms, 4), "algo_GB": round(gb, 4),
+                        "GBps": round(gb / (ms / 1e3), 1) if ms > 0 else None}
+    dominant = max(acc, key=acc.get)
+    d = stages[dominant]
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(d["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                "launch_ms": d["ms"], "algorithmic_bytes_per_launch": int(bps[dominant] * args.nsym)}
+
+    if rank == 0:
+        total_sym = args.steps * args.nsym * world
+        out = {
+            "metric": "SOQPSK-TG Msym/s mod+Viterbi-detect @8sps",
+            "value": round(total_sym / elapsed / 1e6, 2), "unit": "Msym/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"SOQPSK-TG {args.nsym:.0e} symbols @{args.sps} sps, modulate + AWGN + "
+                                   f"{args.detector} matched filter + 4-state Viterbi detect (BASELINE configs[1])",
+                       "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
+                       "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
+                       "parallelism": f"independent trial blocks x{world}"},
+            "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
+                    "ber": be / max(compared, 1)},
+            "roofline": roofline,
+            "stages": stages,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,204 @@
+/*
+ * wfhip.h — C ABI of libwfhip.so: the MI355X (gfx950) kernels behind the
+ * `waveforms.cpm` / `waveforms.filters` / `waveforms.viterbi` / `waveforms.glfsr` /
+ * `waveforms.noise` Python API of mcdiarmid/waveforms.
+ *
+ * The reference has no FFI of its own (it is pure Python + NumPy); the boundary
+ * is its Python module API.  Each entry point below replaces the NumPy / Python
+ * loop at the cited reference location (paths relative to the reference repo)
+ * and is bound from Python with ctypes (waveforms_amd/_hip.py; binding stub in
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every `d_*` pointer is DEVICE memory on the
+ *    context's GPU, every `h_*` pointer is host memory; `stream` is a
+ *    hipStream_t passed as void* (NULL = the default stream);
+ *  - all entry points are asynchronous on `stream` unless stated otherwise and
+ *    allocate nothing (graph-capturable) — scratch lives in the wf_ctx;
+ *  - complex128 arrays are interleaved (re, im) doubles, as numpy stores them;
+ *  - return value: 0 on success, a negative wf_status otherwise;
+ *    wf_last_error_string() describes the last failure on the calling thread.
+ *    The Python layer maps WF_ERR_VALUE -> ValueError, WF_ERR_KEY -> KeyError
+ *    (the exceptions the reference raises), anything else -> RuntimeError.
+ */
+#ifndef WFHIP_H
+#define WFHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    WF_OK = 0,
+    WF_ERR_VALUE = -1,   /* bad argument (reference raises ValueError)          */
+    WF_ERR_KEY = -2,     /* undefined table entry (reference raises KeyError)   */
+    WF_ERR_HIP = -3,     /* a HIP runtime call failed                           */
+    WF_ERR_DEVICE = -4,  /* a kernel reported a fault (e.g. scan hand-off timeout) */
+    WF_ERR_NOMEM = -5
+} wf_status;
+
+typedef struct wf_ctx wf_ctx;
+
+/* ---- library / context --------------------------------------------------- */
+const char *wf_version(void);
+const char *wf_last_error_string(void);
+
+/* One context per GPU: owns the scan descriptors, LFSR jump tables and the
+ * device fault word.  Synchronous (allocates).  `max_samples` sizes the scan
+ * scratch (it grows on demand outside graph capture). */
+int wf_ctx_create(int device, wf_ctx **out);
+int wf_ctx_destroy(wf_ctx *ctx);
+/* Synchronises `stream`, returns WF_ERR_DEVICE if any kernel since the last
+ * check raised the fault word (and clears it). */
+int wf_ctx_check(wf_ctx *ctx, void *stream);
+
+/* ---- K1: PRBS ------------------------------------------------------------
+ * GLFSR.next_bit x n   (waveforms/glfsr/glfsr.py:6-19, pn.py:98-107).
+ * Writes bits `skip .. skip+n-1` of the sequence started from `state` as one
+ * u8 (0/1) per bit.  Leap-ahead by GF(2) matrix powers, bit-exact.
+ * If h_state_out != NULL it receives the register after skip+n steps (host
+ * arithmetic, available immediately).  `degree` in 2..64, mask as
+ * generate_mask (pn.py:75-90) builds it. */
+int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
+                     uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream);
+
+/* ---- K2: bits -> symbols ---------------------------------------------------
+ * TrellisEncoder.encode (waveforms/cpm/trellis/encoder.py:17-48) for any
+ * trellis of <= 16 states, <= 4 input bits per symbol.  Tables are HOST arrays,
+ * dense [column][state][input]: h_next (u8) / h_out (i8), i.e. forward_map
+ * (waveforms/cpm/trellis/model.py:127-137).  `i0`/`state0` are TrellisEncoder.i
+ * / .state on entry; *h_state_out receives .state after the call (this one
+ * value is copied back synchronously).  nbits % card != 0 -> WF_ERR_VALUE
+ * (encoder.py:28-30). */
+int wf_fsm_encode(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, int columns, int states,
+                  int card, const uint8_t *d_bits, int64_t nbits, int64_t i0, int state0,
+                  int8_t *d_symbols, int *h_state_out, void *stream);
+
+/* Stateless-per-element mappers (a2'):
+ *  kind 0: SOQPSKPrecoder.__call__  (waveforms/cpm/soqpsk/precoder.py:10-24),
+ *          parity = precoder .i, mem0/mem1 = precoder .mem, out in {-1,0,1};
+ *  kind 1: MultiHSymbolMapper.__call__ (waveforms/cpm/multih/precoder.py:9-23),
+ *          parity = mapper .i AFTER its update, n must be even, out n/2 symbols;
+ *  kind 2: PCMFMSymbolMapper.__call__ (waveforms/cpm/pcmfm/precoder.py:6-15). */
+int wf_symbol_map(wf_ctx *ctx, int kind, const uint8_t *d_bits, int64_t n, int parity, int mem0,
+                  int mem1, int8_t *d_symbols, void *stream);
+
+/* ---- K3: zero-stuffed upsample + frequency-pulse FIR -----------------------
+ * interpolated[sps:-1:sps] = symbols*h ; np.convolve(.., pulse, "same")
+ * (waveforms/cpm/modulate.py:91-99).  Symbol m uses h[m % nh].  Output length
+ * is wf_fir_out_len(nsym, sps, ntaps) = max((nsym+1)*sps, ntaps) — numpy's
+ * "same" returns the longer operand's length. */
+int64_t wf_fir_out_len(int64_t nsym, int sps, int ntaps);
+int wf_upsample_fir_f64(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h,
+                        int nh, const double *d_pulse, int ntaps, int sps, double *d_out,
+                        void *stream);
+
+/* ---- K4: phase accumulate (mod sps) + complex exponential ------------------
+ * frequency_modulate (waveforms/cpm/modulate.py:28-54):
+ *   revs_k = (revs_{k-1} + f_k) mod sps ; out_k = exp(j (revs_k 2pi/sps + phi0)).
+ * Single-pass chained prefix scan; `revs_in` continues a previous chunk
+ * (0 for a fresh call), *d_revs_out (may be NULL) receives the final revs. */
+int wf_phase_cexp_f64(wf_ctx *ctx, const double *d_freq, int64_t n, int sps, double phi0,
+                      double revs_in, double *d_out_ri, double *d_revs_out, void *stream);
+/* phase_modulate (waveforms/cpm/modulate.py:12-25): out = exp(j * sens * phase). */
+int wf_phase_modulate_f64(wf_ctx *ctx, const double *d_phase, int64_t n, double sens,
+                          double *d_out_ri, void *stream);
+
+/* ---- K5: AWGN ---------------------------------------------------------------
+ * Device counterpart of generate_complex_awgn (waveforms/noise.py:8-32) and of
+ * `signal * exp(-j pi/4) + noise` (examples/soqpsk_detection.py:85-89):
+ *   out_k = in_k * (rot_re + j rot_im) + sigma * (n_re + j n_im)_k
+ * with (n_re, n_im)_k = Box-Muller of Philox4x32-10(counter = (first_index + k,
+ * stream_id), key = seed).  d_in may be NULL (pure noise).  In-place allowed. */
+int wf_awgn_c128(wf_ctx *ctx, const double *d_in_ri, int64_t n, double rot_re, double rot_im,
+                 double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
+                 double *d_out_ri, void *stream);
+
+/* ---- K6/K7: matched-filter bank ----------------------------------------------
+ * nfilt complex FIRs, each np.convolve(r, taps[f], "same") sampled at
+ * n = first + k*step, k < ncols   (examples/soqpsk_detection.py:141-156 PT bank,
+ * :164-173 PAM bank with the pseudo-symbol weights folded into the taps,
+ * :189-196 decimation).  d_taps is nfilt x ntaps complex128; output is
+ * ncols x nfilt complex128 (one row per detector call).  step = 1, first = 0,
+ * ncols = nsamp gives the full-rate bank.  Requires nsamp >= ntaps. */
+int wf_mf_bank_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_taps_ri,
+                    int nfilt, int ntaps, int64_t first, int step, int64_t ncols,
+                    double *d_out_ri, void *stream);
+
+/* ---- K8-K10: SOQPSK 4-state Viterbi detector ---------------------------------
+ * SOQPSKTrellisDetector (waveforms/viterbi/algorithm.py:18-101) with
+ * length = 2: for every row of d_mf (ncalls x 3 complex128, alpha = -2,0,+2)
+ * element [0] of the bits / symbols arrays that .iteration() returns.
+ * Chunk-parallel: each thread re-derives the path metrics over `warmup` rows
+ * before its chunk; decisions equal the sequential detector's once survivors
+ * have merged (warmup >= 32 recommended, 0 = library default).
+ * d_state (may be NULL) is the detector state carried across calls for streaming:
+ * [i, M0[4], inc_prev[8], pad[3]] + 16 doubles of staging (32 doubles,
+ * zero-initialised = a fresh detector); NULL = a fresh detector, no carry-out. */
+int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
+                       int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
+                       void *stream);
+/* One literal .iteration() for any window `length` <= 64 (algorithm.py:44-101),
+ * detector state resident on the device (wf_viterbi4_state_bytes(length) bytes,
+ * zero-initialised = a new detector).  d_mf3: 3 complex128.  Outputs: `length`
+ * doubles each, as the reference returns. */
+int64_t wf_viterbi4_state_bytes(int length);
+int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int differential,
+                          const double *d_mf3_ri, double *d_bits_out, double *d_syms_out,
+                          void *stream);
+
+/* ---- K11: error counting ------------------------------------------------------
+ * examples/soqpsk_detection.py:200-209: number of j < m with
+ * det_syms[j] != ref_syms[j] and with det_bits[j] != ref_bits[j]; the two counts
+ * are ADDED to d_counts[0], d_counts[1] (int64; zero them first). */
+int wf_count_errors(wf_ctx *ctx, const int8_t *d_det_syms, const int8_t *d_ref_syms,
+                    const uint8_t *d_det_bits, const uint8_t *d_ref_bits, int64_t m,
+                    int64_t *d_counts, void *stream);
+
+/* ---- a5 helper: normalized time axis -----------------------------------------
+ * np.linspace(0, N+1, (N+1)*sps, endpoint=False) (waveforms/cpm/modulate.py:81-88):
+ * out[k] = k * step. */
+int wf_time_axis_f64(wf_ctx *ctx, int64_t n, double step, double *d_out, void *stream);
+
+/* ---- device-resident link (one Monte-Carlo trial block / one bench step) -------
+ * PRBS -> TrellisEncoder(SOQPSKTrellis4x2[DiffEncoded]) -> cpm_modulate -> *exp(-j pi/4)
+ * + AWGN -> matched-filter bank sampled at (n + timing_offset) % sps == 0 ->
+ * SOQPSKTrellisDetector(length = 2) -> error count: the per-waveform body of
+ * examples/soqpsk_detection.py:45-216, every stage one of the kernels above, all
+ * intermediates in the caller's HBM workspace.  d_counts[0] += symbol errors,
+ * d_counts[1] += bit errors; *h_compared (host, may be NULL) = number of symbols
+ * compared (min_size of :204). */
+typedef struct {
+    int64_t nsym;           /* symbols (= bits) in the block                          */
+    int sps;
+    int degree;             /* PRBS register: degree, mask, start state, bits to skip */
+    uint64_t mask, state, skip;
+    int differential;       /* 1: SOQPSKTrellis4x2DiffEncoded, 0: SOQPSKTrellis4x2     */
+    const double *d_h;      /* device: modulation index (1 double)                    */
+    const double *d_pulse;  /* device: frequency pulse, ntaps doubles                 */
+    int ntaps;
+    const double *d_mf_taps; /* device: mf_nfilt x mf_ntaps complex128                */
+    int mf_ntaps, mf_nfilt; /* mf_nfilt must be 3                                     */
+    int timing_offset;      /* -1 for the PT bank, 0 for PAM-TG (:184-187)            */
+    double sigma;           /* noise std-dev per real dimension                       */
+    uint64_t seed, stream_id; /* Philox key / subsequence                             */
+    int warmup;             /* Viterbi chunk warm-up, 0 = default                     */
+    int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
+                            /* around every stage into that slot (wf_link_stage_ms)   */
+} wf_link_config;
+#define WF_LINK_EVENT_SLOTS 64
+#define WF_LINK_STAGES 8    /* prbs, encode, fir, phase, awgn, mfbank, viterbi, count */
+int64_t wf_link_workspace_bytes(const wf_link_config *cfg);
+int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
+                int64_t *d_counts, int64_t *h_compared, void *stream);
+/* Elapsed milliseconds of the WF_LINK_STAGES stages of the run that last used
+ * `event_slot` (HIP events on the run's own stream).  Synchronises on that slot's
+ * final event. */
+int wf_link_stage_ms(wf_ctx *ctx, int event_slot, float *h_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFHIP_H */

@@ -1,0 +1,342 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+reference-generated goldens.  Integer / index work must be bit-exact; floating-point
+samples are held to FLOAT_ATOL = 1e-9 absolute on unit-magnitude baseband samples
+(three orders tighter than the 1e-6 relative bound BASELINE.json states).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_ATOL = 1e-9
+TRELLIS_NAMES = ["SOQPSKTrellis8x1", "SOQPSKTrellis4x2", "SOQPSKTrellis4x2DiffEncoded",
+                 "SimpleTrellis2", "SimpleTrellis4"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _native_library_loaded():
+    """The tests below must run the in-tree HIP library, never a fallback."""
+    import torch
+
+    from waveforms_amd import _hip
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    assert _hip.lib().wf_version().decode().startswith("waveforms-amd")
+    _hip.ctx()
+    yield
+    _hip.device_check()
+
+
+def pn_padded(oracle, degree):
+    return np.unpackbits(np.packbits(oracle.pn_sequence(degree)))
+
+
+# ------------------------------------------------------------------ K1
+@pytest.mark.parametrize("deg", [2, 3, 7, 9, 15, 16])
+def test_lfsr_full_period(golden, deg):
+    from waveforms.glfsr import PNSequence
+
+    p = PNSequence(deg)
+    seq = p.generate_sequence()
+    assert isinstance(seq, list) and len(seq) == (1 << deg) - 1
+    assert np.array_equal(np.packbits(np.array(seq, dtype=np.uint8)), golden("glfsr")[f"pn{deg}_packed"])
+    assert p.state == (1 << deg) - 1                       # one full period later
+    assert p.generate_sequence() == seq                    # reference tests/test_glfsr.py:6-25
+
+
+@pytest.mark.parametrize("deg,n", [(23, 1_000_003), (31, 70_001), (47, 16_384), (64, 33_000), (15, 5)])
+def test_lfsr_long_and_stateful(oracle, deg, n):
+    from waveforms.glfsr import PNSequence
+
+    want, st = oracle.glfsr_bits(oracle.lfsr_mask(deg), (1 << deg) - 1, n + 200 + 4097)
+    p = PNSequence(deg)
+    a = p.generate(n)
+    singles = [p.next_bit() for _ in range(200)]            # host single steps interleave
+    b = p.generate(4097)
+    assert np.array_equal(np.concatenate((a, singles, b)), want)
+    assert p.state == st
+
+
+def test_lfsr_full_size_properties(oracle):
+    """BASELINE config 2 size (1e7 PN23 bits): bit-exact against the C oracle, balanced."""
+    from waveforms.glfsr import PNSequence
+
+    n = 10_000_000
+    got = PNSequence(23).generate(n)
+    want, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, n)
+    assert np.array_equal(got, want)
+    period = (1 << 23) - 1
+    assert np.array_equal(got[:n - period], got[period:])  # periodicity
+    assert int(got[:period].sum()) == 1 << 22              # 2^(n-1) ones per period
+
+
+# ------------------------------------------------------------------ K2
+@pytest.mark.parametrize("name", TRELLIS_NAMES)
+def test_trellis_encoder(oracle, golden, name):
+    from waveforms.cpm.trellis import model as tm
+    from waveforms.cpm.trellis.encoder import TrellisEncoder
+
+    g = golden("encode")
+    tr = getattr(tm, name)
+    rand = g["rand_bits"]
+    enc = TrellisEncoder(tr)
+    out = enc(rand)
+    assert out.dtype == np.int8 and np.array_equal(out, g[f"{name}__rand"])
+    assert [enc.i, enc.state] == [int(v) for v in g[f"{name}__final_i_state"]]
+    enc = TrellisEncoder(tr)
+    assert np.array_equal(np.concatenate((enc(rand[:1002]), enc(rand[1002:]))), g[f"{name}__rand_chunked"])
+    for deg in (9, 15):
+        assert np.array_equal(TrellisEncoder(tr)(pn_padded(oracle, deg)), g[f"{name}__pn{deg}"])
+    # ragged / empty
+    assert TrellisEncoder(tr).encode(np.zeros(0, dtype=np.uint8)).size == 0
+    if tr.input_cardinality > 1:
+        with pytest.raises(ValueError):
+            TrellisEncoder(tr).encode(np.zeros(5, dtype=np.uint8))
+    # a long random stream, odd split so the column phase and state carry matter
+    rng = np.random.Generator(np.random.PCG64(11))
+    bits = rng.integers(0, 2, size=2_000_000 * tr.input_cardinality, dtype=np.uint8)
+    cut = 777_777 * tr.input_cardinality
+    enc = TrellisEncoder(tr)
+    got = np.concatenate((enc(bits[:cut]), enc(bits[cut:])))
+    want, i, st = oracle.fsm_encode(name, bits)
+    assert np.array_equal(got, want) and (enc.i, enc.state) == (i, st)
+
+
+def test_precoder_and_mappers(golden):
+    from waveforms.cpm.multih import MultiHSymbolMapper
+    from waveforms.cpm.pcmfm import PCMFMSymbolMapper
+    from waveforms.cpm.soqpsk import SOQPSKPrecoder
+
+    g = golden("encode")
+    rand = g["rand_bits"]
+    assert np.array_equal(SOQPSKPrecoder()(rand), g["precoder__rand"])
+    pre = SOQPSKPrecoder()
+    assert np.array_equal(np.concatenate((pre(rand[:1001]), pre(rand[1001:]))), g["precoder__rand_chunked"])
+    assert np.array_equal(MultiHSymbolMapper()(rand), g["multih__rand"])
+    assert np.array_equal(PCMFMSymbolMapper()(rand), g["pcmfm__rand"])
+    with pytest.raises(ValueError):
+        MultiHSymbolMapper()(rand[:7])
+
+
+# ------------------------------------------------------------------ K3 / K4
+CASES = ["tg8", "tg10", "mil8", "mh8", "pcm8", "pcm5", "tiny", "one"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cpm_modulate_golden(golden, case):
+    from waveforms.cpm.modulate import cpm_modulate
+
+    g = golden("modulate")
+    sym, h, pulse, sps = (g[f"{case}__symbols"], g[f"{case}__h"], g[f"{case}__pulse"], int(g[f"{case}__sps"][0]))
+    t, s = cpm_modulate(sym, h if h.size > 1 else float(h[0]), pulse, sps)
+    np.testing.assert_array_equal(t, g[f"{case}__time"])              # k * step, bit-exact
+    assert s.dtype == np.complex128 and s.shape == g[f"{case}__signal"].shape
+    np.testing.assert_allclose(s, g[f"{case}__signal"], rtol=0, atol=FLOAT_ATOL)
+    assert np.abs(s - g[f"{case}__signal"]).max() < 1e-12            # what we actually expect
+    s[:] *= 2                                                         # fresh, writable host array
+
+
+@pytest.mark.parametrize("sps,ntaps,nsym,nh", [(8, 65, 100_000, 1), (10, 81, 50_001, 1), (8, 25, 40_000, 2),
+                                                (5, 14, 7_777, 3), (20, 47, 3_000, 1), (8, 82, 9_000, 1),
+                                                (3, 100, 5_000, 1), (1, 3, 4_000, 1), (8, 65, 0, 1), (8, 65, 1, 1)])
+def test_fir_stage_against_oracle(oracle, sps, ntaps, nsym, nh):
+    from waveforms_amd import _hip, device as dev
+
+    rng = np.random.Generator(np.random.PCG64(sps * 1000 + ntaps))
+    sym = rng.integers(-3, 4, size=nsym, dtype=np.int8)
+    h = rng.uniform(0.2, 0.8, size=nh)
+    pulse = rng.normal(size=ntaps)
+    got = _hip.to_host(dev.upsample_fir(_hip.to_device(sym), _hip.to_device(h), _hip.to_device(pulse), sps))
+    want = oracle.upsample_fir(sym, h, pulse, sps)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
+
+
+def test_fir_stage_golden(golden):
+    from waveforms_amd import _hip, device as dev
+
+    g = golden("modulate")
+    got = _hip.to_host(dev.upsample_fir(_hip.to_device(g["tg8__symbols"]), _hip.to_device(np.array([0.25])),
+                                        _hip.to_device(g["tg8__pulse"]), 8))
+    np.testing.assert_allclose(got, g["tg8__freq_pulses"], rtol=0, atol=1e-15)
+
+
+def test_frequency_and_phase_modulate(oracle, golden):
+    from waveforms.cpm.modulate import frequency_modulate, phase_modulate
+
+    g = golden("modulate")
+    np.testing.assert_allclose(frequency_modulate(g["fm_in"], 8, 0.25), g["fm_out_sps8"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(frequency_modulate(g["fm_in"], 5), g["fm_out_sps5"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(phase_modulate(g["fm_in"], 1.7), g["pm_out"], rtol=0, atol=1e-14)
+    assert frequency_modulate(np.zeros(0), 8).size == 0
+    # many tiles: the chained scan against the sequential accumulate-with-modulo
+    rng = np.random.Generator(np.random.PCG64(3))
+    for n, sps in ((3_000_001, 8), (2048 * 37, 10), (2047, 8), (2049, 3)):
+        fp = rng.normal(0.05, 0.4, size=n)
+        np.testing.assert_allclose(frequency_modulate(fp, sps, 0.3), oracle.frequency_modulate(fp, sps, 0.3),
+                                   rtol=0, atol=FLOAT_ATOL)
+
+
+def test_modulate_full_size_properties(oracle):
+    """1e7 SOQPSK-TG symbols @ 8 sps (BASELINE config 2): unit envelope, and agreement
+    with the oracle on windows spread over the burst (the oracle's sequential scan over
+    8e7 samples takes seconds in C)."""
+    from waveforms_amd import _hip, device as dev
+    from waveforms.cpm.modulate import cpm_modulate_device
+    from waveforms.cpm.soqpsk import freq_pulse_soqpsk_tg
+
+    n = 10_000_000
+    bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, n)
+    sym = oracle.fsm_encode("SOQPSKTrellis4x2DiffEncoded", bits)[0]
+    d_sig = cpm_modulate_device(_hip.to_device(sym), 0.25, freq_pulse_soqpsk_tg(8), 8)
+    _hip.device_check()
+    mag = (d_sig * d_sig).sum(dim=1)
+    assert float((mag - 1).abs().max()) < 1e-12
+    _t, want = oracle.cpm_modulate(sym, 0.25, oracle.freq_pulse_soqpsk_tg(8), 8)
+    got = _hip.to_host(d_sig, complex_pairs=True)
+    assert got.shape == want.shape == ((n + 1) * 8,)
+    err = np.abs(got - want)
+    assert err.max() < FLOAT_ATOL, err.max()
+
+
+# ------------------------------------------------------------------ K5
+def test_philox_awgn(oracle):
+    from waveforms.noise import PhiloxStream, generate_complex_awgn
+
+    st = PhiloxStream(seed=0x1234567887654321, stream=(5 << 32) | 9, offset=(1 << 32) - 1000)
+    got = generate_complex_awgn(0.75, 200_001, st)
+    want = oracle.philox_awgn(0.75, 0x1234567887654321, (5 << 32) | 9, (1 << 32) - 1000, 200_001)
+    assert got.dtype == np.complex128
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    assert st.offset == (1 << 32) - 1000 + 200_001
+    # fused derotate + add
+    from waveforms_amd import _hip
+
+    rng = np.random.Generator(np.random.PCG64(8))
+    sig = np.exp(1j * rng.uniform(0, 6.28, size=5000))
+    rot = np.exp(-1j * np.pi / 4)
+    out = PhiloxStream(7, 3).draw(0.5, sig.size, _hip.to_device(sig), rot)
+    np.testing.assert_allclose(_hip.to_host(out, complex_pairs=True),
+                               sig * rot + oracle.philox_awgn(0.5, 7, 3, 0, sig.size), rtol=0, atol=1e-12)
+    # moments of a large draw
+    big = generate_complex_awgn(1.0, 4_000_000, PhiloxStream(99))
+    assert abs(big.real.std() - 1) < 2e-3 and abs(big.imag.std() - 1) < 2e-3 and abs(big.mean()) < 2e-3
+    assert abs(np.mean(np.abs(big.real) > 3) - 0.0026998) < 2e-4       # Gaussian tail
+
+
+# ------------------------------------------------------------------ K6 / K7
+def test_matched_filter_banks(oracle, golden):
+    from waveforms.filters.matched import MatchedFilterBank, pam_matched_filter_taps, pt_matched_filter_taps
+
+    g = golden("detect")
+    r = g["pn9_tg8__received"]
+    pulse = oracle.freq_pulse_soqpsk_tg(8)
+    for kind, taps in (("PT", pt_matched_filter_taps(pulse, 0.25, 8)), ("PAM", pam_matched_filter_taps(pulse, 0.25, 8))):
+        bank = MatchedFilterBank(taps)
+        full = g["pn9_tg8__pt_full"] if kind == "PT" else g["pn9_tg8__pam_full"]
+        cols = g[f"pn9_tg8__{kind}_cols"]
+        rows = bank(r, first=int(cols[0]), step=8, ncols=cols.size)
+        np.testing.assert_allclose(rows, full[:, cols].T, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(bank(r), full.T, rtol=0, atol=1e-12)        # full rate, both edges
+    # other decimations / odd step / long filters / multi-block
+    rng = np.random.Generator(np.random.PCG64(21))
+    r = rng.normal(size=60_000) + 1j * rng.normal(size=60_000)
+    for step, ntaps, nf, first in ((10, 11, 3, 1), (5, 7, 3, 2), (20, 91, 3, 0), (8, 73, 3, 0), (1, 82, 1, 0), (3, 4, 5, 1)):
+        taps = rng.normal(size=(nf, ntaps)) + 1j * rng.normal(size=(nf, ntaps))
+        ncols = (r.size - first + step - 1) // step
+        got = MatchedFilterBank(taps)(r, first=first, step=step, ncols=ncols)
+        want = np.array([np.convolve(r, t, mode="same")[first::step] for t in taps]).T
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
+
+
+# ------------------------------------------------------------------ K8-K10
+@pytest.mark.parametrize("diff", [True, False])
+def test_detector_batch_on_triplets(golden, diff):
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detect")
+    bits, syms = SOQPSKTrellisDetector(2, differantial_encoding=diff).detect(g["triplets"])
+    assert np.array_equal(bits, g[f"trip_L2_diff{int(diff)}_bits"][:, 0])
+    assert np.array_equal(syms, g[f"trip_L2_diff{int(diff)}_syms"][:, 0])
+
+
+@pytest.mark.parametrize("length", [2, 4, 6])
+def test_detector_iteration_api(golden, length):
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detect")
+    for diff in (True, False):
+        det = SOQPSKTrellisDetector(length, differantial_encoding=diff)
+        for k in range(260):
+            b, s = det.iteration(g["triplets"][k])
+            assert b.dtype == np.float64 and b.shape == (length,)
+            assert np.array_equal(b, g[f"trip_L{length}_diff{int(diff)}_bits"][k]), k
+            assert np.array_equal(s, g[f"trip_L{length}_diff{int(diff)}_syms"][k]), k
+        assert det.i == 260
+
+
+@pytest.mark.parametrize("ebn0", [0.0, 4.0, 10.0])
+def test_detector_chunk_parallel_equals_sequential(oracle, ebn0):
+    """Chunk-parallel ACS with warm-up vs the sequential oracle on a long noisy burst —
+    every decision must be identical (low SNR = slowest survivor merging)."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    n = 400_000
+    bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, n)
+    noise = oracle.philox_awgn(oracle.sigma_for_ebn0(ebn0, 8), 5, 1, 0, (n + 1) * 8)
+    res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise)
+    got_b, got_s = SOQPSKTrellisDetector().detect(res["mf_rows"])
+    assert np.array_equal(got_b, res["det_bits"]) and np.array_equal(got_s, res["det_syms"])
+    assert res["bit_errors"] > 0 or ebn0 >= 10
+
+
+def test_count_errors():
+    from waveforms_amd import _hip, device as dev
+
+    rng = np.random.Generator(np.random.PCG64(2))
+    a = rng.integers(-1, 2, size=1_000_003).astype(np.int8) * 2
+    b = a.copy(); b[rng.integers(0, a.size, 5000)] += 2
+    x = rng.integers(0, 2, size=a.size, dtype=np.uint8)
+    y = x.copy(); y[rng.integers(0, a.size, 3000)] ^= 1
+    da, db, dx, dy = map(_hip.to_device, (a, b, x, y))
+    c = dev.count_errors(da[2:], db[:-2], dx[2:], dy[:-2], a.size - 2)
+    assert c.cpu().tolist() == [int(np.count_nonzero(a[2:] != b[:-2])), int(np.count_nonzero(x[2:] != y[:-2]))]
+
+
+# ------------------------------------------------------------------ end to end
+def test_example_reproduces_published_counts(golden):
+    """The reference's published result (images/soqpsk_pam.png)."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location(
+        "soqpsk_detection_amd", Path(__file__).resolve().parent.parent / "examples" / "soqpsk_detection.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    e = golden("e2e.json")
+    res = mod.run(sps=10)
+    for label in ("MIL", "TG"):
+        for kind in ("PT", "PAM"):
+            assert list(res[(label, kind)]) == e[f"example_sps10_{label}_{kind}"], (label, kind)
+    # the per-symbol iteration() drop-in path gives the same numbers
+    res = mod.run(sps=8, sigma=float(np.sqrt(0.4)), per_symbol=True, labels=("TG",))
+    assert list(res[("TG", "PT")]) == e["sps8_10dB_TG_PT"] and list(res[("TG", "PAM")]) == e["sps8_10dB_TG_PAM"]
+
+
+@pytest.mark.parametrize("detector,nsym", [("PT", 1 << 15), ("PAM", 1 << 15), ("PT", 100_000)])
+def test_device_link_equals_oracle_chain(oracle, detector, nsym):
+    """wf_link_run (all stages chained in HBM) vs the oracle chain fed the same Philox noise."""
+    from waveforms_amd.link import SOQPSKLink
+
+    link = SOQPSKLink(nsym, 8, detector=detector)
+    for ebn0, block in ((3.0, 0), (7.0, 5)):
+        link.reset_counts()
+        link.run_block(ebn0, seed=1, stream_id=block, skip_bits=block * nsym)
+        se, be, m = link.result()
+        bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, (block + 1) * nsym)
+        bits = bits[block * nsym:]
+        noise = oracle.philox_awgn(oracle.sigma_for_ebn0(ebn0, 8), 1, block, 0, (nsym + 1) * 8)
+        res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise,
+                                   detector=detector, timing_offset=-1 if detector == "PT" else 0)
+        assert (se, be, m) == (res["sym_errors"], res["bit_errors"], res["compared"])
+        assert be > 0

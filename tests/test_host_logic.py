@@ -1,0 +1,206 @@
+"""Host-side logic of the product package (tap design, trellis model, alias import,
+sweep sharding) against the reference-generated goldens.  CPU only."""
+import numpy as np
+import pytest
+
+TRELLIS_NAMES = ["SOQPSKTrellis8x1", "SOQPSKTrellis4x2", "SOQPSKTrellis4x2DiffEncoded",
+                 "SimpleTrellis2", "SimpleTrellis4"]
+
+
+def test_alias_serves_the_same_modules():
+    import waveforms
+    import waveforms.noise
+    import waveforms_amd.noise
+    from waveforms.cpm.trellis.model import SOQPSKTrellis4x2DiffEncoded as a
+    from waveforms_amd.cpm.trellis.model import SOQPSKTrellis4x2DiffEncoded as b
+
+    assert waveforms.__version__ == "0.1.0"
+    assert waveforms.noise is waveforms_amd.noise and a is b
+    # the names examples/soqpsk_detection.py:10-22 imports
+    from waveforms.cpm.modulate import cpm_modulate, frequency_modulate, phase_modulate  # noqa: F401
+    from waveforms.cpm.pamapprox import rho_pulses  # noqa: F401
+    from waveforms.cpm.soqpsk import freq_pulse_soqpsk_mil, freq_pulse_soqpsk_tg  # noqa: F401
+    from waveforms.cpm.trellis.encoder import TrellisEncoder  # noqa: F401
+    from waveforms.glfsr import PNSequence  # noqa: F401
+    from waveforms.noise import generate_complex_awgn  # noqa: F401
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector  # noqa: F401
+    from waveforms.filters.lpf import kaiser_fir_lpf  # noqa: F401
+    with pytest.raises(ImportError):
+        import waveforms.does_not_exist  # noqa: F401
+
+
+def test_glfsr_host_side(golden):
+    from waveforms.glfsr import GLFSR, PNSequence
+    from waveforms.glfsr.pn import GALOIS_LFSR_POLYS, generate_mask
+
+    g = golden("glfsr")
+    assert [generate_mask(k) for k in range(2, len(GALOIS_LFSR_POLYS))] == [int(m) for m in g["masks"]]
+    for bad in (0, 1, 65, 100):
+        with pytest.raises(KeyError):
+            generate_mask(bad)
+    p = PNSequence(23)
+    assert (p.mask, p.state, p.degree) == (0x420000, 0x7FFFFF, 23)
+    assert [p.next_bit() for _ in range(200)] == g["pn23_first200"].tolist()
+    assert p.state == int(g["pn23_state200"][0])
+    q = GLFSR(0x6000, 0x7FFF)
+    bits = np.array([q.next_bit() for _ in range(32767)], dtype=np.uint8)
+    assert np.array_equal(np.packbits(bits), g["pn15_packed"]) and q.state == 0x7FFF
+
+
+@pytest.mark.parametrize("name", TRELLIS_NAMES)
+def test_trellis_model(golden, name):
+    from waveforms.cpm.trellis import model as tm
+
+    g = golden("encode")
+    tr = getattr(tm, name)
+    flat = np.array([[b.inp, b.out, b.start, b.end] for col in tr.branches for b in col], dtype=np.int8)
+    assert np.array_equal(flat, g[f"{name}__branches"])
+    assert [tr.columns, tr.states, tr.input_cardinality, tr.output_cardinality,
+            tr.branches_per_column] == [int(v) for v in g[f"{name}__dims"]]
+    fsm = tm.FiniteStateMachine(tr)
+    assert fsm.symbols == sorted({int(v) for v in flat[:, 1]})
+    for c, col in enumerate(tr.branches):
+        for b in col:
+            assert fsm.forward_branch_mapping[c][b.start][b.inp] is b
+            assert fsm.reverse_transitions[c][b.end][b.start] is b
+            assert tm.forward_map(b.start, col)[b.inp] is b
+            assert b in tm.reverse_branches(b.end, col) and b in tm.forward_branches(b.start, col)
+    nxt, out = tr.dense_tables()
+    assert nxt.shape == (tr.columns, tr.states, 1 << tr.input_cardinality)
+
+
+def test_trellis_rejects_non_power_of_two_inputs():
+    from waveforms.cpm.trellis.model import Branch, Trellis
+
+    bad = Trellis(branches=[[Branch(0, 0, 0, 0), Branch(1, 0, 0, 0), Branch(2, 0, 0, 0)]])
+    with pytest.raises(ValueError):
+        _ = bad.input_cardinality
+
+
+def test_pulse_design(golden):
+    from waveforms.cpm.helpers import normalize_cpm_filter
+    from waveforms.cpm.multih import MULTIH_IRIG_DENOM, MULTIH_IRIG_NUMER, freq_pulse_multih_irig
+    from waveforms.cpm.pamapprox import pam_unit_pulse, pam_unit_pulse2, rho_pulses
+    from waveforms.cpm.pcmfm import PCMFM_DENOM, PCMFM_NUMER, freq_pulse_pcmfm
+    from waveforms.cpm.soqpsk import (SOQPSK_DENOM, SOQPSK_NUMER, freq_pulse_soqpsk_a, freq_pulse_soqpsk_b,
+                                      freq_pulse_soqpsk_mil, freq_pulse_soqpsk_tg)
+    from waveforms.filters.lpf import kaiser_fir_lpf
+
+    g = golden("pulses")
+    for sps in (4, 8, 10):
+        np.testing.assert_array_equal(freq_pulse_soqpsk_tg(sps), g[f"tg_{sps}"])
+        np.testing.assert_array_equal(freq_pulse_soqpsk_mil(sps), g[f"mil_{sps}"])
+        np.testing.assert_array_equal(freq_pulse_soqpsk_a(sps), g[f"a_{sps}"])
+        np.testing.assert_array_equal(freq_pulse_soqpsk_b(sps), g[f"b_{sps}"])
+        np.testing.assert_array_equal(freq_pulse_multih_irig(sps), g[f"multih_{sps}"])
+        for w, f in (("tg", freq_pulse_soqpsk_tg), ("mil", freq_pulse_soqpsk_mil)):
+            for k, r in enumerate(rho_pulses(f(sps), 0.25, sps, 2)):
+                np.testing.assert_array_equal(r, g[f"rho{k}_{w}_{sps}"])
+    for sps, order in ((8, 4), (8, 6), (20, 4), (20, 8)):
+        np.testing.assert_array_equal(freq_pulse_pcmfm(sps, order), g[f"pcmfm_{sps}_{order}"])
+    np.testing.assert_array_equal(kaiser_fir_lpf(8, 0.5), g["kaiser_8_0p5"])
+    np.testing.assert_array_equal(kaiser_fir_lpf(10, 0.7, 0.2, 60.0), g["kaiser_10_0p7_w0p2_r60"])
+    q = np.cumsum(freq_pulse_soqpsk_tg(8)) / 8
+    np.testing.assert_array_equal(pam_unit_pulse(q, 0.25), g["unit_pulse_tg_8"])
+    np.testing.assert_array_equal(pam_unit_pulse2(q, 0.25), g["unit_pulse2_tg_8"])
+    np.testing.assert_array_equal(normalize_cpm_filter(8, g["normalize_in"]), g["normalize_out"])
+    assert [SOQPSK_NUMER, SOQPSK_DENOM, PCMFM_NUMER, PCMFM_DENOM, MULTIH_IRIG_DENOM, *MULTIH_IRIG_NUMER] == \
+        [int(v) for v in g["consts"]]
+
+
+def test_numpy_generator_noise_contract(golden):
+    """generate_complex_awgn keeps honouring a caller-supplied numpy Generator and the
+    module-level DEFAULT_RNG (reference waveforms/noise.py:5,23)."""
+    import waveforms.noise as noise
+
+    g = golden("awgn")
+    rng = np.random.Generator(np.random.PCG64(seed=1))
+    np.testing.assert_array_equal(noise.generate_complex_awgn(np.sqrt(2) / 2, 4104, rng),
+                                  g["seed1_sigma_sqrt_half_4104"])
+    saved = noise.DEFAULT_RNG
+    try:
+        noise.DEFAULT_RNG = np.random.Generator(np.random.PCG64(seed=1))
+        np.testing.assert_array_equal(noise.generate_complex_awgn(np.sqrt(2) / 2, 100),
+                                      g["seed1_sigma_sqrt_half_4104"][:100])
+    finally:
+        noise.DEFAULT_RNG = saved
+
+
+def test_matched_filter_taps(oracle):
+    from waveforms.cpm.soqpsk import freq_pulse_soqpsk_mil, freq_pulse_soqpsk_tg
+    from waveforms.filters.matched import pam_matched_filter_taps, pt_matched_filter_taps
+
+    for sps in (8, 10):
+        for pulse in (freq_pulse_soqpsk_tg(sps), freq_pulse_soqpsk_mil(sps)):
+            np.testing.assert_array_equal(pt_matched_filter_taps(pulse, 0.25, sps), oracle.pt_taps(pulse, 0.25, sps))
+            # folding the pseudo-symbol weights into the taps == weighting the outputs
+            taps = pam_matched_filter_taps(pulse, 0.25, sps)
+            rng = np.random.Generator(np.random.PCG64(5))
+            r = rng.normal(size=700) + 1j * rng.normal(size=700)
+            want = oracle.pam_bank(r, pulse, 0.25, sps)
+            got = np.array([np.convolve(r, t, mode="same") for t in taps])
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_sweep_plan_and_interpolation():
+    from waveforms.bert import SweepPlan, ber_table, ebn0_at_ber
+
+    plan = SweepPlan(ebn0_db=list(range(13)), blocks_per_point=5, nsym=1 << 17)
+    assert len(plan.jobs) == 65
+    shards = [plan.shard(r, 8) for r in range(8)]
+    assert sorted(j for s in shards for j in s) == sorted(plan.jobs)          # a partition
+    assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1     # balanced
+    assert plan.stream_id(3, 7) != plan.stream_id(7, 3) and plan.skip_bits(4) == 4 << 17
+    tab = ber_table([0, 1], np.array([[10, 8, 100], [2, 1, 100]]))
+    assert tab[0]["ber"] == 0.08 and tab[1]["ser"] == 0.02
+    assert abs(ebn0_at_ber([8, 9, 10], [1e-2, 1e-3, 1e-4], 1e-3) - 9.0) < 1e-12
+    assert abs(ebn0_at_ber([8, 10], [1e-2, 1e-4], 1e-3) - 9.0) < 1e-12
+    with pytest.raises(ValueError):
+        ebn0_at_ber([8, 9], [1e-2, 1e-3], 1e-6)
+
+
+def _gloo_worker(rank, world, port, out):
+    import os
+
+    import torch.distributed as dist
+
+    from waveforms.bert import SweepPlan, ber_sweep
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = SweepPlan(ebn0_db=[0.0, 4.0, 8.0], blocks_per_point=5, nsym=1000)
+
+    def fake_runner(plan):
+        acc = np.zeros((3, 3), dtype=np.int64)
+
+        def run(point, block):          # deterministic stand-in for the GPU block
+            acc[point] += (100 * point + block, 10 * point + block, plan.nsym)
+
+        return run, lambda: acc
+
+    res = ber_sweep(plan, runner=fake_runner)
+    out.put((rank, res.tolist()))
+    dist.destroy_process_group()
+
+
+def test_sweep_sharding_and_reduce_gloo_world2():
+    """N > 1 path: shards are disjoint, the single all-reduce gives every rank the totals."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    blocks = np.arange(5).sum()
+    want = [[100 * p * 5 + blocks, 10 * p * 5 + blocks, 5000] for p in range(3)]
+    assert got[0] == want and got[1] == want

@@ -1,0 +1,168 @@
+"""ctypes binding of libwfhip.so (C ABI declared in include/wfhip.h).
+
+PyTorch-ROCm is used for exactly three things here: device buffers
+(``torch.empty(..., device="cuda")``), the current HIP stream handle, and H2D/D2H
+copies.  There is NO CPU fallback: if the shared library is missing or no HIP device
+is visible every numeric entry point raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_uint64, c_void_p
+from pathlib import Path
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwfhip.so"
+
+WF_ERR_VALUE, WF_ERR_KEY, WF_ERR_HIP, WF_ERR_DEVICE, WF_ERR_NOMEM = -1, -2, -3, -4, -5
+
+# name -> (restype, argtypes); must list every function include/wfhip.h declares
+# (tests/test_cabi.py parses the header and compares).
+_P = c_void_p
+SIGNATURES = {
+    "wf_version": (c_char_p, []),
+    "wf_last_error_string": (c_char_p, []),
+    "wf_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "wf_ctx_destroy": (c_int, [_P]),
+    "wf_ctx_check": (c_int, [_P, _P]),
+    "wf_lfsr_generate": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, _P, c_int64, POINTER(c_uint64), _P]),
+    "wf_fsm_encode": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_int64, c_int, _P, POINTER(c_int), _P]),
+    "wf_symbol_map": (c_int, [_P, c_int, _P, c_int64, c_int, c_int, c_int, _P, _P]),
+    "wf_fir_out_len": (c_int64, [c_int64, c_int, c_int]),
+    "wf_upsample_fir_f64": (c_int, [_P, _P, c_int64, _P, c_int, _P, c_int, c_int, _P, _P]),
+    "wf_phase_cexp_f64": (c_int, [_P, _P, c_int64, c_int, c_double, c_double, _P, _P, _P]),
+    "wf_phase_modulate_f64": (c_int, [_P, _P, c_int64, c_double, _P, _P]),
+    "wf_time_axis_f64": (c_int, [_P, c_int64, c_double, _P, _P]),
+    "wf_awgn_c128": (c_int, [_P, _P, c_int64, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64, _P, _P]),
+    "wf_mf_bank_c128": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
+    "wf_viterbi4_detect": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "wf_viterbi4_state_bytes": (c_int64, [c_int]),
+    "wf_viterbi4_iteration": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "wf_count_errors": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P]),
+    "wf_link_workspace_bytes": (c_int64, [_P]),
+    "wf_link_run": (c_int, [_P, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
+    "wf_link_stage_ms": (c_int, [_P, c_int, POINTER(ctypes.c_float)]),
+}
+
+
+class LinkConfig(ctypes.Structure):
+    """wf_link_config of include/wfhip.h."""
+
+    _fields_ = [
+        ("nsym", c_int64), ("sps", c_int), ("degree", c_int), ("mask", c_uint64), ("state", c_uint64),
+        ("skip", c_uint64), ("differential", c_int), ("d_h", c_void_p), ("d_pulse", c_void_p),
+        ("ntaps", c_int), ("d_mf_taps", c_void_p), ("mf_ntaps", c_int), ("mf_nfilt", c_int),
+        ("timing_offset", c_int), ("sigma", c_double), ("seed", c_uint64), ("stream_id", c_uint64),
+        ("warmup", c_int), ("event_slot", c_int),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+_ctxs: dict[int, int] = {}
+
+
+def lib() -> ctypes.CDLL:
+    """Load libwfhip.so (no GPU needed for loading / symbol lookup)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not _LIB_PATH.exists():
+                    raise RuntimeError(
+                        f"{_LIB_PATH} is missing - build it with `python -m waveforms_amd.csrc.build` "
+                        "(there is no CPU fallback)")
+                handle = ctypes.CDLL(str(_LIB_PATH))
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def torch():
+    import torch as _t
+
+    return _t
+
+
+def require_device() -> int:
+    t = torch()
+    if not t.cuda.is_available():
+        raise RuntimeError("waveforms_amd needs a HIP device (MI355X); none is visible and there is "
+                           "no CPU fallback")
+    return t.cuda.current_device()
+
+
+def check(rc: int) -> None:
+    if rc == 0:
+        return
+    msg = lib().wf_last_error_string().decode(errors="replace")
+    if rc == WF_ERR_VALUE:
+        raise ValueError(msg)
+    if rc == WF_ERR_KEY:
+        raise KeyError(msg)
+    raise RuntimeError(f"libwfhip error {rc}: {msg}")
+
+
+def ctx() -> int:
+    """The wf_ctx* of the current torch device (created on first use)."""
+    dev = require_device()
+    if dev not in _ctxs:
+        with _lock:
+            if dev not in _ctxs:
+                out = c_void_p()
+                check(lib().wf_ctx_create(dev, ctypes.byref(out)))
+                _ctxs[dev] = out.value
+    return _ctxs[dev]
+
+
+def stream() -> int:
+    return torch().cuda.current_stream().cuda_stream
+
+
+def device_check() -> None:
+    """Synchronise and raise if a kernel raised the device fault word."""
+    check(lib().wf_ctx_check(ctx(), stream()))
+
+
+# ------------------------------------------------------------------ buffers
+_NP2T = {"uint8": "uint8", "int8": "int8", "float64": "float64", "int64": "int64"}
+
+
+def empty(n, dtype: str):
+    t = torch()
+    require_device()
+    return t.empty(n, dtype=getattr(t, _NP2T[dtype]), device="cuda")
+
+
+def zeros(n, dtype: str):
+    t = torch()
+    require_device()
+    return t.zeros(n, dtype=getattr(t, _NP2T[dtype]), device="cuda")
+
+
+def to_device(a: np.ndarray):
+    """Host ndarray -> device tensor.  complex128 becomes float64[..., 2]."""
+    t = torch()
+    require_device()
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.complex128:
+        a = a.view(np.float64).reshape(a.shape + (2,))
+    if a.size == 0:
+        return t.empty(a.shape, dtype=getattr(t, _NP2T[str(a.dtype)]), device="cuda")
+    return t.from_numpy(a).to("cuda")
+
+
+def to_host(x, complex_pairs: bool = False) -> np.ndarray:
+    """Device tensor -> fresh host ndarray (float64[..., 2] -> complex128 if asked)."""
+    a = x.cpu().numpy()
+    if complex_pairs:
+        a = np.ascontiguousarray(a).view(np.complex128).reshape(a.shape[:-1])
+    return a
+
+
+def ptr(x) -> int | None:
+    return None if x is None else x.data_ptr()

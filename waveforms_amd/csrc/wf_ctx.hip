@@ -1,0 +1,106 @@
+// wf_ctx.hip — context, error reporting, scratch management.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "wf_common.h"
+
+static thread_local char g_err[512] = "";
+
+void wf_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *wf_version(void) { return "waveforms-amd 0.1.0 (gfx950)"; }
+extern "C" const char *wf_last_error_string(void) { return g_err; }
+
+extern "C" int wf_ctx_create(int device, wf_ctx **out)
+{
+    WF_REQUIRE(out != nullptr, "wf_ctx_create: out is NULL");
+    int ndev = 0;
+    WF_HIP(hipGetDeviceCount(&ndev));
+    WF_REQUIRE(device >= 0 && device < ndev, "wf_ctx_create: device %d of %d", device, ndev);
+    WF_HIP(hipSetDevice(device));
+    wf_ctx *c = new wf_ctx();
+    c->device = device;
+    WF_HIP(hipMalloc(&c->d_fault, 64));
+    WF_HIP(hipMemset(c->d_fault, 0, 64));
+    WF_HIP(hipHostMalloc(&c->h_fault, 64, hipHostMallocDefault));
+    WF_HIP(hipMalloc(&c->d_tables, 4096));
+    WF_HIP(hipMalloc(&c->d_small, 256));
+    WF_HIP(hipHostMalloc(&c->h_small, 256, hipHostMallocDefault));
+    *out = c;
+    int rc = wf_ctx_reserve_scan(c, 1 << 16);
+    if (rc) return rc;
+    return wf_ctx_reserve_fsm(c, 1 << 16);
+}
+
+extern "C" int wf_ctx_destroy(wf_ctx *c)
+{
+    if (!c) return WF_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : c->lfsr) {
+        if (kv.second->dev) (void)hipFree(kv.second->dev);
+        delete kv.second;
+    }
+    if (c->events) {
+        for (int k = 0; k < WF_LINK_EVENT_SLOTS * (WF_LINK_STAGES + 1); ++k) (void)hipEventDestroy(c->events[k]);
+        delete[] c->events;
+    }
+    if (c->d_scan) (void)hipFree(c->d_scan);
+    if (c->d_fsm_scratch) (void)hipFree(c->d_fsm_scratch);
+    if (c->d_fault) (void)hipFree(c->d_fault);
+    if (c->h_fault) (void)hipHostFree(c->h_fault);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    delete c;
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_check(wf_ctx *c, void *stream)
+{
+    WF_REQUIRE(c != nullptr, "wf_ctx_check: ctx is NULL");
+    WF_HIP(hipMemcpyAsync(c->h_fault, c->d_fault, sizeof(unsigned), hipMemcpyDeviceToHost,
+                          wf_stream(stream)));
+    WF_HIP(hipStreamSynchronize(wf_stream(stream)));
+    unsigned f = *c->h_fault;
+    if (f) {
+        WF_HIP(hipMemsetAsync(c->d_fault, 0, sizeof(unsigned), wf_stream(stream)));
+        wf_set_error("device fault word 0x%x (bit0 = scan hand-off timeout)", f);
+        return WF_ERR_DEVICE;
+    }
+    return WF_OK;
+}
+
+// Grow-only scratch.  Growing synchronises the device (not capturable) — callers
+// that capture graphs warm the context up with their largest size first.
+int wf_ctx_reserve_scan(wf_ctx *c, size_t words)
+{
+    if (words <= c->scan_words) return WF_OK;
+    WF_HIP(hipDeviceSynchronize());
+    if (c->d_scan) WF_HIP(hipFree(c->d_scan));
+    c->d_scan = nullptr;
+    size_t cap = c->scan_words ? c->scan_words : (1 << 16);
+    while (cap < words) cap *= 2;
+    WF_HIP(hipMalloc(&c->d_scan, cap * sizeof(uint64_t)));
+    c->scan_words = cap;
+    return WF_OK;
+}
+
+int wf_ctx_reserve_fsm(wf_ctx *c, size_t words)
+{
+    if (words <= c->fsm_scratch_words) return WF_OK;
+    WF_HIP(hipDeviceSynchronize());
+    if (c->d_fsm_scratch) WF_HIP(hipFree(c->d_fsm_scratch));
+    c->d_fsm_scratch = nullptr;
+    size_t cap = c->fsm_scratch_words ? c->fsm_scratch_words : (1 << 16);
+    while (cap < words) cap *= 2;
+    WF_HIP(hipMalloc(&c->d_fsm_scratch, cap * sizeof(uint64_t)));
+    c->fsm_scratch_words = cap;
+    return WF_OK;
+}

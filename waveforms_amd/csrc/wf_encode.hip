@@ -1,0 +1,287 @@
+// wf_encode.hip — K2: bits -> symbols.
+//  * wf_fsm_encode: TrellisEncoder.encode (reference waveforms/cpm/trellis/encoder.py:17-48)
+//    for any trellis (<= 16 states, <= 4 bits/symbol, any number of columns) as a
+//    prefix scan over state-transition maps: a run of symbols is a function
+//    state -> state, packed 16 x 4 bit in one u64; composition is associative, so
+//    thread maps are scanned per wave (shuffles), per block (LDS) and across blocks
+//    (one small kernel), then every thread re-walks its 16 symbols from its now known
+//    start state and emits them.  Integer path, bit-exact.
+//  * wf_symbol_map: the element-wise precoder / mappers (a2').
+#include "wf_common.h"
+
+#define ENC_THREADS 256
+#define ENC_SYM_PER_THREAD 16
+#define ENC_SYM_PER_BLOCK (ENC_THREADS * ENC_SYM_PER_THREAD)
+
+struct enc_params {
+    int columns, states, card, ninp;
+    int col0;  // i0 % columns
+    int state0;
+    int64_t nsym;
+};
+
+__device__ __forceinline__ uint64_t map_identity()
+{
+    return 0xFEDCBA9876543210ull;
+}
+
+// h = g after f  (apply f first)
+__device__ __forceinline__ uint64_t map_compose(uint64_t f, uint64_t g)
+{
+    uint64_t h = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const unsigned fs = (unsigned)(f >> (4 * s)) & 15u;
+        h |= ((g >> (4 * fs)) & 15ull) << (4 * s);
+    }
+    return h;
+}
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d)
+{
+    return (uint64_t)__shfl_up((unsigned long long)v, d, WF_WAVE);
+}
+
+// Gather the input values of this thread's 16 symbols (4 bits each) into one u64.
+__device__ __forceinline__ uint64_t load_inputs(const uint8_t *__restrict__ bits, int64_t sym0,
+                                                int64_t nsym, int card, int *nvalid)
+{
+    int64_t rem = nsym - sym0;
+    const int nv = rem >= ENC_SYM_PER_THREAD ? ENC_SYM_PER_THREAD : (rem > 0 ? (int)rem : 0);
+    *nvalid = nv;
+    uint64_t packed = 0;
+    const uint8_t *p = bits + sym0 * card;
+    if (nv == ENC_SYM_PER_THREAD) {
+        // card * 16 bytes, 16-byte aligned (sym0 is a multiple of 16)
+        for (int q = 0; q < card; ++q) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + 16 * q);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned bit = (unsigned)(((k < 8 ? v.x : v.y) >> (8 * (k & 7))) & 1ull);
+                const int bi = q * 16 + k;  // bit index inside the thread's run
+                const int sym = bi / card, x = bi % card;
+                packed |= (uint64_t)bit << (4 * sym + (card - x - 1));
+            }
+        }
+    } else {
+        for (int sym = 0; sym < nv; ++sym)
+            for (int x = 0; x < card; ++x)
+                packed |= (uint64_t)(p[sym * card + x] & 1) << (4 * sym + (card - x - 1));
+    }
+    return packed;
+}
+
+// Kernel A: per-thread maps, block-exclusive prefix maps, block aggregates.
+__global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
+    const uint8_t *__restrict__ bits, const uint8_t *__restrict__ tab_next, enc_params P,
+    uint64_t *__restrict__ thread_excl, uint64_t *__restrict__ block_agg)
+{
+    __shared__ uint8_t s_next[1024];
+    __shared__ uint64_t s_wave[ENC_THREADS / WF_WAVE];
+    const int t = threadIdx.x;
+    const int tabn = P.columns * P.states * P.ninp;
+    for (int k = t; k < tabn; k += ENC_THREADS) s_next[k] = tab_next[k];
+    __syncthreads();
+
+    const int64_t gthread = (int64_t)blockIdx.x * ENC_THREADS + t;
+    const int64_t sym0 = gthread * ENC_SYM_PER_THREAD;
+    int nv;
+    const uint64_t inps = load_inputs(bits, sym0, P.nsym, P.card, &nv);
+    const int colstart = (int)((P.col0 + sym0) % P.columns);
+
+    uint64_t m = 0;
+    for (int s0 = 0; s0 < 16; ++s0) {
+        int st = s0;
+        if (s0 < P.states) {
+            int col = colstart;
+            for (int k = 0; k < nv; ++k) {
+                const int inp = (int)((inps >> (4 * k)) & 15ull);
+                st = s_next[(col * P.states + st) * P.ninp + inp];
+                col = col + 1 == P.columns ? 0 : col + 1;
+            }
+        }
+        m |= (uint64_t)st << (4 * s0);
+    }
+    // wave inclusive scan (compose in thread order)
+    const int lane = t & 63, wave = t >> 6;
+    uint64_t inc = m;
+#pragma unroll
+    for (int d = 1; d < WF_WAVE; d <<= 1) {
+        const uint64_t o = shfl_up_u64(inc, d);
+        if (lane >= d) inc = map_compose(o, inc);
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    uint64_t excl = shfl_up_u64(inc, 1);
+    if (lane == 0) excl = map_identity();
+    __syncthreads();
+    uint64_t pre = map_identity();
+    for (int w = 0; w < wave; ++w) pre = map_compose(pre, s_wave[w]);
+    thread_excl[gthread] = map_compose(pre, excl);
+    if (t == ENC_THREADS - 1) block_agg[blockIdx.x] = map_compose(pre, inc);
+}
+
+// Kernel B: start state of every block (single wave; lanes own contiguous runs).
+__global__ __launch_bounds__(WF_WAVE) void enc_block_scan_kernel(const uint64_t *__restrict__ block_agg,
+                                                                  int nblocks, int state0,
+                                                                  uint8_t *__restrict__ block_state)
+{
+    const int lane = threadIdx.x;
+    const int per = (nblocks + WF_WAVE - 1) / WF_WAVE;
+    const int b0 = lane * per, b1 = min(nblocks, b0 + per);
+    uint64_t run = map_identity();
+    for (int b = b0; b < b1; ++b) run = map_compose(run, block_agg[b]);
+    uint64_t inc = run;
+#pragma unroll
+    for (int d = 1; d < WF_WAVE; d <<= 1) {
+        const uint64_t o = shfl_up_u64(inc, d);
+        if (lane >= d) inc = map_compose(o, inc);
+    }
+    uint64_t excl = shfl_up_u64(inc, 1);
+    if (lane == 0) excl = map_identity();
+    int st = (int)((excl >> (4 * state0)) & 15ull);
+    for (int b = b0; b < b1; ++b) {
+        block_state[b] = (uint8_t)st;
+        st = (int)((block_agg[b] >> (4 * st)) & 15ull);
+    }
+}
+
+// Kernel C: emit symbols.
+__global__ __launch_bounds__(ENC_THREADS) void enc_emit_kernel(
+    const uint8_t *__restrict__ bits, const uint8_t *__restrict__ tab_next,
+    const int8_t *__restrict__ tab_out, enc_params P, const uint64_t *__restrict__ thread_excl,
+    const uint8_t *__restrict__ block_state, int8_t *__restrict__ symbols, int *__restrict__ final_state)
+{
+    __shared__ uint8_t s_next[1024];
+    __shared__ int8_t s_out[1024];
+    const int t = threadIdx.x;
+    const int tabn = P.columns * P.states * P.ninp;
+    for (int k = t; k < tabn; k += ENC_THREADS) {
+        s_next[k] = tab_next[k];
+        s_out[k] = tab_out[k];
+    }
+    __syncthreads();
+    const int64_t gthread = (int64_t)blockIdx.x * ENC_THREADS + t;
+    const int64_t sym0 = gthread * ENC_SYM_PER_THREAD;
+    int nv;
+    const uint64_t inps = load_inputs(bits, sym0, P.nsym, P.card, &nv);
+    if (nv == 0) return;
+    int st = (int)((thread_excl[gthread] >> (4 * block_state[blockIdx.x])) & 15ull);
+    int col = (int)((P.col0 + sym0) % P.columns);
+    uint64_t lo = 0, hi = 0;
+    for (int k = 0; k < nv; ++k) {
+        const int inp = (int)((inps >> (4 * k)) & 15ull);
+        const int idx = (col * P.states + st) * P.ninp + inp;
+        const uint64_t o = (uint8_t)s_out[idx];
+        if (k < 8) lo |= o << (8 * k); else hi |= o << (8 * (k - 8));
+        st = s_next[idx];
+        col = col + 1 == P.columns ? 0 : col + 1;
+    }
+    if (nv == ENC_SYM_PER_THREAD) {
+        *reinterpret_cast<ulonglong2 *>(symbols + sym0) = make_ulonglong2(lo, hi);
+    } else {
+        for (int k = 0; k < nv; ++k)
+            symbols[sym0 + k] = (int8_t)(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFF);
+    }
+    if (sym0 + nv == P.nsym) *final_state = st;
+}
+
+extern "C" int wf_fsm_encode(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, int columns,
+                             int states, int card, const uint8_t *d_bits, int64_t nbits, int64_t i0,
+                             int state0, int8_t *d_symbols, int *h_state_out, void *stream)
+{
+    WF_REQUIRE(ctx && h_next && h_out, "wf_fsm_encode: NULL argument");
+    WF_REQUIRE(columns >= 1 && states >= 1 && states <= 16 && card >= 1 && card <= 4,
+               "wf_fsm_encode: unsupported trellis (columns %d states %d card %d)", columns, states, card);
+    const int ninp = 1 << card;
+    const int tabn = columns * states * ninp;
+    WF_REQUIRE(tabn <= 1024, "wf_fsm_encode: trellis table too large (%d)", tabn);
+    WF_REQUIRE(state0 >= 0 && state0 < states && i0 >= 0, "wf_fsm_encode: bad i/state");
+    if (nbits % card) {
+        wf_set_error("Input length must be a multiple of FSM cardinality.");
+        return WF_ERR_VALUE;
+    }
+    const int64_t nsym = nbits / card;
+    if (h_state_out) *h_state_out = state0;
+    if (nsym == 0) return WF_OK;
+    WF_REQUIRE(d_bits && d_symbols && (reinterpret_cast<uintptr_t>(d_bits) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(d_symbols) & 15) == 0,
+               "wf_fsm_encode: device pointers must be non-NULL and 16-byte aligned");
+    WF_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = wf_stream(stream);
+    const int64_t nblocks = (nsym + ENC_SYM_PER_BLOCK - 1) / ENC_SYM_PER_BLOCK;
+    WF_REQUIRE(nblocks < (1ll << 30), "wf_fsm_encode: input too large for one launch");
+    // scratch: thread maps (nblocks*256) + block aggregates (nblocks) + block states (bytes)
+    const size_t words = (size_t)nblocks * ENC_THREADS + (size_t)nblocks + ((size_t)nblocks + 7) / 8 + 8;
+    int rc = wf_ctx_reserve_fsm(ctx, words);
+    if (rc) return rc;
+    uint64_t *thread_excl = ctx->d_fsm_scratch;
+    uint64_t *block_agg = thread_excl + (size_t)nblocks * ENC_THREADS;
+    uint8_t *block_state = reinterpret_cast<uint8_t *>(block_agg + nblocks);
+    // tables: next at d_tables[0..1023], out at d_tables[1024..2047]
+    WF_HIP(hipMemcpyAsync(ctx->d_tables, h_next, tabn, hipMemcpyHostToDevice, s));
+    WF_HIP(hipMemcpyAsync(ctx->d_tables + 1024, h_out, tabn, hipMemcpyHostToDevice, s));
+    enc_params P{columns, states, card, ninp, (int)(i0 % columns), state0, nsym};
+    hipLaunchKernelGGL(enc_reduce_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
+                       ctx->d_tables, P, thread_excl, block_agg);
+    WF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(enc_block_scan_kernel, dim3(1), dim3(WF_WAVE), 0, s, block_agg, (int)nblocks,
+                       state0, block_state);
+    WF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(enc_emit_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
+                       ctx->d_tables, reinterpret_cast<const int8_t *>(ctx->d_tables + 1024), P,
+                       thread_excl, block_state, d_symbols, ctx->d_small);
+    WF_LAUNCH_CHECK();
+    if (h_state_out) {
+        WF_HIP(hipMemcpyAsync(ctx->h_small, ctx->d_small, sizeof(int), hipMemcpyDeviceToHost, s));
+        WF_HIP(hipStreamSynchronize(s));
+        *h_state_out = ctx->h_small[0];
+    }
+    return WF_OK;
+}
+
+// ------------------------------------------------------------------ a2' mappers
+__global__ void symbol_map_kernel(int kind, const uint8_t *__restrict__ bits, int64_t n, int parity,
+                                  int mem0, int mem1, int8_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nout = kind == 1 ? n / 2 : n;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nout; k += stride) {
+        int v;
+        if (kind == 0) {
+            // a = mem ++ bits; out[k] = sign_k * (2 a[k+1] - 1) * (a[k] - a[k+2]);
+            // sign is -1 where (k - parity) is even and k >= parity (i_arr[i::2] = -1)
+            const int a0 = k >= 2 ? bits[k - 2] : (k == 0 ? mem0 : mem1);
+            const int a1 = k >= 1 ? bits[k - 1] : mem1;
+            const int a2 = bits[k];
+            const int sign = (k >= parity && ((k - parity) & 1) == 0) ? -1 : 1;
+            v = sign * (2 * a1 - 1) * (a0 - a2);
+        } else if (kind == 1) {
+            // 2*(2*bits[i::2] + bits[(i+1)%2::2]) - 3 with i = parity (already updated)
+            const int hi = bits[2 * k + parity];
+            const int lo = bits[2 * k + ((parity + 1) & 1)];
+            v = 2 * (2 * hi + lo) - 3;
+        } else {
+            v = 2 * (int)bits[k] - 1;
+        }
+        out[k] = (int8_t)v;
+    }
+}
+
+extern "C" int wf_symbol_map(wf_ctx *ctx, int kind, const uint8_t *d_bits, int64_t n, int parity,
+                             int mem0, int mem1, int8_t *d_symbols, void *stream)
+{
+    WF_REQUIRE(ctx && kind >= 0 && kind <= 2 && n >= 0, "wf_symbol_map: bad argument");
+    if (kind == 1 && (n & 1)) {
+        wf_set_error("Odd length bit array passed into quaternary mapper.");
+        return WF_ERR_VALUE;
+    }
+    if (n == 0) return WF_OK;
+    WF_REQUIRE(d_bits && d_symbols, "wf_symbol_map: NULL device pointer");
+    WF_REQUIRE(parity == 0 || parity == 1, "wf_symbol_map: parity must be 0 or 1");
+    WF_HIP(hipSetDevice(ctx->device));
+    const int grid = wf_grid_for(n, 256, 4096);
+    hipLaunchKernelGGL(symbol_map_kernel, dim3(grid), dim3(256), 0, wf_stream(stream), kind, d_bits,
+                       n, parity, mem0, mem1, d_symbols);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}

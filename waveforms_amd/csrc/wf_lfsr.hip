@@ -1,0 +1,147 @@
+// wf_lfsr.hip — K1: Galois LFSR PRBS by GF(2) leap-ahead.
+// Replaces GLFSR.next_bit loops (reference waveforms/glfsr/glfsr.py:6-19,
+// waveforms/glfsr/pn.py:98-107).  Integer path, bit-exact.
+//
+// One step of the register is the linear map T over GF(2)^64:
+//   T e_0 = mask, T e_c = e_{c-1}.
+// The context caches T^(2^j), j = 0..63 (column form) per mask; block b jumps to
+// position skip + b*2^14 with one wave doing matrix-vector products in parallel
+// (lane c holds column c, XOR-reduce over the wave), then every thread jumps a
+// further t*64 steps with the 8 matrices T^(2^6..2^13) staged in LDS and emits 64
+// bits.  Bits are re-packed through LDS so that global stores are 16 B per lane,
+// fully coalesced.
+#include "wf_common.h"
+
+#define LFSR_THREADS 256
+#define LFSR_BITS_PER_THREAD 64
+#define LFSR_BITS_PER_BLOCK (LFSR_THREADS * LFSR_BITS_PER_THREAD)  // 2^14
+
+static inline uint64_t host_matvec(const uint64_t *cols, uint64_t v)
+{
+    uint64_t y = 0;
+    while (v) {
+        int c = __builtin_ctzll(v);
+        y ^= cols[c];
+        v &= v - 1;
+    }
+    return y;
+}
+
+static wf_lfsr_tables *get_tables(wf_ctx *ctx, uint64_t mask)
+{
+    auto it = ctx->lfsr.find(mask);
+    if (it != ctx->lfsr.end()) return it->second;
+    wf_lfsr_tables *t = new wf_lfsr_tables();
+    t->host[0][0] = mask;
+    for (int c = 1; c < 64; ++c) t->host[0][c] = 1ull << (c - 1);
+    for (int j = 1; j < 64; ++j)
+        for (int c = 0; c < 64; ++c) t->host[j][c] = host_matvec(t->host[j - 1], t->host[j - 1][c]);
+    if (hipMalloc(&t->dev, sizeof(t->host)) != hipSuccess ||
+        hipMemcpy(t->dev, t->host, sizeof(t->host), hipMemcpyHostToDevice) != hipSuccess) {
+        delete t;
+        return nullptr;
+    }
+    ctx->lfsr[mask] = t;
+    return t;
+}
+
+static uint64_t host_jump(const wf_lfsr_tables *t, uint64_t state, uint64_t steps)
+{
+    for (int j = 0; j < 64; ++j)
+        if ((steps >> j) & 1) state = host_matvec(t->host[j], state);
+    return state;
+}
+
+__global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__restrict__ jump,
+                                                              uint64_t mask, uint64_t state,
+                                                              uint64_t skip, uint8_t *__restrict__ bits,
+                                                              int64_t n)
+{
+    __shared__ uint64_t s_mat[8][64];
+    __shared__ uint64_t s_words[LFSR_THREADS];
+    __shared__ uint64_t s_base;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const uint64_t pos0 = skip + (uint64_t)blockIdx.x * LFSR_BITS_PER_BLOCK;
+
+    // stage T^(2^6) .. T^(2^13)
+    for (int k = t; k < 8 * 64; k += LFSR_THREADS) s_mat[k >> 6][k & 63] = jump[(6 + (k >> 6)) * 64 + (k & 63)];
+
+    if (t < 64) {  // wave 0: block base state = T^pos0 * state
+        uint64_t s = state;
+        for (int j = 0; j < 64; ++j) {
+            if ((pos0 >> j) & 1) {  // wave-uniform
+                const uint64_t col = jump[j * 64 + lane];
+                s = wf_wave_xor_reduce(((s >> lane) & 1) ? col : 0ull);
+            }
+        }
+        if (t == 0) s_base = s;
+    }
+    __syncthreads();
+
+    uint64_t s = s_base;
+#pragma unroll 1
+    for (int b = 0; b < 8; ++b) {
+        uint64_t y = 0;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) y ^= ((s >> c) & 1) ? s_mat[b][c] : 0ull;
+        s = ((t >> b) & 1) ? y : s;
+    }
+    uint64_t w = 0;
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) {
+        const uint64_t bit = s & 1;
+        s = (s >> 1) ^ (mask & (0 - bit));
+        w |= bit << k;
+    }
+    s_words[t] = w;
+    __syncthreads();
+
+    const int64_t blk_byte0 = (int64_t)blockIdx.x * LFSR_BITS_PER_BLOCK;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int g = r * 4096 + t * 16;  // byte (= bit) offset inside the block
+        const int64_t gi = blk_byte0 + g;
+        if (gi >= n) break;
+        const uint32_t x = (uint32_t)(s_words[g >> 6] >> (g & 63)) & 0xFFFFu;
+        // spread 8 bits to 8 bytes (LSB first): classic multiply-mask trick
+        const uint64_t lo = (((uint64_t)(x & 0xFF) * 0x0101010101010101ull) & 0x8040201008040201ull);
+        const uint64_t hi = (((uint64_t)(x >> 8) * 0x0101010101010101ull) & 0x8040201008040201ull);
+        const uint64_t blo = ((lo + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+        const uint64_t bhi = ((hi + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+        if (gi + 16 <= n) {
+            *reinterpret_cast<ulonglong2 *>(bits + gi) = make_ulonglong2(blo, bhi);
+        } else {
+            for (int k = 0; k < 16 && gi + k < n; ++k)
+                bits[gi + k] = (uint8_t)(((k < 8 ? blo : bhi) >> (8 * (k & 7))) & 0xFF);
+        }
+    }
+}
+
+extern "C" int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state,
+                                uint64_t skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out,
+                                void *stream)
+{
+    WF_REQUIRE(ctx != nullptr, "wf_lfsr_generate: ctx is NULL");
+    if (degree < 2 || degree > 64) {
+        wf_set_error("PRBS Polynomial Not Defined for %d.", degree);
+        return WF_ERR_KEY;
+    }
+    WF_REQUIRE(n >= 0, "wf_lfsr_generate: n = %lld", (long long)n);
+    WF_REQUIRE(n == 0 || (d_bits && (reinterpret_cast<uintptr_t>(d_bits) & 15) == 0),
+               "wf_lfsr_generate: d_bits must be non-NULL and 16-byte aligned");
+    WF_HIP(hipSetDevice(ctx->device));
+    wf_lfsr_tables *t = get_tables(ctx, mask);
+    if (!t) {
+        wf_set_error("wf_lfsr_generate: could not build jump tables");
+        return WF_ERR_NOMEM;
+    }
+    if (h_state_out) *h_state_out = host_jump(t, state, skip + (uint64_t)n);
+    if (n == 0) return WF_OK;
+    const int64_t blocks = (n + LFSR_BITS_PER_BLOCK - 1) / LFSR_BITS_PER_BLOCK;
+    WF_REQUIRE(blocks < (1ll << 31), "wf_lfsr_generate: n too large for one launch");
+    hipLaunchKernelGGL(lfsr_kernel, dim3((unsigned)blocks), dim3(LFSR_THREADS), 0, wf_stream(stream),
+                       t->dev, mask, state, skip, d_bits, n);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}

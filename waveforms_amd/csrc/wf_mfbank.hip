@@ -1,0 +1,144 @@
+// wf_mfbank.hip — K6/K7: decimating matched-filter correlation bank.
+// Replaces the 3 x np.convolve(received, taps_alpha, "same") of the pulse-truncation
+// bank (reference examples/soqpsk_detection.py:141-156) and the 6 convolutions of the
+// PAM bank (:164-173; the conj(pseudo-symbol) weights are folded into 3 complex tap
+// rows on the host), evaluated ONLY at the samples the detector consumes (:189-196):
+//     out[k][f] = sum_t r[first + k*step + c - t] * taps[f][t],   c = (ntaps-1)/2.
+// With step = 1 it is the plain full-rate bank.
+//
+// A workgroup stages the contiguous input span of its outputs in LDS with coalesced
+// 16 B loads (each received sample is read from HBM once), then every thread owns one
+// output column and runs the taps out of LDS.  For an even `step` one 16 B pad slot per
+// `step` samples makes the ds_read_b128 column accesses bank-conflict free; taps are
+// wave-uniform (scalar loads).  128 B read + nfilt*16 B written per symbol at sps = 8:
+// HBM-bound for the 9-tap PT bank.
+#include "wf_common.h"
+
+#define MF_THREADS 256
+#define MF_LDS_SLOTS 3072  // 48 KiB of complex128
+
+struct mf_params {
+    int64_t nsamp, first, ncols;
+    int step, ntaps, nfilt;
+    int c;
+    int ob;    // outputs per workgroup iteration (<= MF_THREADS)
+    int span;  // input samples staged per iteration
+    int pad;   // 1: one pad slot every `step` samples
+    int64_t nblk;
+};
+
+template <int NF>
+__global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__restrict__ r,
+                                                              const double *__restrict__ taps,
+                                                              double *__restrict__ out, mf_params P)
+{
+    extern __shared__ double2 s_win[];
+    const int t = threadIdx.x;
+    for (int64_t blk = blockIdx.x; blk < P.nblk; blk += gridDim.x) {
+        const int64_t k0 = blk * P.ob;
+        // first input sample of the span: oldest sample of output k0
+        const int64_t ws = P.first + k0 * P.step + P.c - (P.ntaps - 1);
+        __syncthreads();
+        {
+            int q = t / P.step, rem = t - q * P.step;
+            const int dq = MF_THREADS / P.step, dr = MF_THREADS - dq * P.step;
+            for (int i = t; i < P.span; i += MF_THREADS) {
+                const int64_t s = ws + i;
+                double2 v = make_double2(0.0, 0.0);
+                if (s >= 0 && s < P.nsamp) v = *reinterpret_cast<const double2 *>(r + 2 * s);
+                s_win[i + (P.pad ? q : 0)] = v;
+                q += dq;
+                rem += dr;
+                if (rem >= P.step) {
+                    rem -= P.step;
+                    ++q;
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t k = k0 + t;
+        if (t < P.ob && k < P.ncols) {
+            double ar[NF], ai[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) ar[f] = ai[f] = 0.0;
+            // window offset j = 0 is the OLDEST sample => tap index ntaps-1-j
+            const int base = t * (P.step + P.pad);
+            int extra = 0, jm = 0;
+            for (int j = 0; j < P.ntaps; ++j) {
+                const double2 x = s_win[base + j + extra];
+                const int tt = P.ntaps - 1 - j;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    if (f < P.nfilt) {
+                        const double tr = taps[2 * (f * P.ntaps + tt)];
+                        const double ti = taps[2 * (f * P.ntaps + tt) + 1];
+                        ar[f] = fma(x.x, tr, fma(-x.y, ti, ar[f]));
+                        ai[f] = fma(x.x, ti, fma(x.y, tr, ai[f]));
+                    }
+                }
+                if (++jm == P.step) {
+                    jm = 0;
+                    extra += P.pad;
+                }
+            }
+            double2 *o = reinterpret_cast<double2 *>(out + 2 * (k * P.nfilt));
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                if (f < P.nfilt) o[f] = make_double2(ar[f], ai[f]);
+        }
+    }
+}
+
+extern "C" int wf_mf_bank_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp,
+                               const double *d_taps_ri, int nfilt, int ntaps, int64_t first, int step,
+                               int64_t ncols, double *d_out_ri, void *stream)
+{
+    WF_REQUIRE(ctx && d_r_ri && d_taps_ri, "wf_mf_bank_c128: NULL argument");
+    WF_REQUIRE(nfilt >= 1 && nfilt <= 8 && ntaps >= 1 && step >= 1 && ncols >= 0 && first >= 0,
+               "wf_mf_bank_c128: nfilt %d ntaps %d step %d", nfilt, ntaps, step);
+    WF_REQUIRE(nsamp >= ntaps, "wf_mf_bank_c128: input (%lld) shorter than the filter (%d)",
+               (long long)nsamp, ntaps);
+    WF_REQUIRE(ncols == 0 || first + (ncols - 1) * step < nsamp, "wf_mf_bank_c128: columns run past the input");
+    if (ncols == 0) return WF_OK;
+    WF_REQUIRE(d_out_ri && (reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(d_r_ri) & 15) == 0,
+               "wf_mf_bank_c128: device pointers must be 16-byte aligned");
+    WF_HIP(hipSetDevice(ctx->device));
+    mf_params P;
+    P.nsamp = nsamp;
+    P.first = first;
+    P.ncols = ncols;
+    P.step = step;
+    P.ntaps = ntaps;
+    P.nfilt = nfilt;
+    P.c = (ntaps - 1) / 2;
+    P.pad = (step % 2 == 0) ? 1 : 0;
+    // slots(ob) = (ob-1)*step + ntaps + pad*(that/step + 1) <= MF_LDS_SLOTS
+    int ob = MF_THREADS;
+    for (;;) {
+        const int span = (ob - 1) * step + ntaps;
+        const int slots = span + (P.pad ? span / step + 1 : 0);
+        if (slots <= MF_LDS_SLOTS || ob == 1) {
+            P.ob = ob;
+            P.span = span;
+            WF_REQUIRE(slots <= 9216, "wf_mf_bank_c128: filter too long for LDS staging (%d taps)", ntaps);
+            break;
+        }
+        ob = ob > 16 ? ob - 16 : ob - 1;
+    }
+    const int slots = P.span + (P.pad ? P.span / step + 1 : 0);
+    P.nblk = (ncols + P.ob - 1) / P.ob;
+    const int grid = (int)(P.nblk < 4096 ? P.nblk : 4096);
+    hipStream_t s = wf_stream(stream);
+    const size_t lds = (size_t)slots * sizeof(double2);
+    if (lds > 48 * 1024) {
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nfilt <= 3 ? mf_bank_kernel<3> : mf_bank_kernel<8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (nfilt <= 3)
+        hipLaunchKernelGGL(mf_bank_kernel<3>, dim3(grid), dim3(MF_THREADS), lds, s, d_r_ri, d_taps_ri, d_out_ri, P);
+    else
+        hipLaunchKernelGGL(mf_bank_kernel<8>, dim3(grid), dim3(MF_THREADS), lds, s, d_r_ri, d_taps_ri, d_out_ri, P);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}

@@ -1,0 +1,158 @@
+// wf_pipeline.hip — device-resident SOQPSK link: one C-ABI call runs
+//   PRBS -> trellis encode -> upsample+FIR -> phase scan + cexp -> derotate + AWGN ->
+//   decimating MF bank -> Viterbi -> error count
+// entirely out of a caller-provided HBM workspace (the per-waveform body of reference
+// examples/soqpsk_detection.py:45-216 without the plotting).  It only sequences the stage
+// kernels of this library on one stream; nothing is allocated and nothing comes back to
+// the host except the caller's own counters, so the call is graph-capturable and one
+// "Monte-Carlo trial block" of the BER sweep / one bench step.
+#include "wf_common.h"
+
+// ---------------------------------------------------------------- time axis (a5)
+// np.linspace(0, N+1, (N+1)*sps, endpoint=False) (reference waveforms/cpm/modulate.py:81-88)
+// evaluates arange(num) * step: one multiply per element, reproduced bit-exactly.
+__global__ void time_axis_kernel(int64_t n, double step, double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        out[k] = (double)k * step;
+}
+
+extern "C" int wf_time_axis_f64(wf_ctx *ctx, int64_t n, double step, double *d_out, void *stream)
+{
+    WF_REQUIRE(ctx && n >= 0, "wf_time_axis_f64: bad argument");
+    if (n == 0) return WF_OK;
+    WF_REQUIRE(d_out != nullptr, "wf_time_axis_f64: NULL output");
+    WF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(time_axis_kernel, dim3(wf_grid_for(n, 256, 4096)), dim3(256), 0, wf_stream(stream), n,
+                       step, d_out);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}
+
+// ---------------------------------------------------------------- link
+static inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct link_layout {
+    int64_t nsym, npts, ncols, first;
+    size_t off_bits, off_syms, off_freq, off_sig, off_mf, off_dbits, off_dsyms, total;
+};
+
+static link_layout make_layout(int64_t nsym, int sps, int ntaps, int nfilt, int length, int timing_offset)
+{
+    link_layout L;
+    L.nsym = nsym;
+    L.npts = wf_fir_out_len(nsym, sps, ntaps);
+    // columns n in range(size - length*sps) with (n + timing_offset) % sps == 0
+    // (reference examples/soqpsk_detection.py:189-192)
+    const int64_t limit = L.npts - (int64_t)length * sps;
+    int64_t first = (-(int64_t)timing_offset) % sps;
+    if (first < 0) first += sps;
+    L.first = first;
+    L.ncols = limit > first ? (limit - first + sps - 1) / sps : 0;
+    size_t o = 0;
+    L.off_bits = o;  o += (size_t)round_up(nsym + 16, 256);
+    L.off_syms = o;  o += (size_t)round_up(nsym + 16, 256);
+    L.off_freq = o;  o += (size_t)round_up(L.npts * 8, 256);
+    L.off_sig = o;   o += (size_t)round_up(L.npts * 16, 256);
+    L.off_mf = o;    o += (size_t)round_up(L.ncols * nfilt * 16, 256);
+    L.off_dbits = o; o += (size_t)round_up(L.ncols + 16, 256);
+    L.off_dsyms = o; o += (size_t)round_up(L.ncols + 16, 256);
+    L.total = o;
+    return L;
+}
+
+extern "C" int64_t wf_link_workspace_bytes(const wf_link_config *cfg)
+{
+    if (!cfg || cfg->nsym < 1 || cfg->sps < 1) return -1;
+    return (int64_t)make_layout(cfg->nsym, cfg->sps, cfg->ntaps, cfg->mf_nfilt, 2, cfg->timing_offset).total;
+}
+
+extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
+                           int64_t *d_counts, int64_t *h_compared, void *stream)
+{
+    WF_REQUIRE(ctx && cfg && d_workspace && d_counts, "wf_link_run: NULL argument");
+    WF_REQUIRE(cfg->nsym >= 1 && cfg->sps >= 1 && cfg->mf_nfilt == 3, "wf_link_run: bad configuration");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_workspace) & 255) == 0, "wf_link_run: workspace must be 256-byte aligned");
+    const int length = 2;
+    const link_layout L = make_layout(cfg->nsym, cfg->sps, cfg->ntaps, cfg->mf_nfilt, length, cfg->timing_offset);
+    WF_REQUIRE((int64_t)L.total <= workspace_bytes, "wf_link_run: workspace too small (%lld < %lld)",
+               (long long)workspace_bytes, (long long)L.total);
+    WF_REQUIRE(L.npts >= cfg->mf_ntaps, "wf_link_run: burst shorter than the matched filter");
+    char *w = static_cast<char *>(d_workspace);
+    uint8_t *bits = reinterpret_cast<uint8_t *>(w + L.off_bits);
+    int8_t *syms = reinterpret_cast<int8_t *>(w + L.off_syms);
+    double *freq = reinterpret_cast<double *>(w + L.off_freq);
+    double *sig = reinterpret_cast<double *>(w + L.off_sig);
+    double *mf = reinterpret_cast<double *>(w + L.off_mf);
+    uint8_t *dbits = reinterpret_cast<uint8_t *>(w + L.off_dbits);
+    int8_t *dsyms = reinterpret_cast<int8_t *>(w + L.off_dsyms);
+
+    // SOQPSKTrellis4x2 / 4x2DiffEncoded as dense [column][state][input] tables
+    // (reference waveforms/cpm/trellis/model.py:205-258).
+    uint8_t next[2][4][2];
+    int8_t outp[2][4][2];
+    static const int8_t kOut[2][8] = {{0, 2, 0, -2, -2, 0, 2, 0}, {0, -2, 2, 0, 0, 2, -2, 0}};
+    for (int c = 0; c < 2; ++c)
+        for (int b = 0; b < 8; ++b) {
+            const int s = b >> 1;
+            const int e = c == 0 ? (s & 1) + 2 * (b & 1) : (s & 2) + (b & 1);
+            const int flip = cfg->differential ? (c == 0 ? (s >> 1) : (s & 1)) : 0;
+            const int inp = (b & 1) ^ flip;
+            next[c][s][inp] = (uint8_t)e;
+            outp[c][s][inp] = kOut[c][b];
+        }
+    hipEvent_t *ev = nullptr;
+    if (cfg->event_slot >= 0) {
+        WF_REQUIRE(cfg->event_slot < WF_LINK_EVENT_SLOTS, "wf_link_run: event_slot %d", cfg->event_slot);
+        if (!ctx->events) {
+            ctx->events = new hipEvent_t[WF_LINK_EVENT_SLOTS * (WF_LINK_STAGES + 1)];
+            for (int k = 0; k < WF_LINK_EVENT_SLOTS * (WF_LINK_STAGES + 1); ++k) WF_HIP(hipEventCreate(&ctx->events[k]));
+        }
+        ev = ctx->events + cfg->event_slot * (WF_LINK_STAGES + 1);
+    }
+#define MARK(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(stream))); } while (0)
+    int rc;
+    MARK(0);
+    if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, cfg->nsym, nullptr, stream))) return rc;
+    MARK(1);
+    if ((rc = wf_fsm_encode(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, cfg->nsym, 0, 0, syms, nullptr, stream))) return rc;
+    MARK(2);
+    if ((rc = wf_upsample_fir_f64(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, freq, stream))) return rc;
+    MARK(3);
+    if ((rc = wf_phase_cexp_f64(ctx, freq, L.npts, cfg->sps, M_PI / 4, 0.0, sig, nullptr, stream))) return rc;
+    MARK(4);
+    // modulated *= exp(-j pi/4); received = modulated + noise   (in place)
+    if ((rc = wf_awgn_c128(ctx, sig, L.npts, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id,
+                           0, sig, stream))) return rc;
+    MARK(5);
+    if (L.ncols > 0) {
+        if ((rc = wf_mf_bank_c128(ctx, sig, L.npts, cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, L.first, cfg->sps,
+                                  L.ncols, mf, stream))) return rc;
+        MARK(6);
+        if ((rc = wf_viterbi4_detect(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream))) return rc;
+    }
+    // drop the first `length` detector outputs, compare min_size elements
+    // (reference examples/soqpsk_detection.py:201-209)
+    if (L.ncols <= 0) MARK(6);
+    MARK(7);
+    int64_t m = L.ncols - length;
+    if (m > cfg->nsym) m = cfg->nsym;
+    if (m < 0) m = 0;
+    if (m > 0)
+        if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m, d_counts, stream))) return rc;
+    MARK(8);
+#undef MARK
+    if (h_compared) *h_compared = m;
+    return WF_OK;
+}
+
+extern "C" int wf_link_stage_ms(wf_ctx *ctx, int event_slot, float *h_ms)
+{
+    WF_REQUIRE(ctx && h_ms && event_slot >= 0 && event_slot < WF_LINK_EVENT_SLOTS && ctx->events,
+               "wf_link_stage_ms: no events recorded in slot %d", event_slot);
+    hipEvent_t *ev = ctx->events + event_slot * (WF_LINK_STAGES + 1);
+    WF_HIP(hipEventSynchronize(ev[WF_LINK_STAGES]));
+    for (int k = 0; k < WF_LINK_STAGES; ++k) WF_HIP(hipEventElapsedTime(&h_ms[k], ev[k], ev[k + 1]));
+    return WF_OK;
+}

@@ -1,0 +1,325 @@
+// wf_viterbi.hip — K8-K10: SOQPSK 4-state, 2-column Viterbi detector.
+// Replaces SOQPSKTrellisDetector.iteration (reference waveforms/viterbi/algorithm.py:18-101):
+// branch increments Re(c[start] * mf[idx(out)]) (:57-63), add-compare-select with MIN and a
+// strict '<' (ties -> first branch in list order, :69-87), per-call min-normalisation of
+// the carried metrics (:65-67), traceback of `length` stages from the first arg-min state
+// (:90-98).
+//
+//  * viterbi_batch_kernel: length = 2 over a whole burst.  The reference recomputes a
+//    2-stage window on every call; that equals a streaming ACS (stage 0 commits the
+//    previous call's increments from the normalised carried metrics, stage 1 looks one
+//    symbol ahead from the un-normalised result) + a depth-2 traceback, restated here
+//    literally so that compare outcomes are bit-identical.  Parallelism: every thread owns
+//    a chunk of consecutive calls and first re-derives the path metrics over `warmup`
+//    earlier rows starting from zero metrics; once the survivors have merged (a few tens
+//    of symbols on this 4-state trellis) the carried metric vector equals the sequential
+//    one, hence so do all decisions.  The trellis (reference
+//    waveforms/cpm/trellis/model.py:205-258) is compile-time: it is the only one the
+//    reference detector supports (state_exp_term has 4 entries, algorithm.py:30).
+//  * viterbi_iteration_kernel: one literal .iteration() for any window length, detector
+//    state resident in device memory (drop-in for the per-symbol API).
+#include "wf_common.h"
+
+#define VIT_THREADS 256
+#define VIT_CHUNK 64
+#define VIT_DEFAULT_WARMUP 48
+#define VIT_MAX_LEN 64
+
+// Branch b of column c: start = b >> 1; ends / output-symbol index (0: -2, 1: 0, 2: +2):
+//   column 0 (even / I): end = (start & 1) + 2*(b & 1)
+//   column 1 (odd  / Q): end = (start & 2) + (b & 1)
+// (model.py:205-230; the diff-encoded trellis :233-258 only relabels the inputs).
+__device__ __constant__ const int8_t kOutIdx[2][8] = {{1, 2, 1, 0, 0, 1, 2, 1}, {1, 0, 2, 1, 1, 2, 0, 1}};
+
+__device__ __forceinline__ int br_end(int col, int b)
+{
+    const int s = b >> 1;
+    return col == 0 ? (s & 1) + 2 * (b & 1) : (s & 2) + (b & 1);
+}
+
+__device__ __forceinline__ int br_inp(int col, int b, int diff)
+{
+    const int s = b >> 1;
+    const int flip = diff ? (col == 0 ? (s >> 1) : (s & 1)) : 0;
+    return (b & 1) ^ flip;
+}
+
+// Re(state_exp_term[start] * z), state_exp_term = [+1j, -1, +1, -1j] (algorithm.py:30)
+__device__ __forceinline__ double br_inc(int start, double re, double im)
+{
+    return start == 0 ? -im : start == 1 ? -re : start == 2 ? re : im;
+}
+
+template <int COL>
+__device__ __forceinline__ void increments(const double2 z[3], double inc[8])
+{
+    // compile-time version of kOutIdx
+    constexpr int oi[2][8] = {{1, 2, 1, 0, 0, 1, 2, 1}, {1, 0, 2, 1, 1, 2, 0, 1}};
+#pragma unroll
+    for (int b = 0; b < 8; ++b) inc[b] = br_inc(b >> 1, z[oi[COL][b]].x, z[oi[COL][b]].y);
+}
+
+// One ACS stage of column COL: for every end state the two incoming branches in LIST
+// order (lower branch index first), strict '<'.
+template <int COL>
+__device__ __forceinline__ void acs(const double m_in[4], const double inc[8], double m_out[4], int path[4])
+{
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        // incoming branches: column 0: b = st>>1 + {0,4}|... derive from br_end at compile time
+        int first = -1, second = -1;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int s = b >> 1;
+            const int e = COL == 0 ? (s & 1) + 2 * (b & 1) : (s & 2) + (b & 1);
+            if (e == st) {
+                if (first < 0) first = b; else second = b;
+            }
+        }
+        const double ma = m_in[first >> 1] + inc[first];
+        const double mb = m_in[second >> 1] + inc[second];
+        // min_m = inf; ma < inf -> take a (NaN -> stays inf, min_k = 0, as the reference)
+        double mm = INFINITY;
+        int k = 0;
+        if (ma < mm) { mm = ma; k = first >> 1; }
+        if (mb < mm) { mm = mb; k = second >> 1; }
+        m_out[st] = mm;
+        path[st] = k;
+    }
+}
+
+struct vit_carry {
+    double i;          // call counter (exact in a double up to 2^53)
+    double m0[4];      // metrics[:, 0] of the previous call
+    double inc_prev[8];
+    double pad[3];
+};
+
+template <int COL_NOW>
+__device__ __forceinline__ void viterbi_call(const double2 z[3], double m0[4], double inc_prev[8], int diff,
+                                             int *bit, int *sym)
+{
+    constexpr int COL_PREV = COL_NOW ^ 1;
+    double inc_now[8];
+    increments<COL_NOW>(z, inc_now);
+    // algorithm.py:65-67
+    const double mn = fmin(fmin(m0[0], m0[1]), fmin(m0[2], m0[3]));
+    double carried[4] = {m0[0] - mn, m0[1] - mn, m0[2] - mn, m0[3] - mn};
+    double ma[4], mb[4];
+    int p0[4], p1[4];
+    acs<COL_PREV>(carried, inc_prev, ma, p0);   // stage j = 0
+    acs<COL_NOW>(ma, inc_now, mb, p1);          // stage j = 1
+    // np.argmin: first minimum
+    int s1 = 0;
+    double best = mb[0];
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+        if (mb[s] < best) { best = mb[s]; s1 = s; }
+    const int e0 = p1[s1];        // state after stage 0
+    const int st0 = p0[e0];       // state before stage 0
+    // branch (COL_PREV, start st0, end e0)
+    const int b = 2 * st0 + (COL_PREV == 0 ? (e0 >> 1) : (e0 & 1));
+    *bit = br_inp(COL_PREV, b, diff);
+    *sym = 2 * (int)kOutIdx[COL_PREV][b] - 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) m0[s] = ma[s];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) inc_prev[k] = inc_now[k];
+}
+
+__global__ __launch_bounds__(VIT_THREADS) void viterbi_batch_kernel(const double *__restrict__ mf,
+                                                                     int64_t ncalls, int diff, int warmup,
+                                                                     uint8_t *__restrict__ bits,
+                                                                     int8_t *__restrict__ syms,
+                                                                     double *__restrict__ state)
+{
+    const int64_t gt = (int64_t)blockIdx.x * VIT_THREADS + threadIdx.x;
+    const int64_t a = gt * VIT_CHUNK;
+    if (a >= ncalls) return;
+    const int64_t b_end = a + VIT_CHUNK < ncalls ? a + VIT_CHUNK : ncalls;
+    int64_t s = a - warmup;
+    if (s < 0) s = 0;
+
+    double m0[4] = {0, 0, 0, 0}, inc_prev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t i0 = 0;
+    if (state) i0 = (int64_t)state[0];
+    const double2 *rows = reinterpret_cast<const double2 *>(mf);
+    if (s == 0) {
+        if (state) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m0[k] = state[1 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) inc_prev[k] = state[5 + k];
+        }
+    } else {
+        // exact increments of the row before the warm-up start
+        const double2 z[3] = {rows[3 * (s - 1)], rows[3 * (s - 1) + 1], rows[3 * (s - 1) + 2]};
+        if ((i0 + s - 1) & 1) increments<1>(z, inc_prev); else increments<0>(z, inc_prev);
+    }
+
+    uint64_t pb_lo = 0, pb_hi = 0, ps_lo = 0, ps_hi = 0;
+    double2 z[3] = {rows[3 * s], rows[3 * s + 1], rows[3 * s + 2]};
+    for (int64_t k = s; k < b_end; ++k) {
+        double2 zn[3] = {z[0], z[1], z[2]};
+        if (k + 1 < b_end) {  // prefetch the next row
+            zn[0] = rows[3 * (k + 1)];
+            zn[1] = rows[3 * (k + 1) + 1];
+            zn[2] = rows[3 * (k + 1) + 2];
+        }
+        int bit, sym;
+        if ((i0 + k) & 1) viterbi_call<1>(z, m0, inc_prev, diff, &bit, &sym);
+        else viterbi_call<0>(z, m0, inc_prev, diff, &bit, &sym);
+        if (k >= a) {
+            const int j = (int)(k - a) & 15;
+            const uint64_t bv = (uint64_t)(bit & 0xFF), sv = (uint64_t)(sym & 0xFF);
+            if (j < 8) { pb_lo |= bv << (8 * j); ps_lo |= sv << (8 * j); }
+            else { pb_hi |= bv << (8 * (j - 8)); ps_hi |= sv << (8 * (j - 8)); }
+            if (j == 15) {
+                *reinterpret_cast<ulonglong2 *>(bits + k - 15) = make_ulonglong2(pb_lo, pb_hi);
+                *reinterpret_cast<ulonglong2 *>(syms + k - 15) = make_ulonglong2(ps_lo, ps_hi);
+                pb_lo = pb_hi = ps_lo = ps_hi = 0;
+            } else if (k + 1 == b_end) {  // ragged tail of the burst
+                for (int q = 0; q <= j; ++q) {
+                    bits[k - j + q] = (uint8_t)(((q < 8 ? pb_lo : pb_hi) >> (8 * (q & 7))) & 0xFF);
+                    syms[k - j + q] = (int8_t)(((q < 8 ? ps_lo : ps_hi) >> (8 * (q & 7))) & 0xFF);
+                }
+            }
+        }
+        z[0] = zn[0];
+        z[1] = zn[1];
+        z[2] = zn[2];
+    }
+    if (state && b_end == ncalls) {
+        // the thread that owns the last call hands the detector state on (streaming).
+        // Written to the second half of the carry block so concurrent readers of the
+        // first half (other threads' i0 / thread 0's metrics) are not disturbed.
+        state[16] = (double)(i0 + ncalls);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) state[17 + k] = m0[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) state[21 + k] = inc_prev[k];
+    }
+}
+
+__global__ void viterbi_carry_commit_kernel(double *state)
+{
+    const int t = threadIdx.x;
+    if (t < 16) state[t] = state[16 + t];
+}
+
+extern "C" int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
+                                  int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
+                                  void *stream)
+{
+    WF_REQUIRE(ctx && ncalls >= 0 && warmup >= 0, "wf_viterbi4_detect: bad argument");
+    if (ncalls == 0) return WF_OK;
+    WF_REQUIRE(d_mf_ri && d_bits && d_syms, "wf_viterbi4_detect: NULL device pointer");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_mf_ri) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_bits) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(d_syms) & 15) == 0,
+               "wf_viterbi4_detect: device pointers must be 16-byte aligned");
+    WF_HIP(hipSetDevice(ctx->device));
+    if (warmup == 0) warmup = VIT_DEFAULT_WARMUP;
+    warmup = (warmup + 1) & ~1;  // even: keeps the column parity wave-uniform
+    const int64_t nthreads = (ncalls + VIT_CHUNK - 1) / VIT_CHUNK;
+    const int64_t nblocks = (nthreads + VIT_THREADS - 1) / VIT_THREADS;
+    WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
+    hipStream_t s = wf_stream(stream);
+    hipLaunchKernelGGL(viterbi_batch_kernel, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
+                       ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
+    WF_LAUNCH_CHECK();
+    if (d_state) {
+        hipLaunchKernelGGL(viterbi_carry_commit_kernel, dim3(1), dim3(64), 0, s, d_state);
+        WF_LAUNCH_CHECK();
+    }
+    return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Literal single-call form for any window length (the per-symbol drop-in API).
+struct vit_state {
+    long long i;
+    double bi_history[8][VIT_MAX_LEN];
+    double metrics[4][VIT_MAX_LEN];
+    unsigned char path[4][VIT_MAX_LEN];
+};
+
+extern "C" int64_t wf_viterbi4_state_bytes(int length)
+{
+    return (length >= 1 && length <= VIT_MAX_LEN) ? (int64_t)sizeof(vit_state) : -1;
+}
+
+__global__ void viterbi_iteration_kernel(vit_state *st, int L, int diff, const double *__restrict__ mf3,
+                                         double *__restrict__ bits_out, double *__restrict__ syms_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long i = st->i;
+    const int col_now = (int)(((i % 2) + 2) % 2);
+    // algorithm.py:57-63: np.roll(-1) then overwrite the last column
+    for (int b = 0; b < 8; ++b) {
+        for (int j = 0; j + 1 < L; ++j) st->bi_history[b][j] = st->bi_history[b][j + 1];
+        const int oi = kOutIdx[col_now][b];
+        st->bi_history[b][L - 1] = br_inc(b >> 1, mf3[2 * oi], mf3[2 * oi + 1]);
+    }
+    // algorithm.py:65-67
+    double mn = st->metrics[0][0];
+    for (int s = 1; s < 4; ++s) mn = st->metrics[s][0] < mn ? st->metrics[s][0] : mn;
+    double carried[4];
+    for (int s = 0; s < 4; ++s) carried[s] = st->metrics[s][0] - mn;
+    for (int s = 0; s < 4; ++s) {
+        for (int j = 0; j + 1 < L; ++j) st->metrics[s][j] = 0.0;
+        st->metrics[s][L - 1] = carried[s];
+        for (int j = 0; j < L; ++j) st->path[s][j] = 0;
+    }
+    // algorithm.py:69-87 (in-place, stage by stage, end state by end state)
+    for (int j = 0; j < L; ++j) {
+        const int col = (int)((((i + j - 1) % 2) + 2) % 2);
+        const int jm1 = (j - 1 + L) % L;
+        for (int s = 0; s < 4; ++s) {
+            int min_k = 0;
+            double min_m = INFINITY;
+            for (int b = 0; b < 8; ++b) {
+                if (br_end(col, b) != s) continue;
+                const double mm = st->metrics[b >> 1][jm1] + st->bi_history[b][j];
+                if (mm < min_m) {
+                    min_m = mm;
+                    min_k = b >> 1;
+                }
+            }
+            st->metrics[s][j] = min_m;
+            st->path[s][j] = (unsigned char)min_k;
+        }
+    }
+    // algorithm.py:90-98
+    int state = 0;
+    for (int s = 1; s < 4; ++s)
+        if (st->metrics[s][L - 1] < st->metrics[state][L - 1]) state = s;
+    for (int j = L - 1; j >= 0; --j) {
+        const int col = (int)((((i + j - 1) % 2) + 2) % 2);
+        const int pred = st->path[state][j];
+        const int b = 2 * pred + (col == 0 ? (state >> 1) : (state & 1));
+        // reverse_transitions lookup: the branch must really end in `state`
+        if (br_end(col, b) != state) {
+            bits_out[j] = nan("");
+            syms_out[j] = nan("");
+        } else {
+            bits_out[j] = (double)br_inp(col, b, diff);
+            syms_out[j] = (double)(2 * (int)kOutIdx[col][b] - 2);
+        }
+        state = pred;
+    }
+    st->i = i + 1;
+}
+
+extern "C" int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int differential,
+                                     const double *d_mf3_ri, double *d_bits_out, double *d_syms_out,
+                                     void *stream)
+{
+    WF_REQUIRE(ctx && d_state && d_mf3_ri && d_bits_out && d_syms_out, "wf_viterbi4_iteration: NULL argument");
+    WF_REQUIRE(length >= 1 && length <= VIT_MAX_LEN, "wf_viterbi4_iteration: length %d", length);
+    WF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(viterbi_iteration_kernel, dim3(1), dim3(64), 0, wf_stream(stream),
+                       static_cast<vit_state *>(d_state), length, differential ? 1 : 0, d_mf3_ri,
+                       d_bits_out, d_syms_out);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}

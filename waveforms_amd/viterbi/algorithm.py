@@ -1,0 +1,94 @@
+"""SOQPSK trellis detector — API of reference waveforms/viterbi/algorithm.py:18-101.
+
+``iteration`` is the reference's per-symbol call: one literal window recomputation on
+the GPU with the detector state resident in HBM (csrc/wf_viterbi.hip,
+viterbi_iteration_kernel), any window ``length``.  ``detect`` is the batch form the
+MI355X path is built for: a whole burst of matched-filter rows in one launch
+(chunk-parallel ACS + depth-2 traceback), ``length == 2`` only, returning for every row
+exactly what ``iteration(row)[...][0]`` would.
+"""
+from __future__ import annotations
+
+from typing import TYPE_CHECKING
+
+import numpy as np
+
+from waveforms_amd.cpm.trellis.model import (
+    FiniteStateMachine,
+    SOQPSKTrellis4x2,
+    SOQPSKTrellis4x2DiffEncoded,
+)
+
+if TYPE_CHECKING:
+    from numpy.typing import NDArray
+
+
+class SOQPSKTrellisDetector:
+    def __init__(
+        self,
+        length: int = 2,
+        *,
+        differantial_encoding: bool = True,  # (sic) the reference's keyword
+    ) -> None:
+        self.i = 0
+        self.length = length
+        self.differential = bool(differantial_encoding)
+        self.fsm = FiniteStateMachine(
+            trellis=SOQPSKTrellis4x2DiffEncoded if differantial_encoding else SOQPSKTrellis4x2,
+        )
+        self.state_exp_term = [+1j, -1, +1, -1j]
+        self._d_state = None
+        self._d_io = None
+
+    # ------------------------------------------------------------------ per-symbol API
+    def _ensure_state(self):
+        from waveforms_amd import _hip
+
+        if self._d_state is None:
+            nbytes = _hip.lib().wf_viterbi4_state_bytes(int(self.length))
+            if nbytes < 0:
+                raise ValueError(f"unsupported traceback length {self.length}")
+            self._d_state = _hip.zeros(nbytes, "uint8")
+            self._d_io = _hip.zeros(6 + 2 * int(self.length), "float64")
+
+    def iteration(
+        self,
+        mf_outputs: NDArray[np.complex128],
+    ) -> tuple[NDArray[np.float64], NDArray[np.float64]]:
+        """One detector step on the matched-filter outputs of one symbol time
+        (rows ordered alpha = -2, 0, +2).  Returns (bits, symbols), ``length`` each,
+        oldest first, float64 like the reference."""
+        from waveforms_amd import _hip
+
+        self._ensure_state()
+        L = int(self.length)
+        z = np.asarray(mf_outputs, dtype=np.complex128).reshape(3)
+        self._d_io[:6].copy_(_hip.torch().from_numpy(z.view(np.float64).copy()))
+        base = self._d_io.data_ptr()
+        _hip.check(_hip.lib().wf_viterbi4_iteration(
+            _hip.ctx(), _hip.ptr(self._d_state), L, int(self.differential), base, base + 48,
+            base + 48 + 8 * L, _hip.stream()))
+        out = self._d_io[6:].cpu().numpy()
+        if np.isnan(out).any():
+            raise KeyError("traceback reached a state pair with no connecting branch")
+        self.i += 1
+        return out[:L].copy(), out[L:].copy()
+
+    # ------------------------------------------------------------------ batch API
+    def detect_device(self, mf_rows, warmup: int = 0):
+        """``mf_rows``: float64[n, 3, 2] device tensor -> (bits u8[n], symbols i8[n]) on device."""
+        from waveforms_amd import device as dev
+
+        if self.length != 2:
+            raise ValueError("batch detection implements the reference default length=2")
+        if self.i != 0:
+            raise ValueError("batch detection starts a fresh burst; use iteration() to continue one")
+        return dev.viterbi_detect(mf_rows, self.differential, warmup)
+
+    def detect(self, mf_rows: NDArray[np.complex128], warmup: int = 0):
+        """Host in / host out batch form: complex128[n, 3] -> (bits u8[n], symbols i8[n])."""
+        from waveforms_amd import _hip
+
+        rows = np.ascontiguousarray(mf_rows, dtype=np.complex128).reshape(-1, 3)
+        bits, syms = self.detect_device(_hip.to_device(rows), warmup)
+        return _hip.to_host(bits), _hip.to_host(syms)

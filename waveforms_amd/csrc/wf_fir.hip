@@ -111,6 +111,10 @@ extern "C" int wf_upsample_fir_f64(wf_ctx *ctx, const int8_t *d_symbols, int64_t
 {
     WF_REQUIRE(ctx && d_h && d_pulse && d_out, "wf_upsample_fir_f64: NULL argument");
     WF_REQUIRE(nsym >= 0 && (nsym == 0 || d_symbols), "wf_upsample_fir_f64: bad symbols");
+    // sps = 1: the reference's interpolated[sps:-1:sps] has N-1 slots for N symbols and
+    // numpy raises ValueError (waveforms/cpm/modulate.py:96) — same error here.
+    WF_REQUIRE(sps >= 2 || nsym == 0, "could not broadcast input array from shape (%lld,) into shape (%lld,)",
+               (long long)nsym, (long long)(nsym - 1));
     WF_REQUIRE(sps >= 1 && sps <= 256 && nh >= 1 && ntaps >= 1,
                "wf_upsample_fir_f64: sps %d nh %d ntaps %d", sps, nh, ntaps);
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_out) & 15) == 0, "wf_upsample_fir_f64: d_out alignment");

@@ -74,6 +74,11 @@ def lib() -> ctypes.CDLL:
                     raise RuntimeError(
                         f"{_LIB_PATH} is missing - build it with `python -m waveforms_amd.csrc.build` "
                         "(there is no CPU fallback)")
+                # torch first: it ships its own libamdhip64.so.7; whichever copy of that
+                # SONAME is loaded first serves the whole process, and the GPU boxes only
+                # enumerate devices through torch's.
+                import torch  # noqa: F401
+
                 handle = ctypes.CDLL(str(_LIB_PATH))
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(handle, name)

@@ -39,16 +39,29 @@ __device__ __forceinline__ philox_out philox4x32_10(uint32_t c0, uint32_t c1, ui
 __device__ __forceinline__ void gaussian_pair(uint64_t idx, uint64_t stream_id, uint64_t seed,
                                               double sigma, double *re, double *im)
 {
+#ifdef WF_ABL_NO_PHILOX   // ablation only: NOT a valid generator
+    const philox_out p = {(uint32_t)idx * 2654435761u, (uint32_t)(idx >> 7) ^ (uint32_t)seed,
+                          (uint32_t)idx * 40503u, (uint32_t)stream_id ^ (uint32_t)idx};
+#else
     const philox_out p = philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id,
                                        (uint32_t)(stream_id >> 32), (uint32_t)seed,
                                        (uint32_t)(seed >> 32));
+#endif
     const uint64_t a = ((uint64_t)p.x1 << 32) | p.x0;
     const uint64_t b = ((uint64_t)p.x3 << 32) | p.x2;
     const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;  // (0, 1]
     const double u2 = (double)(b >> 11) * 0x1.0p-53;        // [0, 1)
-    const double r = sigma * sqrt(-2.0 * log(u1));
+#ifdef WF_ABL_NO_LOG
+    const double r = sigma * u1;
+#else
+    const double r = sigma * wf_sqrt_pos(-2.0 * wf_log_normal(u1));
+#endif
     double s, c;
-    sincos(2.0 * M_PI * u2, &s, &c);
+#ifdef WF_ABL_NO_SINCOS
+    s = u2; c = 1.0 - u2;
+#else
+    wf_sincos_turns(u2, &s, &c);
+#endif
     *re = r * c;
     *im = r * s;
 }

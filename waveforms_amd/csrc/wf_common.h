@@ -85,6 +85,83 @@ __device__ __forceinline__ double wf_wave_incl_scan(double v)
     return v;
 }
 
+// sin / cos of 2*pi*t, t in TURNS.  The quadrant reduction is exact (scaling by 4, floor
+// and the subtraction are exact in binary floating point), so there is no Payne-Hanek
+// path and no cancellation; the residual angle in [0, pi/4] goes through the classic
+// minimax kernels (Sun fdlibm __kernel_sin / __kernel_cos coefficient sets, < 1 ulp).
+__device__ __forceinline__ void wf_sincos_turns(double t, double *sn, double *cs)
+{
+    const double y = t * 4.0;
+    const double q = floor(y);
+    const double f = y - q;                 // [0, 1) quarter turns, exact
+    const bool fold = f > 0.5;
+    const double g = fold ? 1.0 - f : f;    // [0, 0.5], exact
+    const double x = g * 1.57079632679489661923;  // [0, pi/4]
+    const double z = x * x;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    ps = fma(x * z, ps, x);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    pc = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const double sq = fold ? pc : ps;       // sin / cos inside the quadrant
+    const double cq = fold ? ps : pc;
+    const int qi = (int)q & 3;
+    const double s1 = (qi & 1) ? cq : sq;
+    const double c1 = (qi & 1) ? sq : cq;
+    *sn = (qi & 2) ? -s1 : s1;
+    *cs = ((qi + 1) & 2) ? -c1 : c1;
+}
+
+// Natural log of a NORMAL positive double (no zero / subnormal / inf / nan handling:
+// callers pass u in [2^-53, 1]).  Exponent split + the fdlibm e_log.c minimax series
+// in s = f / (2 + f); the quotient uses v_rcp_f64 + two Newton steps.  < 1 ulp.
+__device__ __forceinline__ double wf_log_normal(double x)
+{
+    const long long ix = __double_as_longlong(x);
+    int e = (int)(ix >> 52) - 1023;
+    const long long mant = ix & 0x000FFFFFFFFFFFFFll;
+    const bool up = mant >= 0x0006A09E667F3BCDll;            // m >= sqrt(2): use m/2
+    e += up ? 1 : 0;
+    const double m = __longlong_as_double(mant | (up ? 0x3FE0000000000000ll : 0x3FF0000000000000ll));
+    const double f = m - 1.0;                                 // [-0.2929, 0.4142]
+    const double d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);
+    r = r * fma(-d, r, 2.0);
+    r = r * fma(-d, r, 2.0);
+    const double s = f * r;
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return fma(dk, 6.93147180369123816490e-01, f - (hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)));
+}
+
+// sqrt of a non-negative normal double (0 allowed): v_rsq_f64 seed + Goldschmidt, then
+// one residual correction.
+__device__ __forceinline__ double wf_sqrt_pos(double a)
+{
+    const double y = __builtin_amdgcn_rsq(fmax(a, 0x1.0p-1000));
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double dres = fma(-g, g, a);
+    return fma(dres, h, g);
+}
+
 __device__ __forceinline__ uint64_t wf_wave_xor_reduce(uint64_t v)
 {
 #pragma unroll

@@ -17,7 +17,9 @@
 #include "wf_common.h"
 
 #define PH_THREADS 256
-#define PH_ROWS 4
+#ifndef PH_ROWS
+#define PH_ROWS 8
+#endif
 #define PH_ROW (2 * PH_THREADS)
 #define PH_TILE (PH_ROWS * PH_ROW)
 #define PH_WAVES (PH_THREADS / WF_WAVE)
@@ -33,8 +35,7 @@ struct phase_params {
     int64_t ntiles;
     double sps;      // modulus as a double
     double inv_sps;
-    double sens;     // 2 pi / sps
-    double phi0;
+    double phi0_turns;  // phi0 / (2 pi)
     uint64_t q_in;   // carried-in revs as a 62-bit fraction of sps
 };
 
@@ -79,9 +80,13 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
     const int lane = t & 63, wave = t >> 6;
     uint64_t *desc = scan + PH_DESC0;
 
-    for (;;) {
+    for (long long iter_ = 0;; ++iter_) {
         __syncthreads();  // previous iteration's LDS reads are done
+#ifdef WF_ABL_NO_TICKET    // ablation only: static tile order (can deadlock in general)
+        if (t == 0) s_tile = (long long)blockIdx.x + (long long)gridDim.x * iter_;
+#else
         if (t == 0) s_tile = (long long)atomicAdd((unsigned long long *)&scan[0], 1ull);
+#endif
         __syncthreads();
         const int64_t tile = s_tile;
         if (tile >= P.ntiles) break;
@@ -121,7 +126,12 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
         // `running` = tile total, identical in every thread
         const uint64_t q_agg = to_fixed(mod_pos(running, P.sps, P.inv_sps), P.inv_sps);
 
+#ifdef WF_ABL_NO_LOOKBACK   // ablation only: wrong prefixes
+        if (t == 0) s_prefix = 0;
+        if (false) {
+#else
         if (wave == 0) {
+#endif
             if (lane == 0)
                 __hip_atomic_store(&desc[tile], PH_FLAG_A | q_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint64_t q_ex = 0;
@@ -174,9 +184,14 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
             const double v1 = v0 + x1[u];
             const double r0 = mod_pos(v0, P.sps, P.inv_sps);
             const double r1 = mod_pos(v1, P.sps, P.inv_sps);
+            // phase = revs * 2 pi / sps + phi0, evaluated in turns (exact quadrant reduction)
             double s0, c0, s1, c1;
-            sincos(r0 * P.sens + P.phi0, &s0, &c0);
-            sincos(r1 * P.sens + P.phi0, &s1, &c1);
+#ifdef WF_ABL_NO_SINCOS
+            s0 = r0; c0 = r0 + 1; s1 = r1; c1 = r1 + 1;
+#else
+            wf_sincos_turns(fma(r0, P.inv_sps, P.phi0_turns), &s0, &c0);
+            wf_sincos_turns(fma(r1, P.inv_sps, P.phi0_turns), &s1, &c1);
+#endif
             if (i + 1 < P.n) {
                 double2 *o = reinterpret_cast<double2 *>(out + 2 * i);
                 o[0] = make_double2(c0, s0);
@@ -207,8 +222,7 @@ extern "C" int wf_phase_cexp_f64(wf_ctx *ctx, const double *d_freq, int64_t n, i
     P.ntiles = (n + PH_TILE - 1) / PH_TILE;
     P.sps = (double)sps;
     P.inv_sps = 1.0 / (double)sps;
-    P.sens = 2.0 * M_PI / (double)sps;
-    P.phi0 = phi0;
+    P.phi0_turns = phi0 / (2.0 * M_PI);
     double r = fmod(revs_in, (double)sps);
     if (r < 0) r += sps;
     P.q_in = (uint64_t)(r / sps * 0x1.0p62) & PH_MASK;

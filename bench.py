@@ -64,6 +64,7 @@ def main() -> None:
     ap.add_argument("--sps", type=int, default=8)
     ap.add_argument("--ebn0", type=float, default=10.0)
     ap.add_argument("--detector", default="PT")
+    ap.add_argument("--fuse", type=int, default=1, help="bit 0: fused modulator (FIR + phase scan in one pass)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -86,7 +87,7 @@ def main() -> None:
     from waveforms_amd import _hip
     from waveforms_amd.link import SOQPSKLink
 
-    link = SOQPSKLink(args.nsym, args.sps, detector=args.detector)
+    link = SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse)
     slots = 64
     assert args.steps >= 1
 
@@ -128,6 +129,10 @@ def main() -> None:
         for name, ms in link.stage_ms(k % slots).items():
             acc[name] = acc.get(name, 0.0) + ms / n_ev
     bps = stage_bytes_per_symbol(args.sps)
+    if args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
+        acc["modulate"] = acc.pop("fir")
+        acc.pop("phase", None)
+        bps["modulate"] = 1 + 16 * args.sps
     stages = {}
     for name, ms in acc.items():
         gb = bps[name] * args.nsym / 1e9
@@ -152,7 +157,7 @@ def main() -> None:
                                    f"{args.detector} matched filter + 4-state Viterbi detect (BASELINE configs[1])",
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
-                       "parallelism": f"independent trial blocks x{world}"},
+                       "fuse": args.fuse, "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared, 1)},
             "roofline": roofline,

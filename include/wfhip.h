@@ -102,6 +102,16 @@ int wf_upsample_fir_f64(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, cons
  * (0 for a fresh call), *d_revs_out (may be NULL) receives the final revs. */
 int wf_phase_cexp_f64(wf_ctx *ctx, const double *d_freq, int64_t n, int sps, double phi0,
                       double revs_in, double *d_out_ri, double *d_revs_out, void *stream);
+/* Fused K3 + K4: cpm_modulate (waveforms/cpm/modulate.py:57-101) straight from symbols
+ * to the complex baseband signal, one pass over HBM (1 B in, 16*sps B out per symbol);
+ * tile carries come from a symbol-rate prefix sum instead of an inter-workgroup scan.
+ * Same results as wf_upsample_fir_f64 followed by wf_phase_cexp_f64 (to rounding).
+ * Returns 1 — not an error — when the configuration is outside the fused kernel's
+ * envelope (signal shorter than the pulse, pulse longer than 33 symbols or than a tile);
+ * the caller then runs the two stage kernels. */
+int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
+                         const double *d_pulse, int ntaps, int sps, double phi0, double *d_out_ri,
+                         void *stream);
 /* phase_modulate (waveforms/cpm/modulate.py:12-25): out = exp(j * sens * phase). */
 int wf_phase_modulate_f64(wf_ctx *ctx, const double *d_phase, int64_t n, double sens,
                           double *d_out_ri, void *stream);
@@ -185,6 +195,8 @@ typedef struct {
     double sigma;           /* noise std-dev per real dimension                       */
     uint64_t seed, stream_id; /* Philox key / subsequence                             */
     int warmup;             /* Viterbi chunk warm-up, 0 = default                     */
+    int fuse;               /* bit 0: fused modulator (wf_cpm_modulate_c128) instead   */
+                            /* of the FIR + phase-scan stage kernels                   */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
                             /* around every stage into that slot (wf_link_stage_ms)   */
 } wf_link_config;

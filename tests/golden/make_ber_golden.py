@@ -87,9 +87,13 @@ def job(args):
 
 
 if __name__ == "__main__":
+    # usage: make_ber_golden.py [n_blocks] [procs] [first_block] [first_ebn0] [out.csv]
     nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     procs = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-    jobs = [(e, b) for b in range(nblk) for e in range(13)]
+    blk0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    e0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    out_name = sys.argv[5] if len(sys.argv) > 5 else "ber_golden.csv"
+    jobs = [(e, b) for b in range(blk0, blk0 + nblk) for e in range(e0, 13)]
     rows = []
     with Pool(procs) as pool:
         for k, row in enumerate(pool.imap_unordered(job, jobs)):
@@ -98,5 +102,5 @@ if __name__ == "__main__":
                 print(k, "/", len(jobs), flush=True)
     rows.sort()
     hdr = "ebn0_db,block,pt_compared,pt_sym_err,pt_bit_err,pam_compared,pam_sym_err,pam_bit_err"
-    (OUT / "ber_golden.csv").write_text(hdr + "\n" + "\n".join(",".join(map(str, r)) for r in rows) + "\n")
+    (OUT / out_name).write_text(hdr + "\n" + "\n".join(",".join(map(str, r)) for r in rows) + "\n")
     print("wrote", len(rows), "rows")

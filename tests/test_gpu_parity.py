@@ -184,10 +184,37 @@ def test_frequency_and_phase_modulate(oracle, golden):
                                    rtol=0, atol=FLOAT_ATOL)
 
 
-def test_modulate_full_size_properties(oracle):
+@pytest.mark.parametrize("sps,pulse_name,hs,alphabet,nsym", [
+    (8, "tg", (0.25,), (-2, 0, 2), 300_000), (10, "tg", (0.25,), (-2, 0, 2), 123_457),
+    (8, "mil", (0.25,), (-2, 0, 2), 50_000), (8, "multih", (4 / 16, 5 / 16), (-3, -1, 1, 3), 200_001),
+    (8, "pcmfm", (0.7,), (-1, 1), 100_000), (5, "pcmfm", (0.7,), (-1, 1), 33_333), (20, "pcmfm", (0.7,), (-1, 1), 20_000),
+    (8, "b", (0.25,), (-2, 0, 2), 70_000), (8, "tg", (0.25,), (-2, 0, 2), 600), (4, "tg", (0.3,), (-2, 0, 2), 5_000)])
+def test_fused_modulator_equals_stage_kernels_and_oracle(oracle, sps, pulse_name, hs, alphabet, nsym):
+    """wf_cpm_modulate_c128 (analytic tile carries) vs FIR + chained scan vs the oracle."""
+    from waveforms_amd import _hip
+    from waveforms.cpm.modulate import cpm_modulate_device
+
+    pulse = {"tg": oracle.freq_pulse_soqpsk_tg, "mil": oracle.freq_pulse_soqpsk_mil, "b": oracle.freq_pulse_soqpsk_b,
+             "multih": oracle.freq_pulse_multih_irig, "pcmfm": oracle.freq_pulse_pcmfm}[pulse_name](sps)
+    rng = np.random.Generator(np.random.PCG64(nsym + sps))
+    sym = rng.choice(np.array(alphabet, dtype=np.int8), size=nsym)
+    h = list(hs) if len(hs) > 1 else hs[0]
+    d_sym = _hip.to_device(sym)
+    fused = _hip.to_host(cpm_modulate_device(d_sym, h, pulse, sps, fused=True), complex_pairs=True)
+    staged = _hip.to_host(cpm_modulate_device(d_sym, h, pulse, sps, fused=False), complex_pairs=True)
+    _hip.device_check()
+    _t, want = oracle.cpm_modulate(sym, np.array(hs) if len(hs) > 1 else hs[0], pulse, sps)
+    assert fused.shape == staged.shape == want.shape
+    assert np.abs(staged - want).max() < FLOAT_ATOL
+    assert np.abs(fused - want).max() < FLOAT_ATOL
+    assert np.abs(fused - staged).max() < 1e-10
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_modulate_full_size_properties(oracle, fused):
     """1e7 SOQPSK-TG symbols @ 8 sps (BASELINE config 2): unit envelope, and agreement
-    with the oracle on windows spread over the burst (the oracle's sequential scan over
-    8e7 samples takes seconds in C)."""
+    with the oracle over the whole burst (the oracle's sequential scan over 8e7 samples
+    takes seconds in C)."""
     from waveforms_amd import _hip, device as dev
     from waveforms.cpm.modulate import cpm_modulate_device
     from waveforms.cpm.soqpsk import freq_pulse_soqpsk_tg
@@ -195,7 +222,7 @@ def test_modulate_full_size_properties(oracle):
     n = 10_000_000
     bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, n)
     sym = oracle.fsm_encode("SOQPSKTrellis4x2DiffEncoded", bits)[0]
-    d_sig = cpm_modulate_device(_hip.to_device(sym), 0.25, freq_pulse_soqpsk_tg(8), 8)
+    d_sig = cpm_modulate_device(_hip.to_device(sym), 0.25, freq_pulse_soqpsk_tg(8), 8, fused=fused)
     _hip.device_check()
     mag = (d_sig * d_sig).sum(dim=1)
     assert float((mag - 1).abs().max()) < 1e-12

@@ -45,7 +45,7 @@ def main():
     first, ncols = dev.decimation(npts, sps, 2, -1)
     rows = dev.mf_bank(sig, taps, first, sps, ncols)
     bytes_per_sym = {"fir": 1 + 8 * sps, "phase": 24 * sps, "awgn": 32 * sps, "mfbank": 16 * sps + 48,
-                     "viterbi": 50, "modulate": 1 + 16 * sps}[a.stage]
+                     "viterbi": 50, "modulate": 1 + 16 * sps, "modfused": 1 + 16 * sps}[a.stage]
     out = torch.empty_like(sig)
 
     def run():
@@ -60,7 +60,9 @@ def main():
         elif a.stage == "viterbi":
             dev.viterbi_detect(rows)
         elif a.stage == "modulate":
-            dev.phase_cexp(dev.upsample_fir(sym, h, d_pulse, sps), sps, np.pi / 4)
+            dev.cpm_modulate(sym, h, d_pulse, sps, np.pi / 4, fused=False)
+        elif a.stage == "modfused":
+            dev.cpm_modulate(sym, h, d_pulse, sps, np.pi / 4, fused=True)
 
     for _ in range(3):
         run()

@@ -33,6 +33,7 @@ SIGNATURES = {
     "wf_fir_out_len": (c_int64, [c_int64, c_int, c_int]),
     "wf_upsample_fir_f64": (c_int, [_P, _P, c_int64, _P, c_int, _P, c_int, c_int, _P, _P]),
     "wf_phase_cexp_f64": (c_int, [_P, _P, c_int64, c_int, c_double, c_double, _P, _P, _P]),
+    "wf_cpm_modulate_c128": (c_int, [_P, _P, c_int64, _P, c_int, _P, c_int, c_int, c_double, _P, _P]),
     "wf_phase_modulate_f64": (c_int, [_P, _P, c_int64, c_double, _P, _P]),
     "wf_time_axis_f64": (c_int, [_P, c_int64, c_double, _P, _P]),
     "wf_awgn_c128": (c_int, [_P, _P, c_int64, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64, _P, _P]),
@@ -55,7 +56,7 @@ class LinkConfig(ctypes.Structure):
         ("skip", c_uint64), ("differential", c_int), ("d_h", c_void_p), ("d_pulse", c_void_p),
         ("ntaps", c_int), ("d_mf_taps", c_void_p), ("mf_ntaps", c_int), ("mf_nfilt", c_int),
         ("timing_offset", c_int), ("sigma", c_double), ("seed", c_uint64), ("stream_id", c_uint64),
-        ("warmup", c_int), ("event_slot", c_int),
+        ("warmup", c_int), ("fuse", c_int), ("event_slot", c_int),
     ]
 
 

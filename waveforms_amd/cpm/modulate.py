@@ -47,15 +47,15 @@ def _mod_index_vector(mod_index) -> np.ndarray:
     return np.atleast_1d(np.asarray(mod_index, dtype=np.float64))
 
 
-def cpm_modulate_device(symbols, mod_index, pulse_filter, sps: int = 8):
+def cpm_modulate_device(symbols, mod_index, pulse_filter, sps: int = 8, fused: bool = True):
     """Device-resident modulator: ``symbols`` an int8 device tensor; returns the complex
-    baseband signal as a float64[n, 2] device tensor (no time axis, no host copies)."""
+    baseband signal as a float64[n, 2] device tensor (no time axis, no host copies).
+    ``fused=False`` forces the two stage kernels (FIR, then phase scan)."""
     from waveforms_amd import _hip, device as dev
 
     h = _hip.to_device(_mod_index_vector(mod_index))
     g = _hip.to_device(np.asarray(pulse_filter, dtype=np.float64))
-    freq = dev.upsample_fir(symbols, h, g, int(sps))
-    return dev.phase_cexp(freq, int(sps), np.pi / 4)
+    return dev.cpm_modulate(symbols, h, g, int(sps), np.pi / 4, fused)
 
 
 def cpm_modulate(

@@ -12,7 +12,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SO = HERE / "libwfhip.so"
-SOURCES = ["wf_ctx.hip", "wf_lfsr.hip", "wf_encode.hip", "wf_fir.hip", "wf_phase.hip", "wf_awgn.hip",
+SOURCES = ["wf_ctx.hip", "wf_lfsr.hip", "wf_encode.hip", "wf_fir.hip", "wf_phase.hip", "wf_modulate.hip", "wf_awgn.hip",
            "wf_mfbank.hip", "wf_viterbi.hip", "wf_count.hip", "wf_pipeline.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall",
          "-Wno-unused-function"]

@@ -53,6 +53,8 @@ struct wf_ctx {
     int *h_small = nullptr;  // pinned, small D2H results
     int *d_small = nullptr;
     std::map<uint64_t, wf_lfsr_tables *> lfsr;
+    double *d_mod_scratch = nullptr;  // fused modulator: constants, tile sums, tile carries
+    size_t mod_scratch_words = 0;
     hipEvent_t *events = nullptr;  // WF_LINK_EVENT_SLOTS x (WF_LINK_STAGES + 1), created lazily
 };
 
@@ -60,6 +62,7 @@ static inline hipStream_t wf_stream(void *s) { return reinterpret_cast<hipStream
 
 int wf_ctx_reserve_scan(wf_ctx *ctx, size_t words);
 int wf_ctx_reserve_fsm(wf_ctx *ctx, size_t words);
+int wf_ctx_reserve_mod(wf_ctx *ctx, size_t words);
 
 static inline int wf_grid_for(int64_t work_items, int per_block, int max_blocks)
 {

@@ -53,6 +53,7 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
     }
     if (c->d_scan) (void)hipFree(c->d_scan);
     if (c->d_fsm_scratch) (void)hipFree(c->d_fsm_scratch);
+    if (c->d_mod_scratch) (void)hipFree(c->d_mod_scratch);
     if (c->d_fault) (void)hipFree(c->d_fault);
     if (c->h_fault) (void)hipHostFree(c->h_fault);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -102,5 +103,18 @@ int wf_ctx_reserve_fsm(wf_ctx *c, size_t words)
     while (cap < words) cap *= 2;
     WF_HIP(hipMalloc(&c->d_fsm_scratch, cap * sizeof(uint64_t)));
     c->fsm_scratch_words = cap;
+    return WF_OK;
+}
+
+int wf_ctx_reserve_mod(wf_ctx *c, size_t words)
+{
+    if (words <= c->mod_scratch_words) return WF_OK;
+    WF_HIP(hipDeviceSynchronize());
+    if (c->d_mod_scratch) WF_HIP(hipFree(c->d_mod_scratch));
+    c->d_mod_scratch = nullptr;
+    size_t cap = c->mod_scratch_words ? c->mod_scratch_words : (1 << 16);
+    while (cap < words) cap *= 2;
+    WF_HIP(hipMalloc(&c->d_mod_scratch, cap * sizeof(double)));
+    c->mod_scratch_words = cap;
     return WF_OK;
 }

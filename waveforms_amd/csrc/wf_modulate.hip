@@ -1,0 +1,309 @@
+// wf_modulate.hip — fused CPM modulator: symbols -> complex baseband in ONE pass over HBM.
+// cpm_modulate = upsample + pulse FIR ("same") + accumulate-mod-sps + exp(j.)
+// (reference waveforms/cpm/modulate.py:57-101) without materialising the f64
+// frequency-pulse array: 1 B read + 16*sps B written per symbol.
+//
+// Why no inter-workgroup scan is needed: the frequency-pulse train is a FIR of symbol
+// impulses, so its running sum up to any sample is
+//     T * S(m_full)  +  sum over the <= J+1 symbols still under the pulse of
+//                       amp[m] * Gcum[...]  -  (head truncation constant K0)
+// with T = sum(g), Gcum = cumsum(g), S = symbol-rate prefix sum of amp = symbol * h.
+// Two tiny kernels build T*S at tile granularity (exact modular accumulation in 62-bit
+// fixed point, like wf_phase.hip); the main kernel then handles every tile
+// independently: symbol amplitudes of the tile in LDS, per-thread tap phases in
+// registers (wf_fir.hip), in-tile fp64 scan by wave shuffles + LDS wave totals
+// (wf_phase.hip), carry, mod, sincos, 16 B coalesced stores.
+#include "wf_common.h"
+
+#define MOD_THREADS 256
+#define MOD_ROWS 8
+#define MOD_WAVES (MOD_THREADS / WF_WAVE)
+#define MOD_MASK ((1ull << 62) - 1)
+#define MOD_MAX_PART 40
+
+struct mod_params {
+    int64_t nsym, out_len, ntiles;
+    int sps, ntaps, nh, c, rs;
+    int spt;      // symbols per tile = MOD_ROWS * rs / sps
+    int dsh;      // D = ceil((ntaps - c) / sps): symbols not yet fully elapsed at a tile edge
+    int npart;    // symbols partially elapsed at a tile edge
+    int nhead;    // symbols whose pulse starts before sample 0
+    double sps_d, inv_sps, phi0_turns;
+};
+
+// scratch layout (doubles): [0] T, [1] K0, [2 .. 2+MOD_MAX_PART) Gpart, then ntiles tile sums P,
+// then ntiles u64 carries Wq.
+#define MOD_OFF_GPART 2
+#define MOD_OFF_P (2 + MOD_MAX_PART)
+
+__device__ __forceinline__ double mod_pos_d(double v, double sps, double inv_sps)
+{
+    double k = floor(v * inv_sps);
+    double m = fma(-k, sps, v);
+    if (m < 0.0) m += sps;
+    if (m >= sps) m -= sps;
+    return m;
+}
+
+// P[j] = sum of amp[m] over m in [(j-1)*spt - D, j*spt - D) ∩ [0, nsym): one wave per tile.
+__global__ __launch_bounds__(MOD_THREADS) void mod_tile_sums_kernel(const int8_t *__restrict__ symbols,
+                                                                     const double *__restrict__ hvec, mod_params P,
+                                                                     double *__restrict__ scratch)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * MOD_WAVES + (threadIdx.x >> 6);
+    if (j >= P.ntiles) return;
+    const int64_t lo = (j - 1) * P.spt - P.dsh;
+    double acc = 0.0;
+    for (int k = lane; k < P.spt; k += WF_WAVE) {
+        const int64_t m = lo + k;
+        if (m >= 0 && m < P.nsym) acc += (double)symbols[m] * hvec[P.nh == 1 ? 0 : (int)(m % P.nh)];
+    }
+#pragma unroll
+    for (int d = WF_WAVE / 2; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, WF_WAVE);
+    if (lane == 0) scratch[MOD_OFF_P + j] = acc;
+}
+
+// Single block: Gcum-derived constants, then Wq[j] = fixed(sum_{i<=j} T*P[i] - K0) (mod sps).
+__global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__restrict__ symbols,
+                                                              const double *__restrict__ hvec,
+                                                              const double *__restrict__ pulse, mod_params P,
+                                                              double *__restrict__ scratch)
+{
+    __shared__ double s_T, s_K0;
+    __shared__ uint64_t s_part[1024];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        // Gcum at the few indices needed, by one sequential pass over the taps
+        // idx_l = ntaps - 1 + R - (l+1)*sps, R = (c - ntaps) mod sps   (partial symbols)
+        // head:  c - 1 - mp1*sps, mp1 = 1..nhead
+        int R = (P.c - P.ntaps) % P.sps;
+        if (R < 0) R += P.sps;
+        double run = 0.0, k0 = 0.0;
+        for (int l = 0; l < MOD_MAX_PART; ++l) scratch[MOD_OFF_GPART + l] = 0.0;
+        for (int k = 0; k < P.ntaps; ++k) {
+            run += pulse[k];
+            // partial table
+            const int num = P.ntaps - 1 + R - k;  // = (l+1)*sps ?
+            if (num > 0 && num % P.sps == 0) {
+                const int l = num / P.sps - 1;
+                if (l >= 0 && l < P.npart) scratch[MOD_OFF_GPART + l] = run;
+            }
+            // head correction: k = c - 1 - mp1*sps
+            const int hn = P.c - 1 - k;
+            if (hn > 0 && hn % P.sps == 0) {
+                const int64_t mp1 = hn / P.sps;
+                if (mp1 >= 1 && mp1 <= P.nhead && mp1 <= P.nsym) {
+                    const int64_t m = mp1 - 1;
+                    k0 += (double)symbols[m] * hvec[P.nh == 1 ? 0 : (int)(m % P.nh)] * run;
+                }
+            }
+        }
+        scratch[0] = run;
+        scratch[1] = k0;
+        s_T = run;
+        s_K0 = k0;
+    }
+    __syncthreads();
+    const double T = s_T;
+    const double *Pj = scratch + MOD_OFF_P;
+    uint64_t *Wq = reinterpret_cast<uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
+    const int64_t per = (P.ntiles + 1023) / 1024;
+    const int64_t j0 = (int64_t)t * per, j1 = min(P.ntiles, j0 + per);
+    uint64_t run = 0;
+    for (int64_t j = j0; j < j1; ++j)
+        run += (uint64_t)(mod_pos_d(T * Pj[j], P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+    s_part[t] = run;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t acc = (uint64_t)(mod_pos_d(-s_K0, P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+        for (int k = 0; k < 1024; ++k) {
+            const uint64_t v = s_part[k];
+            s_part[k] = acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    run = s_part[t];
+    for (int64_t j = j0; j < j1; ++j) {
+        run += (uint64_t)(mod_pos_d(T * Pj[j], P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+        Wq[j] = run & MOD_MASK;
+    }
+}
+
+template <int JMAX>
+__global__ __launch_bounds__(MOD_THREADS) void mod_main_kernel(const int8_t *__restrict__ symbols,
+                                                                const double *__restrict__ hvec,
+                                                                const double *__restrict__ pulse,
+                                                                const double *__restrict__ scratch,
+                                                                double *__restrict__ out, mod_params P)
+{
+    extern __shared__ double s_amp[];       // window of symbol amplitudes
+    __shared__ double s_tot[MOD_ROWS * MOD_WAVES];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int sps = P.sps;
+    const bool active = 2 * t < P.rs;
+    const int tile_len = MOD_ROWS * P.rs;
+    const int sym_per_row = P.rs / sps;
+    const int cq = P.c / sps;
+    const int q0 = (2 * t + P.c) / sps;
+    const int r0 = (2 * t + P.c) - q0 * sps;
+    const int wrap = (r0 + 1 == sps) ? 1 : 0;
+    const int r1 = wrap ? 0 : r0 + 1;
+    double tap0[JMAX + 1], tap1[JMAX + 1];
+#pragma unroll
+    for (int i = 0; i <= JMAX; ++i) {
+        const int j0 = i - 1, k0 = r0 + j0 * sps;
+        tap0[i] = (j0 >= 0 && k0 < P.ntaps) ? pulse[k0] : 0.0;
+        const int j1 = i - 1 + wrap, k1 = r1 + j1 * sps;
+        tap1[i] = (j1 >= 0 && j1 < JMAX && k1 < P.ntaps) ? pulse[k1] : 0.0;
+    }
+    const int l_top0p1 = (q0 - cq) + JMAX;
+    const int win = MOD_ROWS * sym_per_row + JMAX + 2;
+    const uint64_t *Wq = reinterpret_cast<const uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
+    const double *Gpart = scratch + MOD_OFF_GPART;
+
+    for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const int64_t tile_base = tile * tile_len;
+        const int64_t sym_base = tile_base / sps;
+        const int64_t mp1_lo = sym_base + cq - JMAX + 1;
+        __syncthreads();
+        for (int k = t; k < win; k += MOD_THREADS) {
+            const int64_t mp1 = mp1_lo + k;
+            double a = 0.0;
+            if (mp1 >= 1 && mp1 <= P.nsym) {
+                const int64_t m = mp1 - 1;
+                a = (double)symbols[m] * hvec[P.nh == 1 ? 0 : (int)(m % P.nh)];
+            }
+            s_amp[k] = a;
+        }
+        __syncthreads();
+        // frequency pulses of this thread's 2 x ROWS samples, and their row-wise wave scans
+        double x0[MOD_ROWS], x1[MOD_ROWS], ex[MOD_ROWS];
+#pragma unroll
+        for (int u = 0; u < MOD_ROWS; ++u) {
+            double acc0 = 0.0, acc1 = 0.0;
+            if (active) {
+                const double *a = &s_amp[l_top0p1 + u * sym_per_row];
+#pragma unroll
+                for (int i = 0; i <= JMAX; ++i) {
+                    const double v = a[-i];
+                    acc0 = fma(tap0[i], v, acc0);
+                    acc1 = fma(tap1[i], v, acc1);
+                }
+            }
+            x0[u] = acc0;
+            x1[u] = acc1;
+            const double inc = wf_wave_incl_scan(acc0 + acc1);
+            const double e = __shfl_up(inc, 1, WF_WAVE);
+            ex[u] = lane == 0 ? 0.0 : e;
+            if (lane == 63) s_tot[u * MOD_WAVES + wave] = inc;
+        }
+        // carry into the tile: T*S(m_full) - K0 (fixed point, from the scan kernel) + the
+        // symbols still under the pulse at the tile edge
+        double carry = 0.0;
+        if (tile > 0) {
+            carry = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
+            // first partial symbol: mp1 = sym_base - D + 1  -> local index in s_amp
+            const int lpart = (int)((sym_base - P.dsh + 1) - mp1_lo);
+            double part = 0.0;
+            for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + l], Gpart[l], part);
+            carry += part;
+        }
+        __syncthreads();
+        double off[MOD_ROWS];
+        double running = 0.0;
+#pragma unroll
+        for (int u = 0; u < MOD_ROWS; ++u) {
+#pragma unroll
+            for (int w = 0; w < MOD_WAVES; ++w) {
+                if (w == wave) off[u] = running;
+                running += s_tot[u * MOD_WAVES + w];
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < MOD_ROWS; ++u) {
+                const int64_t n = tile_base + (int64_t)u * P.rs + 2 * t;
+                const double v0 = carry + (off[u] + ex[u] + x0[u]);
+                const double v1 = v0 + x1[u];
+                const double ra = mod_pos_d(v0, P.sps_d, P.inv_sps);
+                const double rb = mod_pos_d(v1, P.sps_d, P.inv_sps);
+                double s0, c0, s1, c1;
+                wf_sincos_turns(fma(ra, P.inv_sps, P.phi0_turns), &s0, &c0);
+                wf_sincos_turns(fma(rb, P.inv_sps, P.phi0_turns), &s1, &c1);
+                if (n + 1 < P.out_len) {
+                    double2 *o = reinterpret_cast<double2 *>(out + 2 * n);
+                    o[0] = make_double2(c0, s0);
+                    o[1] = make_double2(c1, s1);
+                } else if (n < P.out_len) {
+                    *reinterpret_cast<double2 *>(out + 2 * n) = make_double2(c0, s0);
+                }
+            }
+        }
+    }
+}
+
+static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h,
+                                    int nh, const double *d_pulse, int ntaps, int sps, double phi0,
+                                    double *d_out_ri, void *stream)
+{
+    WF_REQUIRE(ctx && d_h && d_pulse && d_out_ri, "wf_cpm_modulate_c128: NULL argument");
+    WF_REQUIRE(nsym >= 0 && (nsym == 0 || d_symbols), "wf_cpm_modulate_c128: bad symbols");
+    WF_REQUIRE(sps >= 2 || nsym == 0, "could not broadcast input array from shape (%lld,) into shape (%lld,)",
+               (long long)nsym, (long long)(nsym - 1));
+    WF_REQUIRE(sps >= 1 && sps <= 256 && nh >= 1 && ntaps >= 1, "wf_cpm_modulate_c128: sps %d nh %d ntaps %d", sps, nh, ntaps);
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0, "wf_cpm_modulate_c128: d_out alignment");
+    WF_HIP(hipSetDevice(ctx->device));
+    const int64_t npts = (nsym + 1) * (int64_t)sps;
+    const int J = (ntaps + sps - 1) / sps;
+    mod_params P;
+    P.nsym = nsym;
+    P.out_len = npts >= ntaps ? npts : ntaps;
+    P.c = (int)(((npts >= ntaps ? (int64_t)ntaps : npts) - 1) / 2);
+    P.sps = sps;
+    P.ntaps = ntaps;
+    P.nh = nh;
+    const int l = sps / gcd_i(sps, 2) * 2;
+    P.rs = (2 * MOD_THREADS / l) * l;
+    const int64_t tile_len = (int64_t)MOD_ROWS * P.rs;
+    P.spt = (int)(tile_len / sps);
+    P.ntiles = (P.out_len + tile_len - 1) / tile_len;
+    P.dsh = (ntaps - P.c + sps - 1) / sps;
+    int R = (P.c - ntaps) % sps;
+    if (R < 0) R += sps;
+    P.npart = (ntaps - 1 + R) / sps;          // l = 0 .. npart-1 with idx_l >= 0
+    P.nhead = P.c >= 1 ? (P.c - 1) / sps : 0;
+    P.sps_d = (double)sps;
+    P.inv_sps = 1.0 / (double)sps;
+    P.phi0_turns = phi0 / (2.0 * M_PI);
+    // the analytic carry needs: pulse no longer than the signal, J within the register
+    // budget, and every head / partial symbol of a tile edge inside the staged window
+    const bool fused_ok = npts >= ntaps && J <= 33 && P.npart <= MOD_MAX_PART && P.spt >= P.dsh + J + P.nhead + 2;
+    if (!fused_ok) return 1;  // caller falls back to wf_upsample_fir_f64 + wf_phase_cexp_f64
+    hipStream_t s = wf_stream(stream);
+    const size_t words = (size_t)MOD_OFF_P + 2 * (size_t)P.ntiles + 8;
+    int rc = wf_ctx_reserve_mod(ctx, words);
+    if (rc) return rc;
+    double *scratch = ctx->d_mod_scratch;
+    hipLaunchKernelGGL(mod_tile_sums_kernel, dim3((unsigned)((P.ntiles + MOD_WAVES - 1) / MOD_WAVES)), dim3(MOD_THREADS),
+                       0, s, d_symbols, d_h, P, scratch);
+    WF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mod_tile_scan_kernel, dim3(1), dim3(1024), 0, s, d_symbols, d_h, d_pulse, P, scratch);
+    WF_LAUNCH_CHECK();
+    const int grid = (int)(P.ntiles < 2048 ? P.ntiles : 2048);
+#define MOD_LAUNCH(JM)                                                                              \
+    hipLaunchKernelGGL(mod_main_kernel<JM>, dim3(grid), dim3(MOD_THREADS),                          \
+                       (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2) * sizeof(double), s, d_symbols, d_h, \
+                       d_pulse, scratch, d_out_ri, P)
+    if (J <= 4) MOD_LAUNCH(4);
+    else if (J <= 9) MOD_LAUNCH(9);
+    else if (J <= 17) MOD_LAUNCH(17);
+    else MOD_LAUNCH(33);
+#undef MOD_LAUNCH
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}

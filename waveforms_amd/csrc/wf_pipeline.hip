@@ -118,9 +118,19 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     MARK(1);
     if ((rc = wf_fsm_encode(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, cfg->nsym, 0, 0, syms, nullptr, stream))) return rc;
     MARK(2);
-    if ((rc = wf_upsample_fir_f64(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, freq, stream))) return rc;
-    MARK(3);
-    if ((rc = wf_phase_cexp_f64(ctx, freq, L.npts, cfg->sps, M_PI / 4, 0.0, sig, nullptr, stream))) return rc;
+    bool fused_mod = false;
+    if (cfg->fuse & 1) {
+        rc = wf_cpm_modulate_c128(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, sig, stream);
+        if (rc < 0) return rc;
+        fused_mod = rc == 0;
+    }
+    if (fused_mod) {
+        MARK(3);   // the "fir" slot times the fused modulator, the "phase" slot is empty
+    } else {
+        if ((rc = wf_upsample_fir_f64(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, freq, stream))) return rc;
+        MARK(3);
+        if ((rc = wf_phase_cexp_f64(ctx, freq, L.npts, cfg->sps, M_PI / 4, 0.0, sig, nullptr, stream))) return rc;
+    }
     MARK(4);
     // modulated *= exp(-j pi/4); received = modulated + noise   (in place)
     if ((rc = wf_awgn_c128(ctx, sig, L.npts, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id,

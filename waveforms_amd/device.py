@@ -71,6 +71,22 @@ def phase_cexp(freq, sps: int, phi0: float, revs_in: float = 0.0, revs_out=None)
     return out
 
 
+def cpm_modulate(symbols, h, pulse, sps: int, phi0: float = math.pi / 4, fused: bool = True):
+    """K3 + K4.  Fused single-pass kernel when the configuration allows it, otherwise (or
+    with fused=False) the FIR stage followed by the phase-scan stage."""
+    nsym, ntaps = int(symbols.numel()), int(pulse.numel())
+    if fused:
+        n = _hip.lib().wf_fir_out_len(nsym, sps, ntaps)
+        out = _hip.empty((n, 2), "float64")
+        rc = _hip.lib().wf_cpm_modulate_c128(_hip.ctx(), _hip.ptr(symbols), nsym, _hip.ptr(h), int(h.numel()),
+                                            _hip.ptr(pulse), ntaps, sps, float(phi0), _hip.ptr(out), _hip.stream())
+        if rc == 0:
+            return out
+        if rc < 0:
+            _hip.check(rc)
+    return phase_cexp(upsample_fir(symbols, h, pulse, sps), sps, phi0)
+
+
 def phase_modulate(phase, sens: float):
     n = int(phase.numel())
     out = _hip.empty((n, 2), "float64")

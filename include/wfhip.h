@@ -137,6 +137,14 @@ int wf_mf_bank_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const doub
                     int nfilt, int ntaps, int64_t first, int step, int64_t ncols,
                     double *d_out_ri, void *stream);
 
+/* Fused K5 + K6: the channel of wf_awgn_c128 applied while the matched-filter bank stages
+ * its input (received samples never materialise in HBM).  Output identical to
+ * wf_awgn_c128 followed by wf_mf_bank_c128 with the same noise coordinates. */
+int wf_awgn_mf_bank_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,
+                         double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
+                         const double *d_taps_ri, int nfilt, int ntaps, int64_t first, int step,
+                         int64_t ncols, double *d_out_ri, void *stream);
+
 /* ---- K8-K10: SOQPSK 4-state Viterbi detector ---------------------------------
  * SOQPSKTrellisDetector (waveforms/viterbi/algorithm.py:18-101) with
  * length = 2: for every row of d_mf (ncalls x 3 complex128, alpha = -2,0,+2)
@@ -150,6 +158,13 @@ int wf_mf_bank_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const doub
 int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
                        int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
                        void *stream);
+/* wf_viterbi4_detect + wf_count_errors in one launch (fresh detector): decision k is
+ * compared with reference element k - skip for 0 <= k - skip < ncompare
+ * (examples/soqpsk_detection.py:201-209: skip = length); counts are ADDED to d_counts[0..1]. */
+int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential, int warmup,
+                             uint8_t *d_bits, int8_t *d_syms, const uint8_t *d_ref_bits,
+                             const int8_t *d_ref_syms, int skip, int64_t ncompare, int64_t *d_counts,
+                             void *stream);
 /* One literal .iteration() for any window `length` <= 64 (algorithm.py:44-101),
  * detector state resident on the device (wf_viterbi4_state_bytes(length) bytes,
  * zero-initialised = a new detector).  d_mf3: 3 complex128.  Outputs: `length`
@@ -196,7 +211,9 @@ typedef struct {
     uint64_t seed, stream_id; /* Philox key / subsequence                             */
     int warmup;             /* Viterbi chunk warm-up, 0 = default                     */
     int fuse;               /* bit 0: fused modulator (wf_cpm_modulate_c128) instead   */
-                            /* of the FIR + phase-scan stage kernels                   */
+                            /* of the FIR + phase-scan stage kernels; bit 1: AWGN      */
+                            /* inside the MF bank (wf_awgn_mf_bank_c128); bit 2: error */
+                            /* count inside the Viterbi kernel                         */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
                             /* around every stage into that slot (wf_link_stage_ms)   */
 } wf_link_config;

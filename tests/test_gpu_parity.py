@@ -357,12 +357,48 @@ def test_example_reproduces_published_counts(golden):
     assert list(res[("TG", "PT")]) == e["sps8_10dB_TG_PT"] and list(res[("TG", "PAM")]) == e["sps8_10dB_TG_PAM"]
 
 
+def test_fused_channel_and_count_equal_stage_kernels(oracle):
+    """wf_awgn_mf_bank_c128 == wf_awgn_c128 -> wf_mf_bank_c128 (same noise coordinates), and
+    wf_viterbi4_detect_count == wf_viterbi4_detect -> wf_count_errors."""
+    from waveforms_amd import _hip, device as dev
+    from waveforms.filters.matched import pam_matched_filter_taps, pt_matched_filter_taps
+
+    rng = np.random.Generator(np.random.PCG64(31))
+    n = 70_003
+    sig = np.exp(1j * rng.uniform(0, 6.28, size=n))
+    d_sig = _hip.to_device(sig)
+    rot = np.exp(-1j * np.pi / 4)
+    pulse = oracle.freq_pulse_soqpsk_tg(8)
+    for taps, first in ((pt_matched_filter_taps(pulse, 0.25, 8), 1), (pam_matched_filter_taps(pulse, 0.25, 8), 0)):
+        d_taps = _hip.to_device(taps)
+        first_, ncols = dev.decimation(n, 8, 2, -first)
+        noisy = dev.awgn(d_sig, n, 0.7, 11, 5, 1000, rot)
+        want = _hip.to_host(dev.mf_bank(noisy, d_taps, first_, 8, ncols), complex_pairs=True)
+        got = _hip.to_host(dev.awgn_mf_bank(d_sig, d_taps, first_, 8, ncols, 0.7, 11, 5, 1000, rot), complex_pairs=True)
+        np.testing.assert_array_equal(got, want)            # same arithmetic, same order
+        ref = np.array([np.convolve(sig * rot + oracle.philox_awgn(0.7, 11, 5, 1000, n), t, mode="same")[first_::8][:ncols]
+                        for t in taps]).T
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
+    rows = _hip.to_device(want)
+    ref_bits = _hip.to_device(rng.integers(0, 2, size=ncols, dtype=np.uint8))
+    ref_syms = _hip.to_device((rng.integers(-1, 2, size=ncols) * 2).astype(np.int8))
+    b, s_ = dev.viterbi_detect(rows)
+    m = ncols - 2
+    c1 = dev.count_errors(s_[2:], ref_syms, b[2:], ref_bits, m)
+    c2 = _hip.zeros(2, "int64")
+    b2, s2 = dev.viterbi_detect_count(rows, ref_bits, ref_syms, 2, m, c2)
+    assert c1.cpu().tolist() == c2.cpu().tolist() and c1.cpu().tolist()[1] > 0
+    assert np.array_equal(_hip.to_host(b), _hip.to_host(b2)) and np.array_equal(_hip.to_host(s_), _hip.to_host(s2))
+
+
+@pytest.mark.parametrize("fuse", [0, 7])
 @pytest.mark.parametrize("detector,nsym", [("PT", 1 << 15), ("PAM", 1 << 15), ("PT", 100_000)])
-def test_device_link_equals_oracle_chain(oracle, detector, nsym):
-    """wf_link_run (all stages chained in HBM) vs the oracle chain fed the same Philox noise."""
+def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
+    """wf_link_run (all stages chained in HBM, unfused and fused forms) vs the oracle chain
+    fed the same Philox noise."""
     from waveforms_amd.link import SOQPSKLink
 
-    link = SOQPSKLink(nsym, 8, detector=detector)
+    link = SOQPSKLink(nsym, 8, detector=detector, fuse=fuse)
     for ebn0, block in ((3.0, 0), (7.0, 5)):
         link.reset_counts()
         link.run_block(ebn0, seed=1, stream_id=block, skip_bits=block * nsym)

@@ -45,7 +45,7 @@ def main():
     first, ncols = dev.decimation(npts, sps, 2, -1)
     rows = dev.mf_bank(sig, taps, first, sps, ncols)
     bytes_per_sym = {"fir": 1 + 8 * sps, "phase": 24 * sps, "awgn": 32 * sps, "mfbank": 16 * sps + 48,
-                     "viterbi": 50, "modulate": 1 + 16 * sps, "modfused": 1 + 16 * sps}[a.stage]
+                     "viterbi": 50, "chan": 16 * sps + 48, "modulate": 1 + 16 * sps, "modfused": 1 + 16 * sps}[a.stage]
     out = torch.empty_like(sig)
 
     def run():
@@ -57,6 +57,8 @@ def main():
             dev.awgn(sig, npts, 0.6, 1, 0, 0, np.exp(-1j * np.pi / 4), out)
         elif a.stage == "mfbank":
             dev.mf_bank(sig, taps, first, sps, ncols)
+        elif a.stage == "chan":
+            dev.awgn_mf_bank(sig, taps, first, sps, ncols, 0.6, 1, 0, 0, np.exp(-1j * np.pi / 4))
         elif a.stage == "viterbi":
             dev.viterbi_detect(rows)
         elif a.stage == "modulate":

@@ -165,6 +165,60 @@ __device__ __forceinline__ double wf_sqrt_pos(double a)
     return fma(dres, h, g);
 }
 
+// ---- Philox4x32-10 + Box-Muller: the device Gaussian source (see wf_awgn.hip) ----
+struct wf_philox_out {
+    uint32_t x0, x1, x2, x3;
+};
+
+__device__ __forceinline__ wf_philox_out wf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ void wf_gaussian_pair(uint64_t idx, uint64_t stream_id, uint64_t seed,
+                                              double sigma, double *re, double *im)
+{
+#ifdef WF_ABL_NO_PHILOX   // ablation only: NOT a valid generator
+    const wf_philox_out p = {(uint32_t)idx * 2654435761u, (uint32_t)(idx >> 7) ^ (uint32_t)seed,
+                          (uint32_t)idx * 40503u, (uint32_t)stream_id ^ (uint32_t)idx};
+#else
+    const wf_philox_out p = wf_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id,
+                                       (uint32_t)(stream_id >> 32), (uint32_t)seed,
+                                       (uint32_t)(seed >> 32));
+#endif
+    const uint64_t a = ((uint64_t)p.x1 << 32) | p.x0;
+    const uint64_t b = ((uint64_t)p.x3 << 32) | p.x2;
+    const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;  // (0, 1]
+    const double u2 = (double)(b >> 11) * 0x1.0p-53;        // [0, 1)
+#ifdef WF_ABL_NO_LOG
+    const double r = sigma * u1;
+#else
+    const double r = sigma * wf_sqrt_pos(-2.0 * wf_log_normal(u1));
+#endif
+    double s, c;
+#ifdef WF_ABL_NO_SINCOS
+    s = u2; c = 1.0 - u2;
+#else
+    wf_sincos_turns(u2, &s, &c);
+#endif
+    *re = r * c;
+    *im = r * s;
+}
+
 __device__ __forceinline__ uint64_t wf_wave_xor_reduce(uint64_t v)
 {
 #pragma unroll

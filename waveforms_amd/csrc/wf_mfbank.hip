@@ -25,9 +25,12 @@ struct mf_params {
     int span;  // input samples staged per iteration
     int pad;   // 1: one pad slot every `step` samples
     int64_t nblk;
+    // fused channel (NOISE instantiation): staged sample = r*rot + sigma*N(idx)
+    double rot_re, rot_im, sigma;
+    uint64_t seed, stream_id, first_index;
 };
 
-template <int NF>
+template <int NF, bool NOISE>
 __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__restrict__ r,
                                                               const double *__restrict__ taps,
                                                               double *__restrict__ out, mf_params P)
@@ -45,7 +48,16 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
             for (int i = t; i < P.span; i += MF_THREADS) {
                 const int64_t s = ws + i;
                 double2 v = make_double2(0.0, 0.0);
-                if (s >= 0 && s < P.nsamp) v = *reinterpret_cast<const double2 *>(r + 2 * s);
+                if (s >= 0 && s < P.nsamp) {
+                    v = *reinterpret_cast<const double2 *>(r + 2 * s);
+                    if (NOISE) {  // the channel of wf_awgn_c128, applied on the fly
+                        double nr, ni;
+                        wf_gaussian_pair(P.first_index + (uint64_t)s, P.stream_id, P.seed, P.sigma, &nr, &ni);
+                        const double re = fma(v.x, P.rot_re, fma(-v.y, P.rot_im, nr));
+                        const double im = fma(v.x, P.rot_im, fma(v.y, P.rot_re, ni));
+                        v = make_double2(re, im);
+                    }
+                }
                 s_win[i + (P.pad ? q : 0)] = v;
                 q += dq;
                 rem += dr;
@@ -89,9 +101,10 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
     }
 }
 
-extern "C" int wf_mf_bank_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp,
-                               const double *d_taps_ri, int nfilt, int ntaps, int64_t first, int step,
-                               int64_t ncols, double *d_out_ri, void *stream)
+static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_taps_ri, int nfilt,
+                          int ntaps, int64_t first, int step, int64_t ncols, double *d_out_ri, void *stream,
+                          bool noise, double rot_re, double rot_im, double sigma, uint64_t seed,
+                          uint64_t stream_id, uint64_t first_index)
 {
     WF_REQUIRE(ctx && d_r_ri && d_taps_ri, "wf_mf_bank_c128: NULL argument");
     WF_REQUIRE(nfilt >= 1 && nfilt <= 8 && ntaps >= 1 && step >= 1 && ncols >= 0 && first >= 0,
@@ -113,6 +126,12 @@ extern "C" int wf_mf_bank_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp,
     P.nfilt = nfilt;
     P.c = (ntaps - 1) / 2;
     P.pad = (step % 2 == 0) ? 1 : 0;
+    P.rot_re = rot_re;
+    P.rot_im = rot_im;
+    P.sigma = sigma;
+    P.seed = seed;
+    P.stream_id = stream_id;
+    P.first_index = first_index;
     // slots(ob) = (ob-1)*step + ntaps + pad*(that/step + 1) <= MF_LDS_SLOTS
     int ob = MF_THREADS;
     for (;;) {
@@ -131,14 +150,29 @@ extern "C" int wf_mf_bank_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp,
     const int grid = (int)(P.nblk < 4096 ? P.nblk : 4096);
     hipStream_t s = wf_stream(stream);
     const size_t lds = (size_t)slots * sizeof(double2);
-    if (lds > 48 * 1024) {
-        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nfilt <= 3 ? mf_bank_kernel<3> : mf_bank_kernel<8>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    if (nfilt <= 3)
-        hipLaunchKernelGGL(mf_bank_kernel<3>, dim3(grid), dim3(MF_THREADS), lds, s, d_r_ri, d_taps_ri, d_out_ri, P);
-    else
-        hipLaunchKernelGGL(mf_bank_kernel<8>, dim3(grid), dim3(MF_THREADS), lds, s, d_r_ri, d_taps_ri, d_out_ri, P);
+    using kern_t = void (*)(const double *, const double *, double *, mf_params);
+    kern_t k = nfilt <= 3 ? (noise ? mf_bank_kernel<3, true> : mf_bank_kernel<3, false>)
+                          : (noise ? mf_bank_kernel<8, true> : mf_bank_kernel<8, false>);
+    if (lds > 48 * 1024)
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(MF_THREADS), lds, s, d_r_ri, d_taps_ri, d_out_ri, P);
     WF_LAUNCH_CHECK();
     return WF_OK;
+}
+
+extern "C" int wf_mf_bank_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_taps_ri,
+                               int nfilt, int ntaps, int64_t first, int step, int64_t ncols, double *d_out_ri,
+                               void *stream)
+{
+    return mf_bank_launch(ctx, d_r_ri, nsamp, d_taps_ri, nfilt, ntaps, first, step, ncols, d_out_ri, stream, false,
+                          1.0, 0.0, 0.0, 0, 0, 0);
+}
+
+extern "C" int wf_awgn_mf_bank_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re,
+                                    double rot_im, double sigma, uint64_t seed, uint64_t stream_id,
+                                    uint64_t first_index, const double *d_taps_ri, int nfilt, int ntaps,
+                                    int64_t first, int step, int64_t ncols, double *d_out_ri, void *stream)
+{
+    return mf_bank_launch(ctx, d_signal_ri, nsamp, d_taps_ri, nfilt, ntaps, first, step, ncols, d_out_ri, stream, true,
+                          rot_re, rot_im, sigma, seed, stream_id, first_index);
 }

@@ -132,24 +132,38 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
         if ((rc = wf_phase_cexp_f64(ctx, freq, L.npts, cfg->sps, M_PI / 4, 0.0, sig, nullptr, stream))) return rc;
     }
     MARK(4);
-    // modulated *= exp(-j pi/4); received = modulated + noise   (in place)
-    if ((rc = wf_awgn_c128(ctx, sig, L.npts, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id,
-                           0, sig, stream))) return rc;
+    const double rot_re = cos(-M_PI / 4), rot_im = sin(-M_PI / 4);
+    const bool fused_chan = (cfg->fuse & 2) && L.ncols > 0;
+    // modulated *= exp(-j pi/4); received = modulated + noise   (in place, or inside the bank)
+    if (!fused_chan)
+        if ((rc = wf_awgn_c128(ctx, sig, L.npts, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id, 0, sig, stream))) return rc;
     MARK(5);
-    if (L.ncols > 0) {
-        if ((rc = wf_mf_bank_c128(ctx, sig, L.npts, cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, L.first, cfg->sps,
-                                  L.ncols, mf, stream))) return rc;
-        MARK(6);
-        if ((rc = wf_viterbi4_detect(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream))) return rc;
-    }
     // drop the first `length` detector outputs, compare min_size elements
     // (reference examples/soqpsk_detection.py:201-209)
-    if (L.ncols <= 0) MARK(6);
-    MARK(7);
     int64_t m = L.ncols - length;
     if (m > cfg->nsym) m = cfg->nsym;
     if (m < 0) m = 0;
-    if (m > 0)
+    const bool fused_count = (cfg->fuse & 4) && m > 0;
+    if (L.ncols > 0) {
+        if (fused_chan)
+            rc = wf_awgn_mf_bank_c128(ctx, sig, L.npts, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id, 0,
+                                      cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, L.first, cfg->sps, L.ncols, mf, stream);
+        else
+            rc = wf_mf_bank_c128(ctx, sig, L.npts, cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, L.first, cfg->sps,
+                                 L.ncols, mf, stream);
+        if (rc) return rc;
+        MARK(6);
+        if (fused_count)
+            rc = wf_viterbi4_detect_count(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, bits, syms,
+                                          length, m, d_counts, stream);
+        else
+            rc = wf_viterbi4_detect(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream);
+        if (rc) return rc;
+    } else {
+        MARK(6);
+    }
+    MARK(7);
+    if (m > 0 && !fused_count)
         if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m, d_counts, stream))) return rc;
     MARK(8);
 #undef MARK

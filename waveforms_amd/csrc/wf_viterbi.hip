@@ -131,11 +131,18 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_batch_kernel(const double
                                                                      int64_t ncalls, int diff, int warmup,
                                                                      uint8_t *__restrict__ bits,
                                                                      int8_t *__restrict__ syms,
-                                                                     double *__restrict__ state)
+                                                                     double *__restrict__ state,
+                                                                     const uint8_t *__restrict__ ref_bits,
+                                                                     const int8_t *__restrict__ ref_syms,
+                                                                     int skip, int64_t ncompare,
+                                                                     unsigned long long *__restrict__ counts)
 {
     const int64_t gt = (int64_t)blockIdx.x * VIT_THREADS + threadIdx.x;
     const int64_t a = gt * VIT_CHUNK;
-    if (a >= ncalls) return;
+    // fused K11: decision k is compared with reference element k - skip, for k - skip < ncompare
+    // (examples/soqpsk_detection.py:201-209 drops the first `length` detector outputs)
+    int my_se = 0, my_be = 0;
+    if (a < ncalls) {
     const int64_t b_end = a + VIT_CHUNK < ncalls ? a + VIT_CHUNK : ncalls;
     int64_t s = a - warmup;
     if (s < 0) s = 0;
@@ -170,6 +177,13 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_batch_kernel(const double
         if ((i0 + k) & 1) viterbi_call<1>(z, m0, inc_prev, diff, &bit, &sym);
         else viterbi_call<0>(z, m0, inc_prev, diff, &bit, &sym);
         if (k >= a) {
+            if (counts) {
+                const int64_t q = k - skip;
+                if (q >= 0 && q < ncompare) {
+                    my_se += ((int8_t)sym != ref_syms[q]);
+                    my_be += ((uint8_t)bit != ref_bits[q]);
+                }
+            }
             const int j = (int)(k - a) & 15;
             const uint64_t bv = (uint64_t)(bit & 0xFF), sv = (uint64_t)(sym & 0xFF);
             if (j < 8) { pb_lo |= bv << (8 * j); ps_lo |= sv << (8 * j); }
@@ -199,6 +213,25 @@ __global__ __launch_bounds__(VIT_THREADS) void viterbi_batch_kernel(const double
 #pragma unroll
         for (int k = 0; k < 8; ++k) state[21 + k] = inc_prev[k];
     }
+    }  // a < ncalls
+    if (counts) {   // every thread of the block reaches this point
+        __shared__ long long s_cnt[2][VIT_THREADS / WF_WAVE];
+        const long long se = wf_wave_sum_i64(my_se), be = wf_wave_sum_i64(my_be);
+        if ((threadIdx.x & 63) == 0) {
+            s_cnt[0][threadIdx.x >> 6] = se;
+            s_cnt[1][threadIdx.x >> 6] = be;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long x = 0, y = 0;
+            for (int w = 0; w < VIT_THREADS / WF_WAVE; ++w) {
+                x += s_cnt[0][w];
+                y += s_cnt[1][w];
+            }
+            if (x) atomicAdd(&counts[0], (unsigned long long)x);
+            if (y) atomicAdd(&counts[1], (unsigned long long)y);
+        }
+    }
 }
 
 __global__ void viterbi_carry_commit_kernel(double *state)
@@ -207,9 +240,9 @@ __global__ void viterbi_carry_commit_kernel(double *state)
     if (t < 16) state[t] = state[16 + t];
 }
 
-extern "C" int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
-                                  int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
-                                  void *stream)
+static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential, int warmup,
+                          uint8_t *d_bits, int8_t *d_syms, double *d_state, const uint8_t *d_ref_bits,
+                          const int8_t *d_ref_syms, int skip, int64_t ncompare, int64_t *d_counts, void *stream)
 {
     WF_REQUIRE(ctx && ncalls >= 0 && warmup >= 0, "wf_viterbi4_detect: bad argument");
     if (ncalls == 0) return WF_OK;
@@ -225,13 +258,33 @@ extern "C" int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t nc
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
     hipStream_t s = wf_stream(stream);
     hipLaunchKernelGGL(viterbi_batch_kernel, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
-                       ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
+                       ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state, d_ref_bits, d_ref_syms, skip,
+                       ncompare, reinterpret_cast<unsigned long long *>(d_counts));
     WF_LAUNCH_CHECK();
     if (d_state) {
         hipLaunchKernelGGL(viterbi_carry_commit_kernel, dim3(1), dim3(64), 0, s, d_state);
         WF_LAUNCH_CHECK();
     }
     return WF_OK;
+}
+
+extern "C" int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
+                                  int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
+                                  void *stream)
+{
+    return viterbi_launch(ctx, d_mf_ri, ncalls, differential, warmup, d_bits, d_syms, d_state, nullptr, nullptr,
+                          0, 0, nullptr, stream);
+}
+
+extern "C" int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
+                                        int warmup, uint8_t *d_bits, int8_t *d_syms, const uint8_t *d_ref_bits,
+                                        const int8_t *d_ref_syms, int skip, int64_t ncompare, int64_t *d_counts,
+                                        void *stream)
+{
+    WF_REQUIRE(d_ref_bits && d_ref_syms && d_counts && skip >= 0 && ncompare >= 0,
+               "wf_viterbi4_detect_count: bad reference arguments");
+    return viterbi_launch(ctx, d_mf_ri, ncalls, differential, warmup, d_bits, d_syms, nullptr, d_ref_bits,
+                          d_ref_syms, skip, ncompare, d_counts, stream);
 }
 
 // ------------------------------------------------------------------------------------

@@ -123,6 +123,31 @@ def mf_bank(received, taps, first: int, step: int, ncols: int):
     return out
 
 
+def awgn_mf_bank(signal, taps, first: int, step: int, ncols: int, sigma: float, seed: int, stream_id: int = 0,
+                 first_index: int = 0, rot: complex = 1.0):
+    """K5 + K6 fused: rows of MF(signal*rot + noise) without materialising the noisy signal."""
+    nsamp = int(signal.shape[0])
+    nfilt, ntaps = int(taps.shape[0]), int(taps.shape[1])
+    out = _hip.empty((max(ncols, 0), nfilt, 2), "float64")
+    rot = complex(rot)
+    _hip.check(_hip.lib().wf_awgn_mf_bank_c128(_hip.ctx(), _hip.ptr(signal), nsamp, rot.real, rot.imag, float(sigma),
+                                               _u64(seed), _u64(stream_id), _u64(first_index), _hip.ptr(taps), nfilt,
+                                               ntaps, first, step, ncols, _hip.ptr(out), _hip.stream()))
+    return out
+
+
+def viterbi_detect_count(mf_rows, ref_bits, ref_syms, skip: int, ncompare: int, counts, differential: bool = True,
+                         warmup: int = 0):
+    """K8-K11 fused: decisions + error counts (added to ``counts``) in one launch."""
+    ncalls = int(mf_rows.shape[0])
+    bits = _hip.empty(ncalls + 16, "uint8")
+    syms = _hip.empty(ncalls + 16, "int8")
+    _hip.check(_hip.lib().wf_viterbi4_detect_count(_hip.ctx(), _hip.ptr(mf_rows), ncalls, int(bool(differential)), warmup,
+                                                   _hip.ptr(bits), _hip.ptr(syms), _hip.ptr(ref_bits), _hip.ptr(ref_syms),
+                                                   skip, ncompare, _hip.ptr(counts), _hip.stream()))
+    return bits[:ncalls], syms[:ncalls]
+
+
 def viterbi_detect(mf_rows, differential: bool = True, warmup: int = 0, state=None):
     """K8-K10 (length 2) -> (bits u8[ncalls], symbols i8[ncalls]) on device."""
     ncalls = int(mf_rows.shape[0])

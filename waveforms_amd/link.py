@@ -26,7 +26,7 @@ def sigma_for_ebn0(ebn0_db: float, sps: int) -> float:
 class SOQPSKLink:
     def __init__(self, nsym: int, sps: int = 8, pulse=None, mod_index: float = 0.25, detector: str = "PT",
                  pn_degree: int = 23, differential: bool = True, timing_offset: int | None = None,
-                 warmup: int = 0, fuse: int = 1) -> None:
+                 warmup: int = 0, fuse: int = 3) -> None:
         self.nsym, self.sps = int(nsym), int(sps)
         pulse = freq_pulse_soqpsk_tg(sps) if pulse is None else np.asarray(pulse, dtype=np.float64)
         if detector == "PT":

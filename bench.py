@@ -66,7 +66,7 @@ def main() -> None:
     ap.add_argument("--detector", default="PT")
     ap.add_argument("--fuse", type=int, default=3,
                     help="bit 0: fused modulator (FIR + phase scan in one pass); bit 1: AWGN inside the MF bank; "
-                         "bit 2: error count inside the Viterbi kernel; 0 = every stage its own kernel")
+                         "0 = every stage its own kernel")
     ap.add_argument("--cpu-sample", type=int, default=1 << 22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -138,9 +138,6 @@ def main() -> None:
     if args.fuse & 2:   # noisy samples never materialise: clean c128 in, 3 c128 per symbol out
         acc["awgn+mfbank"] = acc.pop("mfbank") + acc.pop("awgn")
         bps["awgn+mfbank"] = bps["mfbank"]
-    if args.fuse & 4:
-        acc["viterbi+count"] = acc.pop("viterbi") + acc.pop("count")
-        bps["viterbi+count"] = bps["viterbi"] + 2
     stages = {}
     for name, ms in acc.items():
         gb = bps[name] * args.nsym / 1e9

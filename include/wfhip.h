@@ -158,7 +158,7 @@ int wf_awgn_mf_bank_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, 
 int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
                        int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
                        void *stream);
-/* wf_viterbi4_detect + wf_count_errors in one launch (fresh detector): decision k is
+/* wf_viterbi4_detect + wf_count_errors in one call (fresh detector): decision k is
  * compared with reference element k - skip for 0 <= k - skip < ncompare
  * (examples/soqpsk_detection.py:201-209: skip = length); counts are ADDED to d_counts[0..1]. */
 int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential, int warmup,
@@ -212,8 +212,7 @@ typedef struct {
     int warmup;             /* Viterbi chunk warm-up, 0 = default                     */
     int fuse;               /* bit 0: fused modulator (wf_cpm_modulate_c128) instead   */
                             /* of the FIR + phase-scan stage kernels; bit 1: AWGN      */
-                            /* inside the MF bank (wf_awgn_mf_bank_c128); bit 2: error */
-                            /* count inside the Viterbi kernel                         */
+                            /* inside the MF bank (wf_awgn_mf_bank_c128)               */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
                             /* around every stage into that slot (wf_link_stage_ms)   */
 } wf_link_config;

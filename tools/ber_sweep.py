@@ -1,0 +1,95 @@
+"""SOQPSK-TG BER sweep on the device-resident link (BASELINE config 4).
+
+    python tools/ber_sweep.py [--ebn0 0:12] [--symbols-per-point 1e8] [--block 4194304] [--detector PT]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/ber_sweep.py ...
+
+Independent trial blocks are dealt round-robin to the ranks; the only collective is one
+all-reduce of the error-counter table at the end.  Rank 0 prints the table, the Eb/N0 at
+BER 1e-3 / 1e-4 and (if tests/golden/ber_golden*.csv are present) the offset in dB from the
+reference's curve.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def golden_curve(detector: str):
+    """(ebn0, ber, bit_errors, symbols) per point from the committed reference runs."""
+    import csv
+
+    acc = {}
+    key = "pt" if detector == "PT" else "pam"
+    for name in ("ber_golden.csv", "ber_golden_hi.csv", "ber_golden_hi2.csv"):
+        path = ROOT / "tests" / "golden" / name
+        if not path.exists():
+            continue
+        for r in csv.DictReader(open(path)):
+            a = acc.setdefault(int(r["ebn0_db"]), [0, 0])
+            a[0] += int(r[f"{key}_compared"])
+            a[1] += int(r[f"{key}_bit_err"])
+    e = sorted(acc)
+    return (np.array(e, dtype=float), np.array([acc[k][1] / acc[k][0] for k in e]),
+            np.array([acc[k][1] for k in e]), np.array([acc[k][0] for k in e]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ebn0", default="0:12")
+    ap.add_argument("--symbols-per-point", type=float, default=1e8)
+    ap.add_argument("--block", type=int, default=1 << 22)
+    ap.add_argument("--detector", default="PT")
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    lo, hi = (int(v) for v in a.ebn0.split(":"))
+    ebn0 = list(range(lo, hi + 1))
+
+    import torch
+
+    from waveforms_amd.bert import SweepPlan, ber_sweep, ber_table, dist_env, ebn0_at_ber
+
+    rank, world, local = dist_env()
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    blocks = max(1, int(round(a.symbols_per_point / a.block)))
+    plan = SweepPlan(ebn0_db=ebn0, blocks_per_point=blocks, nsym=a.block, seed=a.seed, detector=a.detector)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    counts = ber_sweep(plan)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        tab = ber_table(ebn0, counts)
+        for row in tab:
+            print(f"Eb/N0 {row['ebn0_db']:5.1f} dB  symbols {row['symbols']:>12d}  SER {row['ser']:.3e}  BER {row['ber']:.3e}")
+        out = {"detector": a.detector, "n_gpus": world, "seconds": round(dt, 3),
+               "Msym_per_s": round(int(counts[:, 2].sum()) / dt / 1e6, 1), "table": tab}
+        ber = [r["ber"] for r in tab]
+        ge, gb, _, _ = golden_curve(a.detector)
+        for target in (1e-3, 1e-4):
+            try:
+                mine = ebn0_at_ber(ebn0, ber, target)
+                out[f"ebn0_at_{target:g}"] = round(mine, 4)
+                if ge.size:
+                    out[f"delta_db_vs_reference_at_{target:g}"] = round(mine - ebn0_at_ber(ge, gb, target), 4)
+            except ValueError:
+                pass
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@
 
 #define MF_THREADS 256
 #define MF_LDS_SLOTS 3072  // 48 KiB of complex128
+#define MF_MAXI 12         // staged samples per thread: MF_LDS_SLOTS / MF_THREADS
 
 struct mf_params {
     int64_t nsamp, first, ncols;
@@ -42,23 +43,54 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
         // first input sample of the span: oldest sample of output k0
         const int64_t ws = P.first + k0 * P.step + P.c - (P.ntaps - 1);
         __syncthreads();
-        {
+        if (NOISE) {
+            // rolled loop (the Gaussian source is ~400 instructions): next sample's load is
+            // in flight while the channel is applied to the current one
             int q = t / P.step, rem = t - q * P.step;
             const int dq = MF_THREADS / P.step, dr = MF_THREADS - dq * P.step;
-            for (int i = t; i < P.span; i += MF_THREADS) {
+            auto fetch = [&](int i) {
                 const int64_t s = ws + i;
-                double2 v = make_double2(0.0, 0.0);
-                if (s >= 0 && s < P.nsamp) {
-                    v = *reinterpret_cast<const double2 *>(r + 2 * s);
-                    if (NOISE) {  // the channel of wf_awgn_c128, applied on the fly
-                        double nr, ni;
-                        wf_gaussian_pair(P.first_index + (uint64_t)s, P.stream_id, P.seed, P.sigma, &nr, &ni);
-                        const double re = fma(v.x, P.rot_re, fma(-v.y, P.rot_im, nr));
-                        const double im = fma(v.x, P.rot_im, fma(v.y, P.rot_re, ni));
-                        v = make_double2(re, im);
-                    }
+                return (i < P.span && s >= 0 && s < P.nsamp) ? *reinterpret_cast<const double2 *>(r + 2 * s)
+                                                              : make_double2(0.0, 0.0);
+            };
+            double2 cur = fetch(t);
+#pragma unroll 1
+            for (int i = t; i < P.span; i += MF_THREADS) {
+                const double2 nxt = fetch(i + MF_THREADS);
+                const int64_t s = ws + i;
+                double2 x = cur;
+                if (s >= 0 && s < P.nsamp) {  // the channel of wf_awgn_c128, on the fly
+                    double nr, ni;
+                    wf_gaussian_pair(P.first_index + (uint64_t)s, P.stream_id, P.seed, P.sigma, &nr, &ni);
+                    x = make_double2(fma(cur.x, P.rot_re, fma(-cur.y, P.rot_im, nr)),
+                                     fma(cur.x, P.rot_im, fma(cur.y, P.rot_re, ni)));
                 }
-                s_win[i + (P.pad ? q : 0)] = v;
+                s_win[i + (P.pad ? q : 0)] = x;
+                cur = nxt;
+                q += dq;
+                rem += dr;
+                if (rem >= P.step) {
+                    rem -= P.step;
+                    ++q;
+                }
+            }
+        } else {
+            // all of this thread's loads are issued before the first one is consumed
+            // (MF_MAXI x 16 B in flight per lane), then the LDS writes
+            double2 v[MF_MAXI];
+#pragma unroll
+            for (int u = 0; u < MF_MAXI; ++u) {
+                const int i = t + u * MF_THREADS;
+                const int64_t s = ws + i;
+                v[u] = make_double2(0.0, 0.0);
+                if (i < P.span && s >= 0 && s < P.nsamp) v[u] = *reinterpret_cast<const double2 *>(r + 2 * s);
+            }
+            int q = t / P.step, rem = t - q * P.step;
+            const int dq = MF_THREADS / P.step, dr = MF_THREADS - dq * P.step;
+#pragma unroll
+            for (int u = 0; u < MF_MAXI; ++u) {
+                const int i = t + u * MF_THREADS;
+                if (i < P.span) s_win[i + (P.pad ? q : 0)] = v[u];
                 q += dq;
                 rem += dr;
                 if (rem >= P.step) {
@@ -140,7 +172,7 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
         if (slots <= MF_LDS_SLOTS || ob == 1) {
             P.ob = ob;
             P.span = span;
-            WF_REQUIRE(slots <= 9216, "wf_mf_bank_c128: filter too long for LDS staging (%d taps)", ntaps);
+            WF_REQUIRE(span <= MF_MAXI * MF_THREADS, "wf_mf_bank_c128: filter too long for LDS staging (%d taps)", ntaps);
             break;
         }
         ob = ob > 16 ? ob - 16 : ob - 1;

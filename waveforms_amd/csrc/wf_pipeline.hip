@@ -143,7 +143,7 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     int64_t m = L.ncols - length;
     if (m > cfg->nsym) m = cfg->nsym;
     if (m < 0) m = 0;
-    const bool fused_count = (cfg->fuse & 4) && m > 0;
+    const bool fused_count = false;
     if (L.ncols > 0) {
         if (fused_chan)
             rc = wf_awgn_mf_bank_c128(ctx, sig, L.npts, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id, 0,

@@ -21,8 +21,7 @@
 #include "wf_common.h"
 
 #define VIT_THREADS 256
-#define VIT_CHUNK 64
-#define VIT_DEFAULT_WARMUP 48
+#define VIT_DEFAULT_WARMUP 47   // + 1 priming row + 64 output rows = 28 batches of 4
 #define VIT_MAX_LEN 64
 
 // Branch b of column c: start = b >> 1; ends / output-symbol index (0: -2, 1: 0, 2: +2):
@@ -127,111 +126,159 @@ __device__ __forceinline__ void viterbi_call(const double2 z[3], double m0[4], d
     for (int k = 0; k < 8; ++k) inc_prev[k] = inc_now[k];
 }
 
-__global__ __launch_bounds__(VIT_THREADS) void viterbi_batch_kernel(const double *__restrict__ mf,
-                                                                     int64_t ncalls, int diff, int warmup,
-                                                                     uint8_t *__restrict__ bits,
-                                                                     int8_t *__restrict__ syms,
-                                                                     double *__restrict__ state,
-                                                                     const uint8_t *__restrict__ ref_bits,
-                                                                     const int8_t *__restrict__ ref_syms,
-                                                                     int skip, int64_t ncompare,
-                                                                     unsigned long long *__restrict__ counts)
+// Batch kernel.  Lane g owns calls [g*CH, (g+1)*CH) and walks rows g*CH - W - 1 ... (one
+// priming row for the exact previous increments, W warm-up rows, CH output rows).  Rows are
+// 48 B each and a lane's rows are contiguous, so per-lane loads would touch 64 different
+// cache lines per instruction and thrash L1 (measured 2.4x HBM over-fetch).  Instead each
+// wave stages VIT_S rows of all its 64 lanes per batch with COOPERATIVE loads — 12 lanes
+// cover one lane-segment of 192 B, every 16 B piece of every cache line is fetched once —
+// into a wave-private LDS tile (13 slots of 16 B per lane: the odd slot count makes the
+// per-lane ds_read_b128 conflict-free), with the next batch's global loads in flight
+// while the current one is being decoded.
+#define VIT_S 4
+#define VIT_PIECES (3 * VIT_S)        // 16-byte pieces per lane-segment
+#define VIT_LANE_SLOTS (VIT_PIECES + 1)
+
+struct vit_lane {
+    double m0[4], inc_prev[8];
+    uint64_t pb_lo, pb_hi, ps_lo, ps_hi;
+};
+
+// One step (= one detector call k, COL = k's column parity) of lane-private state.
+template <int COL>
+__device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict__ zrow, bool prime, int diff,
+                                         int64_t k, int64_t a, int64_t ncalls, uint8_t *__restrict__ bits,
+                                         int8_t *__restrict__ syms)
 {
-    const int64_t gt = (int64_t)blockIdx.x * VIT_THREADS + threadIdx.x;
-    const int64_t a = gt * VIT_CHUNK;
-    // fused K11: decision k is compared with reference element k - skip, for k - skip < ncompare
-    // (examples/soqpsk_detection.py:201-209 drops the first `length` detector outputs)
-    int my_se = 0, my_be = 0;
-    if (a < ncalls) {
-    const int64_t b_end = a + VIT_CHUNK < ncalls ? a + VIT_CHUNK : ncalls;
-    int64_t s = a - warmup;
-    if (s < 0) s = 0;
+    const double2 z[3] = {zrow[0], zrow[1], zrow[2]};
+    if (prime) {   // priming row: exact increments of the call before the warm-up
+        increments<COL>(z, L.inc_prev);
+        return;
+    }
+    int bit, sym;
+    viterbi_call<COL>(z, L.m0, L.inc_prev, diff, &bit, &sym);
+    if (k >= a) {
+        const int c = (int)(k - a) & 15;
+        const uint64_t bv = (uint64_t)(bit & 0xFF), sv = (uint64_t)(sym & 0xFF);
+        if (c < 8) { L.pb_lo |= bv << (8 * c); L.ps_lo |= sv << (8 * c); }
+        else { L.pb_hi |= bv << (8 * (c - 8)); L.ps_hi |= sv << (8 * (c - 8)); }
+        if (c == 15) {
+            *reinterpret_cast<ulonglong2 *>(bits + k - 15) = make_ulonglong2(L.pb_lo, L.pb_hi);
+            *reinterpret_cast<ulonglong2 *>(syms + k - 15) = make_ulonglong2(L.ps_lo, L.ps_hi);
+            L.pb_lo = L.pb_hi = L.ps_lo = L.ps_hi = 0;
+        } else if (k + 1 == ncalls) {  // ragged tail of the burst
+            for (int q = 0; q <= c; ++q) {
+                bits[k - c + q] = (uint8_t)(((q < 8 ? L.pb_lo : L.pb_hi) >> (8 * (q & 7))) & 0xFF);
+                syms[k - c + q] = (int8_t)(((q < 8 ? L.ps_lo : L.ps_hi) >> (8 * (q & 7))) & 0xFF);
+            }
+        }
+    }
+}
 
-    double m0[4] = {0, 0, 0, 0}, inc_prev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t i0 = 0;
-    if (state) i0 = (int64_t)state[0];
+// Batch kernel.  Lane g owns calls [g*CH, (g+1)*CH) and walks rows g*CH - W - 1 ... (one
+// priming row for the exact previous increments, W warm-up rows, CH output rows).  Rows are
+// 48 B each and a lane's rows are contiguous, so per-lane loads would touch 64 different
+// cache lines per instruction and thrash L1 (measured 2.4x HBM over-fetch).  Instead each
+// wave stages VIT_S rows of all its 64 lanes per batch with COOPERATIVE loads — 12 lanes
+// cover one lane-segment of 192 B, every 16 B piece of every cache line is fetched once —
+// into a wave-private LDS tile (13 slots of 16 B per lane: the odd slot count makes the
+// per-lane ds_read_b128 conflict-free), with the next batch's global loads in flight
+// while the current one is being decoded.  Steps are decoded in (even, odd) column pairs
+// so only two ACS bodies are live at a time.
+#define VIT_S 4
+#define VIT_PIECES (3 * VIT_S)        // 16-byte pieces per lane-segment
+#define VIT_LANE_SLOTS (VIT_PIECES + 1)
+
+template <int CH, int PAR0>   // PAR0: column parity of step 0's call index
+__device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf, int64_t ncalls, int diff, int warmup,
+                                                   uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
+                                                   double *__restrict__ state, int64_t i0, double2 (*s_rows)[WF_WAVE * VIT_LANE_SLOTS])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t g0 = ((int64_t)blockIdx.x * (VIT_THREADS / WF_WAVE) + wave) * WF_WAVE;  // first lane of the wave
+    const int64_t a = (g0 + lane) * CH;
+    const bool live = a < ncalls;
+    const int nsteps = warmup + 1 + CH;
+    const int nbatch = (nsteps + VIT_S - 1) / VIT_S;
     const double2 *rows = reinterpret_cast<const double2 *>(mf);
-    if (s == 0) {
-        if (state) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) m0[k] = state[1 + k];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) inc_prev[k] = state[5 + k];
-        }
-    } else {
-        // exact increments of the row before the warm-up start
-        const double2 z[3] = {rows[3 * (s - 1)], rows[3 * (s - 1) + 1], rows[3 * (s - 1) + 2]};
-        if ((i0 + s - 1) & 1) increments<1>(z, inc_prev); else increments<0>(z, inc_prev);
-    }
+    double2 *tile = s_rows[wave];
 
-    uint64_t pb_lo = 0, pb_hi = 0, ps_lo = 0, ps_hi = 0;
-    double2 z[3] = {rows[3 * s], rows[3 * s + 1], rows[3 * s + 2]};
-    for (int64_t k = s; k < b_end; ++k) {
-        double2 zn[3] = {z[0], z[1], z[2]};
-        if (k + 1 < b_end) {  // prefetch the next row
-            zn[0] = rows[3 * (k + 1)];
-            zn[1] = rows[3 * (k + 1) + 1];
-            zn[2] = rows[3 * (k + 1) + 2];
-        }
-        int bit, sym;
-        if ((i0 + k) & 1) viterbi_call<1>(z, m0, inc_prev, diff, &bit, &sym);
-        else viterbi_call<0>(z, m0, inc_prev, diff, &bit, &sym);
-        if (k >= a) {
-            if (counts) {
-                const int64_t q = k - skip;
-                if (q >= 0 && q < ncompare) {
-                    my_se += ((int8_t)sym != ref_syms[q]);
-                    my_be += ((uint8_t)bit != ref_bits[q]);
-                }
-            }
-            const int j = (int)(k - a) & 15;
-            const uint64_t bv = (uint64_t)(bit & 0xFF), sv = (uint64_t)(sym & 0xFF);
-            if (j < 8) { pb_lo |= bv << (8 * j); ps_lo |= sv << (8 * j); }
-            else { pb_hi |= bv << (8 * (j - 8)); ps_hi |= sv << (8 * (j - 8)); }
-            if (j == 15) {
-                *reinterpret_cast<ulonglong2 *>(bits + k - 15) = make_ulonglong2(pb_lo, pb_hi);
-                *reinterpret_cast<ulonglong2 *>(syms + k - 15) = make_ulonglong2(ps_lo, ps_hi);
-                pb_lo = pb_hi = ps_lo = ps_hi = 0;
-            } else if (k + 1 == b_end) {  // ragged tail of the burst
-                for (int q = 0; q <= j; ++q) {
-                    bits[k - j + q] = (uint8_t)(((q < 8 ? pb_lo : pb_hi) >> (8 * (q & 7))) & 0xFF);
-                    syms[k - j + q] = (int8_t)(((q < 8 ? ps_lo : ps_hi) >> (8 * (q & 7))) & 0xFF);
-                }
-            }
-        }
-        z[0] = zn[0];
-        z[1] = zn[1];
-        z[2] = zn[2];
+    // cooperative piece p = u*64 + lane  ->  (segment = lane of the wave it belongs to, piece index)
+    int seg[VIT_PIECES], within[VIT_PIECES];
+#pragma unroll
+    for (int u = 0; u < VIT_PIECES; ++u) {
+        const int p = u * WF_WAVE + lane;
+        seg[u] = p / VIT_PIECES;
+        within[u] = p - seg[u] * VIT_PIECES;
     }
-    if (state && b_end == ncalls) {
-        // the thread that owns the last call hands the detector state on (streaming).
-        // Written to the second half of the carry block so concurrent readers of the
-        // first half (other threads' i0 / thread 0's metrics) are not disturbed.
+    auto fetch = [&](int b, double2 dst[VIT_PIECES]) {
+#pragma unroll
+        for (int u = 0; u < VIT_PIECES; ++u) {
+            const int64_t row = (g0 + seg[u]) * CH - warmup - 1 + (int64_t)b * VIT_S + within[u] / 3;
+            dst[u] = (row >= 0 && row < ncalls) ? rows[3 * row + within[u] % 3] : make_double2(0.0, 0.0);
+        }
+    };
+    auto stash = [&](const double2 src[VIT_PIECES]) {
+#pragma unroll
+        for (int u = 0; u < VIT_PIECES; ++u) tile[seg[u] * VIT_LANE_SLOTS + within[u]] = src[u];
+    };
+
+    vit_lane L;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L.m0[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) L.inc_prev[k] = 0.0;
+    L.pb_lo = L.pb_hi = L.ps_lo = L.ps_hi = 0;
+    if (state && a == 0) {   // the lane that starts the burst continues the carried detector
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L.m0[k] = state[1 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) L.inc_prev[k] = state[5 + k];
+    }
+    double2 pend[VIT_PIECES];
+    fetch(0, pend);
+    stash(pend);
+    __syncthreads();
+    const int64_t kbase = a - warmup - 1;
+    for (int b = 0; b < nbatch; ++b) {
+        if (b + 1 < nbatch) fetch(b + 1, pend);          // in flight during the decode below
+        if (live) {
+#pragma unroll 1
+            for (int jj = 0; jj < VIT_S; jj += 2) {
+                const int j = b * VIT_S + jj;
+                const int64_t k = kbase + j;              // call index of the even step
+                const double2 *zr = tile + lane * VIT_LANE_SLOTS + 3 * jj;
+                if (j < nsteps && k >= 0 && k < ncalls)
+                    vit_step<PAR0>(L, zr, j == 0, diff, k, a, ncalls, bits, syms);
+                if (j + 1 < nsteps && k + 1 >= 0 && k + 1 < ncalls)
+                    vit_step<PAR0 ^ 1>(L, zr + 3, false, diff, k + 1, a, ncalls, bits, syms);
+            }
+        }
+        __syncthreads();                                  // batch b fully consumed
+        if (b + 1 < nbatch) stash(pend);
+        __syncthreads();
+    }
+    if (state && live && a + CH >= ncalls) {
+        // the lane that owns the last call hands the detector state on (streaming).  Written
+        // to the second half of the carry block; viterbi_carry_commit_kernel moves it.
         state[16] = (double)(i0 + ncalls);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) state[17 + k] = m0[k];
+        for (int k = 0; k < 4; ++k) state[17 + k] = L.m0[k];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) state[21 + k] = inc_prev[k];
+        for (int k = 0; k < 8; ++k) state[21 + k] = L.inc_prev[k];
     }
-    }  // a < ncalls
-    if (counts) {   // every thread of the block reaches this point
-        __shared__ long long s_cnt[2][VIT_THREADS / WF_WAVE];
-        const long long se = wf_wave_sum_i64(my_se), be = wf_wave_sum_i64(my_be);
-        if ((threadIdx.x & 63) == 0) {
-            s_cnt[0][threadIdx.x >> 6] = se;
-            s_cnt[1][threadIdx.x >> 6] = be;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long x = 0, y = 0;
-            for (int w = 0; w < VIT_THREADS / WF_WAVE; ++w) {
-                x += s_cnt[0][w];
-                y += s_cnt[1][w];
-            }
-            if (x) atomicAdd(&counts[0], (unsigned long long)x);
-            if (y) atomicAdd(&counts[1], (unsigned long long)y);
-        }
-    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(VIT_THREADS) void viterbi_batch_kernel(const double *__restrict__ mf, int64_t ncalls,
+                                                                     int diff, int warmup, uint8_t *__restrict__ bits,
+                                                                     int8_t *__restrict__ syms, double *__restrict__ state)
+{
+    __shared__ double2 s_rows[VIT_THREADS / WF_WAVE][WF_WAVE * VIT_LANE_SLOTS];
+    const int64_t i0 = state ? (int64_t)state[0] : 0;
+    // call index of step 0 is lane_start - warmup - 1 with lane_start a multiple of CH (even)
+    if ((i0 - warmup - 1) & 1) viterbi_batch_body<CH, 1>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows);
+    else viterbi_batch_body<CH, 0>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows);
 }
 
 __global__ void viterbi_carry_commit_kernel(double *state)
@@ -241,8 +288,7 @@ __global__ void viterbi_carry_commit_kernel(double *state)
 }
 
 static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential, int warmup,
-                          uint8_t *d_bits, int8_t *d_syms, double *d_state, const uint8_t *d_ref_bits,
-                          const int8_t *d_ref_syms, int skip, int64_t ncompare, int64_t *d_counts, void *stream)
+                          uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream)
 {
     WF_REQUIRE(ctx && ncalls >= 0 && warmup >= 0, "wf_viterbi4_detect: bad argument");
     if (ncalls == 0) return WF_OK;
@@ -252,14 +298,20 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
                "wf_viterbi4_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
     if (warmup == 0) warmup = VIT_DEFAULT_WARMUP;
-    warmup = (warmup + 1) & ~1;  // even: keeps the column parity wave-uniform
-    const int64_t nthreads = (ncalls + VIT_CHUNK - 1) / VIT_CHUNK;
+    if (warmup > 4096) warmup = 4096;
+    // long bursts: 128 calls per lane (warm-up re-reads 37 % instead of 75 %); short ones
+    // keep 64 so that enough lanes exist to fill the chip
+    const int ch = ncalls >= (1 << 22) ? 128 : 64;
+    const int64_t nthreads = (ncalls + ch - 1) / ch;
     const int64_t nblocks = (nthreads + VIT_THREADS - 1) / VIT_THREADS;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
     hipStream_t s = wf_stream(stream);
-    hipLaunchKernelGGL(viterbi_batch_kernel, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
-                       ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state, d_ref_bits, d_ref_syms, skip,
-                       ncompare, reinterpret_cast<unsigned long long *>(d_counts));
+    if (ch == 128)
+        hipLaunchKernelGGL(viterbi_batch_kernel<128>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
+                           ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
+    else
+        hipLaunchKernelGGL(viterbi_batch_kernel<64>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
+                           ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
     WF_LAUNCH_CHECK();
     if (d_state) {
         hipLaunchKernelGGL(viterbi_carry_commit_kernel, dim3(1), dim3(64), 0, s, d_state);
@@ -272,8 +324,7 @@ extern "C" int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t nc
                                   int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
                                   void *stream)
 {
-    return viterbi_launch(ctx, d_mf_ri, ncalls, differential, warmup, d_bits, d_syms, d_state, nullptr, nullptr,
-                          0, 0, nullptr, stream);
+    return viterbi_launch(ctx, d_mf_ri, ncalls, differential, warmup, d_bits, d_syms, d_state, stream);
 }
 
 extern "C" int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
@@ -283,8 +334,12 @@ extern "C" int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int6
 {
     WF_REQUIRE(d_ref_bits && d_ref_syms && d_counts && skip >= 0 && ncompare >= 0,
                "wf_viterbi4_detect_count: bad reference arguments");
-    return viterbi_launch(ctx, d_mf_ri, ncalls, differential, warmup, d_bits, d_syms, nullptr, d_ref_bits,
-                          d_ref_syms, skip, ncompare, d_counts, stream);
+    int rc = viterbi_launch(ctx, d_mf_ri, ncalls, differential, warmup, d_bits, d_syms, nullptr, stream);
+    if (rc) return rc;
+    int64_t m = ncalls - skip;
+    if (m > ncompare) m = ncompare;
+    if (m <= 0) return WF_OK;
+    return wf_count_errors(ctx, d_syms + skip, d_ref_syms, d_bits + skip, d_ref_bits, m, d_counts, stream);
 }
 
 // ------------------------------------------------------------------------------------

@@ -67,6 +67,8 @@ def main() -> None:
     ap.add_argument("--fuse", type=int, default=3,
                     help="bit 0: fused modulator (FIR + phase scan in one pass); bit 1: AWGN inside the MF bank; "
                          "0 = every stage its own kernel")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent trial blocks in flight on separate HIP streams (own workspace + context each)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -89,15 +91,20 @@ def main() -> None:
     from waveforms_amd import _hip
     from waveforms_amd.link import SOQPSKLink
 
-    link = SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse)
+    nstreams = max(1, args.streams)
+    links = [SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse, private_ctx=nstreams > 1)
+             for _ in range(nstreams)]
+    streams = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
+    link = links[0]
     slots = 64
     assert args.steps >= 1
 
     def step(k: int, timed: bool) -> None:
         # every (rank, step) is its own trial block: distinct PRBS segment and Philox subsequence
         block = k * world + rank
-        link.run_block(args.ebn0, seed=1, stream_id=block, skip_bits=block * args.nsym,
-                       event_slot=(k % slots) if timed else -1)
+        with torch.cuda.stream(streams[k % nstreams]):
+            links[k % nstreams].run_block(args.ebn0, seed=1, stream_id=block & 0xFFFFFFFF, skip_bits=(block % 4096) * args.nsym,
+                                          event_slot=(k % slots) if timed else -1)
 
     def fence() -> None:
         if dist is not None:
@@ -106,7 +113,9 @@ def main() -> None:
 
     for k in range(args.warmup):
         step(-1 - k, False)
-    link.reset_counts() if args.warmup else None
+    torch.cuda.synchronize()
+    for l in links:
+        l.reset_counts()
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -118,7 +127,10 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    se, be, compared = link.result()
+    se = be = compared = 0
+    for l in links:
+        a_, b_, c_ = l.result()
+        se, be, compared = se + a_, be + b_, compared + c_
     counts = torch.tensor([se, be, compared], dtype=torch.int64, device="cuda")
     if dist is not None:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)     # the one collective of the job
@@ -128,7 +140,7 @@ def main() -> None:
     n_ev = min(args.steps, slots)
     acc = {}
     for k in range(args.steps - n_ev, args.steps):
-        for name, ms in link.stage_ms(k % slots).items():
+        for name, ms in links[k % nstreams].stage_ms(k % slots).items():
             acc[name] = acc.get(name, 0.0) + ms / n_ev
     bps = stage_bytes_per_symbol(args.sps)
     if args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
@@ -162,7 +174,7 @@ def main() -> None:
                                    f"{args.detector} matched filter + 4-state Viterbi detect (BASELINE configs[1])",
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
-                       "fuse": args.fuse, "parallelism": f"independent trial blocks x{world}"},
+                       "fuse": args.fuse, "streams": nstreams, "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared, 1)},
             "roofline": roofline,

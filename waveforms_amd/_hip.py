@@ -64,7 +64,7 @@ class LinkConfig(ctypes.Structure):
 
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()
 _ctxs: dict[int, int] = {}
 
 
@@ -126,6 +126,14 @@ def ctx() -> int:
                 check(lib().wf_ctx_create(dev, ctypes.byref(out)))
                 _ctxs[dev] = out.value
     return _ctxs[dev]
+
+
+def new_ctx() -> int:
+    """A private wf_ctx* on the current device (own scratch: needed by anything that runs
+    concurrently with other library calls on a different stream)."""
+    out = c_void_p()
+    check(lib().wf_ctx_create(require_device(), ctypes.byref(out)))
+    return out.value
 
 
 def stream() -> int:

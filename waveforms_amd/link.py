@@ -26,8 +26,10 @@ def sigma_for_ebn0(ebn0_db: float, sps: int) -> float:
 class SOQPSKLink:
     def __init__(self, nsym: int, sps: int = 8, pulse=None, mod_index: float = 0.25, detector: str = "PT",
                  pn_degree: int = 23, differential: bool = True, timing_offset: int | None = None,
-                 warmup: int = 0, fuse: int = 3) -> None:
+                 warmup: int = 0, fuse: int = 3, private_ctx: bool = False) -> None:
         self.nsym, self.sps = int(nsym), int(sps)
+        # a link that runs on its own stream next to other links needs its own scratch
+        self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()
         pulse = freq_pulse_soqpsk_tg(sps) if pulse is None else np.asarray(pulse, dtype=np.float64)
         if detector == "PT":
             taps = pt_matched_filter_taps(pulse, mod_index, sps)
@@ -69,7 +71,7 @@ class SOQPSKLink:
     def stage_ms(self, event_slot: int) -> dict[str, float]:
         """Per-stage HIP-event times (ms) of the last run that used ``event_slot``."""
         buf = (ctypes.c_float * len(self.STAGES))()
-        _hip.check(_hip.lib().wf_link_stage_ms(_hip.ctx(), event_slot, buf))
+        _hip.check(_hip.lib().wf_link_stage_ms(self._ctx, event_slot, buf))
         return dict(zip(self.STAGES, (float(v) for v in buf)))
 
     def run_block(self, ebn0_db: float, seed: int = 1, stream_id: int = 0, skip_bits: int = 0,
@@ -80,13 +82,13 @@ class SOQPSKLink:
         c.sigma, c.seed, c.stream_id, c.skip = sigma_for_ebn0(ebn0_db, self.sps), seed, stream_id, skip_bits
         c.event_slot = event_slot
         m = ctypes.c_int64(0)
-        _hip.check(_hip.lib().wf_link_run(_hip.ctx(), ctypes.byref(c), self.workspace.data_ptr(),
+        _hip.check(_hip.lib().wf_link_run(self._ctx, ctypes.byref(c), self.workspace.data_ptr(),
                                           self.workspace_bytes, self.counts.data_ptr(), ctypes.byref(m),
                                           _hip.stream()))
         self.compared += m.value
 
     def result(self) -> tuple[int, int, int]:
         """(symbol errors, bit errors, symbols compared) — synchronises."""
-        _hip.device_check()
+        _hip.check(_hip.lib().wf_ctx_check(self._ctx, _hip.stream()))
         se, be = (int(v) for v in self.counts.cpu().tolist())
         return se, be, self.compared

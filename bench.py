@@ -35,6 +35,29 @@ def stage_bytes_per_symbol(sps: int, nfilt: int = 3) -> dict:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 
+# stage -> kernel that dominates it (names as rocprofv3 prints them)
+STAGE_KERNEL = {"fir": "fir_kernel<9>", "phase": "phase_kernel", "modulate": "mod_main_kernel<9>",
+                "awgn": "awgn_kernel", "mfbank": "mf_bank_kernel<3, false>", "awgn+mfbank": "mf_bank_kernel<3, true>",
+                "viterbi": "viterbi_batch_kernel<128>", "count": "count_errors_kernel", "prbs": "lfsr_kernel",
+                "encode": "enc_reduce_kernel"}
+
+
+def measured_traffic(stage: str, nsym: int, sps: int):
+    """HBM bytes per launch of the stage's kernel from the committed PMC summary
+    (profiles/*_summary.json, produced by tools/pmc_summary.py from separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command);
+    None if no summary matches this workload."""
+    best = None
+    for path in sorted((ROOT / "profiles").glob("*_summary.json")):
+        try:
+            d = json.loads(path.read_text())
+        except (OSError, ValueError):
+            continue
+        k = d.get("kernels", {}).get(STAGE_KERNEL.get(stage, ""))
+        if d.get("nsym") == nsym and d.get("sps") == sps and k:
+            best = (int(k["hbm_traffic_bytes"]), path.name)
+    return best
+
 
 def cpu_baseline(sps: int, ebn0: float, nsym: int) -> dict:
     """The oracle (CPU port of the reference algorithm: C loops + numpy) timed on one host
@@ -80,13 +103,20 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
+    # Rehearsal switch for a 1-GPU box: WF_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses
+    # gloo for the two collectives, so the N > 1 code path can be exercised without N GPUs.
+    rehearsal = os.environ.get("WF_BENCH_REHEARSAL") == "1"
+    torch.cuda.set_device(0 if rehearsal else local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    coll_dev = "cpu" if rehearsal else "cuda"
 
     from waveforms_amd import _hip
     from waveforms_amd.link import SOQPSKLink
@@ -123,7 +153,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -131,7 +161,7 @@ def main() -> None:
     for l in links:
         a_, b_, c_ = l.result()
         se, be, compared = se + a_, be + b_, compared + c_
-    counts = torch.tensor([se, be, compared], dtype=torch.int64, device="cuda")
+    counts = torch.tensor([se, be, compared], dtype=torch.int64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)     # the one collective of the job
     se, be, compared = (int(v) for v in counts.cpu().tolist())
@@ -157,8 +187,11 @@ def main() -> None:
                         "GBps": round(gb / (ms / 1e3), 1) if ms > 0 else None}
     dominant = max(acc, key=acc.get)
     d = stages[dominant]
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(d["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+    traffic = measured_traffic(dominant, args.nsym, args.sps)
+    roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dominant, dominant), "stage": dominant,
+                "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(d["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic[0] if traffic else None,
+                "traffic_source": traffic[1] if traffic else None,
                 "launch_ms": d["ms"], "algorithmic_bytes_per_launch": int(bps[dominant] * args.nsym)}
 
     if rank == 0:

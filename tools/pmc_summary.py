@@ -1,0 +1,65 @@
+"""Summarise rocprofv3 output of `bench.py` into profiles/<tag>_summary.json.
+
+    python tools/pmc_summary.py <tag> <kernel_stats.csv> <fetch counter_collection.csv> <write counter_collection.csv> \
+        --nsym 10000000 --sps 8
+
+HBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE
+reports half the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM section);
+WRITE_SIZE is exact for 16 B-per-lane stores.  FETCH_SIZE and WRITE_SIZE come from
+separate --pmc passes (they do not fit one pass).
+"""
+import argparse
+import csv
+import json
+import re
+import statistics
+from collections import defaultdict
+from pathlib import Path
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    return name.split("(")[0]
+
+
+def counters(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
+    return {k: statistics.median(v) for k, v in acc.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("kernel_stats")
+    ap.add_argument("fetch_csv")
+    ap.add_argument("write_csv")
+    ap.add_argument("--nsym", type=int, required=True)
+    ap.add_argument("--sps", type=int, default=8)
+    a = ap.parse_args()
+    stats = {}
+    for r in csv.DictReader(open(a.kernel_stats)):
+        stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                   "pct": float(r["Percentage"])}
+    fetch, write = counters(a.fetch_csv, "FETCH_SIZE"), counters(a.write_csv, "WRITE_SIZE")
+    kernels = {}
+    for k, st in stats.items():
+        if not (k.startswith(("lfsr", "enc_", "fir_", "phase_", "mod_", "awgn", "mf_bank", "viterbi", "count_"))):
+            continue
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        kernels[k] = {**st, "fetch_size_bytes_raw": int(f), "write_size_bytes": int(w),
+                      "hbm_traffic_bytes": int(2 * f + w)}
+    out = {"tag": a.tag, "nsym": a.nsym, "sps": a.sps,
+           "note": "traffic = 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE correction), medians over launches",
+           "kernels": kernels}
+    path = Path(__file__).resolve().parent.parent / "profiles" / f"{a.tag}_summary.json"
+    path.write_text(json.dumps(out, indent=1) + "\n")
+    print(path)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["avg_ns"]):
+        print(f"{k:34s} {v['avg_ns'] / 1e6:8.4f} ms  traffic {v['hbm_traffic_bytes'] / 1e9:7.3f} GB")
+
+
+if __name__ == "__main__":
+    main()

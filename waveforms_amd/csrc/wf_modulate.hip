@@ -16,7 +16,9 @@
 #include "wf_common.h"
 
 #define MOD_THREADS 256
+#ifndef MOD_ROWS
 #define MOD_ROWS 8
+#endif
 #define MOD_WAVES (MOD_THREADS / WF_WAVE)
 #define MOD_MASK ((1ull << 62) - 1)
 #define MOD_MAX_PART 40
@@ -131,8 +133,11 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
     }
 }
 
+#ifndef MOD_MIN_WAVES
+#define MOD_MIN_WAVES 1
+#endif
 template <int JMAX>
-__global__ __launch_bounds__(MOD_THREADS) void mod_main_kernel(const int8_t *__restrict__ symbols,
+__global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(const int8_t *__restrict__ symbols,
                                                                 const double *__restrict__ hvec,
                                                                 const double *__restrict__ pulse,
                                                                 const double *__restrict__ scratch,
@@ -184,7 +189,11 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_main_kernel(const int8_t *__r
 #pragma unroll
         for (int u = 0; u < MOD_ROWS; ++u) {
             double acc0 = 0.0, acc1 = 0.0;
+#ifdef WF_ABL_NO_FIR
+            if (false) {
+#else
             if (active) {
+#endif
                 const double *a = &s_amp[l_top0p1 + u * sym_per_row];
 #pragma unroll
                 for (int i = 0; i <= JMAX; ++i) {
@@ -195,7 +204,11 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_main_kernel(const int8_t *__r
             }
             x0[u] = acc0;
             x1[u] = acc1;
+#ifdef WF_ABL_NO_SCAN
+            const double inc = acc0 + acc1;
+#else
             const double inc = wf_wave_incl_scan(acc0 + acc1);
+#endif
             const double e = __shfl_up(inc, 1, WF_WAVE);
             ex[u] = lane == 0 ? 0.0 : e;
             if (lane == 63) s_tot[u * MOD_WAVES + wave] = inc;
@@ -231,8 +244,12 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_main_kernel(const int8_t *__r
                 const double ra = mod_pos_d(v0, P.sps_d, P.inv_sps);
                 const double rb = mod_pos_d(v1, P.sps_d, P.inv_sps);
                 double s0, c0, s1, c1;
+#ifdef WF_ABL_NO_SINCOS
+                s0 = ra; c0 = ra + 1; s1 = rb; c1 = rb + 1;
+#else
                 wf_sincos_turns(fma(ra, P.inv_sps, P.phi0_turns), &s0, &c0);
                 wf_sincos_turns(fma(rb, P.inv_sps, P.phi0_turns), &s1, &c1);
+#endif
                 if (n + 1 < P.out_len) {
                     double2 *o = reinterpret_cast<double2 *>(out + 2 * n);
                     o[0] = make_double2(c0, s0);

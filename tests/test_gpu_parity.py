@@ -210,6 +210,50 @@ def test_fused_modulator_equals_stage_kernels_and_oracle(oracle, sps, pulse_name
     assert np.abs(fused - staged).max() < 1e-10
 
 
+def test_baseline_config0_pcmfm_1e4(oracle):
+    """BASELINE configs[0]: PCM/FM, first 1e4 symbols of SimpleTrellis2(PN15 bits), h = 0.7,
+    freq_pulse_pcmfm(8, 4), sps 8, modulate only (reference examples/pcmfm_test.py)."""
+    from waveforms.cpm.modulate import cpm_modulate
+    from waveforms.cpm.pcmfm import PCMFM_DENOM, PCMFM_NUMER, PCMFMSymbolMapper, freq_pulse_pcmfm
+    from waveforms.cpm.trellis.encoder import TrellisEncoder
+    from waveforms.cpm.trellis.model import SimpleTrellis2
+    from waveforms.glfsr import PNSequence
+
+    bits = np.array(PNSequence(15).generate_sequence(), dtype=np.uint8)[:10_000]
+    sym = TrellisEncoder(SimpleTrellis2)(bits)
+    assert np.array_equal(sym, PCMFMSymbolMapper()(bits))
+    _t, s = cpm_modulate(sym, PCMFM_NUMER / PCMFM_DENOM, freq_pulse_pcmfm(8, 4), 8)
+    assert s.size == 80008
+    assert abs(s.sum() - (-892.7936490036517 - 386.3385670668806j)) < 1e-8      # SURVEY 8(c)-4
+    _t2, want = oracle.cpm_modulate(oracle.pcmfm_mapper(oracle.pn_sequence(15)[:10_000]), 0.7,
+                                    oracle.freq_pulse_pcmfm(8, 4), 8)
+    assert np.abs(s - want).max() < 1e-11
+
+
+def test_baseline_config2_multih_modulator_full_size(oracle):
+    """BASELINE configs[2], modulator half (the reference has no multi-h detector): 1e7
+    quaternary ARTM symbols from 2e7 PN23 bits, h = {4/16, 5/16}, 25-tap 3RC, sps 8."""
+    from waveforms_amd import _hip, device as dev
+    from waveforms.cpm.modulate import cpm_modulate_device
+    from waveforms.cpm.multih import MULTIH_IRIG_DENOM, MULTIH_IRIG_NUMER, freq_pulse_multih_irig
+    from waveforms.glfsr import PNSequence
+
+    n = 10_000_000
+    d_bits = PNSequence(23).generate(2 * n, device=True)
+    d_sym = dev.symbol_map(1, d_bits)
+    want_bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, 2 * n)
+    sym = oracle.multih_mapper(want_bits)[0]
+    assert np.array_equal(_hip.to_host(d_sym), sym)
+    assert np.array_equal(sym, oracle.fsm_encode("SimpleTrellis4", want_bits)[0])
+    h = MULTIH_IRIG_NUMER / MULTIH_IRIG_DENOM
+    d_sig = cpm_modulate_device(d_sym, h, freq_pulse_multih_irig(8), 8)
+    _hip.device_check()
+    _t, want = oracle.cpm_modulate(sym, h, oracle.freq_pulse_multih_irig(8), 8)
+    got = _hip.to_host(d_sig, complex_pairs=True)
+    assert got.shape == want.shape == ((n + 1) * 8,)
+    assert np.abs(got - want).max() < FLOAT_ATOL
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_modulate_full_size_properties(oracle, fused):
     """1e7 SOQPSK-TG symbols @ 8 sps (BASELINE config 2): unit envelope, and agreement

@@ -12,7 +12,25 @@ __global__ __launch_bounds__(256) void count_errors_kernel(const int8_t *__restr
     __shared__ long long s_part[2][4];
     long long se = 0, be = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    // 16 elements per thread and iteration; the arrays may start at any byte offset
+    // (the detector output is compared from element `length` on), gfx950 global loads
+    // need no alignment
+    const int64_t nvec = m / 16;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        ulonglong2 a, b, c, d;
+        __builtin_memcpy(&a, det_syms + 16 * v, 16);
+        __builtin_memcpy(&b, ref_syms + 16 * v, 16);
+        __builtin_memcpy(&c, det_bits + 16 * v, 16);
+        __builtin_memcpy(&d, ref_bits + 16 * v, 16);
+        // count non-zero bytes of the XOR: fold each byte to its low bit
+        auto nz = [](unsigned long long x) {
+            x |= x >> 4; x |= x >> 2; x |= x >> 1;
+            return __popcll(x & 0x0101010101010101ull);
+        };
+        se += nz(a.x ^ b.x) + nz(a.y ^ b.y);
+        be += nz(c.x ^ d.x) + nz(c.y ^ d.y);
+    }
+    for (int64_t k = 16 * nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
         se += det_syms[k] != ref_syms[k];
         be += det_bits[k] != ref_bits[k];
     }
@@ -43,7 +61,7 @@ extern "C" int wf_count_errors(wf_ctx *ctx, const int8_t *d_det_syms, const int8
     if (m == 0) return WF_OK;
     WF_REQUIRE(d_det_syms && d_ref_syms && d_det_bits && d_ref_bits, "wf_count_errors: NULL device pointer");
     WF_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(count_errors_kernel, dim3(wf_grid_for(m, 256 * 8, 1024)), dim3(256), 0, wf_stream(stream),
+    hipLaunchKernelGGL(count_errors_kernel, dim3(wf_grid_for(m, 256 * 16 * 8, 256))  /* <= 512 same-address atomics */, dim3(256), 0, wf_stream(stream),
                        d_det_syms, d_ref_syms, d_det_bits, d_ref_bits, m,
                        reinterpret_cast<unsigned long long *>(d_counts));
     WF_LAUNCH_CHECK();

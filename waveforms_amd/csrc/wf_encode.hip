@@ -120,14 +120,16 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
     if (t == ENC_THREADS - 1) block_agg[blockIdx.x] = map_compose(pre, inc);
 }
 
-// Kernel B: start state of every block (single wave; lanes own contiguous runs).
-__global__ __launch_bounds__(WF_WAVE) void enc_block_scan_kernel(const uint64_t *__restrict__ block_agg,
-                                                                  int nblocks, int state0,
-                                                                  uint8_t *__restrict__ block_state)
+// Kernel B: start state of every block (one workgroup; threads own contiguous runs).
+#define ENC_SCAN_THREADS 1024
+__global__ __launch_bounds__(ENC_SCAN_THREADS) void enc_block_scan_kernel(const uint64_t *__restrict__ block_agg,
+                                                                           int nblocks, int state0,
+                                                                           uint8_t *__restrict__ block_state)
 {
-    const int lane = threadIdx.x;
-    const int per = (nblocks + WF_WAVE - 1) / WF_WAVE;
-    const int b0 = lane * per, b1 = min(nblocks, b0 + per);
+    __shared__ uint64_t s_wave[ENC_SCAN_THREADS / WF_WAVE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (nblocks + ENC_SCAN_THREADS - 1) / ENC_SCAN_THREADS;
+    const int b0 = min(nblocks, t * per), b1 = min(nblocks, b0 + per);
     uint64_t run = map_identity();
     for (int b = b0; b < b1; ++b) run = map_compose(run, block_agg[b]);
     uint64_t inc = run;
@@ -136,8 +138,13 @@ __global__ __launch_bounds__(WF_WAVE) void enc_block_scan_kernel(const uint64_t 
         const uint64_t o = shfl_up_u64(inc, d);
         if (lane >= d) inc = map_compose(o, inc);
     }
+    if (lane == 63) s_wave[wave] = inc;
     uint64_t excl = shfl_up_u64(inc, 1);
     if (lane == 0) excl = map_identity();
+    __syncthreads();
+    uint64_t pre = map_identity();
+    for (int w = 0; w < wave; ++w) pre = map_compose(pre, s_wave[w]);
+    excl = map_compose(pre, excl);
     int st = (int)((excl >> (4 * state0)) & 15ull);
     for (int b = b0; b < b1; ++b) {
         block_state[b] = (uint8_t)st;
@@ -224,7 +231,7 @@ extern "C" int wf_fsm_encode(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h
     hipLaunchKernelGGL(enc_reduce_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
                        ctx->d_tables, P, thread_excl, block_agg);
     WF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(enc_block_scan_kernel, dim3(1), dim3(WF_WAVE), 0, s, block_agg, (int)nblocks,
+    hipLaunchKernelGGL(enc_block_scan_kernel, dim3(1), dim3(ENC_SCAN_THREADS), 0, s, block_agg, (int)nblocks,
                        state0, block_state);
     WF_LAUNCH_CHECK();
     hipLaunchKernelGGL(enc_emit_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,

@@ -5,16 +5,18 @@
 // One step of the register is the linear map T over GF(2)^64:
 //   T e_0 = mask, T e_c = e_{c-1}.
 // The context caches T^(2^j), j = 0..63 (column form) per mask; block b jumps to
-// position skip + b*2^14 with one wave doing matrix-vector products in parallel
+// position skip + b*2^16 with one wave doing matrix-vector products in parallel
 // (lane c holds column c, XOR-reduce over the wave), then every thread jumps a
-// further t*64 steps with the 8 matrices T^(2^6..2^13) staged in LDS and emits 64
+// further t*256 steps with the 8 matrices T^(2^8..2^15) staged in LDS and emits 256
 // bits.  Bits are re-packed through LDS so that global stores are 16 B per lane,
 // fully coalesced.
 #include "wf_common.h"
 
 #define LFSR_THREADS 256
-#define LFSR_BITS_PER_THREAD 64
-#define LFSR_BITS_PER_BLOCK (LFSR_THREADS * LFSR_BITS_PER_THREAD)  // 2^14
+#define LFSR_WORDS 4                                               // 64-bit words per thread
+#define LFSR_BITS_PER_THREAD (64 * LFSR_WORDS)                     // 2^8
+#define LFSR_LOG2_BPT 8
+#define LFSR_BITS_PER_BLOCK (LFSR_THREADS * LFSR_BITS_PER_THREAD)  // 2^16
 
 static inline uint64_t host_matvec(const uint64_t *cols, uint64_t v)
 {
@@ -55,52 +57,63 @@ static uint64_t host_jump(const wf_lfsr_tables *t, uint64_t state, uint64_t step
 __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__restrict__ jump,
                                                               uint64_t mask, uint64_t state,
                                                               uint64_t skip, uint8_t *__restrict__ bits,
-                                                              int64_t n)
+                                                              int64_t n, int degree)
 {
-    __shared__ uint64_t s_mat[8][64];
-    __shared__ uint64_t s_words[LFSR_THREADS];
+    __shared__ uint64_t s_tab[64][64];   // all 64 jump matrices (32 KB), staged with parallel loads
+    __shared__ uint64_t s_words[LFSR_THREADS * LFSR_WORDS];
     __shared__ uint64_t s_base;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const uint64_t pos0 = skip + (uint64_t)blockIdx.x * LFSR_BITS_PER_BLOCK;
 
-    // stage T^(2^6) .. T^(2^13)
-    for (int k = t; k < 8 * 64; k += LFSR_THREADS) s_mat[k >> 6][k & 63] = jump[(6 + (k >> 6)) * 64 + (k & 63)];
-
+    // the block jump below is a serial chain of matrix-vector products: fetching each
+    // matrix from global memory inside the chain cost ~1.5 us of latency per set bit of
+    // pos0, so the whole table is staged first (16 independent 16 B loads per thread)
+    {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(jump);
+        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(&s_tab[0][0]);
+#pragma unroll
+        for (int k = 0; k < (64 * 64 / 2) / LFSR_THREADS; ++k) dst[k * LFSR_THREADS + t] = src[k * LFSR_THREADS + t];
+    }
+    __syncthreads();
     if (t < 64) {  // wave 0: block base state = T^pos0 * state
         uint64_t s = state;
         for (int j = 0; j < 64; ++j) {
             if ((pos0 >> j) & 1) {  // wave-uniform
-                const uint64_t col = jump[j * 64 + lane];
+                const uint64_t col = s_tab[j][lane];
                 s = wf_wave_xor_reduce(((s >> lane) & 1) ? col : 0ull);
             }
         }
         if (t == 0) s_base = s;
     }
     __syncthreads();
+    const uint64_t (*s_mat)[64] = &s_tab[LFSR_LOG2_BPT];   // T^(2^8) .. T^(2^15): thread t jumps t * 2^8 further
 
     uint64_t s = s_base;
 #pragma unroll 1
     for (int b = 0; b < 8; ++b) {
         uint64_t y = 0;
 #pragma unroll 8
-        for (int c = 0; c < 64; ++c) y ^= ((s >> c) & 1) ? s_mat[b][c] : 0ull;
+        for (int c = 0; c < degree; ++c) y ^= ((s >> c) & 1) ? s_mat[b][c] : 0ull;   // bits >= degree are zero
         s = ((t >> b) & 1) ? y : s;
     }
-    uint64_t w = 0;
+#pragma unroll 1
+    for (int wi = 0; wi < LFSR_WORDS; ++wi) {
+        uint64_t w = 0;
 #pragma unroll 16
-    for (int k = 0; k < 64; ++k) {
-        const uint64_t bit = s & 1;
-        s = (s >> 1) ^ (mask & (0 - bit));
-        w |= bit << k;
+        for (int k = 0; k < 64; ++k) {
+            const uint64_t bit = s & 1;
+            s = (s >> 1) ^ (mask & (0 - bit));
+            w |= bit << k;
+        }
+        s_words[t * LFSR_WORDS + wi] = w;
     }
-    s_words[t] = w;
     __syncthreads();
 
     const int64_t blk_byte0 = (int64_t)blockIdx.x * LFSR_BITS_PER_BLOCK;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int g = r * 4096 + t * 16;  // byte (= bit) offset inside the block
+#pragma unroll 4
+    for (int r = 0; r < LFSR_BITS_PER_BLOCK / (LFSR_THREADS * 16); ++r) {
+        const int g = r * (LFSR_THREADS * 16) + t * 16;  // byte (= bit) offset inside the block
         const int64_t gi = blk_byte0 + g;
         if (gi >= n) break;
         const uint32_t x = (uint32_t)(s_words[g >> 6] >> (g & 63)) & 0xFFFFu;
@@ -128,6 +141,8 @@ extern "C" int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t
         return WF_ERR_KEY;
     }
     WF_REQUIRE(n >= 0, "wf_lfsr_generate: n = %lld", (long long)n);
+    WF_REQUIRE(degree == 64 || ((mask >> degree) == 0 && (state >> degree) == 0),
+               "wf_lfsr_generate: mask/state wider than the register (degree %d)", degree);
     WF_REQUIRE(n == 0 || (d_bits && (reinterpret_cast<uintptr_t>(d_bits) & 15) == 0),
                "wf_lfsr_generate: d_bits must be non-NULL and 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
@@ -141,7 +156,7 @@ extern "C" int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t
     const int64_t blocks = (n + LFSR_BITS_PER_BLOCK - 1) / LFSR_BITS_PER_BLOCK;
     WF_REQUIRE(blocks < (1ll << 31), "wf_lfsr_generate: n too large for one launch");
     hipLaunchKernelGGL(lfsr_kernel, dim3((unsigned)blocks), dim3(LFSR_THREADS), 0, wf_stream(stream),
-                       t->dev, mask, state, skip, d_bits, n);
+                       t->dev, mask, state, skip, d_bits, n, degree);
     WF_LAUNCH_CHECK();
     return WF_OK;
 }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
                                                               double *__restrict__ scratch)
 {
     __shared__ double s_T, s_K0;
-    __shared__ uint64_t s_part[1024];
+    __shared__ uint64_t s_part[1024 / WF_WAVE];
     const int t = threadIdx.x;
     if (t == 0) {
         // Gcum at the few indices needed, by one sequential pass over the taps
@@ -112,23 +112,27 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
     uint64_t *Wq = reinterpret_cast<uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
     const int64_t per = (P.ntiles + 1023) / 1024;
     const int64_t j0 = (int64_t)t * per, j1 = min(P.ntiles, j0 + per);
+    auto fixed = [&](int64_t j) {
+        return (uint64_t)(mod_pos_d(T * Pj[j], P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+    };
     uint64_t run = 0;
-    for (int64_t j = j0; j < j1; ++j)
-        run += (uint64_t)(mod_pos_d(T * Pj[j], P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
-    s_part[t] = run;
-    __syncthreads();
-    if (t == 0) {
-        uint64_t acc = (uint64_t)(mod_pos_d(-s_K0, P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
-        for (int k = 0; k < 1024; ++k) {
-            const uint64_t v = s_part[k];
-            s_part[k] = acc;
-            acc += v;
-        }
+    for (int64_t j = j0; j < j1; ++j) run += fixed(j);
+    // block-wide exclusive scan of the per-thread sums (u64, wraps mod 2^64 — only the low
+    // 62 bits are kept): wave shuffles, then the 16 wave totals through LDS
+    const int lane = t & 63, wave = t >> 6;
+    uint64_t inc = run;
+#pragma unroll
+    for (int d = 1; d < WF_WAVE; d <<= 1) {
+        const uint64_t o = (uint64_t)__shfl_up((unsigned long long)inc, d, WF_WAVE);
+        if (lane >= d) inc += o;
     }
+    if (lane == 63) s_part[wave] = inc;
     __syncthreads();
-    run = s_part[t];
+    uint64_t base = (uint64_t)(mod_pos_d(-s_K0, P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+    for (int w = 0; w < wave; ++w) base += s_part[w];
+    run = base + inc - run;   // exclusive prefix of this thread
     for (int64_t j = j0; j < j1; ++j) {
-        run += (uint64_t)(mod_pos_d(T * Pj[j], P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+        run += fixed(j);
         Wq[j] = run & MOD_MASK;
     }
 }

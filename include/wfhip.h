@@ -120,8 +120,9 @@ int wf_phase_modulate_f64(wf_ctx *ctx, const double *d_phase, int64_t n, double 
  * Device counterpart of generate_complex_awgn (waveforms/noise.py:8-32) and of
  * `signal * exp(-j pi/4) + noise` (examples/soqpsk_detection.py:85-89):
  *   out_k = in_k * (rot_re + j rot_im) + sigma * (n_re + j n_im)_k
- * with (n_re, n_im)_k = Box-Muller of Philox4x32-10(counter = (first_index + k,
- * stream_id), key = seed).  d_in may be NULL (pure noise).  In-place allowed. */
+ * with (n_re, n_im)_k = Box-Muller (two 32-bit uniforms) of half a Philox4x32-10 block:
+ * absolute index a = first_index + k, counter = (a >> 1, stream_id), key = seed, words
+ * (x0,x1) for even a, (x2,x3) for odd a.  d_in may be NULL (pure noise).  In-place allowed. */
 int wf_awgn_c128(wf_ctx *ctx, const double *d_in_ri, int64_t n, double rot_re, double rot_im,
                  double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
                  double *d_out_ri, void *stream);

@@ -243,23 +243,23 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     memcpy(out, c, sizeof(c));
 }
 
-/* One Philox block per complex sample: counter = (index lo, index hi, stream lo,
- * stream hi), key = (seed lo, seed hi); u1 in (0,1], u2 in [0,1) from 53 bits
- * each; Box-Muller.  out_ri interleaved (re, im).  If `signal_ri` is non-NULL the
- * noise is added to it (the `modulated + noise` of
- * examples/soqpsk_detection.py:89). */
+/* One Philox block per PAIR of complex samples: absolute sample index a -> counter =
+ * (a >> 1 lo, a >> 1 hi, stream lo, stream hi), key = (seed lo, seed hi); the even sample
+ * uses words (x0, x1), the odd one (x2, x3); u1 = (xa + 1) 2^-32 in (0,1], u2 = xb 2^-32 in
+ * [0,1); Box-Muller.  out_ri interleaved (re, im).  If `signal_ri` is non-NULL the noise is
+ * added to it (the `modulated + noise` of examples/soqpsk_detection.py:89). */
 void orc_philox_awgn(double sigma, uint64_t seed, uint64_t stream, uint64_t first_index,
                      int64_t n, const double *signal_ri, double *out_ri)
 {
     for (int64_t k = 0; k < n; ++k) {
         const uint64_t idx = first_index + (uint64_t)k;
-        uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream,
+        const uint64_t pair = idx >> 1;
+        uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)stream,
                          (uint32_t)(stream >> 32)};
         philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        const uint64_t a = ((uint64_t)c[1] << 32) | c[0];
-        const uint64_t b = ((uint64_t)c[3] << 32) | c[2];
-        const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;
-        const double u2 = (double)(b >> 11) * 0x1.0p-53;
+        const uint32_t xa = (idx & 1) ? c[2] : c[0], xb = (idx & 1) ? c[3] : c[1];
+        const double u1 = ((double)xa + 1.0) * 0x1.0p-32;
+        const double u2 = (double)xb * 0x1.0p-32;
         const double r = sigma * sqrt(-2.0 * log(u1));
         const double th = 2.0 * M_PI * u2;
         double re = r * cos(th), im = r * sin(th);

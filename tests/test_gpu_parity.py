@@ -287,6 +287,9 @@ def test_philox_awgn(oracle):
     assert got.dtype == np.complex128
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
     assert st.offset == (1 << 32) - 1000 + 200_001
+    for first, n in ((7, 1), (7, 2), (8, 1), (12345, 4097), (1, 50_000)):     # odd / even starts, ragged ends
+        got = generate_complex_awgn(1.5, n, PhiloxStream(3, 9, first))
+        np.testing.assert_allclose(got, oracle.philox_awgn(1.5, 3, 9, first, n), rtol=0, atol=1e-12)
     # fused derotate + add
     from waveforms_amd import _hip
 
@@ -416,11 +419,11 @@ def test_fused_channel_and_count_equal_stage_kernels(oracle):
     for taps, first in ((pt_matched_filter_taps(pulse, 0.25, 8), 1), (pam_matched_filter_taps(pulse, 0.25, 8), 0)):
         d_taps = _hip.to_device(taps)
         first_, ncols = dev.decimation(n, 8, 2, -first)
-        noisy = dev.awgn(d_sig, n, 0.7, 11, 5, 1000, rot)
+        noisy = dev.awgn(d_sig, n, 0.7, 11, 5, 1001, rot)
         want = _hip.to_host(dev.mf_bank(noisy, d_taps, first_, 8, ncols), complex_pairs=True)
-        got = _hip.to_host(dev.awgn_mf_bank(d_sig, d_taps, first_, 8, ncols, 0.7, 11, 5, 1000, rot), complex_pairs=True)
+        got = _hip.to_host(dev.awgn_mf_bank(d_sig, d_taps, first_, 8, ncols, 0.7, 11, 5, 1001, rot), complex_pairs=True)
         np.testing.assert_array_equal(got, want)            # same arithmetic, same order
-        ref = np.array([np.convolve(sig * rot + oracle.philox_awgn(0.7, 11, 5, 1000, n), t, mode="same")[first_::8][:ncols]
+        ref = np.array([np.convolve(sig * rot + oracle.philox_awgn(0.7, 11, 5, 1001, n), t, mode="same")[first_::8][:ncols]
                         for t in taps]).T
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
     rows = _hip.to_device(want)

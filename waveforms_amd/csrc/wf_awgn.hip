@@ -6,29 +6,38 @@
 // The reference draws from numpy's PCG64 + ziggurat, a sequential generator with a
 // data-dependent number of draws per sample; it cannot be evaluated in parallel, so
 // the host API keeps honouring a caller-supplied numpy Generator (waveforms_amd/noise.py)
-// and THIS kernel is the Monte-Carlo source: one Philox4x32-10 block per complex
-// sample (counter = sample index, stream id; key = seed), two 53-bit uniforms,
-// Box-Muller in fp64.  Counter-based => any shard / chunk of a stream reproduces
+// and THIS kernel is the Monte-Carlo source: one Philox4x32-10 block per PAIR of complex
+// samples (counter = absolute sample index >> 1, stream id; key = seed), two 32-bit
+// uniforms per sample, Box-Muller in fp64 (Gaussian tail to 6.66 sigma).  Counter-based => any shard / chunk of a stream reproduces
 // independently of launch geometry (what the 8-GPU BER sweep relies on).
 // Element-wise, 16 B in + 16 B out per lane: HBM-bound (32 B/sample).
 #include "wf_common.h"
 
-__global__ __launch_bounds__(256) void awgn_kernel(const double *in, int64_t n,
-                                                    double rot_re, double rot_im, double sigma,
-                                                    uint64_t seed, uint64_t stream_id,
+__global__ __launch_bounds__(256) void awgn_kernel(const double *in, int64_t n, double rot_re, double rot_im,
+                                                    double sigma, uint64_t seed, uint64_t stream_id,
                                                     uint64_t first_index, double *out)
 {
+    // one thread per PAIR of absolute sample indices (2P, 2P+1): one Philox block serves both
+    const uint64_t pair0 = first_index >> 1;
+    const int64_t npairs = (int64_t)(((first_index + (uint64_t)n - 1) >> 1) - pair0) + 1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        double nr, ni;
-        wf_gaussian_pair(first_index + (uint64_t)k, stream_id, seed, sigma, &nr, &ni);
-        double re = nr, im = ni;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += stride) {
+        const uint64_t pair = pair0 + (uint64_t)q;
+        const int64_t k0 = (int64_t)(2 * pair - first_index);   // local index of the even sample (may be -1)
+        double2 v0 = make_double2(0.0, 0.0), v1 = v0;
+        const bool ok0 = k0 >= 0, ok1 = k0 + 1 < n;
         if (in) {
-            const double2 v = *reinterpret_cast<const double2 *>(in + 2 * k);
-            re = fma(v.x, rot_re, fma(-v.y, rot_im, nr));
-            im = fma(v.x, rot_im, fma(v.y, rot_re, ni));
+            if (ok0) v0 = *reinterpret_cast<const double2 *>(in + 2 * k0);
+            if (ok1) v1 = *reinterpret_cast<const double2 *>(in + 2 * (k0 + 1));
         }
-        *reinterpret_cast<double2 *>(out + 2 * k) = make_double2(re, im);
+        double g[4];
+        wf_gaussian_two(pair, stream_id, seed, sigma, g);
+        if (ok0)
+            *reinterpret_cast<double2 *>(out + 2 * k0) =
+                make_double2(fma(v0.x, rot_re, fma(-v0.y, rot_im, g[0])), fma(v0.x, rot_im, fma(v0.y, rot_re, g[1])));
+        if (ok1)
+            *reinterpret_cast<double2 *>(out + 2 * (k0 + 1)) =
+                make_double2(fma(v1.x, rot_re, fma(-v1.y, rot_im, g[2])), fma(v1.x, rot_im, fma(v1.y, rot_re, g[3])));
     }
 }
 
@@ -42,7 +51,7 @@ extern "C" int wf_awgn_c128(wf_ctx *ctx, const double *d_in_ri, int64_t n, doubl
                    (reinterpret_cast<uintptr_t>(d_in_ri) & 15) == 0,
                "wf_awgn_c128: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(awgn_kernel, dim3(wf_grid_for(n, 256, 256 * 16)), dim3(256), 0, wf_stream(stream),
+    hipLaunchKernelGGL(awgn_kernel, dim3(wf_grid_for((n + 1) / 2 + 1, 256, 256 * 16)), dim3(256), 0, wf_stream(stream),
                        d_in_ri, n, rot_re, rot_im, sigma, seed, stream_id, first_index, d_out_ri);
     WF_LAUNCH_CHECK();
     return WF_OK;

@@ -190,21 +190,11 @@ __device__ __forceinline__ wf_philox_out wf_philox4x32_10(uint32_t c0, uint32_t 
     return {c0, c1, c2, c3};
 }
 
-__device__ __forceinline__ void wf_gaussian_pair(uint64_t idx, uint64_t stream_id, uint64_t seed,
-                                              double sigma, double *re, double *im)
+// Box-Muller from two 32-bit words: u1 = (xa + 1) 2^-32 in (0, 1], u2 = xb 2^-32 in [0, 1).
+__device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double sigma, double *re, double *im)
 {
-#ifdef WF_ABL_NO_PHILOX   // ablation only: NOT a valid generator
-    const wf_philox_out p = {(uint32_t)idx * 2654435761u, (uint32_t)(idx >> 7) ^ (uint32_t)seed,
-                          (uint32_t)idx * 40503u, (uint32_t)stream_id ^ (uint32_t)idx};
-#else
-    const wf_philox_out p = wf_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id,
-                                       (uint32_t)(stream_id >> 32), (uint32_t)seed,
-                                       (uint32_t)(seed >> 32));
-#endif
-    const uint64_t a = ((uint64_t)p.x1 << 32) | p.x0;
-    const uint64_t b = ((uint64_t)p.x3 << 32) | p.x2;
-    const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;  // (0, 1]
-    const double u2 = (double)(b >> 11) * 0x1.0p-53;        // [0, 1)
+    const double u1 = ((double)xa + 1.0) * 0x1.0p-32;
+    const double u2 = (double)xb * 0x1.0p-32;
 #ifdef WF_ABL_NO_LOG
     const double r = sigma * u1;
 #else
@@ -218,6 +208,23 @@ __device__ __forceinline__ void wf_gaussian_pair(uint64_t idx, uint64_t stream_i
 #endif
     *re = r * c;
     *im = r * s;
+}
+
+// The two complex Gaussian samples with absolute indices 2*pair and 2*pair + 1: ONE
+// Philox4x32-10 block (counter = pair index, stream id; key = seed), words (x0, x1) for the
+// even sample, (x2, x3) for the odd one.  g = {re0, im0, re1, im1}.
+__device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_id, uint64_t seed, double sigma,
+                                                double g[4])
+{
+#ifdef WF_ABL_NO_PHILOX   // ablation only: NOT a valid generator
+    const wf_philox_out p = {(uint32_t)pair * 2654435761u, (uint32_t)(pair >> 7) ^ (uint32_t)seed,
+                             (uint32_t)pair * 40503u, (uint32_t)stream_id ^ (uint32_t)pair};
+#else
+    const wf_philox_out p = wf_philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)stream_id,
+                                             (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+#endif
+    wf_box_muller32(p.x0, p.x1, sigma, &g[0], &g[1]);
+    wf_box_muller32(p.x2, p.x3, sigma, &g[2], &g[3]);
 }
 
 __device__ __forceinline__ uint64_t wf_wave_xor_reduce(uint64_t v)

@@ -44,35 +44,45 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
         const int64_t ws = P.first + k0 * P.step + P.c - (P.ntaps - 1);
         __syncthreads();
         if (NOISE) {
-            // rolled loop (the Gaussian source is ~400 instructions): next sample's load is
-            // in flight while the channel is applied to the current one
-            int q = t / P.step, rem = t - q * P.step;
-            const int dq = MF_THREADS / P.step, dr = MF_THREADS - dq * P.step;
-            auto fetch = [&](int i) {
-                const int64_t s = ws + i;
-                return (i < P.span && s >= 0 && s < P.nsamp) ? *reinterpret_cast<const double2 *>(r + 2 * s)
-                                                              : make_double2(0.0, 0.0);
+            // rolled loop over PAIRS of absolute sample indices (one Philox block per pair; the
+            // Gaussian source is ~400 instructions); the next pair's loads are in flight while
+            // the channel is applied to the current one
+            const int64_t a0 = (int64_t)P.first_index + ws;          // absolute index of the window start
+            const int64_t pair_lo = a0 >> 1;                           // floor, also for negative a0
+            const int npairs = (int)(((a0 + P.span - 1) >> 1) - pair_lo) + 1;
+            auto fetch = [&](int64_t s, int w) {
+                return (w >= 0 && w < P.span && s >= 0 && s < P.nsamp) ? *reinterpret_cast<const double2 *>(r + 2 * s)
+                                                                        : make_double2(0.0, 0.0);
             };
-            double2 cur = fetch(t);
+            int64_t s0 = 2 * (pair_lo + t) - (int64_t)P.first_index;  // sample index of the even half
+            int w0 = (int)(s0 - ws);                                   // its window offset (-1 possible)
+            double2 c0 = fetch(s0, w0), c1 = fetch(s0 + 1, w0 + 1);
 #pragma unroll 1
-            for (int i = t; i < P.span; i += MF_THREADS) {
-                const double2 nxt = fetch(i + MF_THREADS);
-                const int64_t s = ws + i;
-                double2 x = cur;
-                if (s >= 0 && s < P.nsamp) {  // the channel of wf_awgn_c128, on the fly
-                    double nr, ni;
-                    wf_gaussian_pair(P.first_index + (uint64_t)s, P.stream_id, P.seed, P.sigma, &nr, &ni);
-                    x = make_double2(fma(cur.x, P.rot_re, fma(-cur.y, P.rot_im, nr)),
-                                     fma(cur.x, P.rot_im, fma(cur.y, P.rot_re, ni)));
+            for (int i = t; i < npairs; i += MF_THREADS) {
+                const double2 n0 = fetch(s0 + 2 * MF_THREADS, w0 + 2 * MF_THREADS);
+                const double2 n1 = fetch(s0 + 2 * MF_THREADS + 1, w0 + 2 * MF_THREADS + 1);
+                double g[4] = {0.0, 0.0, 0.0, 0.0};
+                const bool v0 = w0 >= 0 && w0 < P.span, v1 = w0 + 1 >= 0 && w0 + 1 < P.span;
+                const bool in0 = s0 >= 0 && s0 < P.nsamp, in1 = s0 + 1 >= 0 && s0 + 1 < P.nsamp;
+                if ((v0 && in0) || (v1 && in1))   // the channel of wf_awgn_c128, on the fly
+                    wf_gaussian_two((uint64_t)(pair_lo + i), P.stream_id, P.seed, P.sigma, g);
+                if (v0) {
+                    const double2 x = in0 ? make_double2(fma(c0.x, P.rot_re, fma(-c0.y, P.rot_im, g[0])),
+                                                         fma(c0.x, P.rot_im, fma(c0.y, P.rot_re, g[1])))
+                                          : make_double2(0.0, 0.0);
+                    s_win[w0 + (P.pad ? w0 / P.step : 0)] = x;
                 }
-                s_win[i + (P.pad ? q : 0)] = x;
-                cur = nxt;
-                q += dq;
-                rem += dr;
-                if (rem >= P.step) {
-                    rem -= P.step;
-                    ++q;
+                if (v1) {
+                    const int w1 = w0 + 1;
+                    const double2 x = in1 ? make_double2(fma(c1.x, P.rot_re, fma(-c1.y, P.rot_im, g[2])),
+                                                         fma(c1.x, P.rot_im, fma(c1.y, P.rot_re, g[3])))
+                                          : make_double2(0.0, 0.0);
+                    s_win[w1 + (P.pad ? w1 / P.step : 0)] = x;
                 }
+                c0 = n0;
+                c1 = n1;
+                s0 += 2 * MF_THREADS;
+                w0 += 2 * MF_THREADS;
             }
         } else {
             // all of this thread's loads are issued before the first one is consumed

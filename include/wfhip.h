@@ -227,6 +227,30 @@ int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_workspace, int64
  * final event. */
 int wf_link_stage_ms(wf_ctx *ctx, int event_slot, float *h_ms);
 
+/* Workspace offsets of a wf_link_run block, for callers that want the intermediates:
+ * info8 = {ncols, 0, off(detected bits), off(detected symbols), off(signal), 0,
+ *          signal samples, off(MF rows)} (offsets in bytes into the workspace). */
+int wf_link_layout(const wf_link_config *cfg, int64_t *info8);
+
+/* ---- streaming link (continuous stream in chunks) -------------------------------
+ * The same chain over a stream of cfg->nsym symbols, `chunk_symbols` detector calls per
+ * call, chunk_index = 0, 1, ... in order on one stream.  Neighbouring context is
+ * re-generated as a halo (PRBS leap-ahead, counter-based noise, one modulator tile of
+ * samples) or carried in `d_state` (WF_LINK_STREAM_STATE_BYTES, zero-initialised before
+ * chunk 0: Viterbi state, encoder state, modulator phase).  Decisions and error counts
+ * equal wf_link_run over the whole stream.  chunk_symbols must be a multiple of the
+ * modulator tile (wf_mod_tile_geometry) and of 128.  Requires the fused modulator. */
+#define WF_LINK_STREAM_STATE_BYTES 512
+int wf_mod_tile_geometry(int sps, int ntaps, int64_t nsym_total, int64_t *tile_len, int64_t *sym_per_tile,
+                         int64_t *ntiles_total);
+int64_t wf_link_stream_workspace_bytes(const wf_link_config *cfg, int64_t chunk_symbols);
+/* info8 = {calls in the chunk, first call index, off(detected bits), off(detected symbols),
+ *          off(signal), global index of signal[0], signal samples resident, off(MF rows)} */
+int wf_link_stream_layout(const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index, int64_t *info8);
+int wf_link_stream_chunk(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
+                         void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
+                         int64_t *h_compared, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

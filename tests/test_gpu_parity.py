@@ -457,3 +457,43 @@ def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
                                    detector=detector, timing_offset=-1 if detector == "PT" else 0)
         assert (se, be, m) == (res["sym_errors"], res["bit_errors"], res["compared"])
         assert be > 0
+
+
+# ------------------------------------------------------------------ streaming (config 5)
+@pytest.mark.parametrize("detector,fuse,chunk", [("PT", 3, 1 << 16), ("PAM", 3, 1 << 15), ("PT", 1, 3 << 14)])
+def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
+    """wf_link_stream_chunk over a stream == wf_link_run over the whole burst: identical
+    modulated samples, matched-filter rows, decisions and error counts."""
+    import torch
+
+    from waveforms_amd.link import SOQPSKLink, SOQPSKStream
+
+    total = 5 * chunk + 4321
+    one = SOQPSKLink(total, 8, detector=detector, fuse=fuse)
+    st = SOQPSKStream(total, chunk, 8, detector=detector, fuse=fuse)
+    assert st.nchunks == 6
+    lay = one.layout()
+    for ebn0 in (2.0, 8.0):
+        one.reset_counts()
+        one.run_block(ebn0, seed=3, stream_id=7)
+        want = one.result()
+        ws = one.workspace
+        calls = lay["calls"]
+        want_bits = ws[lay["off_bits"]:lay["off_bits"] + calls].clone()
+        want_syms = ws[lay["off_syms"]:lay["off_syms"] + calls].clone()
+        want_mf = ws[lay["off_mf"]:lay["off_mf"] + calls * 48].clone()
+        st.reset()
+        seen = 0
+        for c in range(st.nchunks):
+            st.run_chunk(c, ebn0, seed=3, stream_id=7)
+            info = st.chunk_info(c)
+            k0, n = info["first_call"], info["calls"]
+            w = st.workspace
+            assert torch.equal(w[info["off_mf"]:info["off_mf"] + n * 48], want_mf[k0 * 48:(k0 + n) * 48]), c
+            assert torch.equal(w[info["off_bits"]:info["off_bits"] + n], want_bits[k0:k0 + n]), c
+            assert torch.equal(w[info["off_syms"]:info["off_syms"] + n], want_syms[k0:k0 + n]), c
+            seen += n
+        assert seen == calls
+        assert st.result() == want and want[1] > 0
+    with pytest.raises(ValueError):
+        SOQPSKStream(total, 1000, 8)

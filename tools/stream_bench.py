@@ -1,0 +1,43 @@
+"""BASELINE config 5: a continuous SOQPSK-TG stream processed in chunks (wf_link_stream_chunk).
+
+    python tools/stream_bench.py [--total 1e9] [--chunk 4194304] [--ebn0 10] [--detector PT]
+
+HBM use is that of ONE chunk whatever the stream length; prints throughput and the BER.
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--total", type=float, default=1e9)
+    ap.add_argument("--chunk", type=int, default=1 << 22)
+    ap.add_argument("--ebn0", type=float, default=10.0)
+    ap.add_argument("--detector", default="PT")
+    ap.add_argument("--pn-degree", type=int, default=31)
+    a = ap.parse_args()
+    import torch
+
+    from waveforms_amd.link import SOQPSKStream
+
+    st = SOQPSKStream(int(a.total), a.chunk, 8, detector=a.detector, pn_degree=a.pn_degree)
+    st.run_chunk(0, a.ebn0)           # warm-up (allocations, code objects)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    se, be, m = st.run(a.ebn0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"workload": f"SOQPSK-TG continuous stream, {int(a.total):.3g} symbols @8 sps in {st.nchunks} chunks "
+                                  f"of {a.chunk} (PN{a.pn_degree}, {a.detector} detector)",
+                      "Msym_per_s": round(m / dt / 1e6, 1), "seconds": round(dt, 4),
+                      "workspace_GB": round(st.workspace_bytes / 1e9, 3), "symbols": m, "bit_errors": be,
+                      "ber": be / max(m, 1), "ebn0_db": a.ebn0}))
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,11 @@ SIGNATURES = {
     "wf_link_workspace_bytes": (c_int64, [_P]),
     "wf_link_run": (c_int, [_P, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
     "wf_link_stage_ms": (c_int, [_P, c_int, POINTER(ctypes.c_float)]),
+    "wf_link_layout": (c_int, [_P, POINTER(c_int64)]),
+    "wf_mod_tile_geometry": (c_int, [c_int, c_int, c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "wf_link_stream_workspace_bytes": (c_int64, [_P, c_int64]),
+    "wf_link_stream_layout": (c_int, [_P, c_int64, c_int64, POINTER(c_int64)]),
+    "wf_link_stream_chunk": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
 }
 
 

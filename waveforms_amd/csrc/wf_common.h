@@ -64,6 +64,15 @@ int wf_ctx_reserve_scan(wf_ctx *ctx, size_t words);
 int wf_ctx_reserve_fsm(wf_ctx *ctx, size_t words);
 int wf_ctx_reserve_mod(wf_ctx *ctx, size_t words);
 
+// Internal (not exported) forms with device-resident carries, used by the streaming link.
+int wf_cpm_modulate_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total,
+                           const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
+                           int64_t tile_lo, int64_t ntiles, double *d_out_ri, int64_t out_origin,
+                           const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile, void *stream);
+int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, int columns, int states, int card,
+                       const uint8_t *d_bits, int64_t nbits, int64_t i0, int state0, const int *d_state_in,
+                       int8_t *d_symbols, int *h_state_out, int *d_state_at, int64_t at_index, void *stream);
+
 static inline int wf_grid_for(int64_t work_items, int per_block, int max_blocks)
 {
     int64_t b = (work_items + per_block - 1) / per_block;

@@ -124,8 +124,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
 #define ENC_SCAN_THREADS 1024
 __global__ __launch_bounds__(ENC_SCAN_THREADS) void enc_block_scan_kernel(const uint64_t *__restrict__ block_agg,
                                                                            int nblocks, int state0,
+                                                                           const int *__restrict__ state_in,
                                                                            uint8_t *__restrict__ block_state)
 {
+    if (state_in) state0 = *state_in & 15;   // streaming: encoder state carried on the device
     __shared__ uint64_t s_wave[ENC_SCAN_THREADS / WF_WAVE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (nblocks + ENC_SCAN_THREADS - 1) / ENC_SCAN_THREADS;
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(ENC_SCAN_THREADS) void enc_block_scan_kernel(const 
 __global__ __launch_bounds__(ENC_THREADS) void enc_emit_kernel(
     const uint8_t *__restrict__ bits, const uint8_t *__restrict__ tab_next,
     const int8_t *__restrict__ tab_out, enc_params P, const uint64_t *__restrict__ thread_excl,
-    const uint8_t *__restrict__ block_state, int8_t *__restrict__ symbols, int *__restrict__ final_state)
+    const uint8_t *__restrict__ block_state, int8_t *__restrict__ symbols, int *__restrict__ final_state,
+    int *__restrict__ state_at, int64_t at_index)
 {
     __shared__ uint8_t s_next[1024];
     __shared__ int8_t s_out[1024];
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_emit_kernel(
     if (nv == 0) return;
     int st = (int)((thread_excl[gthread] >> (4 * block_state[blockIdx.x])) & 15ull);
     int col = (int)((P.col0 + sym0) % P.columns);
+    if (state_at && sym0 == at_index) *state_at = st;   // encoder state BEFORE symbol at_index
     uint64_t lo = 0, hi = 0;
     for (int k = 0; k < nv; ++k) {
         const int inp = (int)((inps >> (4 * k)) & 15ull);
@@ -189,12 +193,15 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_emit_kernel(
         for (int k = 0; k < nv; ++k)
             symbols[sym0 + k] = (int8_t)(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFF);
     }
-    if (sym0 + nv == P.nsym) *final_state = st;
+    if (sym0 + nv == P.nsym) {
+        *final_state = st;
+        if (state_at && at_index == P.nsym) *state_at = st;
+    }
 }
 
-extern "C" int wf_fsm_encode(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, int columns,
-                             int states, int card, const uint8_t *d_bits, int64_t nbits, int64_t i0,
-                             int state0, int8_t *d_symbols, int *h_state_out, void *stream)
+int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, int columns, int states, int card,
+                       const uint8_t *d_bits, int64_t nbits, int64_t i0, int state0, const int *d_state_in,
+                       int8_t *d_symbols, int *h_state_out, int *d_state_at, int64_t at_index, void *stream)
 {
     WF_REQUIRE(ctx && h_next && h_out, "wf_fsm_encode: NULL argument");
     WF_REQUIRE(columns >= 1 && states >= 1 && states <= 16 && card >= 1 && card <= 4,
@@ -231,12 +238,14 @@ extern "C" int wf_fsm_encode(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h
     hipLaunchKernelGGL(enc_reduce_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
                        ctx->d_tables, P, thread_excl, block_agg);
     WF_LAUNCH_CHECK();
+    WF_REQUIRE(!d_state_at || (at_index >= 0 && at_index <= nsym && at_index % ENC_SYM_PER_THREAD == 0),
+               "wf_fsm_encode: carry index must be a multiple of %d inside the block", ENC_SYM_PER_THREAD);
     hipLaunchKernelGGL(enc_block_scan_kernel, dim3(1), dim3(ENC_SCAN_THREADS), 0, s, block_agg, (int)nblocks,
-                       state0, block_state);
+                       state0, d_state_in, block_state);
     WF_LAUNCH_CHECK();
     hipLaunchKernelGGL(enc_emit_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
                        ctx->d_tables, reinterpret_cast<const int8_t *>(ctx->d_tables + 1024), P,
-                       thread_excl, block_state, d_symbols, ctx->d_small);
+                       thread_excl, block_state, d_symbols, ctx->d_small, d_state_at, at_index);
     WF_LAUNCH_CHECK();
     if (h_state_out) {
         WF_HIP(hipMemcpyAsync(ctx->h_small, ctx->d_small, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -244,6 +253,14 @@ extern "C" int wf_fsm_encode(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h
         *h_state_out = ctx->h_small[0];
     }
     return WF_OK;
+}
+
+extern "C" int wf_fsm_encode(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, int columns,
+                             int states, int card, const uint8_t *d_bits, int64_t nbits, int64_t i0,
+                             int state0, int8_t *d_symbols, int *h_state_out, void *stream)
+{
+    return wf_fsm_encode_core(ctx, h_next, h_out, columns, states, card, d_bits, nbits, i0, state0, nullptr,
+                              d_symbols, h_state_out, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------ a2' mappers

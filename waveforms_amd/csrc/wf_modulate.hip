@@ -31,7 +31,22 @@ struct mod_params {
     int npart;    // symbols partially elapsed at a tile edge
     int nhead;    // symbols whose pulse starts before sample 0
     double sps_d, inv_sps, phi0_turns;
+    // window of a longer stream (all zero / full range for a one-shot burst): symbols[0] is
+    // global symbol sym_origin (nloc of them resident), local tile 0 is global tile tile_lo,
+    // out[0] is global sample out_origin, outputs are written for samples < out_hi
+    int64_t sym_origin, nloc, tile_lo, out_origin, out_hi;
+    int64_t q_out_tile;   // local tile whose carry is exported (-1: none)
 };
+
+// symbol amplitude at GLOBAL 0-based index m (0 outside the burst; the caller guarantees
+// that every index a tile needs inside the burst is resident)
+__device__ __forceinline__ double mod_amp(const int8_t *__restrict__ symbols, const double *__restrict__ hvec,
+                                          const mod_params &P, int64_t m)
+{
+    const int64_t l = m - P.sym_origin;
+    if (m < 0 || m >= P.nsym || l < 0 || l >= P.nloc) return 0.0;
+    return (double)symbols[l] * hvec[P.nh == 1 ? 0 : (int)(m % P.nh)];
+}
 
 // scratch layout (doubles): [0] T, [1] K0, [2 .. 2+MOD_MAX_PART) Gpart, then ntiles tile sums P,
 // then ntiles u64 carries Wq.
@@ -55,12 +70,9 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_tile_sums_kernel(const int8_t
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * MOD_WAVES + (threadIdx.x >> 6);
     if (j >= P.ntiles) return;
-    const int64_t lo = (j - 1) * P.spt - P.dsh;
+    const int64_t lo = (P.tile_lo + j - 1) * P.spt - P.dsh;
     double acc = 0.0;
-    for (int k = lane; k < P.spt; k += WF_WAVE) {
-        const int64_t m = lo + k;
-        if (m >= 0 && m < P.nsym) acc += (double)symbols[m] * hvec[P.nh == 1 ? 0 : (int)(m % P.nh)];
-    }
+    for (int k = lane; k < P.spt; k += WF_WAVE) acc += mod_amp(symbols, hvec, P, lo + k);
 #pragma unroll
     for (int d = WF_WAVE / 2; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, WF_WAVE);
     if (lane == 0) scratch[MOD_OFF_P + j] = acc;
@@ -70,7 +82,9 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_tile_sums_kernel(const int8_t
 __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__restrict__ symbols,
                                                               const double *__restrict__ hvec,
                                                               const double *__restrict__ pulse, mod_params P,
-                                                              double *__restrict__ scratch)
+                                                              double *__restrict__ scratch,
+                                                              const uint64_t *__restrict__ q_in,
+                                                              uint64_t *__restrict__ q_out)
 {
     __shared__ double s_T, s_K0;
     __shared__ uint64_t s_part[1024 / WF_WAVE];
@@ -95,10 +109,7 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
             const int hn = P.c - 1 - k;
             if (hn > 0 && hn % P.sps == 0) {
                 const int64_t mp1 = hn / P.sps;
-                if (mp1 >= 1 && mp1 <= P.nhead && mp1 <= P.nsym) {
-                    const int64_t m = mp1 - 1;
-                    k0 += (double)symbols[m] * hvec[P.nh == 1 ? 0 : (int)(m % P.nh)] * run;
-                }
+                if (mp1 >= 1 && mp1 <= P.nhead && mp1 <= P.nsym) k0 += mod_amp(symbols, hvec, P, mp1 - 1) * run;
             }
         }
         scratch[0] = run;
@@ -112,8 +123,15 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
     uint64_t *Wq = reinterpret_cast<uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
     const int64_t per = (P.ntiles + 1023) / 1024;
     const int64_t j0 = (int64_t)t * per, j1 = min(P.ntiles, j0 + per);
-    auto fixed = [&](int64_t j) {
+    auto fixed_raw = [&](int64_t j) -> uint64_t {
         return (uint64_t)(mod_pos_d(T * Pj[j], P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+    };
+    // a stream window that does not start at tile 0 takes the carry of its FIRST tile from the
+    // previous window (its own P[0] would need symbols that are no longer resident)
+    const bool carried = q_in != nullptr && P.tile_lo > 0;
+    auto fixed = [&](int64_t j) -> uint64_t {
+        if (carried && j == 0) return 0;
+        return fixed_raw(j);
     };
     uint64_t run = 0;
     for (int64_t j = j0; j < j1; ++j) run += fixed(j);
@@ -128,13 +146,22 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
     }
     if (lane == 63) s_part[wave] = inc;
     __syncthreads();
-    uint64_t base = (uint64_t)(mod_pos_d(-s_K0, P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+    uint64_t base = carried ? *q_in : ((uint64_t)(mod_pos_d(-s_K0, P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK);
     for (int w = 0; w < wave; ++w) base += s_part[w];
     run = base + inc - run;   // exclusive prefix of this thread
+    uint64_t exported = 0;
+    bool have = false;
     for (int64_t j = j0; j < j1; ++j) {
         run += fixed(j);
         Wq[j] = run & MOD_MASK;
+        if (j == P.q_out_tile) {
+            exported = run & MOD_MASK;
+            have = true;
+        }
     }
+    // q_in and q_out may be the same word: every read of q_in happened before this barrier
+    __syncthreads();
+    if (have && q_out) *q_out = exported;
 }
 
 #ifndef MOD_MIN_WAVES
@@ -174,19 +201,12 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
     const double *Gpart = scratch + MOD_OFF_GPART;
 
     for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
-        const int64_t tile_base = tile * tile_len;
+        const int64_t tile_g = P.tile_lo + tile;          // global tile index
+        const int64_t tile_base = tile_g * tile_len;      // global sample index
         const int64_t sym_base = tile_base / sps;
         const int64_t mp1_lo = sym_base + cq - JMAX + 1;
         __syncthreads();
-        for (int k = t; k < win; k += MOD_THREADS) {
-            const int64_t mp1 = mp1_lo + k;
-            double a = 0.0;
-            if (mp1 >= 1 && mp1 <= P.nsym) {
-                const int64_t m = mp1 - 1;
-                a = (double)symbols[m] * hvec[P.nh == 1 ? 0 : (int)(m % P.nh)];
-            }
-            s_amp[k] = a;
-        }
+        for (int k = t; k < win; k += MOD_THREADS) s_amp[k] = mod_amp(symbols, hvec, P, mp1_lo + k - 1);
         __syncthreads();
         // frequency pulses of this thread's 2 x ROWS samples, and their row-wise wave scans
         double x0[MOD_ROWS], x1[MOD_ROWS], ex[MOD_ROWS];
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
         // carry into the tile: T*S(m_full) - K0 (fixed point, from the scan kernel) + the
         // symbols still under the pulse at the tile edge
         double carry = 0.0;
-        if (tile > 0) {
+        if (tile_g > 0) {
             carry = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
             // first partial symbol: mp1 = sym_base - D + 1  -> local index in s_amp
             const int lpart = (int)((sym_base - P.dsh + 1) - mp1_lo);
@@ -254,12 +274,14 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                 wf_sincos_turns(fma(ra, P.inv_sps, P.phi0_turns), &s0, &c0);
                 wf_sincos_turns(fma(rb, P.inv_sps, P.phi0_turns), &s1, &c1);
 #endif
-                if (n + 1 < P.out_len) {
-                    double2 *o = reinterpret_cast<double2 *>(out + 2 * n);
-                    o[0] = make_double2(c0, s0);
-                    o[1] = make_double2(c1, s1);
-                } else if (n < P.out_len) {
-                    *reinterpret_cast<double2 *>(out + 2 * n) = make_double2(c0, s0);
+                if (n >= P.out_origin) {   // n is even and so is out_origin: a pair is never split below
+                    double2 *o = reinterpret_cast<double2 *>(out + 2 * (n - P.out_origin));
+                    if (n + 1 < P.out_hi) {
+                        o[0] = make_double2(c0, s0);
+                        o[1] = make_double2(c1, s1);
+                    } else if (n < P.out_hi) {
+                        o[0] = make_double2(c0, s0);
+                    }
                 }
             }
         }
@@ -268,20 +290,11 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
 
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
-extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h,
-                                    int nh, const double *d_pulse, int ntaps, int sps, double phi0,
-                                    double *d_out_ri, void *stream)
+// Geometry shared by the one-shot entry point and the streaming link.
+static bool mod_setup(mod_params &P, int64_t nsym, int nh, int ntaps, int sps, double phi0)
 {
-    WF_REQUIRE(ctx && d_h && d_pulse && d_out_ri, "wf_cpm_modulate_c128: NULL argument");
-    WF_REQUIRE(nsym >= 0 && (nsym == 0 || d_symbols), "wf_cpm_modulate_c128: bad symbols");
-    WF_REQUIRE(sps >= 2 || nsym == 0, "could not broadcast input array from shape (%lld,) into shape (%lld,)",
-               (long long)nsym, (long long)(nsym - 1));
-    WF_REQUIRE(sps >= 1 && sps <= 256 && nh >= 1 && ntaps >= 1, "wf_cpm_modulate_c128: sps %d nh %d ntaps %d", sps, nh, ntaps);
-    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0, "wf_cpm_modulate_c128: d_out alignment");
-    WF_HIP(hipSetDevice(ctx->device));
     const int64_t npts = (nsym + 1) * (int64_t)sps;
     const int J = (ntaps + sps - 1) / sps;
-    mod_params P;
     P.nsym = nsym;
     P.out_len = npts >= ntaps ? npts : ntaps;
     P.c = (int)(((npts >= ntaps ? (int64_t)ntaps : npts) - 1) / 2);
@@ -301,10 +314,21 @@ extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_
     P.sps_d = (double)sps;
     P.inv_sps = 1.0 / (double)sps;
     P.phi0_turns = phi0 / (2.0 * M_PI);
+    P.sym_origin = 0;
+    P.nloc = nsym;
+    P.tile_lo = 0;
+    P.out_origin = 0;
+    P.out_hi = P.out_len;
+    P.q_out_tile = -1;
     // the analytic carry needs: pulse no longer than the signal, J within the register
     // budget, and every head / partial symbol of a tile edge inside the staged window
-    const bool fused_ok = npts >= ntaps && J <= 33 && P.npart <= MOD_MAX_PART && P.spt >= P.dsh + J + P.nhead + 2;
-    if (!fused_ok) return 1;  // caller falls back to wf_upsample_fir_f64 + wf_phase_cexp_f64
+    return npts >= ntaps && J <= 33 && P.npart <= MOD_MAX_PART && P.spt >= P.dsh + J + P.nhead + 2;
+}
+
+static int mod_launch(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols, const double *d_h,
+                      const double *d_pulse, double *d_out_ri, const uint64_t *d_q_in, uint64_t *d_q_out, void *stream)
+{
+    const int J = (P.ntaps + P.sps - 1) / P.sps;
     hipStream_t s = wf_stream(stream);
     const size_t words = (size_t)MOD_OFF_P + 2 * (size_t)P.ntiles + 8;
     int rc = wf_ctx_reserve_mod(ctx, words);
@@ -313,9 +337,10 @@ extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_
     hipLaunchKernelGGL(mod_tile_sums_kernel, dim3((unsigned)((P.ntiles + MOD_WAVES - 1) / MOD_WAVES)), dim3(MOD_THREADS),
                        0, s, d_symbols, d_h, P, scratch);
     WF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mod_tile_scan_kernel, dim3(1), dim3(1024), 0, s, d_symbols, d_h, d_pulse, P, scratch);
+    hipLaunchKernelGGL(mod_tile_scan_kernel, dim3(1), dim3(1024), 0, s, d_symbols, d_h, d_pulse, P, scratch, d_q_in, d_q_out);
     WF_LAUNCH_CHECK();
     const int grid = (int)(P.ntiles < 2048 ? P.ntiles : 2048);
+    const int sps = P.sps;
 #define MOD_LAUNCH(JM)                                                                              \
     hipLaunchKernelGGL(mod_main_kernel<JM>, dim3(grid), dim3(MOD_THREADS),                          \
                        (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2) * sizeof(double), s, d_symbols, d_h, \
@@ -327,4 +352,57 @@ extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_
 #undef MOD_LAUNCH
     WF_LAUNCH_CHECK();
     return WF_OK;
+}
+
+extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h,
+                                    int nh, const double *d_pulse, int ntaps, int sps, double phi0,
+                                    double *d_out_ri, void *stream)
+{
+    WF_REQUIRE(ctx && d_h && d_pulse && d_out_ri, "wf_cpm_modulate_c128: NULL argument");
+    WF_REQUIRE(nsym >= 0 && (nsym == 0 || d_symbols), "wf_cpm_modulate_c128: bad symbols");
+    WF_REQUIRE(sps >= 2 || nsym == 0, "could not broadcast input array from shape (%lld,) into shape (%lld,)",
+               (long long)nsym, (long long)(nsym - 1));
+    WF_REQUIRE(sps >= 1 && sps <= 256 && nh >= 1 && ntaps >= 1, "wf_cpm_modulate_c128: sps %d nh %d ntaps %d", sps, nh, ntaps);
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0, "wf_cpm_modulate_c128: d_out alignment");
+    WF_HIP(hipSetDevice(ctx->device));
+    mod_params P;
+    if (!mod_setup(P, nsym, nh, ntaps, sps, phi0)) return 1;  // caller falls back to the two stage kernels
+    return mod_launch(ctx, P, d_symbols, d_h, d_pulse, d_out_ri, nullptr, nullptr, stream);
+}
+
+// Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total
+// symbols.  d_symbols[0] is global symbol sym_origin (nloc resident), d_out_ri[0] is global sample
+// out_origin.  The phase carry of the window's first tile comes from *d_q_in (ignored when tile_lo == 0)
+// and the carry of local tile q_out_tile goes to *d_q_out (same word allowed).
+int wf_cpm_modulate_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total,
+                           const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
+                           int64_t tile_lo, int64_t ntiles, double *d_out_ri, int64_t out_origin,
+                           const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile, void *stream)
+{
+    WF_HIP(hipSetDevice(ctx->device));
+    mod_params P;
+    WF_REQUIRE(mod_setup(P, nsym_total, nh, ntaps, sps, phi0), "wf_cpm_modulate_window: configuration outside the fused kernel");
+    const int64_t tile_len = (int64_t)MOD_ROWS * P.rs;
+    WF_REQUIRE(tile_lo >= 0 && ntiles >= 1 && tile_lo + ntiles <= P.ntiles && out_origin == tile_lo * tile_len,
+               "wf_cpm_modulate_window: bad tile window");
+    P.sym_origin = sym_origin;
+    P.nloc = nloc;
+    P.tile_lo = tile_lo;
+    P.ntiles = ntiles;
+    P.out_origin = out_origin;
+    const int64_t hi = (tile_lo + ntiles) * tile_len;
+    P.out_hi = hi < P.out_len ? hi : P.out_len;
+    P.q_out_tile = q_out_tile;
+    return mod_launch(ctx, P, d_symbols, d_h, d_pulse, d_out_ri, d_q_in, d_q_out, stream);
+}
+
+extern "C" int wf_mod_tile_geometry(int sps, int ntaps, int64_t nsym_total, int64_t *tile_len, int64_t *sym_per_tile,
+                                    int64_t *ntiles_total)
+{
+    mod_params P;
+    const bool ok = mod_setup(P, nsym_total, 1, ntaps, sps, 0.0);
+    if (tile_len) *tile_len = (int64_t)MOD_ROWS * P.rs;
+    if (sym_per_tile) *sym_per_tile = P.spt;
+    if (ntiles_total) *ntiles_total = P.ntiles;
+    return ok ? 0 : 1;
 }

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
     uint64_t *desc = scan + PH_DESC0;
 
     for (long long iter_ = 0;; ++iter_) {
+        (void)iter_;
         __syncthreads();  // previous iteration's LDS reads are done
 #ifdef WF_ABL_NO_TICKET    // ablation only: static tile order (can deadlock in general)
         if (t == 0) s_tile = (long long)blockIdx.x + (long long)gridDim.x * iter_;

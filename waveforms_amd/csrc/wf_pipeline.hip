@@ -180,3 +180,162 @@ extern "C" int wf_link_stage_ms(wf_ctx *ctx, int event_slot, float *h_ms)
     for (int k = 0; k < WF_LINK_STAGES; ++k) WF_HIP(hipEventElapsedTime(&h_ms[k], ev[k], ev[k + 1]));
     return WF_OK;
 }
+
+extern "C" int wf_link_layout(const wf_link_config *cfg, int64_t *info8)
+{
+    if (!cfg || !info8 || cfg->nsym < 1 || cfg->sps < 1) return WF_ERR_VALUE;
+    const link_layout L = make_layout(cfg->nsym, cfg->sps, cfg->ntaps, cfg->mf_nfilt, 2, cfg->timing_offset);
+    info8[0] = L.ncols; info8[1] = 0; info8[2] = (int64_t)L.off_dbits; info8[3] = (int64_t)L.off_dsyms;
+    info8[4] = (int64_t)L.off_sig; info8[5] = 0; info8[6] = L.npts; info8[7] = (int64_t)L.off_mf;
+    return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming link (BASELINE config 5): the same chain over a stream of cfg->nsym symbols, one
+// chunk of `chunk_symbols` detector calls per call.  Chunk c detects calls [c*B, (c+1)*B);
+// what it needs from its neighbours comes from (a) re-generating a halo — PRBS by
+// leap-ahead, noise by absolute counter, one modulator tile of samples and sym_per_tile + 48
+// symbols on either side — and (b) a 512-byte device-resident carry block: Viterbi state
+// (32 doubles), encoder state at the next window start, modulator phase carry (62-bit
+// fixed point) of the next window's first tile.  Decisions and counts equal the one-shot
+// wf_link_run over the whole stream.
+struct stream_layout {
+    int64_t N, B, c, tile_len, spt, ntiles_total, halo, npts, ncols_total, first, m_total;
+    int64_t k_lo, ncols, ws, nloc, tile_lo, ntiles, out_origin, local_len, ws_next, q_out_tile;
+    size_t off_bits, off_syms, off_sig, off_mf, off_dbits, off_dsyms, total;
+    bool ok;
+};
+
+static stream_layout make_stream_layout(const wf_link_config *cfg, int64_t B, int64_t c)
+{
+    stream_layout S;
+    const int length = 2;
+    S.N = cfg->nsym; S.B = B; S.c = c;
+    S.ok = wf_mod_tile_geometry(cfg->sps, cfg->ntaps, cfg->nsym, &S.tile_len, &S.spt, &S.ntiles_total) == 0;
+    S.halo = round_up(S.spt + 48, 16);
+    S.npts = wf_fir_out_len(S.N, cfg->sps, cfg->ntaps);
+    const int64_t limit = S.npts - (int64_t)length * cfg->sps;
+    int64_t first = (-(int64_t)cfg->timing_offset) % cfg->sps;
+    if (first < 0) first += cfg->sps;
+    S.first = first;
+    S.ncols_total = limit > first ? (limit - first + cfg->sps - 1) / cfg->sps : 0;
+    S.m_total = S.ncols_total - length < S.N ? S.ncols_total - length : S.N;
+    if (S.m_total < 0) S.m_total = 0;
+    S.ok = S.ok && B > 0 && B % S.spt == 0 && B % 128 == 0 && B >= 4 * S.halo &&
+           S.tile_len >= cfg->mf_ntaps + 2 * cfg->sps;
+    S.k_lo = c * B;
+    const int64_t k_hi = S.k_lo + B < S.ncols_total ? S.k_lo + B : S.ncols_total;
+    S.ncols = k_hi > S.k_lo ? k_hi - S.k_lo : 0;
+    S.ws = c * B - S.halo > 0 ? c * B - S.halo : 0;
+    const int64_t we = (c + 1) * B + S.halo < S.N ? (c + 1) * B + S.halo : S.N;
+    S.nloc = we > S.ws ? we - S.ws : 0;
+    S.tile_lo = S.spt > 0 && c * B / S.spt - 1 > 0 ? c * B / S.spt - 1 : 0;
+    int64_t tile_hi = S.spt > 0 ? (c + 1) * B / S.spt + 1 : 0;
+    if (tile_hi > S.ntiles_total) tile_hi = S.ntiles_total;
+    S.ntiles = tile_hi > S.tile_lo ? tile_hi - S.tile_lo : 0;
+    S.out_origin = S.tile_lo * S.tile_len;
+    const int64_t hi = tile_hi * S.tile_len < S.npts ? tile_hi * S.tile_len : S.npts;
+    S.local_len = hi > S.out_origin ? hi - S.out_origin : 0;
+    S.ws_next = (c + 1) * B - S.halo > 0 ? (c + 1) * B - S.halo : 0;
+    const int64_t next_tile_lo = S.spt > 0 ? (c + 1) * B / S.spt - 1 : 0;
+    S.q_out_tile = (next_tile_lo >= S.tile_lo && next_tile_lo < tile_hi) ? next_tile_lo - S.tile_lo : -1;
+    size_t o = 0;
+    const int64_t win = B + 2 * S.halo + 32;
+    S.off_bits = o;  o += (size_t)round_up(win, 256);
+    S.off_syms = o;  o += (size_t)round_up(win, 256);
+    S.off_sig = o;   o += (size_t)round_up((B * cfg->sps + 2 * S.tile_len) * 16, 256);
+    S.off_mf = o;    o += (size_t)round_up(B * cfg->mf_nfilt * 16, 256);
+    S.off_dbits = o; o += (size_t)round_up(B + 16, 256);
+    S.off_dsyms = o; o += (size_t)round_up(B + 16, 256);
+    S.total = o;
+    return S;
+}
+
+extern "C" int64_t wf_link_stream_workspace_bytes(const wf_link_config *cfg, int64_t chunk_symbols)
+{
+    if (!cfg || cfg->nsym < 1 || cfg->sps < 2) return -1;
+    const stream_layout S = make_stream_layout(cfg, chunk_symbols, 0);
+    return S.ok ? (int64_t)S.total : -1;
+}
+
+extern "C" int wf_link_stream_layout(const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index, int64_t *info8)
+{
+    if (!cfg || !info8 || cfg->nsym < 1 || cfg->sps < 2) return WF_ERR_VALUE;
+    const stream_layout S = make_stream_layout(cfg, chunk_symbols, chunk_index);
+    if (!S.ok) return WF_ERR_VALUE;
+    info8[0] = S.ncols; info8[1] = S.k_lo; info8[2] = (int64_t)S.off_dbits; info8[3] = (int64_t)S.off_dsyms;
+    info8[4] = (int64_t)S.off_sig; info8[5] = S.out_origin; info8[6] = S.local_len; info8[7] = (int64_t)S.off_mf;
+    return WF_OK;
+}
+
+extern "C" int wf_link_stream_chunk(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
+                                    void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
+                                    int64_t *h_compared, void *stream)
+{
+    WF_REQUIRE(ctx && cfg && d_state && d_workspace && d_counts, "wf_link_stream_chunk: NULL argument");
+    WF_REQUIRE(cfg->nsym >= 1 && cfg->sps >= 2 && cfg->mf_nfilt == 3 && chunk_index >= 0, "wf_link_stream_chunk: bad configuration");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_workspace) & 255) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
+               "wf_link_stream_chunk: workspace must be 256-byte aligned");
+    const int length = 2;
+    const stream_layout S = make_stream_layout(cfg, chunk_symbols, chunk_index);
+    WF_REQUIRE(S.ok, "wf_link_stream_chunk: chunk of %lld symbols is not a multiple of the modulator tile (%lld symbols) "
+               "and of 128, is shorter than 4 halos, or the pulse is outside the fused modulator",
+               (long long)chunk_symbols, (long long)S.spt);
+    WF_REQUIRE((int64_t)S.total <= workspace_bytes, "wf_link_stream_chunk: workspace too small");
+    if (h_compared) *h_compared = 0;
+    if (S.ncols == 0) return WF_OK;
+    char *w = static_cast<char *>(d_workspace);
+    uint8_t *bits = reinterpret_cast<uint8_t *>(w + S.off_bits);
+    int8_t *syms = reinterpret_cast<int8_t *>(w + S.off_syms);
+    double *sig = reinterpret_cast<double *>(w + S.off_sig);
+    double *mf = reinterpret_cast<double *>(w + S.off_mf);
+    uint8_t *dbits = reinterpret_cast<uint8_t *>(w + S.off_dbits);
+    int8_t *dsyms = reinterpret_cast<int8_t *>(w + S.off_dsyms);
+    char *carry = static_cast<char *>(d_state);
+    double *vit_state = reinterpret_cast<double *>(carry);
+    int *enc_state = reinterpret_cast<int *>(carry + 256);
+    uint64_t *q_phase = reinterpret_cast<uint64_t *>(carry + 264);
+
+    uint8_t next[2][4][2];
+    int8_t outp[2][4][2];
+    static const int8_t kOut[2][8] = {{0, 2, 0, -2, -2, 0, 2, 0}, {0, -2, 2, 0, 0, 2, -2, 0}};
+    for (int c = 0; c < 2; ++c)
+        for (int b = 0; b < 8; ++b) {
+            const int s = b >> 1;
+            const int e = c == 0 ? (s & 1) + 2 * (b & 1) : (s & 2) + (b & 1);
+            const int flip = cfg->differential ? (c == 0 ? (s >> 1) : (s & 1)) : 0;
+            next[c][s][(b & 1) ^ flip] = (uint8_t)e;
+            outp[c][s][(b & 1) ^ flip] = kOut[c][b];
+        }
+    int rc;
+    if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip + (uint64_t)S.ws, bits, S.nloc, nullptr, stream))) return rc;
+    const int64_t at = S.ws_next - S.ws;
+    if ((rc = wf_fsm_encode_core(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, S.nloc, S.ws, 0, enc_state, syms, nullptr,
+                                 at <= S.nloc ? enc_state : nullptr, at, stream))) return rc;
+    if ((rc = wf_cpm_modulate_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4,
+                                     S.tile_lo, S.ntiles, sig, S.out_origin, q_phase, q_phase, S.q_out_tile, stream))) return rc;
+    const double rot_re = cos(-M_PI / 4), rot_im = sin(-M_PI / 4);
+    const int64_t first_local = S.first + S.k_lo * cfg->sps - S.out_origin;
+    if (cfg->fuse & 2) {
+        rc = wf_awgn_mf_bank_c128(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
+                                  (uint64_t)S.out_origin, cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, first_local, cfg->sps,
+                                  S.ncols, mf, stream);
+    } else {
+        if ((rc = wf_awgn_c128(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
+                               (uint64_t)S.out_origin, sig, stream))) return rc;
+        rc = wf_mf_bank_c128(ctx, sig, S.local_len, cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, first_local, cfg->sps, S.ncols,
+                             mf, stream);
+    }
+    if (rc) return rc;
+    if ((rc = wf_viterbi4_detect(ctx, mf, S.ncols, cfg->differential, cfg->warmup, dbits, dsyms, vit_state, stream))) return rc;
+    // decision of call k is compared with symbol k - length (examples/soqpsk_detection.py:201-209)
+    const int64_t j0 = S.k_lo >= length ? 0 : length - S.k_lo;
+    int64_t ncmp = S.ncols - j0;
+    const int64_t sym0 = S.k_lo + j0 - length;            // global index of the first reference symbol
+    if (ncmp > S.m_total - sym0) ncmp = S.m_total - sym0;
+    if (ncmp > 0) {
+        if ((rc = wf_count_errors(ctx, dsyms + j0, syms + (sym0 - S.ws), dbits + j0, bits + (sym0 - S.ws), ncmp, d_counts, stream))) return rc;
+        if (h_compared) *h_compared = ncmp;
+    }
+    return WF_OK;
+}

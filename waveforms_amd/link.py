@@ -24,9 +24,18 @@ def sigma_for_ebn0(ebn0_db: float, sps: int) -> float:
 
 
 class SOQPSKLink:
-    def __init__(self, nsym: int, sps: int = 8, pulse=None, mod_index: float = 0.25, detector: str = "PT",
-                 pn_degree: int = 23, differential: bool = True, timing_offset: int | None = None,
-                 warmup: int = 0, fuse: int = 3, private_ctx: bool = False) -> None:
+    def __init__(self, nsym: int, sps: int = 8, **kw) -> None:
+        self._configure(nsym, sps, **kw)
+        self.workspace_bytes = _hip.lib().wf_link_workspace_bytes(ctypes.byref(self.cfg))
+        if self.workspace_bytes < 0:
+            raise ValueError("invalid link configuration")
+        self.workspace = _hip.empty(self.workspace_bytes, "uint8")
+        self.counts = _hip.zeros(2, "int64")
+        self.compared = 0
+
+    def _configure(self, nsym: int, sps: int = 8, pulse=None, mod_index: float = 0.25, detector: str = "PT",
+                   pn_degree: int = 23, differential: bool = True, timing_offset: int | None = None,
+                   warmup: int = 0, fuse: int = 3, private_ctx: bool = False) -> None:
         self.nsym, self.sps = int(nsym), int(sps)
         # a link that runs on its own stream next to other links needs its own scratch
         self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()
@@ -55,12 +64,13 @@ class SOQPSKLink:
         cfg.event_slot = -1
         cfg.fuse = int(fuse)
         self.cfg = cfg
-        self.workspace_bytes = _hip.lib().wf_link_workspace_bytes(ctypes.byref(cfg))
-        if self.workspace_bytes < 0:
-            raise ValueError("invalid link configuration")
-        self.workspace = _hip.empty(self.workspace_bytes, "uint8")
-        self.counts = _hip.zeros(2, "int64")
-        self.compared = 0
+
+    def layout(self) -> dict:
+        """Byte offsets of the intermediates inside ``self.workspace``."""
+        info = (ctypes.c_int64 * 8)()
+        _hip.check(_hip.lib().wf_link_layout(ctypes.byref(self.cfg), info))
+        keys = ("calls", "first_call", "off_bits", "off_syms", "off_signal", "signal_origin", "signal_len", "off_mf")
+        return dict(zip(keys, (int(v) for v in info)))
 
     def reset_counts(self) -> None:
         self.counts.zero_()
@@ -89,6 +99,70 @@ class SOQPSKLink:
 
     def result(self) -> tuple[int, int, int]:
         """(symbol errors, bit errors, symbols compared) — synchronises."""
+        _hip.check(_hip.lib().wf_ctx_check(self._ctx, _hip.stream()))
+        se, be = (int(v) for v in self.counts.cpu().tolist())
+        return se, be, self.compared
+
+
+class SOQPSKStream:
+    """The same chain over a continuous stream of ``total_symbols`` symbols, processed in
+    chunks of ``chunk_symbols`` detector calls (``wf_link_stream_chunk``; BASELINE config 5).
+    Neighbouring context is re-generated as a halo or carried in a 512-byte device block;
+    decisions and error counts equal a one-shot :class:`SOQPSKLink` over the whole stream,
+    while HBM use is that of one chunk."""
+
+    def __init__(self, total_symbols: int, chunk_symbols: int, sps: int = 8, **kw) -> None:
+        # reuse the link's configuration (taps, pulse, PRBS ...) without its one-shot workspace
+        self._proto = SOQPSKLink.__new__(SOQPSKLink)
+        SOQPSKLink._configure(self._proto, int(total_symbols), sps, **kw)
+        self.cfg, self._ctx, self.sps = self._proto.cfg, self._proto._ctx, int(sps)
+        self.total_symbols, self.chunk_symbols = int(total_symbols), int(chunk_symbols)
+        lib = _hip.lib()
+        nbytes = lib.wf_link_stream_workspace_bytes(ctypes.byref(self.cfg), self.chunk_symbols)
+        if nbytes < 0:
+            tl, spt, nt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+            lib.wf_mod_tile_geometry(self.sps, self.cfg.ntaps, self.total_symbols, ctypes.byref(tl), ctypes.byref(spt),
+                                     ctypes.byref(nt))
+            raise ValueError(f"chunk_symbols must be a multiple of {spt.value} (one modulator tile) and of 128, and at "
+                             f"least {4 * (spt.value + 48)}")
+        self.workspace_bytes = nbytes
+        self.workspace = _hip.empty(nbytes, "uint8")
+        self.state = _hip.zeros(64, "float64")          # WF_LINK_STREAM_STATE_BYTES = 512
+        self.counts = _hip.zeros(2, "int64")
+        self.compared = 0
+        info = (ctypes.c_int64 * 8)()
+        _hip.check(lib.wf_link_layout(ctypes.byref(self.cfg), info))
+        self.total_calls = int(info[0])
+        self.nchunks = -(-self.total_calls // self.chunk_symbols)
+
+    def reset(self) -> None:
+        self.state.zero_()
+        self.counts.zero_()
+        self.compared = 0
+
+    def chunk_info(self, c: int) -> dict:
+        info = (ctypes.c_int64 * 8)()
+        _hip.check(_hip.lib().wf_link_stream_layout(ctypes.byref(self.cfg), self.chunk_symbols, c, info))
+        keys = ("calls", "first_call", "off_bits", "off_syms", "off_signal", "signal_origin", "signal_len", "off_mf")
+        return dict(zip(keys, (int(v) for v in info)))
+
+    def run_chunk(self, c: int, ebn0_db: float, seed: int = 1, stream_id: int = 0) -> None:
+        cfg = self.cfg
+        cfg.sigma, cfg.seed, cfg.stream_id, cfg.event_slot = sigma_for_ebn0(ebn0_db, self.sps), seed, stream_id, -1
+        m = ctypes.c_int64(0)
+        _hip.check(_hip.lib().wf_link_stream_chunk(self._ctx, ctypes.byref(cfg), self.chunk_symbols, c,
+                                                   self.state.data_ptr(), self.workspace.data_ptr(), self.workspace_bytes,
+                                                   self.counts.data_ptr(), ctypes.byref(m), _hip.stream()))
+        self.compared += m.value
+
+    def run(self, ebn0_db: float, seed: int = 1, stream_id: int = 0) -> tuple[int, int, int]:
+        """All chunks in order; returns (symbol errors, bit errors, symbols compared)."""
+        self.reset()
+        for c in range(self.nchunks):
+            self.run_chunk(c, ebn0_db, seed, stream_id)
+        return self.result()
+
+    def result(self) -> tuple[int, int, int]:
         _hip.check(_hip.lib().wf_ctx_check(self._ctx, _hip.stream()))
         se, be = (int(v) for v in self.counts.cpu().tolist())
         return se, be, self.compared

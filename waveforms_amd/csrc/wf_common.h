@@ -48,6 +48,8 @@ struct wf_ctx {
     unsigned *d_fault = nullptr;
     unsigned *h_fault = nullptr;  // pinned
     uint8_t *d_tables = nullptr;  // small table upload area (fsm encode)
+    uint8_t h_tables_cache[2048] = {0};  // what d_tables currently holds (uploads are skipped when unchanged)
+    int tables_cached = 0;
     uint64_t *d_fsm_scratch = nullptr;
     size_t fsm_scratch_words = 0;
     int *h_small = nullptr;  // pinned, small D2H results

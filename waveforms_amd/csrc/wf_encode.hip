@@ -7,6 +7,8 @@
 //    (one small kernel), then every thread re-walks its 16 symbols from its now known
 //    start state and emits them.  Integer path, bit-exact.
 //  * wf_symbol_map: the element-wise precoder / mappers (a2').
+#include <string.h>
+
 #include "wf_common.h"
 
 #define ENC_THREADS 256
@@ -232,8 +234,15 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
     uint64_t *block_agg = thread_excl + (size_t)nblocks * ENC_THREADS;
     uint8_t *block_state = reinterpret_cast<uint8_t *>(block_agg + nblocks);
     // tables: next at d_tables[0..1023], out at d_tables[1024..2047]
-    WF_HIP(hipMemcpyAsync(ctx->d_tables, h_next, tabn, hipMemcpyHostToDevice, s));
-    WF_HIP(hipMemcpyAsync(ctx->d_tables + 1024, h_out, tabn, hipMemcpyHostToDevice, s));
+    // the tables rarely change between calls: upload only when they differ from what the
+    // context already holds on the device
+    if (ctx->tables_cached != tabn || memcmp(ctx->h_tables_cache, h_next, tabn) != 0 ||
+        memcmp(ctx->h_tables_cache + 1024, h_out, tabn) != 0) {
+        memcpy(ctx->h_tables_cache, h_next, tabn);
+        memcpy(ctx->h_tables_cache + 1024, h_out, tabn);
+        ctx->tables_cached = tabn;
+        WF_HIP(hipMemcpyAsync(ctx->d_tables, ctx->h_tables_cache, 2048, hipMemcpyHostToDevice, s));
+    }
     enc_params P{columns, states, card, ninp, (int)(i0 % columns), state0, nsym};
     hipLaunchKernelGGL(enc_reduce_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
                        ctx->d_tables, P, thread_excl, block_agg);

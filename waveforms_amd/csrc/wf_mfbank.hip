@@ -31,17 +31,19 @@ struct mf_params {
     uint64_t seed, stream_id, first_index;
 };
 
-template <int NF, bool NOISE>
+template <int NF, bool NOISE, int STEP>   // STEP: compile-time decimation (0 = take P.step)
 __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__restrict__ r,
                                                               const double *__restrict__ taps,
                                                               double *__restrict__ out, mf_params P)
 {
     extern __shared__ double2 s_win[];
     const int t = threadIdx.x;
+    const int step = STEP ? STEP : P.step;
+    const int pad = STEP ? (STEP % 2 == 0) : P.pad;
     for (int64_t blk = blockIdx.x; blk < P.nblk; blk += gridDim.x) {
         const int64_t k0 = blk * P.ob;
         // first input sample of the span: oldest sample of output k0
-        const int64_t ws = P.first + k0 * P.step + P.c - (P.ntaps - 1);
+        const int64_t ws = P.first + k0 * step + P.c - (P.ntaps - 1);
         __syncthreads();
         if (NOISE) {
             // rolled loop over PAIRS of absolute sample indices (one Philox block per pair; the
@@ -51,8 +53,12 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
             const int64_t pair_lo = a0 >> 1;                           // floor, also for negative a0
             const int npairs = (int)(((a0 + P.span - 1) >> 1) - pair_lo) + 1;
             auto fetch = [&](int64_t s, int w) {
+#ifdef WF_ABL_NO_MEM   // ablation only: no global traffic
+                return make_double2((double)s, (double)w);
+#else
                 return (w >= 0 && w < P.span && s >= 0 && s < P.nsamp) ? *reinterpret_cast<const double2 *>(r + 2 * s)
                                                                         : make_double2(0.0, 0.0);
+#endif
             };
             int64_t s0 = 2 * (pair_lo + t) - (int64_t)P.first_index;  // sample index of the even half
             int w0 = (int)(s0 - ws);                                   // its window offset (-1 possible)
@@ -70,14 +76,14 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                     const double2 x = in0 ? make_double2(fma(c0.x, P.rot_re, fma(-c0.y, P.rot_im, g[0])),
                                                          fma(c0.x, P.rot_im, fma(c0.y, P.rot_re, g[1])))
                                           : make_double2(0.0, 0.0);
-                    s_win[w0 + (P.pad ? w0 / P.step : 0)] = x;
+                    s_win[w0 + (pad ? w0 / step : 0)] = x;
                 }
                 if (v1) {
                     const int w1 = w0 + 1;
                     const double2 x = in1 ? make_double2(fma(c1.x, P.rot_re, fma(-c1.y, P.rot_im, g[2])),
                                                          fma(c1.x, P.rot_im, fma(c1.y, P.rot_re, g[3])))
                                           : make_double2(0.0, 0.0);
-                    s_win[w1 + (P.pad ? w1 / P.step : 0)] = x;
+                    s_win[w1 + (pad ? w1 / step : 0)] = x;
                 }
                 c0 = n0;
                 c1 = n1;
@@ -95,16 +101,16 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 v[u] = make_double2(0.0, 0.0);
                 if (i < P.span && s >= 0 && s < P.nsamp) v[u] = *reinterpret_cast<const double2 *>(r + 2 * s);
             }
-            int q = t / P.step, rem = t - q * P.step;
-            const int dq = MF_THREADS / P.step, dr = MF_THREADS - dq * P.step;
+            int q = t / step, rem = t - q * step;
+            const int dq = MF_THREADS / step, dr = MF_THREADS - dq * step;
 #pragma unroll
             for (int u = 0; u < MF_MAXI; ++u) {
                 const int i = t + u * MF_THREADS;
-                if (i < P.span) s_win[i + (P.pad ? q : 0)] = v[u];
+                if (i < P.span) s_win[i + (pad ? q : 0)] = v[u];
                 q += dq;
                 rem += dr;
-                if (rem >= P.step) {
-                    rem -= P.step;
+                if (rem >= step) {
+                    rem -= step;
                     ++q;
                 }
             }
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
 #pragma unroll
             for (int f = 0; f < NF; ++f) ar[f] = ai[f] = 0.0;
             // window offset j = 0 is the OLDEST sample => tap index ntaps-1-j
-            const int base = t * (P.step + P.pad);
+            const int base = t * (step + pad);
             int extra = 0, jm = 0;
             for (int j = 0; j < P.ntaps; ++j) {
                 const double2 x = s_win[base + j + extra];
@@ -130,12 +136,15 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                         ai[f] = fma(x.x, ti, fma(x.y, tr, ai[f]));
                     }
                 }
-                if (++jm == P.step) {
+                if (++jm == step) {
                     jm = 0;
-                    extra += P.pad;
+                    extra += pad;
                 }
             }
             double2 *o = reinterpret_cast<double2 *>(out + 2 * (k * P.nfilt));
+#ifdef WF_ABL_NO_MEM
+            if (ar[0] == 1.2345e300)
+#endif
 #pragma unroll
             for (int f = 0; f < NF; ++f)
                 if (f < P.nfilt) o[f] = make_double2(ar[f], ai[f]);
@@ -193,8 +202,10 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     hipStream_t s = wf_stream(stream);
     const size_t lds = (size_t)slots * sizeof(double2);
     using kern_t = void (*)(const double *, const double *, double *, mf_params);
-    kern_t k = nfilt <= 3 ? (noise ? mf_bank_kernel<3, true> : mf_bank_kernel<3, false>)
-                          : (noise ? mf_bank_kernel<8, true> : mf_bank_kernel<8, false>);
+    kern_t k;
+    if (step == 8 && nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 8> : mf_bank_kernel<3, false, 8>;
+    else if (nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 0> : mf_bank_kernel<3, false, 0>;
+    else k = noise ? mf_bank_kernel<8, true, 0> : mf_bank_kernel<8, false, 0>;
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(MF_THREADS), lds, s, d_r_ri, d_taps_ri, d_out_ri, P);

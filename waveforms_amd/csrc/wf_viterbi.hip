@@ -49,114 +49,106 @@ __device__ __forceinline__ double br_inc(int start, double re, double im)
     return start == 0 ? -im : start == 1 ? -re : start == 2 ? re : im;
 }
 
-template <int COL>
-__device__ __forceinline__ void increments(const double2 z[3], double inc[8])
-{
-    // compile-time version of kOutIdx
-    constexpr int oi[2][8] = {{1, 2, 1, 0, 0, 1, 2, 1}, {1, 0, 2, 1, 1, 2, 0, 1}};
-#pragma unroll
-    for (int b = 0; b < 8; ++b) inc[b] = br_inc(b >> 1, z[oi[COL][b]].x, z[oi[COL][b]].y);
-}
-
-// One ACS stage of column COL: for every end state the two incoming branches in LIST
-// order (lower branch index first), strict '<'.
-template <int COL>
-__device__ __forceinline__ void acs(const double m_in[4], const double inc[8], double m_out[4], int path[4])
-{
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        // incoming branches: column 0: b = st>>1 + {0,4}|... derive from br_end at compile time
-        int first = -1, second = -1;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int s = b >> 1;
-            const int e = COL == 0 ? (s & 1) + 2 * (b & 1) : (s & 2) + (b & 1);
-            if (e == st) {
-                if (first < 0) first = b; else second = b;
-            }
-        }
-        const double ma = m_in[first >> 1] + inc[first];
-        const double mb = m_in[second >> 1] + inc[second];
-        // min_m = inf; ma < inf -> take a (NaN -> stays inf, min_k = 0, as the reference)
-        double mm = INFINITY;
-        int k = 0;
-        if (ma < mm) { mm = ma; k = first >> 1; }
-        if (mb < mm) { mm = mb; k = second >> 1; }
-        m_out[st] = mm;
-        path[st] = k;
-    }
-}
-
-struct vit_carry {
-    double i;          // call counter (exact in a double up to 2^53)
-    double m0[4];      // metrics[:, 0] of the previous call
-    double inc_prev[8];
-    double pad[3];
+// ---- lean detector step for the batch kernel --------------------------------------------
+// Per trellis section only 4 of the 6 components of a matched-filter row are ever used:
+// Re/Im of z[1] (alpha = 0) in both sections, plus (Re z[0], Im z[2]) in the even (I) section
+// and (Im z[0], Re z[2]) in the odd (Q) one.  Incoming branches per end state, first in
+// LIST order (ties keep the first: strict '<', algorithm.py:79-83), with their increment
+// Re(state_exp_term[start] * z[idx(out)]) written as a signed component:
+//   even: st0: (0: -i1 | 2: +a)   st1: (1: -r1 | 3: +b)   st2: (0: -b | 2: +r1)   st3: (1: -a | 3: +i1)
+//   odd : st0: (0: -i1 | 1: -b)   st1: (0: -a | 1: -r1)   st2: (2: +r1 | 3: +a)   st3: (2: +b | 3: +i1)
+// with r1 = Re z[1], i1 = Im z[1], (a, b) = (Re z[0], Im z[2]) even / (Im z[0], Re z[2]) odd.
+// m + (-x) and m - x are the same IEEE operation, so every compare is bit-identical to the
+// reference's.
+struct vit_comp {
+    double r1, i1, a, b;
 };
 
-template <int COL_NOW>
-__device__ __forceinline__ void viterbi_call(const double2 z[3], double m0[4], double inc_prev[8], int diff,
-                                             int *bit, int *sym)
+template <int COL>
+__device__ __forceinline__ vit_comp vit_components(const double2 *__restrict__ z)
 {
-    constexpr int COL_PREV = COL_NOW ^ 1;
-    double inc_now[8];
-    increments<COL_NOW>(z, inc_now);
-    // algorithm.py:65-67
-    const double mn = fmin(fmin(m0[0], m0[1]), fmin(m0[2], m0[3]));
-    double carried[4] = {m0[0] - mn, m0[1] - mn, m0[2] - mn, m0[3] - mn};
-    double ma[4], mb[4];
-    int p0[4], p1[4];
-    acs<COL_PREV>(carried, inc_prev, ma, p0);   // stage j = 0
-    acs<COL_NOW>(ma, inc_now, mb, p1);          // stage j = 1
-    // np.argmin: first minimum
-    int s1 = 0;
-    double best = mb[0];
-#pragma unroll
-    for (int s = 1; s < 4; ++s)
-        if (mb[s] < best) { best = mb[s]; s1 = s; }
-    const int e0 = p1[s1];        // state after stage 0
-    const int st0 = p0[e0];       // state before stage 0
-    // branch (COL_PREV, start st0, end e0)
-    const int b = 2 * st0 + (COL_PREV == 0 ? (e0 >> 1) : (e0 & 1));
-    *bit = br_inp(COL_PREV, b, diff);
-    *sym = 2 * (int)kOutIdx[COL_PREV][b] - 2;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) m0[s] = ma[s];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) inc_prev[k] = inc_now[k];
+    vit_comp c;
+    c.r1 = z[1].x;
+    c.i1 = z[1].y;
+    c.a = COL == 0 ? z[0].x : z[0].y;
+    c.b = COL == 0 ? z[2].y : z[2].x;
+    return c;
 }
 
-// Batch kernel.  Lane g owns calls [g*CH, (g+1)*CH) and walks rows g*CH - W - 1 ... (one
-// priming row for the exact previous increments, W warm-up rows, CH output rows).  Rows are
-// 48 B each and a lane's rows are contiguous, so per-lane loads would touch 64 different
-// cache lines per instruction and thrash L1 (measured 2.4x HBM over-fetch).  Instead each
-// wave stages VIT_S rows of all its 64 lanes per batch with COOPERATIVE loads — 12 lanes
-// cover one lane-segment of 192 B, every 16 B piece of every cache line is fetched once —
-// into a wave-private LDS tile (13 slots of 16 B per lane: the odd slot count makes the
-// per-lane ds_read_b128 conflict-free), with the next batch's global loads in flight
-// while the current one is being decoded.
-#define VIT_S 4
-#define VIT_PIECES (3 * VIT_S)        // 16-byte pieces per lane-segment
-#define VIT_LANE_SLOTS (VIT_PIECES + 1)
+// one ACS stage of section COL: returns the 4 selection bits (1 = second branch won)
+template <int COL>
+__device__ __forceinline__ unsigned vit_acs(const double m[4], const vit_comp &q, double out[4])
+{
+    double fa[4], fb[4];
+    if (COL == 0) {
+        fa[0] = m[0] - q.i1; fb[0] = m[2] + q.a;
+        fa[1] = m[1] - q.r1; fb[1] = m[3] + q.b;
+        fa[2] = m[0] - q.b;  fb[2] = m[2] + q.r1;
+        fa[3] = m[1] - q.a;  fb[3] = m[3] + q.i1;
+    } else {
+        fa[0] = m[0] - q.i1; fb[0] = m[1] - q.b;
+        fa[1] = m[0] - q.a;  fb[1] = m[1] - q.r1;
+        fa[2] = m[2] + q.r1; fb[2] = m[3] + q.a;
+        fa[3] = m[2] + q.b;  fb[3] = m[3] + q.i1;
+    }
+    unsigned sel = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bool second = fb[s] < fa[s];
+        out[s] = second ? fb[s] : fa[s];
+        sel |= (second ? 1u : 0u) << s;
+    }
+    return sel;
+}
+
+// predecessor state of end state `st` in section COL: first / second branch start
+__device__ __forceinline__ int vit_pred(int col, int st, unsigned second)
+{
+    // even: (0,2) (1,3) (0,2) (1,3); odd: (0,1) (0,1) (2,3) (2,3)
+    return col == 0 ? (st & 1) + 2 * (int)second : (st & 2) + (int)second;
+}
 
 struct vit_lane {
-    double m0[4], inc_prev[8];
+    double m0[4];
+    vit_comp prev;                       // components of the previous call's row
     uint64_t pb_lo, pb_hi, ps_lo, ps_hi;
 };
 
-// One step (= one detector call k, COL = k's column parity) of lane-private state.
+// One detector call k (COL = column parity of k): stage 0 commits the previous call's
+// increments from the min-normalised carried metrics, stage 1 looks one symbol ahead,
+// depth-2 traceback from the first arg-min (algorithm.py:57-101 with length = 2).
 template <int COL>
 __device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict__ zrow, bool prime, int diff,
                                          int64_t k, int64_t a, int64_t ncalls, uint8_t *__restrict__ bits,
                                          int8_t *__restrict__ syms)
 {
-    const double2 z[3] = {zrow[0], zrow[1], zrow[2]};
-    if (prime) {   // priming row: exact increments of the call before the warm-up
-        increments<COL>(z, L.inc_prev);
+    constexpr int PREV = COL ^ 1;
+    const vit_comp now = vit_components<COL>(zrow);
+    if (prime) {   // priming row: exact components of the call before the warm-up
+        L.prev = now;
         return;
     }
-    int bit, sym;
-    viterbi_call<COL>(z, L.m0, L.inc_prev, diff, &bit, &sym);
+    const double mn = fmin(fmin(L.m0[0], L.m0[1]), fmin(L.m0[2], L.m0[3]));
+    const double carried[4] = {L.m0[0] - mn, L.m0[1] - mn, L.m0[2] - mn, L.m0[3] - mn};
+    double ma[4], mb[4];
+    const unsigned sel0 = vit_acs<PREV>(carried, L.prev, ma);   // stage j = 0
+    const unsigned sel1 = vit_acs<COL>(ma, now, mb);            // stage j = 1
+    // np.argmin: first minimum
+    const int i01 = mb[1] < mb[0] ? 1 : 0, i23 = mb[3] < mb[2] ? 3 : 2;
+    const double v01 = mb[1] < mb[0] ? mb[1] : mb[0], v23 = mb[3] < mb[2] ? mb[3] : mb[2];
+    const int s1 = v23 < v01 ? i23 : i01;
+    const int e0 = vit_pred(COL, s1, (sel1 >> s1) & 1u);        // state after stage 0
+    const unsigned w0 = (sel0 >> e0) & 1u;                      // which branch entered e0
+    // branch of section PREV entering e0 through its first / second slot; its start state
+    const int st0 = vit_pred(PREV, e0, w0);
+    const int b = 2 * st0 + (PREV == 0 ? (e0 >> 1) : (e0 & 1));
+    const int bit = br_inp(PREV, b, diff);
+    // output symbols by branch: even {0,+2,0,-2,-2,0,+2,0}, odd {0,-2,+2,0,0,+2,-2,0} as (sym + 2) nibbles
+    constexpr unsigned kSymPlus2 = PREV == 0 ? 0x24200242u : 0x20422402u;
+    const int sym = (int)((kSymPlus2 >> (4 * b)) & 15u) - 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) L.m0[s] = ma[s];
+    L.prev = now;
     if (k >= a) {
         const int c = (int)(k - a) & 15;
         const uint64_t bv = (uint64_t)(bit & 0xFF), sv = (uint64_t)(sym & 0xFF);
@@ -172,6 +164,28 @@ __device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict_
                 syms[k - c + q] = (int8_t)(((q < 8 ? L.ps_lo : L.ps_hi) >> (8 * (q & 7))) & 0xFF);
             }
         }
+    }
+}
+
+// Carry block <-> lane state.  The block keeps the reference's shape (8 branch increments of
+// the last call); section `col` of that call tells which components they hold.
+__device__ __forceinline__ vit_comp vit_comp_from_inc(const double *inc, int col)
+{
+    vit_comp c;
+    c.i1 = inc[7];
+    if (col == 0) { c.a = inc[4]; c.r1 = inc[5]; c.b = inc[6]; }
+    else { c.r1 = inc[4]; c.b = inc[5]; c.a = inc[6]; }
+    return c;
+}
+
+__device__ __forceinline__ void vit_comp_to_inc(const vit_comp &c, int col, double *inc)
+{
+    if (col == 0) {
+        inc[0] = -c.i1; inc[1] = -c.b; inc[2] = -c.r1; inc[3] = -c.a;
+        inc[4] = c.a;   inc[5] = c.r1; inc[6] = c.b;   inc[7] = c.i1;
+    } else {
+        inc[0] = -c.i1; inc[1] = -c.a; inc[2] = -c.b;  inc[3] = -c.r1;
+        inc[4] = c.r1;  inc[5] = c.b;  inc[6] = c.a;   inc[7] = c.i1;
     }
 }
 
@@ -203,37 +217,47 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     const double2 *rows = reinterpret_cast<const double2 *>(mf);
     double2 *tile = s_rows[wave];
 
-    // cooperative piece p = u*64 + lane  ->  (segment = lane of the wave it belongs to, piece index)
-    int seg[VIT_PIECES], within[VIT_PIECES];
+    // cooperative piece p = u*64 + lane  ->  (segment = lane of the wave it belongs to, piece index).
+    // Everything per-lane is 32-bit and batch-invariant; the batch only moves a wave-uniform base.
+    int slot[VIT_PIECES], rrel[VIT_PIECES], off[VIT_PIECES];
 #pragma unroll
     for (int u = 0; u < VIT_PIECES; ++u) {
         const int p = u * WF_WAVE + lane;
-        seg[u] = p / VIT_PIECES;
-        within[u] = p - seg[u] * VIT_PIECES;
+        const int sg = p / VIT_PIECES, wi = p - sg * VIT_PIECES;
+        slot[u] = sg * VIT_LANE_SLOTS + wi;     // LDS slot
+        rrel[u] = sg * CH + wi / 3;             // row relative to the wave's first row of the batch
+        off[u] = 3 * rrel[u] + wi % 3;          // 16-byte piece relative to that row
     }
+    const int64_t g0u = __builtin_amdgcn_readfirstlane((int)(g0 >> 6)) * (int64_t)WF_WAVE;   // wave-uniform copy of g0
     auto fetch = [&](int b, double2 dst[VIT_PIECES]) {
+        const int64_t rb = g0u * CH - warmup - 1 + (int64_t)b * VIT_S;   // first row of the batch (uniform)
+        const int64_t lo64 = -rb, hi64 = ncalls - rb;                     // valid rrel range [lo, hi)
+        const int lo = lo64 < -(1 << 30) ? -(1 << 30) : (lo64 > (1 << 30) ? (1 << 30) : (int)lo64);
+        const int hi = hi64 < -(1 << 30) ? -(1 << 30) : (hi64 > (1 << 30) ? (1 << 30) : (int)hi64);
+        const double2 *basep = rows + 3 * rb;
 #pragma unroll
         for (int u = 0; u < VIT_PIECES; ++u) {
-            const int64_t row = (g0 + seg[u]) * CH - warmup - 1 + (int64_t)b * VIT_S + within[u] / 3;
-            dst[u] = (row >= 0 && row < ncalls) ? rows[3 * row + within[u] % 3] : make_double2(0.0, 0.0);
+#ifdef WF_ABL_NO_MEM   // ablation only
+            dst[u] = make_double2((double)(rrel[u] & 7) - 3.5, (double)(off[u] & 3) - 1.0);
+#else
+            dst[u] = (rrel[u] >= lo && rrel[u] < hi) ? basep[off[u]] : make_double2(0.0, 0.0);
+#endif
         }
     };
     auto stash = [&](const double2 src[VIT_PIECES]) {
 #pragma unroll
-        for (int u = 0; u < VIT_PIECES; ++u) tile[seg[u] * VIT_LANE_SLOTS + within[u]] = src[u];
+        for (int u = 0; u < VIT_PIECES; ++u) tile[slot[u]] = src[u];
     };
 
     vit_lane L;
 #pragma unroll
     for (int k = 0; k < 4; ++k) L.m0[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) L.inc_prev[k] = 0.0;
+    L.prev.r1 = L.prev.i1 = L.prev.a = L.prev.b = 0.0;
     L.pb_lo = L.pb_hi = L.ps_lo = L.ps_hi = 0;
     if (state && a == 0) {   // the lane that starts the burst continues the carried detector
 #pragma unroll
         for (int k = 0; k < 4; ++k) L.m0[k] = state[1 + k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) L.inc_prev[k] = state[5 + k];
+        L.prev = vit_comp_from_inc(state + 5, (int)((i0 - 1) & 1));
     }
     double2 pend[VIT_PIECES];
     fetch(0, pend);
@@ -264,13 +288,18 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
         state[16] = (double)(i0 + ncalls);
 #pragma unroll
         for (int k = 0; k < 4; ++k) state[17 + k] = L.m0[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) state[21 + k] = L.inc_prev[k];
+        vit_comp_to_inc(L.prev, (int)((i0 + ncalls - 1) & 1), state + 21);
     }
 }
 
+#ifndef VIT_MIN_WAVES
+#define VIT_MIN_WAVES 1
+#endif
+#ifndef VIT_LONG_CH
+#define VIT_LONG_CH 128
+#endif
 template <int CH>
-__global__ __launch_bounds__(VIT_THREADS) void viterbi_batch_kernel(const double *__restrict__ mf, int64_t ncalls,
+__global__ __launch_bounds__(VIT_THREADS, VIT_MIN_WAVES) void viterbi_batch_kernel(const double *__restrict__ mf, int64_t ncalls,
                                                                      int diff, int warmup, uint8_t *__restrict__ bits,
                                                                      int8_t *__restrict__ syms, double *__restrict__ state)
 {
@@ -301,13 +330,13 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     if (warmup > 4096) warmup = 4096;
     // long bursts: 128 calls per lane (warm-up re-reads 37 % instead of 75 %); short ones
     // keep 64 so that enough lanes exist to fill the chip
-    const int ch = ncalls >= (1 << 22) ? 128 : 64;
+    const int ch = ncalls >= (1 << 22) ? VIT_LONG_CH : 64;
     const int64_t nthreads = (ncalls + ch - 1) / ch;
     const int64_t nblocks = (nthreads + VIT_THREADS - 1) / VIT_THREADS;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
     hipStream_t s = wf_stream(stream);
-    if (ch == 128)
-        hipLaunchKernelGGL(viterbi_batch_kernel<128>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
+    if (ch == VIT_LONG_CH)
+        hipLaunchKernelGGL(viterbi_batch_kernel<VIT_LONG_CH>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
                            ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
     else
         hipLaunchKernelGGL(viterbi_batch_kernel<64>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,

@@ -87,6 +87,16 @@ static inline int wf_grid_for(int64_t work_items, int per_block, int max_blocks)
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ int wf_lane() { return threadIdx.x & (WF_WAVE - 1); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global load and store of the wave (s_waitcnt vmcnt(0)), which serialises a
+// software pipeline: prefetches issued before the barrier and stores issued after the
+// previous one would all have to land first.  Use ONLY where the waves of the workgroup
+// exchange data through LDS.
+__device__ __forceinline__ void wf_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Inclusive wave64 prefix sum of doubles.
 __device__ __forceinline__ double wf_wave_incl_scan(double v)
 {

@@ -17,7 +17,7 @@
 
 #define MOD_THREADS 256
 #ifndef MOD_ROWS
-#define MOD_ROWS 8
+#define MOD_ROWS 16
 #endif
 #define MOD_WAVES (MOD_THREADS / WF_WAVE)
 #define MOD_MASK ((1ull << 62) - 1)
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                                                                 double *__restrict__ out, mod_params P)
 {
     extern __shared__ double s_amp[];       // window of symbol amplitudes
-    __shared__ double s_tot[MOD_ROWS * MOD_WAVES];
+    __shared__ double s_tot[2 * MOD_WAVES];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int sps = P.sps;
@@ -205,12 +205,24 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
         const int64_t tile_base = tile_g * tile_len;      // global sample index
         const int64_t sym_base = tile_base / sps;
         const int64_t mp1_lo = sym_base + cq - JMAX + 1;
-        __syncthreads();
+        wf_lds_barrier();
         for (int k = t; k < win; k += MOD_THREADS) s_amp[k] = mod_amp(symbols, hvec, P, mp1_lo + k - 1);
-        __syncthreads();
-        // frequency pulses of this thread's 2 x ROWS samples, and their row-wise wave scans
-        double x0[MOD_ROWS], x1[MOD_ROWS], ex[MOD_ROWS];
-#pragma unroll
+        wf_lds_barrier();
+        // carry into the tile: T*S(m_full) - K0 (fixed point, from the scan kernel) + the
+        // symbols still under the pulse at the tile edge
+        double run = 0.0;   // running sum at the start of the current row (identical in every thread)
+        if (tile_g > 0) {
+            run = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
+            // first partial symbol: mp1 = sym_base - D + 1  -> local index in s_amp
+            const int lpart = (int)((sym_base - P.dsh + 1) - mp1_lo);
+            double part = 0.0;
+            for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + l], Gpart[l], part);
+            run += part;
+        }
+        // Row by row: FIR (taps in registers, amplitudes from LDS) -> wave scan -> wave totals
+        // through LDS (double-buffered: ONE barrier per row) -> carry, mod, sincos, store.
+        // The stores of row u drain while row u+1 is being computed.
+#pragma unroll 2
         for (int u = 0; u < MOD_ROWS; ++u) {
             double acc0 = 0.0, acc1 = 0.0;
 #ifdef WF_ABL_NO_FIR
@@ -226,45 +238,26 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                     acc1 = fma(tap1[i], v, acc1);
                 }
             }
-            x0[u] = acc0;
-            x1[u] = acc1;
 #ifdef WF_ABL_NO_SCAN
             const double inc = acc0 + acc1;
 #else
             const double inc = wf_wave_incl_scan(acc0 + acc1);
 #endif
             const double e = __shfl_up(inc, 1, WF_WAVE);
-            ex[u] = lane == 0 ? 0.0 : e;
-            if (lane == 63) s_tot[u * MOD_WAVES + wave] = inc;
-        }
-        // carry into the tile: T*S(m_full) - K0 (fixed point, from the scan kernel) + the
-        // symbols still under the pulse at the tile edge
-        double carry = 0.0;
-        if (tile_g > 0) {
-            carry = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
-            // first partial symbol: mp1 = sym_base - D + 1  -> local index in s_amp
-            const int lpart = (int)((sym_base - P.dsh + 1) - mp1_lo);
-            double part = 0.0;
-            for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + l], Gpart[l], part);
-            carry += part;
-        }
-        __syncthreads();
-        double off[MOD_ROWS];
-        double running = 0.0;
-#pragma unroll
-        for (int u = 0; u < MOD_ROWS; ++u) {
+            const double ex = lane == 0 ? 0.0 : e;
+            double *tot = s_tot + (u & 1) * MOD_WAVES;
+            if (lane == 63) tot[wave] = inc;
+            wf_lds_barrier();
+            double offw = 0.0, rowtot = 0.0;
 #pragma unroll
             for (int w = 0; w < MOD_WAVES; ++w) {
-                if (w == wave) off[u] = running;
-                running += s_tot[u * MOD_WAVES + w];
+                if (w == wave) offw = rowtot;
+                rowtot += tot[w];
             }
-        }
-        if (active) {
-#pragma unroll
-            for (int u = 0; u < MOD_ROWS; ++u) {
+            if (active) {
                 const int64_t n = tile_base + (int64_t)u * P.rs + 2 * t;
-                const double v0 = carry + (off[u] + ex[u] + x0[u]);
-                const double v1 = v0 + x1[u];
+                const double v0 = run + (offw + ex + acc0);
+                const double v1 = v0 + acc1;
                 const double ra = mod_pos_d(v0, P.sps_d, P.inv_sps);
                 const double rb = mod_pos_d(v1, P.sps_d, P.inv_sps);
                 double s0, c0, s1, c1;
@@ -274,6 +267,16 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                 wf_sincos_turns(fma(ra, P.inv_sps, P.phi0_turns), &s0, &c0);
                 wf_sincos_turns(fma(rb, P.inv_sps, P.phi0_turns), &s1, &c1);
 #endif
+#ifdef WF_ABL_CONTIG_STORE   // ablation only: right bytes, wrong places, contiguous 16 B per lane
+                {
+                    const int64_t rowb = tile_base + (int64_t)u * P.rs - P.out_origin;
+                    double2 *o = reinterpret_cast<double2 *>(out + 2 * rowb);
+                    if (rowb + P.rs <= P.out_hi - P.out_origin) {
+                        o[t] = make_double2(c0, s0);
+                        o[t + P.rs / 2] = make_double2(c1, s1);
+                    }
+                }
+#else
                 if (n >= P.out_origin) {   // n is even and so is out_origin: a pair is never split below
                     double2 *o = reinterpret_cast<double2 *>(out + 2 * (n - P.out_origin));
                     if (n + 1 < P.out_hi) {
@@ -283,7 +286,9 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                         o[0] = make_double2(c0, s0);
                     }
                 }
+#endif
             }
+            run += rowtot;
         }
     }
 }

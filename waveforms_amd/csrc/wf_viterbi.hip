@@ -262,7 +262,7 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     double2 pend[VIT_PIECES];
     fetch(0, pend);
     stash(pend);
-    __syncthreads();
+    wf_lds_barrier();
     const int64_t kbase = a - warmup - 1;
     for (int b = 0; b < nbatch; ++b) {
         if (b + 1 < nbatch) fetch(b + 1, pend);          // in flight during the decode below
@@ -278,9 +278,9 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
                     vit_step<PAR0 ^ 1>(L, zr + 3, false, diff, k + 1, a, ncalls, bits, syms);
             }
         }
-        __syncthreads();                                  // batch b fully consumed
+        wf_lds_barrier();                                  // batch b fully consumed
         if (b + 1 < nbatch) stash(pend);
-        __syncthreads();
+        wf_lds_barrier();
     }
     if (state && live && a + CH >= ncalls) {
         // the lane that owns the last call hands the detector state on (streaming).  Written

@@ -124,7 +124,11 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
             // window offset j = 0 is the OLDEST sample => tap index ntaps-1-j
             const int base = t * (step + pad);
             int extra = 0, jm = 0;
+#ifdef WF_ABL_NO_MAC
+            for (int j = 0; j < 1; ++j) {
+#else
             for (int j = 0; j < P.ntaps; ++j) {
+#endif
                 const double2 x = s_win[base + j + extra];
                 const int tt = P.ntaps - 1 - j;
 #pragma unroll

@@ -255,8 +255,21 @@ def e2e():
     print(out)
 
 
+def offset_scan():
+    """Row a9: error counts of the reference chain for every timing offset (sps 8, Eb/N0 = 10 dB,
+    TG, PN15, fresh seed 1 per offset so each run sees the same noise)."""
+    out = {}
+    pn15 = pn_bits(15)
+    for off in range(-4, 4):
+        rng = np.random.Generator(np.random.PCG64(seed=1))
+        res = run_chain(pn15, freq_pulse_soqpsk_tg(8), 0.25, 8, float(np.sqrt(0.4)), rng, {"PT": off, "PAM": off})
+        out[str(off)] = {k: [int(v) for v in res[f"{k}_errors"]] for k in ("PT", "PAM")}
+    (OUT / "offset_scan.json").write_text(json.dumps(out, indent=1) + "\n")
+    print(out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["glfsr", "encode", "pulses", "modulate", "awgn", "detect", "e2e"]
+    which = sys.argv[1:] or ["glfsr", "encode", "pulses", "modulate", "awgn", "detect", "e2e", "offset_scan"]
     for name in which:
         globals()[name]()
         print("done", name)

@@ -497,3 +497,28 @@ def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
         assert st.result() == want and want[1] > 0
     with pytest.raises(ValueError):
         SOQPSKStream(total, 1000, 8)
+
+
+def test_timing_offset_scan_on_gpu(oracle, golden):
+    """Row a9: every decimation phase -4..3 through the GPU bank + detector reproduces the
+    reference's error counts (same PCG64 noise, added on the host like the example does)."""
+    from waveforms.cpm.modulate import cpm_modulate
+    from waveforms.filters.matched import MatchedFilterBank, pam_matched_filter_taps, pt_matched_filter_taps
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    scan = golden("offset_scan.json")
+    bits = pn_padded(oracle, 15)
+    sym = oracle.fsm_encode("SOQPSKTrellis4x2DiffEncoded", bits)[0]
+    pulse = oracle.freq_pulse_soqpsk_tg(8)
+    _t, sig = cpm_modulate(sym, 0.25, pulse, 8)
+    noise = oracle.numpy_awgn(float(np.sqrt(0.4)), sig.size, np.random.Generator(np.random.PCG64(seed=1)))
+    r = sig * np.exp(-1j * np.pi / 4) + noise
+    banks = {"PT": MatchedFilterBank(pt_matched_filter_taps(pulse, 0.25, 8)),
+             "PAM": MatchedFilterBank(pam_matched_filter_taps(pulse, 0.25, 8))}
+    for off in range(-4, 4):
+        first = (-off) % 8
+        ncols = len(range(first, r.size - 2 * 8, 8))
+        for kind, bank in banks.items():
+            db, ds = SOQPSKTrellisDetector().detect(bank(r, first=first, step=8, ncols=ncols))
+            se, be, m = oracle.count_errors(ds, db, sym, bits, 2)
+            assert [se, be, m] == scan[str(off)][kind], (off, kind)

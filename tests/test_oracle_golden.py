@@ -252,3 +252,17 @@ def test_end_to_end_error_counts(oracle, golden):
                                    detector=kind, timing_offset=off)
         assert [res["sym_errors"], res["bit_errors"], res["compared"]] == e[f"sps8_10dB_TG_{kind}"]
     assert e["sps8_10dB_TG_PT"][1] == 16 and e["sps8_10dB_TG_PAM"][1] == 2
+
+
+def test_timing_offset_scan(oracle, golden):
+    """Row a9 (examples/soqpsk_detection.py:181-198): the decimation phase matters by orders
+    of magnitude; the reference's own choice (PT -1, PAM 0) is the optimum at sps 8."""
+    scan = golden("offset_scan.json")
+    bits = pn_padded(oracle, 15)
+    noise = oracle.numpy_awgn(float(np.sqrt(0.4)), (bits.size + 1) * 8, np.random.Generator(np.random.PCG64(seed=1)))
+    for off in (-4, -1, 0, 2):
+        for kind in ("PT", "PAM"):
+            res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise,
+                                       detector=kind, timing_offset=off)
+            assert [res["sym_errors"], res["bit_errors"], res["compared"]] == scan[str(off)][kind], (off, kind)
+    assert min(scan, key=lambda o: scan[o]["PT"][1]) == "-1" and min(scan, key=lambda o: scan[o]["PAM"][1]) == "0"

@@ -48,38 +48,39 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
         if (NOISE) {
             // rolled loop over PAIRS of absolute sample indices (one Philox block per pair; the
             // Gaussian source is ~400 instructions); the next pair's loads are in flight while
-            // the channel is applied to the current one
+            // the channel is applied to the current one.  All per-lane index math is 32-bit
+            // window offsets; the burst bounds become a wave-uniform offset range [vlo, vhi).
             const int64_t a0 = (int64_t)P.first_index + ws;          // absolute index of the window start
-            const int64_t pair_lo = a0 >> 1;                           // floor, also for negative a0
-            const int npairs = (int)(((a0 + P.span - 1) >> 1) - pair_lo) + 1;
-            auto fetch = [&](int64_t s, int w) {
+            const int odd = (int)(a0 & 1);                            // window starts on the odd half of a pair
+            const uint64_t pair_lo = (uint64_t)(a0 >> 1);             // floor, also for negative a0
+            const int64_t lo64 = -ws, hi64 = P.nsamp - ws;            // offsets of burst samples 0 and nsamp
+            const int vlo = lo64 > 0 ? (lo64 < P.span ? (int)lo64 : P.span) : 0;
+            const int vhi = hi64 < P.span ? (hi64 > 0 ? (int)hi64 : 0) : P.span;
+            const double2 *rp = reinterpret_cast<const double2 *>(r) + ws;   // dereferenced only inside [vlo, vhi)
+            auto fetch = [&](int w) {
 #ifdef WF_ABL_NO_MEM   // ablation only: no global traffic
-                return make_double2((double)s, (double)w);
+                return make_double2((double)w, 1.0);
 #else
-                return (w >= 0 && w < P.span && s >= 0 && s < P.nsamp) ? *reinterpret_cast<const double2 *>(r + 2 * s)
-                                                                        : make_double2(0.0, 0.0);
+                return (w >= vlo && w < vhi) ? rp[w] : make_double2(0.0, 0.0);
 #endif
             };
-            int64_t s0 = 2 * (pair_lo + t) - (int64_t)P.first_index;  // sample index of the even half
-            int w0 = (int)(s0 - ws);                                   // its window offset (-1 possible)
-            double2 c0 = fetch(s0, w0), c1 = fetch(s0 + 1, w0 + 1);
+            int w0 = 2 * t - odd;                                      // offset of the even half (-1 possible)
+            double2 c0 = fetch(w0), c1 = fetch(w0 + 1);
 #pragma unroll 1
-            for (int i = t; i < npairs; i += MF_THREADS) {
-                const double2 n0 = fetch(s0 + 2 * MF_THREADS, w0 + 2 * MF_THREADS);
-                const double2 n1 = fetch(s0 + 2 * MF_THREADS + 1, w0 + 2 * MF_THREADS + 1);
+            for (; w0 < P.span; w0 += 2 * MF_THREADS) {
+                const double2 n0 = fetch(w0 + 2 * MF_THREADS), n1 = fetch(w0 + 2 * MF_THREADS + 1);
+                const int w1 = w0 + 1;
+                const bool in0 = w0 >= vlo && w0 < vhi, in1 = w1 >= vlo && w1 < vhi;
                 double g[4] = {0.0, 0.0, 0.0, 0.0};
-                const bool v0 = w0 >= 0 && w0 < P.span, v1 = w0 + 1 >= 0 && w0 + 1 < P.span;
-                const bool in0 = s0 >= 0 && s0 < P.nsamp, in1 = s0 + 1 >= 0 && s0 + 1 < P.nsamp;
-                if ((v0 && in0) || (v1 && in1))   // the channel of wf_awgn_c128, on the fly
-                    wf_gaussian_two((uint64_t)(pair_lo + i), P.stream_id, P.seed, P.sigma, g);
-                if (v0) {
+                if (in0 || in1)   // the channel of wf_awgn_c128, on the fly
+                    wf_gaussian_two(pair_lo + (uint64_t)((w0 + odd) >> 1), P.stream_id, P.seed, P.sigma, g);
+                if (w0 >= 0) {
                     const double2 x = in0 ? make_double2(fma(c0.x, P.rot_re, fma(-c0.y, P.rot_im, g[0])),
                                                          fma(c0.x, P.rot_im, fma(c0.y, P.rot_re, g[1])))
                                           : make_double2(0.0, 0.0);
                     s_win[w0 + (pad ? w0 / step : 0)] = x;
                 }
-                if (v1) {
-                    const int w1 = w0 + 1;
+                if (w1 < P.span) {
                     const double2 x = in1 ? make_double2(fma(c1.x, P.rot_re, fma(-c1.y, P.rot_im, g[2])),
                                                          fma(c1.x, P.rot_im, fma(c1.y, P.rot_re, g[3])))
                                           : make_double2(0.0, 0.0);
@@ -87,8 +88,6 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 }
                 c0 = n0;
                 c1 = n1;
-                s0 += 2 * MF_THREADS;
-                w0 += 2 * MF_THREADS;
             }
         } else {
             // all of this thread's loads are issued before the first one is consumed

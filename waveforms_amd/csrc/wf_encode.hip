@@ -27,12 +27,14 @@ __device__ __forceinline__ uint64_t map_identity()
     return 0xFEDCBA9876543210ull;
 }
 
-// h = g after f  (apply f first)
+// h = g after f  (apply f first).  NS = number of states the maps are defined on (nibbles
+// above NS stay identity-free zeros and are never read).
+template <int NS>
 __device__ __forceinline__ uint64_t map_compose(uint64_t f, uint64_t g)
 {
     uint64_t h = 0;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const unsigned fs = (unsigned)(f >> (4 * s)) & 15u;
         h |= ((g >> (4 * fs)) & 15ull) << (4 * s);
     }
@@ -74,6 +76,7 @@ __device__ __forceinline__ uint64_t load_inputs(const uint8_t *__restrict__ bits
 }
 
 // Kernel A: per-thread maps, block-exclusive prefix maps, block aggregates.
+template <int NS>
 __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
     const uint8_t *__restrict__ bits, const uint8_t *__restrict__ tab_next, enc_params P,
     uint64_t *__restrict__ thread_excl, uint64_t *__restrict__ block_agg)
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
     const int colstart = (int)((P.col0 + sym0) % P.columns);
 
     uint64_t m = 0;
-    for (int s0 = 0; s0 < 16; ++s0) {
+#pragma unroll
+    for (int s0 = 0; s0 < NS; ++s0) {
         int st = s0;
         if (s0 < P.states) {
             int col = colstart;
@@ -110,20 +114,21 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
 #pragma unroll
     for (int d = 1; d < WF_WAVE; d <<= 1) {
         const uint64_t o = shfl_up_u64(inc, d);
-        if (lane >= d) inc = map_compose(o, inc);
+        if (lane >= d) inc = map_compose<NS>(o, inc);
     }
     if (lane == 63) s_wave[wave] = inc;
     uint64_t excl = shfl_up_u64(inc, 1);
     if (lane == 0) excl = map_identity();
     __syncthreads();
     uint64_t pre = map_identity();
-    for (int w = 0; w < wave; ++w) pre = map_compose(pre, s_wave[w]);
-    thread_excl[gthread] = map_compose(pre, excl);
-    if (t == ENC_THREADS - 1) block_agg[blockIdx.x] = map_compose(pre, inc);
+    for (int w = 0; w < wave; ++w) pre = map_compose<NS>(pre, s_wave[w]);
+    thread_excl[gthread] = map_compose<NS>(pre, excl);
+    if (t == ENC_THREADS - 1) block_agg[blockIdx.x] = map_compose<NS>(pre, inc);
 }
 
 // Kernel B: start state of every block (one workgroup; threads own contiguous runs).
 #define ENC_SCAN_THREADS 1024
+template <int NS>
 __global__ __launch_bounds__(ENC_SCAN_THREADS) void enc_block_scan_kernel(const uint64_t *__restrict__ block_agg,
                                                                            int nblocks, int state0,
                                                                            const int *__restrict__ state_in,
@@ -135,20 +140,20 @@ __global__ __launch_bounds__(ENC_SCAN_THREADS) void enc_block_scan_kernel(const 
     const int per = (nblocks + ENC_SCAN_THREADS - 1) / ENC_SCAN_THREADS;
     const int b0 = min(nblocks, t * per), b1 = min(nblocks, b0 + per);
     uint64_t run = map_identity();
-    for (int b = b0; b < b1; ++b) run = map_compose(run, block_agg[b]);
+    for (int b = b0; b < b1; ++b) run = map_compose<NS>(run, block_agg[b]);
     uint64_t inc = run;
 #pragma unroll
     for (int d = 1; d < WF_WAVE; d <<= 1) {
         const uint64_t o = shfl_up_u64(inc, d);
-        if (lane >= d) inc = map_compose(o, inc);
+        if (lane >= d) inc = map_compose<NS>(o, inc);
     }
     if (lane == 63) s_wave[wave] = inc;
     uint64_t excl = shfl_up_u64(inc, 1);
     if (lane == 0) excl = map_identity();
     __syncthreads();
     uint64_t pre = map_identity();
-    for (int w = 0; w < wave; ++w) pre = map_compose(pre, s_wave[w]);
-    excl = map_compose(pre, excl);
+    for (int w = 0; w < wave; ++w) pre = map_compose<NS>(pre, s_wave[w]);
+    excl = map_compose<NS>(pre, excl);
     int st = (int)((excl >> (4 * state0)) & 15ull);
     for (int b = b0; b < b1; ++b) {
         block_state[b] = (uint8_t)st;
@@ -244,13 +249,17 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
         WF_HIP(hipMemcpyAsync(ctx->d_tables, ctx->h_tables_cache, 2048, hipMemcpyHostToDevice, s));
     }
     enc_params P{columns, states, card, ninp, (int)(i0 % columns), state0, nsym};
-    hipLaunchKernelGGL(enc_reduce_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
-                       ctx->d_tables, P, thread_excl, block_agg);
+#define ENC_A(NS) hipLaunchKernelGGL(enc_reduce_kernel<NS>, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits, \
+                                    ctx->d_tables, P, thread_excl, block_agg)
+    if (states <= 4) ENC_A(4); else if (states <= 8) ENC_A(8); else ENC_A(16);
+#undef ENC_A
     WF_LAUNCH_CHECK();
     WF_REQUIRE(!d_state_at || (at_index >= 0 && at_index <= nsym && at_index % ENC_SYM_PER_THREAD == 0),
                "wf_fsm_encode: carry index must be a multiple of %d inside the block", ENC_SYM_PER_THREAD);
-    hipLaunchKernelGGL(enc_block_scan_kernel, dim3(1), dim3(ENC_SCAN_THREADS), 0, s, block_agg, (int)nblocks,
-                       state0, d_state_in, block_state);
+#define ENC_B(NS) hipLaunchKernelGGL(enc_block_scan_kernel<NS>, dim3(1), dim3(ENC_SCAN_THREADS), 0, s, block_agg, \
+                                    (int)nblocks, state0, d_state_in, block_state)
+    if (states <= 4) ENC_B(4); else if (states <= 8) ENC_B(8); else ENC_B(16);
+#undef ENC_B
     WF_LAUNCH_CHECK();
     hipLaunchKernelGGL(enc_emit_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
                        ctx->d_tables, reinterpret_cast<const int8_t *>(ctx->d_tables + 1024), P,

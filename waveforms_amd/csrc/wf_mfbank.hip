@@ -31,7 +31,7 @@ struct mf_params {
     uint64_t seed, stream_id, first_index;
 };
 
-template <int NF, bool NOISE, int STEP>   // STEP: compile-time decimation (0 = take P.step)
+template <int NF, bool NOISE, int STEP, int NTAPS>   // STEP / NTAPS: compile-time fast path (0 = take P.step / P.ntaps)
 __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__restrict__ r,
                                                               const double *__restrict__ taps,
                                                               double *__restrict__ out, mf_params P)
@@ -40,10 +40,11 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
     const int t = threadIdx.x;
     const int step = STEP ? STEP : P.step;
     const int pad = STEP ? (STEP % 2 == 0) : P.pad;
+    const int ntaps = NTAPS ? NTAPS : P.ntaps;
     for (int64_t blk = blockIdx.x; blk < P.nblk; blk += gridDim.x) {
         const int64_t k0 = blk * P.ob;
         // first input sample of the span: oldest sample of output k0
-        const int64_t ws = P.first + k0 * step + P.c - (P.ntaps - 1);
+        const int64_t ws = P.first + k0 * step + P.c - (ntaps - 1);
         __syncthreads();
         if (NOISE) {
             // rolled loop over PAIRS of absolute sample indices (one Philox block per pair; the
@@ -122,26 +123,43 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
             for (int f = 0; f < NF; ++f) ar[f] = ai[f] = 0.0;
             // window offset j = 0 is the OLDEST sample => tap index ntaps-1-j
             const int base = t * (step + pad);
-            int extra = 0, jm = 0;
-#ifdef WF_ABL_NO_MAC
-            for (int j = 0; j < 1; ++j) {
-#else
-            for (int j = 0; j < P.ntaps; ++j) {
-#endif
-                const double2 x = s_win[base + j + extra];
-                const int tt = P.ntaps - 1 - j;
+            if (NTAPS && STEP) {
+                // fully unrolled: LDS offsets and tap addresses are compile-time constants
 #pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    if (f < P.nfilt) {
-                        const double tr = taps[2 * (f * P.ntaps + tt)];
-                        const double ti = taps[2 * (f * P.ntaps + tt) + 1];
-                        ar[f] = fma(x.x, tr, fma(-x.y, ti, ar[f]));
-                        ai[f] = fma(x.x, ti, fma(x.y, tr, ai[f]));
+                for (int j = 0; j < NTAPS; ++j) {
+                    const double2 x = s_win[base + j + (STEP % 2 == 0 ? j / STEP : 0)];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        if (f < P.nfilt) {
+                            const double tr = taps[2 * (f * NTAPS + (NTAPS - 1 - j))];
+                            const double ti = taps[2 * (f * NTAPS + (NTAPS - 1 - j)) + 1];
+                            ar[f] = fma(x.x, tr, fma(-x.y, ti, ar[f]));
+                            ai[f] = fma(x.x, ti, fma(x.y, tr, ai[f]));
+                        }
                     }
                 }
-                if (++jm == step) {
-                    jm = 0;
-                    extra += pad;
+            } else {
+                int extra = 0, jm = 0;
+#ifdef WF_ABL_NO_MAC
+                for (int j = 0; j < 1; ++j) {
+#else
+                for (int j = 0; j < ntaps; ++j) {
+#endif
+                    const double2 x = s_win[base + j + extra];
+                    const int tt = ntaps - 1 - j;
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        if (f < P.nfilt) {
+                            const double tr = taps[2 * (f * ntaps + tt)];
+                            const double ti = taps[2 * (f * ntaps + tt) + 1];
+                            ar[f] = fma(x.x, tr, fma(-x.y, ti, ar[f]));
+                            ai[f] = fma(x.x, ti, fma(x.y, tr, ai[f]));
+                        }
+                    }
+                    if (++jm == step) {
+                        jm = 0;
+                        extra += pad;
+                    }
                 }
             }
             double2 *o = reinterpret_cast<double2 *>(out + 2 * (k * P.nfilt));
@@ -206,9 +224,10 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     const size_t lds = (size_t)slots * sizeof(double2);
     using kern_t = void (*)(const double *, const double *, double *, mf_params);
     kern_t k;
-    if (step == 8 && nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 8> : mf_bank_kernel<3, false, 8>;
-    else if (nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 0> : mf_bank_kernel<3, false, 0>;
-    else k = noise ? mf_bank_kernel<8, true, 0> : mf_bank_kernel<8, false, 0>;
+    if (step == 8 && nfilt == 3 && ntaps == 9) k = noise ? mf_bank_kernel<3, true, 8, 9> : mf_bank_kernel<3, false, 8, 9>;
+    else if (step == 8 && nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 8, 0> : mf_bank_kernel<3, false, 8, 0>;
+    else if (nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 0, 0> : mf_bank_kernel<3, false, 0, 0>;
+    else k = noise ? mf_bank_kernel<8, true, 0, 0> : mf_bank_kernel<8, false, 0, 0>;
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(MF_THREADS), lds, s, d_r_ri, d_taps_ri, d_out_ri, P);

@@ -92,7 +92,7 @@ def main() -> None:
                          "0 = every stage its own kernel")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent trial blocks in flight on separate HIP streams (own workspace + context each)")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 22)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -97,20 +97,25 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
         if (R < 0) R += P.sps;
         double run = 0.0, k0 = 0.0;
         for (int l = 0; l < MOD_MAX_PART; ++l) scratch[MOD_OFF_GPART + l] = 0.0;
+        // num = ntaps - 1 + R - k hits (l+1)*sps at the partial-symbol taps, hn = c - 1 - k hits
+        // mp1*sps at the head-correction taps; both count down with k, so their remainders and
+        // quotients are tracked incrementally (no division in this serial loop)
+        int num = P.ntaps - 1 + R, num_q = num / P.sps, num_r = num - num_q * P.sps;
+        int hn = P.c - 1, hn_q = hn >= 0 ? hn / P.sps : 0, hn_r = hn >= 0 ? hn - hn_q * P.sps : 0;
         for (int k = 0; k < P.ntaps; ++k) {
             run += pulse[k];
-            // partial table
-            const int num = P.ntaps - 1 + R - k;  // = (l+1)*sps ?
-            if (num > 0 && num % P.sps == 0) {
-                const int l = num / P.sps - 1;
+            if (num > 0 && num_r == 0) {
+                const int l = num_q - 1;
                 if (l >= 0 && l < P.npart) scratch[MOD_OFF_GPART + l] = run;
             }
-            // head correction: k = c - 1 - mp1*sps
-            const int hn = P.c - 1 - k;
-            if (hn > 0 && hn % P.sps == 0) {
-                const int64_t mp1 = hn / P.sps;
+            if (hn > 0 && hn_r == 0) {
+                const int64_t mp1 = hn_q;
                 if (mp1 >= 1 && mp1 <= P.nhead && mp1 <= P.nsym) k0 += mod_amp(symbols, hvec, P, mp1 - 1) * run;
             }
+            --num;
+            if (--num_r < 0) { num_r = P.sps - 1; --num_q; }
+            --hn;
+            if (--hn_r < 0) { hn_r = P.sps - 1; --hn_q; }
         }
         scratch[0] = run;
         scratch[1] = k0;

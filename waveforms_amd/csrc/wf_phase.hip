@@ -82,13 +82,13 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
 
     for (long long iter_ = 0;; ++iter_) {
         (void)iter_;
-        __syncthreads();  // previous iteration's LDS reads are done
+        wf_lds_barrier();  // previous iteration's LDS reads are done
 #ifdef WF_ABL_NO_TICKET    // ablation only: static tile order (can deadlock in general)
         if (t == 0) s_tile = (long long)blockIdx.x + (long long)gridDim.x * iter_;
 #else
         if (t == 0) s_tile = (long long)atomicAdd((unsigned long long *)&scan[0], 1ull);
 #endif
-        __syncthreads();
+        wf_lds_barrier();
         const int64_t tile = s_tile;
         if (tile >= P.ntiles) break;
         const int64_t base = tile * PH_TILE;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
             ex[u] = lane == 0 ? 0.0 : e;
             if (lane == 63) s_tot[u * PH_WAVES + wave] = inc;
         }
-        __syncthreads();
+        wf_lds_barrier();
         double off[PH_ROWS];
         double running = 0.0;
 #pragma unroll
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
                 if (revs_out && tile == P.ntiles - 1) *revs_out = from_fixed(q_inc, P.sps);
             }
         }
-        __syncthreads();
+        wf_lds_barrier();
         const double prefix = from_fixed(s_prefix, P.sps);
 #pragma unroll
         for (int u = 0; u < PH_ROWS; ++u) {

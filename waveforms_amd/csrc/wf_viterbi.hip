@@ -219,14 +219,14 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
 
     // cooperative piece p = u*64 + lane  ->  (segment = lane of the wave it belongs to, piece index).
     // Everything per-lane is 32-bit and batch-invariant; the batch only moves a wave-uniform base.
-    int slot[VIT_PIECES], rrel[VIT_PIECES], off[VIT_PIECES];
+    // (segment, piece) of this lane's u-th cooperative piece, packed; LDS slot, row and global
+    // offset are derived from it where needed (keeps 24 registers out of the loop)
+    int sgw[VIT_PIECES];
 #pragma unroll
     for (int u = 0; u < VIT_PIECES; ++u) {
         const int p = u * WF_WAVE + lane;
-        const int sg = p / VIT_PIECES, wi = p - sg * VIT_PIECES;
-        slot[u] = sg * VIT_LANE_SLOTS + wi;     // LDS slot
-        rrel[u] = sg * CH + wi / 3;             // row relative to the wave's first row of the batch
-        off[u] = 3 * rrel[u] + wi % 3;          // 16-byte piece relative to that row
+        const int sg = p / VIT_PIECES;
+        sgw[u] = (sg << 8) | (p - sg * VIT_PIECES);
     }
     const int64_t g0u = __builtin_amdgcn_readfirstlane((int)(g0 >> 6)) * (int64_t)WF_WAVE;   // wave-uniform copy of g0
     auto fetch = [&](int b, double2 dst[VIT_PIECES]) {
@@ -237,16 +237,18 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
         const double2 *basep = rows + 3 * rb;
 #pragma unroll
         for (int u = 0; u < VIT_PIECES; ++u) {
+            const int sg = sgw[u] >> 8, wi = sgw[u] & 255;
+            const int rrel = sg * CH + wi / 3;          // row relative to the wave's first row of the batch
 #ifdef WF_ABL_NO_MEM   // ablation only
-            dst[u] = make_double2((double)(rrel[u] & 7) - 3.5, (double)(off[u] & 3) - 1.0);
+            dst[u] = make_double2((double)(rrel & 7) - 3.5, (double)(wi & 3) - 1.0);
 #else
-            dst[u] = (rrel[u] >= lo && rrel[u] < hi) ? basep[off[u]] : make_double2(0.0, 0.0);
+            dst[u] = (rrel >= lo && rrel < hi) ? basep[3 * CH * sg + wi] : make_double2(0.0, 0.0);
 #endif
         }
     };
     auto stash = [&](const double2 src[VIT_PIECES]) {
 #pragma unroll
-        for (int u = 0; u < VIT_PIECES; ++u) tile[slot[u]] = src[u];
+        for (int u = 0; u < VIT_PIECES; ++u) tile[(sgw[u] >> 8) * VIT_LANE_SLOTS + (sgw[u] & 255)] = src[u];
     };
 
     vit_lane L;

@@ -176,5 +176,3 @@ def decimation(size: int, sps: int, length: int, timing_offset: int):
     ncols = (limit - first + sps - 1) // sps if limit > first else 0
     return first, ncols
 
-
-SQRT_HALF = math.sqrt(0.5)

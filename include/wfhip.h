@@ -250,6 +250,18 @@ int wf_link_stream_layout(const wf_link_config *cfg, int64_t chunk_symbols, int6
 int wf_link_stream_chunk(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
                          void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
                          int64_t *h_compared, void *stream);
+/* Steady state for hipGraph replay: the launch sequence of an INTERIOR chunk with the only
+ * two per-chunk quantities (PRBS position, noise counter) kept in d_state and advanced on the
+ * device, so every call issues identical launches.  Use: chunk 0 with wf_link_stream_chunk,
+ * capture ONE wf_link_stream_steady call (hipStreamBeginCapture / torch.cuda.graph) and
+ * replay it once per interior chunk 1, 2, ... (wf_link_stream_interior tells which chunks
+ * qualify; d_state's position words start at zero and every call ends by advancing them one
+ * chunk), then finish the remaining chunk(s) with wf_link_stream_chunk.  Allocates and
+ * synchronises nothing.  Same results as wf_link_stream_chunk. */
+int wf_link_stream_interior(const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index);
+int wf_link_stream_steady(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, void *d_state,
+                          void *d_workspace, int64_t workspace_bytes, int64_t *d_counts, int64_t *h_compared,
+                          void *stream);
 
 #ifdef __cplusplus
 }

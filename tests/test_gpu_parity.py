@@ -522,3 +522,18 @@ def test_timing_offset_scan_on_gpu(oracle, golden):
             db, ds = SOQPSKTrellisDetector().detect(bank(r, first=first, step=8, ncols=ncols))
             se, be, m = oracle.count_errors(ds, db, sym, bits, 2)
             assert [se, be, m] == scan[str(off)][kind], (off, kind)
+
+
+def test_stream_graph_replay_equals_eager_chunks():
+    """hipGraph steady state (config 5): one captured interior chunk replayed with the PRBS
+    position / noise counter advanced on the device == the eager chunk-by-chunk run."""
+    from waveforms_amd.link import SOQPSKStream
+
+    chunk = 1 << 15
+    st = SOQPSKStream(9 * chunk + 777, chunk, 8)
+    n_int = st.interior_chunks()      # chunks 1..7: chunk 8's halo already runs past the end of the stream
+    assert st.nchunks == 10 and n_int == 7
+    for ebn0 in (3.0, 9.0):
+        want = st.run(ebn0, seed=5, stream_id=2)
+        got = st.run_graph(ebn0, seed=5, stream_id=2)
+        assert got == want and st.graph_replays == n_int and want[1] > 0

@@ -67,6 +67,12 @@ int wf_ctx_reserve_fsm(wf_ctx *ctx, size_t words);
 int wf_ctx_reserve_mod(wf_ctx *ctx, size_t words);
 
 // Internal (not exported) forms with device-resident carries, used by the streaming link.
+int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
+                         const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream);
+int wf_awgn_mf_bank_dyn(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,
+                        double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
+                        const uint64_t *d_dyn_index, const double *d_taps_ri, int nfilt, int ntaps, int64_t first,
+                        int step, int64_t ncols, double *d_out_ri, void *stream);
 int wf_cpm_modulate_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total,
                            const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
                            int64_t tile_lo, int64_t ntiles, double *d_out_ri, int64_t out_origin,

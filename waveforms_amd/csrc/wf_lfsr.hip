@@ -57,8 +57,10 @@ static uint64_t host_jump(const wf_lfsr_tables *t, uint64_t state, uint64_t step
 __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__restrict__ jump,
                                                               uint64_t mask, uint64_t state,
                                                               uint64_t skip, uint8_t *__restrict__ bits,
-                                                              int64_t n, int degree)
+                                                              int64_t n, int degree,
+                                                              const uint64_t *__restrict__ dyn_skip)
 {
+    if (dyn_skip) skip += *dyn_skip;   // stream replayed as a graph: the position lives on the device
     __shared__ uint64_t s_tab[64][64];   // all 64 jump matrices (32 KB), staged with parallel loads
     __shared__ uint64_t s_words[LFSR_THREADS * LFSR_WORDS];
     __shared__ uint64_t s_base;
@@ -131,9 +133,18 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
     }
 }
 
+int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
+                         const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream);
+
 extern "C" int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state,
                                 uint64_t skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out,
                                 void *stream)
+{
+    return wf_lfsr_generate_dyn(ctx, degree, mask, state, skip, nullptr, d_bits, n, h_state_out, stream);
+}
+
+int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
+                         const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream)
 {
     WF_REQUIRE(ctx != nullptr, "wf_lfsr_generate: ctx is NULL");
     if (degree < 2 || degree > 64) {
@@ -156,7 +167,7 @@ extern "C" int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t
     const int64_t blocks = (n + LFSR_BITS_PER_BLOCK - 1) / LFSR_BITS_PER_BLOCK;
     WF_REQUIRE(blocks < (1ll << 31), "wf_lfsr_generate: n too large for one launch");
     hipLaunchKernelGGL(lfsr_kernel, dim3((unsigned)blocks), dim3(LFSR_THREADS), 0, wf_stream(stream),
-                       t->dev, mask, state, skip, d_bits, n, degree);
+                       t->dev, mask, state, skip, d_bits, n, degree, d_dyn_skip);
     WF_LAUNCH_CHECK();
     return WF_OK;
 }

@@ -29,6 +29,7 @@ struct mf_params {
     // fused channel (NOISE instantiation): staged sample = r*rot + sigma*N(idx)
     double rot_re, rot_im, sigma;
     uint64_t seed, stream_id, first_index;
+    const uint64_t *dyn_index;   // optional device addend to first_index (graph replay of a stream)
 };
 
 template <int NF, bool NOISE, int STEP, int NTAPS>   // STEP / NTAPS: compile-time fast path (0 = take P.step / P.ntaps)
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
             // Gaussian source is ~400 instructions); the next pair's loads are in flight while
             // the channel is applied to the current one.  All per-lane index math is 32-bit
             // window offsets; the burst bounds become a wave-uniform offset range [vlo, vhi).
-            const int64_t a0 = (int64_t)P.first_index + ws;          // absolute index of the window start
+            const int64_t a0 = (int64_t)(P.first_index + (P.dyn_index ? *P.dyn_index : 0ull)) + ws;   // absolute index of the window start
             const int odd = (int)(a0 & 1);                            // window starts on the odd half of a pair
             const uint64_t pair_lo = (uint64_t)(a0 >> 1);             // floor, also for negative a0
             const int64_t lo64 = -ws, hi64 = P.nsamp - ws;            // offsets of burst samples 0 and nsamp
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
 static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_taps_ri, int nfilt,
                           int ntaps, int64_t first, int step, int64_t ncols, double *d_out_ri, void *stream,
                           bool noise, double rot_re, double rot_im, double sigma, uint64_t seed,
-                          uint64_t stream_id, uint64_t first_index)
+                          uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index = nullptr)
 {
     WF_REQUIRE(ctx && d_r_ri && d_taps_ri, "wf_mf_bank_c128: NULL argument");
     WF_REQUIRE(nfilt >= 1 && nfilt <= 8 && ntaps >= 1 && step >= 1 && ncols >= 0 && first >= 0,
@@ -204,6 +205,7 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     P.seed = seed;
     P.stream_id = stream_id;
     P.first_index = first_index;
+    P.dyn_index = d_dyn_index;
     // slots(ob) = (ob-1)*step + ntaps + pad*(that/step + 1) <= MF_LDS_SLOTS
     int ob = MF_THREADS;
     for (;;) {
@@ -250,4 +252,15 @@ extern "C" int wf_awgn_mf_bank_c128(wf_ctx *ctx, const double *d_signal_ri, int6
 {
     return mf_bank_launch(ctx, d_signal_ri, nsamp, d_taps_ri, nfilt, ntaps, first, step, ncols, d_out_ri, stream, true,
                           rot_re, rot_im, sigma, seed, stream_id, first_index);
+}
+
+// Internal: fused channel + bank whose noise counter is first_index + *d_dyn_index (read on
+// the device), for the graph-replayed steady state of the streaming link.
+int wf_awgn_mf_bank_dyn(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,
+                        double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
+                        const uint64_t *d_dyn_index, const double *d_taps_ri, int nfilt, int ntaps, int64_t first,
+                        int step, int64_t ncols, double *d_out_ri, void *stream)
+{
+    return mf_bank_launch(ctx, d_signal_ri, nsamp, d_taps_ri, nfilt, ntaps, first, step, ncols, d_out_ri, stream, true,
+                          rot_re, rot_im, sigma, seed, stream_id, first_index, d_dyn_index);
 }

@@ -262,9 +262,10 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
             if (active) {
                 const int64_t n = tile_base + (int64_t)u * P.rs + 2 * t;
                 const double v0 = run + (offw + ex + acc0);
-                const double v1 = v0 + acc1;
+                // one exact reduction per pair; the second sample is a single frequency-pulse value
+                // further and wf_sincos_turns reduces its argument exactly anyway
                 const double ra = mod_pos_d(v0, P.sps_d, P.inv_sps);
-                const double rb = mod_pos_d(v1, P.sps_d, P.inv_sps);
+                const double rb = ra + acc1;
                 double s0, c0, s1, c1;
 #ifdef WF_ABL_NO_SINCOS
                 s0 = ra; c0 = ra + 1; s1 = rb; c1 = rb + 1;

@@ -149,31 +149,94 @@ __device__ __forceinline__ void wf_sincos_turns(double t, double *sn, double *cs
     *cs = ((qi + 1) & 2) ? -c1 : c1;
 }
 
-// Natural log of a NORMAL positive double (no zero / subnormal / inf / nan handling:
-// callers pass u in [2^-53, 1]).  Exponent split + the fdlibm e_log.c minimax series
-// in s = f / (2 + f); the quotient uses v_rcp_f64 + two Newton steps.  < 1 ulp.
-__device__ __forceinline__ double wf_log_normal(double x)
+// ln((xa + 1) * 2^-32) for a 32-bit word: table-driven.  m in [1, 2) from the exponent split of
+// the exact double xa + 1; 128-entry table of {1/c_i (rounded), ln(1/that)} at the bucket
+// centres c_i = 1 + (i + 0.5)/128 (generated with 50-digit arithmetic), r = m/c_i - 1 by one
+// fma (|r| <= 2^-8), log1p(r) by a degree-6 series (next term < 2e-18).  About half the fp64
+// operations of the division-based series, no rcp.  < 1 ulp.
+static __device__ __constant__ double2 kWfLogTab[128] = {
+    {0x1.fe01fe01fe020p-1, 0x1.ff00aa2b10ba0p-9}, {0x1.fa11caa01fa12p-1, 0x1.7dc475f810a69p-7},
+    {0x1.f6310aca0dbb5p-1, 0x1.3cea44346a584p-6}, {0x1.f25f644230ab5p-1, 0x1.b9fc027af919ap-6},
+    {0x1.ee9c7f8458e02p-1, 0x1.1b0d98923d97fp-5}, {0x1.eae807aba01ebp-1, 0x1.58a5bafc8e4d3p-5},
+    {0x1.e741aa59750e4p-1, 0x1.95c830ec8e3f2p-5}, {0x1.e3a9179dc1a73p-1, 0x1.d276b8adb0b56p-5},
+    {0x1.e01e01e01e01ep-1, 0x1.075983598e471p-4}, {0x1.dca01dca01dcap-1, 0x1.253f62f0a1417p-4},
+    {0x1.d92f2231e7f8ap-1, 0x1.42edcbea646eep-4}, {0x1.d5cac807572b2p-1, 0x1.60658a93750c4p-4},
+    {0x1.d272ca3fc5b1ap-1, 0x1.7da766d7b12d0p-4}, {0x1.cf26e5c44bfc6p-1, 0x1.9ab42462033aep-4},
+    {0x1.cbe6d9601cbe7p-1, 0x1.b78c82bb0eda0p-4}, {0x1.c8b265afb8a42p-1, 0x1.d4313d66cb35dp-4},
+    {0x1.c5894d10d4986p-1, 0x1.f0a30c01162a4p-4}, {0x1.c26b5392ea01cp-1, 0x1.0671512ca596fp-3},
+    {0x1.bf583ee868d8bp-1, 0x1.14785846742acp-3}, {0x1.bc4fd65883e7bp-1, 0x1.2266f190a5acdp-3},
+    {0x1.b951e2b18ff23p-1, 0x1.303d718e47fd5p-3}, {0x1.b65e2e3beee05p-1, 0x1.3dfc2b0ecc62ap-3},
+    {0x1.b37484ad806cep-1, 0x1.4ba36f39a55e5p-3}, {0x1.b094b31d922a4p-1, 0x1.59338d9982085p-3},
+    {0x1.adbe87f94905ep-1, 0x1.66acd4272ad51p-3}, {0x1.aaf1d2f87ebfdp-1, 0x1.740f8f54037a3p-3},
+    {0x1.a82e65130e159p-1, 0x1.815c0a14357e9p-3}, {0x1.a574107688a4ap-1, 0x1.8e928de886d41p-3},
+    {0x1.a2c2a87c51ca0p-1, 0x1.9bb362e7dfb85p-3}, {0x1.a01a01a01a01ap-1, 0x1.a8becfc882f19p-3},
+    {0x1.9d79f176b682dp-1, 0x1.b5b519e8fb5a6p-3}, {0x1.9ae24ea5510dap-1, 0x1.c2968558c18c2p-3},
+    {0x1.9852f0d8ec0ffp-1, 0x1.cf6354e09c5ddp-3}, {0x1.95cbb0be377aep-1, 0x1.dc1bca0abec7bp-3},
+    {0x1.934c67f9b2ce6p-1, 0x1.e8c0252aa5a60p-3}, {0x1.90d4f120190d5p-1, 0x1.f550a564b7b37p-3},
+    {0x1.8e6527af1373fp-1, 0x1.00e6c45ad501dp-2}, {0x1.8bfce8062ff3ap-1, 0x1.071b85fcd590dp-2},
+    {0x1.899c0f601899cp-1, 0x1.0d46b579ab74bp-2}, {0x1.87427bcc092b9p-1, 0x1.136870293a8b0p-2},
+    {0x1.84f00c2780614p-1, 0x1.1980d2dd4236fp-2}, {0x1.82a4a0182a4a0p-1, 0x1.1f8ff9e48a2f3p-2},
+    {0x1.8060180601806p-1, 0x1.2596010df763ap-2}, {0x1.7e225515a4f1dp-1, 0x1.2b9303ab89d25p-2},
+    {0x1.7beb3922e017cp-1, 0x1.31871c9544185p-2}, {0x1.79baa6bb6398bp-1, 0x1.3772662bfd85cp-2},
+    {0x1.77908119ac60dp-1, 0x1.3d54fa5c1f710p-2}, {0x1.756cac201756dp-1, 0x1.432ef2a04e813p-2},
+    {0x1.734f0c541fe8dp-1, 0x1.49006804009d0p-2}, {0x1.713786d9c7c09p-1, 0x1.4ec9732600269p-2},
+    {0x1.6f26016f26017p-1, 0x1.548a2c3add263p-2}, {0x1.6d1a62681c861p-1, 0x1.5a42ab0f4cfe2p-2},
+    {0x1.6b1490aa31a3dp-1, 0x1.5ff3070a793d4p-2}, {0x1.691473a88d0c0p-1, 0x1.659b57303e1f2p-2},
+    {0x1.6719f3601671ap-1, 0x1.6b3bb2235943dp-2}, {0x1.6524f853b4aa3p-1, 0x1.70d42e2789236p-2},
+    {0x1.63356b88ac0dep-1, 0x1.7664e1239dbcfp-2}, {0x1.614b36831ae94p-1, 0x1.7bede0a37afbfp-2},
+    {0x1.5f66434292dfcp-1, 0x1.816f41da0d495p-2}, {0x1.5d867c3ece2a5p-1, 0x1.86e919a330ba1p-2},
+    {0x1.5babcc647fa91p-1, 0x1.8c5b7c858b48bp-2}, {0x1.59d61f123ccaap-1, 0x1.91c67eb45a83ep-2},
+    {0x1.5805601580560p-1, 0x1.972a341135159p-2}, {0x1.56397ba7c52e2p-1, 0x1.9c86b02dc0862p-2},
+    {0x1.54725e6bb82fep-1, 0x1.a1dc064d5b995p-2}, {0x1.52aff56a8054bp-1, 0x1.a72a4966bd9e9p-2},
+    {0x1.50f22e111c4c5p-1, 0x1.ac718c258b0e5p-2}, {0x1.4f38f62dd4c9bp-1, 0x1.b1b1e0ebdfc5ap-2},
+    {0x1.4d843bedc2c4cp-1, 0x1.b6eb59d3cf35cp-2}, {0x1.4bd3edda68fe1p-1, 0x1.bc1e08b0dad0ap-2},
+    {0x1.4a27fad76014ap-1, 0x1.c149ff115f027p-2}, {0x1.4880522014880p-1, 0x1.c66f4e3ff6ff9p-2},
+    {0x1.46dce34596066p-1, 0x1.cb8e0744d7acap-2}, {0x1.453d9e2c776cap-1, 0x1.d0a63ae721e64p-2},
+    {0x1.43a2730abee4dp-1, 0x1.d5b7f9ae2c684p-2}, {0x1.420b5265e5951p-1, 0x1.dac353e2c5955p-2},
+    {0x1.40782d10e6566p-1, 0x1.dfc859906d5b5p-2}, {0x1.3ee8f42a5af07p-1, 0x1.e4c71a8687704p-2},
+    {0x1.3d5d991aa75c6p-1, 0x1.e9bfa659861f5p-2}, {0x1.3bd60d9232955p-1, 0x1.eeb20c640ddf3p-2},
+    {0x1.3a524387ac822p-1, 0x1.f39e5bc811e5dp-2}, {0x1.38d22d366088ep-1, 0x1.f884a36fe9ec1p-2},
+    {0x1.3755bd1c945eep-1, 0x1.fd64f20f61571p-2}, {0x1.35dce5f9f2af8p-1, 0x1.011fab125ff8ap-1},
+    {0x1.34679ace01346p-1, 0x1.0389eefce633cp-1}, {0x1.32f5ced6a1dfap-1, 0x1.05f14bd26459cp-1},
+    {0x1.3187758e9ebb6p-1, 0x1.0855c884b450ep-1}, {0x1.301c82ac40260p-1, 0x1.0ab76bece14d2p-1},
+    {0x1.2eb4ea1fed14bp-1, 0x1.0d163ccb9d6b8p-1}, {0x1.2d50a012d50a0p-1, 0x1.0f7241c9b497dp-1},
+    {0x1.2bef98e5a3711p-1, 0x1.11cb81787ccf8p-1}, {0x1.2a91c92f3c105p-1, 0x1.1422025243d45p-1},
+    {0x1.293725bb804a5p-1, 0x1.1675cababa60ep-1}, {0x1.27dfa38a1ce4dp-1, 0x1.18c6e0ff5cf07p-1},
+    {0x1.268b37cd60127p-1, 0x1.1b154b57da29ep-1}, {0x1.2539d7e9177b2p-1, 0x1.1d610fe677003p-1},
+    {0x1.23eb79717605bp-1, 0x1.1faa34b87094cp-1}, {0x1.22a0122a0122ap-1, 0x1.21f0bfc65beecp-1},
+    {0x1.21579804855e6p-1, 0x1.2434b6f483934p-1}, {0x1.2012012012012p-1, 0x1.26762013430e0p-1},
+    {0x1.1ecf43c7fb84cp-1, 0x1.28b500df60783p-1}, {0x1.1d8f5672e4abdp-1, 0x1.2af15f02640acp-1},
+    {0x1.1c522fc1ce059p-1, 0x1.2d2b4012edc9dp-1}, {0x1.1b17c67f2bae3p-1, 0x1.2f62a99509546p-1},
+    {0x1.19e0119e0119ep-1, 0x1.3197a0fa7fe6ap-1}, {0x1.18ab083902bdbp-1, 0x1.33ca2ba328994p-1},
+    {0x1.1778a191bd684p-1, 0x1.35fa4edd36ea0p-1}, {0x1.1648d50fc3201p-1, 0x1.38280fe58797fp-1},
+    {0x1.151b9a3fdd5c9p-1, 0x1.3a5373e7ebdf9p-1}, {0x1.13f0e8d344724p-1, 0x1.3c7c7fff73206p-1},
+    {0x1.12c8b89edc0acp-1, 0x1.3ea33936b2f5bp-1}, {0x1.11a3019a74826p-1, 0x1.40c7a4880dceap-1},
+    {0x1.107fbbe011080p-1, 0x1.42e9c6ddf80bfp-1}, {0x1.0f5edfab325a2p-1, 0x1.4509a5133bb0ap-1},
+    {0x1.0e40655826011p-1, 0x1.472743f33aaadp-1}, {0x1.0d24456359e3ap-1, 0x1.4942a83a2fc07p-1},
+    {0x1.0c0a7868b4171p-1, 0x1.4b5bd6956e273p-1}, {0x1.0af2f722eecb5p-1, 0x1.4d72d3a39fd01p-1},
+    {0x1.09ddba6af8360p-1, 0x1.4f87a3f5026e9p-1}, {0x1.08cabb37565e2p-1, 0x1.519a4c0ba3446p-1},
+    {0x1.07b9f29b8eae2p-1, 0x1.53aad05b99b7cp-1}, {0x1.06ab59c7912fbp-1, 0x1.55b9354b40bcep-1},
+    {0x1.059eea0727586p-1, 0x1.57c57f336f191p-1}, {0x1.04949cc1664c5p-1, 0x1.59cfb25fae87fp-1},
+    {0x1.038c6b78247fcp-1, 0x1.5bd7d30e71c73p-1}, {0x1.02864fc7729e9p-1, 0x1.5ddde57149923p-1},
+    {0x1.0182436517a37p-1, 0x1.5fe1edad18919p-1}, {0x1.0080402010080p-1, 0x1.61e3efda46467p-1},
+};
+
+__device__ __forceinline__ double wf_log_unit32(uint32_t xa)
 {
+    const double x = (double)xa + 1.0;                              // 1 .. 2^32, exact
     const long long ix = __double_as_longlong(x);
-    int e = (int)(ix >> 52) - 1023;
+    const int e = (int)(ix >> 52) - (1023 + 32);
     const long long mant = ix & 0x000FFFFFFFFFFFFFll;
-    const bool up = mant >= 0x0006A09E667F3BCDll;            // m >= sqrt(2): use m/2
-    e += up ? 1 : 0;
-    const double m = __longlong_as_double(mant | (up ? 0x3FE0000000000000ll : 0x3FF0000000000000ll));
-    const double f = m - 1.0;                                 // [-0.2929, 0.4142]
-    const double d = 2.0 + f;
-    double r = __builtin_amdgcn_rcp(d);
-    r = r * fma(-d, r, 2.0);
-    r = r * fma(-d, r, 2.0);
-    const double s = f * r;
-    const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                     2.857142874366239149e-01), 6.666666666666735130e-01);
-    const double R = t1 + t2;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)e;
-    return fma(dk, 6.93147180369123816490e-01, f - (hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)));
+    const double m = __longlong_as_double(mant | 0x3FF0000000000000ll);
+    const double2 tc = kWfLogTab[(int)(mant >> 45)];
+    const double r = fma(m, tc.x, -1.0);
+    double p = fma(r, -1.0 / 6.0, 0.2);
+    p = fma(r, p, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r, p, 1.0);
+    const double de = (double)e;
+    return fma(de, 6.93147180369123816490e-01, fma(r, p, tc.y) + de * 1.90821492927058770002e-10);
 }
 
 // sqrt of a non-negative normal double (0 allowed): v_rsq_f64 seed + Goldschmidt, then
@@ -220,12 +283,11 @@ __device__ __forceinline__ wf_philox_out wf_philox4x32_10(uint32_t c0, uint32_t 
 // Box-Muller from two 32-bit words: u1 = (xa + 1) 2^-32 in (0, 1], u2 = xb 2^-32 in [0, 1).
 __device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double sigma, double *re, double *im)
 {
-    const double u1 = ((double)xa + 1.0) * 0x1.0p-32;
     const double u2 = (double)xb * 0x1.0p-32;
 #ifdef WF_ABL_NO_LOG
-    const double r = sigma * u1;
+    const double r = sigma * ((double)xa + 1.0) * 0x1.0p-32;
 #else
-    const double r = sigma * wf_sqrt_pos(-2.0 * wf_log_normal(u1));
+    const double r = sigma * wf_sqrt_pos(-2.0 * wf_log_unit32(xa));
 #endif
     double s, c;
 #ifdef WF_ABL_NO_SINCOS

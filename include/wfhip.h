@@ -127,6 +127,12 @@ int wf_awgn_c128(wf_ctx *ctx, const double *d_in_ri, int64_t n, double rot_re, d
                  double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
                  double *d_out_ri, void *stream);
 
+/* The Box-Muller half of the source on caller-supplied words: sample k from
+ * (d_words[2k], d_words[2k+1]) = (radius word xa, angle word xb) exactly as wf_awgn_c128
+ * uses the halves of a Philox block.  |sample| <= sigma * sqrt(64 ln 2) = 6.66 sigma. */
+int wf_box_muller32_c128(wf_ctx *ctx, const uint32_t *d_words, int64_t n, double sigma, double *d_out_ri,
+                         void *stream);
+
 /* ---- K6/K7: matched-filter bank ----------------------------------------------
  * nfilt complex FIRs, each np.convolve(r, taps[f], "same") sampled at
  * n = first + k*step, k < ncols   (examples/soqpsk_detection.py:141-156 PT bank,

@@ -18,7 +18,7 @@ __all__ = [
     "freq_pulse_soqpsk", "freq_pulse_soqpsk_tg", "freq_pulse_soqpsk_mil", "freq_pulse_soqpsk_a",
     "freq_pulse_soqpsk_b", "freq_pulse_multih_irig", "freq_pulse_pcmfm", "kaiser_fir_lpf",
     "pam_unit_pulse", "pam_unit_pulse2", "rho_pulses", "upsample_fir", "frequency_modulate",
-    "phase_modulate", "cpm_modulate", "numpy_awgn", "philox4x32_10", "philox_awgn",
+    "phase_modulate", "cpm_modulate", "numpy_awgn", "philox4x32_10", "philox_awgn", "box_muller32",
     "pt_taps", "pt_bank", "pam_bank", "PSEUDO_SYMBOLS", "decimate_columns", "ViterbiOracle",
     "viterbi_detect", "count_errors", "detection_run", "sigma_for_ebn0", "upsample_fir_direct",
     "mf_bank_decim_direct",
@@ -347,6 +347,14 @@ def philox4x32_10(ctr, key):
     out = np.zeros(4, dtype=np.uint32)
     _c().orc_philox4x32_10(_p(np.asarray(ctr, dtype=np.uint32)),
                            _p(np.asarray(key, dtype=np.uint32)), _p(out))
+    return out
+
+
+def box_muller32(words, sigma):
+    """Box-Muller of uint32 word pairs (n x 2), the transform inside philox_awgn."""
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.empty(w.shape[0], dtype=np.complex128)
+    _c().orc_box_muller32(_p(w), ctypes.c_int64(w.shape[0]), ctypes.c_double(sigma), _p(out))
     return out
 
 

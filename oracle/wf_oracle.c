@@ -272,6 +272,19 @@ void orc_philox_awgn(double sigma, uint64_t seed, uint64_t stream, uint64_t firs
     }
 }
 
+/* The Box-Muller step of orc_philox_awgn on caller-supplied words (2 per sample). */
+void orc_box_muller32(const uint32_t *words, int64_t n, double sigma, double *out_ri)
+{
+    for (int64_t k = 0; k < n; ++k) {
+        const double u1 = ((double)words[2 * k] + 1.0) * 0x1.0p-32;
+        const double u2 = (double)words[2 * k + 1] * 0x1.0p-32;
+        const double r = sigma * sqrt(-2.0 * log(u1));
+        const double th = 2.0 * M_PI * u2;
+        out_ri[2 * k] = r * cos(th);
+        out_ri[2 * k + 1] = r * sin(th);
+    }
+}
+
 /* ------------------------------------------------------------------ K3 ---- */
 /* waveforms/cpm/modulate.py:95-99 — zero-stuffed upsample (impulses at
  * sps, 2*sps, ..., N*sps) convolved with the pulse, mode="same"

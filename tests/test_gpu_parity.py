@@ -305,6 +305,28 @@ def test_philox_awgn(oracle):
     assert abs(np.mean(np.abs(big.real) > 3) - 0.0026998) < 2e-4       # Gaussian tail
 
 
+def test_box_muller_edge_words(oracle):
+    """Every extreme of the radius / angle words: u1 = 2^-32 (largest radius), u1 = 1 exactly
+    (radius 0 — the rounding of ln(1) once produced a 1e133 sample), bucket edges of the log
+    table, angle words on the quadrant boundaries; plus a random sweep."""
+    from waveforms_amd import _hip, device as dev
+
+    edge = [0, 1, 2, 3, 0x7FFFFFFF, 0x80000000, 0x80000001, 0xFFFFFFFD, 0xFFFFFFFE, 0xFFFFFFFF,
+            0x00FFFFFF, 0x01000000, 0x3FFFFFFF, 0x40000000, 0xBFFFFFFF, 0xC0000000]
+    edge += [(i << 25) % (1 << 32) for i in range(128)] + [((i << 25) - 1) % (1 << 32) for i in range(128)]
+    xa, xb = np.meshgrid(np.array(edge, dtype=np.uint32), np.array(edge[:16], dtype=np.uint32))
+    rng = np.random.Generator(np.random.PCG64(77))
+    rand = rng.integers(0, 1 << 32, size=(500_000, 2), dtype=np.uint64).astype(np.uint32)
+    words = np.concatenate((np.stack((xa.ravel(), xb.ravel()), axis=1), rand))
+    got = _hip.to_host(dev.box_muller32(_hip.to_device(words.view(np.int32)), 1.25), complex_pairs=True)
+    want = oracle.box_muller32(words, 1.25)
+    assert np.isfinite(got.view(np.float64)).all()
+    assert np.abs(got).max() <= 1.25 * np.sqrt(64 * np.log(2)) * (1 + 1e-12)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    # u1 = 1 -> radius exactly 0
+    assert np.all(got[words[:, 0] == 0xFFFFFFFF] == 0)
+
+
 # ------------------------------------------------------------------ K6 / K7
 def test_matched_filter_banks(oracle, golden):
     from waveforms.filters.matched import MatchedFilterBank, pam_matched_filter_taps, pt_matched_filter_taps

@@ -37,6 +37,7 @@ SIGNATURES = {
     "wf_phase_modulate_f64": (c_int, [_P, _P, c_int64, c_double, _P, _P]),
     "wf_time_axis_f64": (c_int, [_P, c_int64, c_double, _P, _P]),
     "wf_awgn_c128": (c_int, [_P, _P, c_int64, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64, _P, _P]),
+    "wf_box_muller32_c128": (c_int, [_P, _P, c_int64, c_double, _P, _P]),
     "wf_mf_bank_c128": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
     "wf_awgn_mf_bank_c128": (c_int, [_P, _P, c_int64, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64, _P,
                                      c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
@@ -153,7 +154,7 @@ def device_check() -> None:
 
 
 # ------------------------------------------------------------------ buffers
-_NP2T = {"uint8": "uint8", "int8": "int8", "float64": "float64", "int64": "int64"}
+_NP2T = {"uint8": "uint8", "int8": "int8", "float64": "float64", "int64": "int64", "int32": "int32"}
 
 
 def empty(n, dtype: str):

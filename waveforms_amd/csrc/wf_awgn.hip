@@ -56,3 +56,29 @@ extern "C" int wf_awgn_c128(wf_ctx *ctx, const double *d_in_ri, int64_t n, doubl
     WF_LAUNCH_CHECK();
     return WF_OK;
 }
+
+// Box-Muller on caller-supplied 32-bit words (2 per complex sample: radius word, angle word) —
+// the transform of the Gaussian source without Philox in front, so that its edge cases
+// (u1 = 2^-32, u1 = 1, u2 = 0, ...) can be driven directly.
+__global__ void box_muller32_kernel(const uint32_t *__restrict__ words, int64_t n, double sigma, double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double re, im;
+        wf_box_muller32(words[2 * k], words[2 * k + 1], sigma, &re, &im);
+        *reinterpret_cast<double2 *>(out + 2 * k) = make_double2(re, im);
+    }
+}
+
+extern "C" int wf_box_muller32_c128(wf_ctx *ctx, const uint32_t *d_words, int64_t n, double sigma, double *d_out_ri,
+                                    void *stream)
+{
+    WF_REQUIRE(ctx && n >= 0, "wf_box_muller32_c128: bad argument");
+    if (n == 0) return WF_OK;
+    WF_REQUIRE(d_words && d_out_ri && (reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0, "wf_box_muller32_c128: bad device pointer");
+    WF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(box_muller32_kernel, dim3(wf_grid_for(n, 256, 4096)), dim3(256), 0, wf_stream(stream), d_words, n,
+                       sigma, d_out_ri);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}

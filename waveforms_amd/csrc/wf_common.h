@@ -236,13 +236,16 @@ __device__ __forceinline__ double wf_log_unit32(uint32_t xa)
     p = fma(r, p, -0.5);
     p = fma(r, p, 1.0);
     const double de = (double)e;
-    return fma(de, 6.93147180369123816490e-01, fma(r, p, tc.y) + de * 1.90821492927058770002e-10);
+    // u <= 1, so the true value is <= 0: clamp the rounding of ln(1) (xa = 2^32 - 1)
+    return fmin(fma(de, 6.93147180369123816490e-01, fma(r, p, tc.y) + de * 1.90821492927058770002e-10), 0.0);
 }
 
-// sqrt of a non-negative normal double (0 allowed): v_rsq_f64 seed + Goldschmidt, then
-// one residual correction.
+// sqrt(max(a, 0)) for a normal-range double: v_rsq_f64 seed + Goldschmidt, then one residual
+// correction.  Negative inputs (a rounding-level -0.0...01 from -2 ln(1)) give 0 — without the
+// clamp, a * rsq(tiny) would turn them into ~1e133.
 __device__ __forceinline__ double wf_sqrt_pos(double a)
 {
+    a = fmax(a, 0.0);
     const double y = __builtin_amdgcn_rsq(fmax(a, 0x1.0p-1000));
     double g = a * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);

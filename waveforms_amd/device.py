@@ -113,6 +113,15 @@ def awgn(signal, n: int, sigma: float, seed: int, stream_id: int = 0, first_inde
     return out
 
 
+def box_muller32(words, sigma: float):
+    """Box-Muller of caller-supplied word pairs: ``words`` int32[n, 2] (bit patterns of the
+    uint32 radius / angle words) -> complex samples f64[n, 2]."""
+    n = int(words.shape[0])
+    out = _hip.empty((n, 2), "float64")
+    _hip.check(_hip.lib().wf_box_muller32_c128(_hip.ctx(), _hip.ptr(words), n, float(sigma), _hip.ptr(out), _hip.stream()))
+    return out
+
+
 def mf_bank(received, taps, first: int, step: int, ncols: int):
     """K6/K7 -> rows f64[ncols, nfilt, 2] on device; taps f64[nfilt, ntaps, 2]."""
     nsamp = int(received.shape[0])

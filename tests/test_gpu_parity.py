@@ -393,6 +393,23 @@ def test_detector_chunk_parallel_equals_sequential(oracle, ebn0):
     assert res["bit_errors"] > 0 or ebn0 >= 10
 
 
+@pytest.mark.parametrize("diff", [True, False])
+def test_detector_batch_is_stateful(golden, diff):
+    """detect() called on consecutive pieces of a burst — odd sizes, so the carried call
+    counter takes both parities — equals one call on the whole burst (and the reference)."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detect")
+    trip = g["triplets"]
+    det = SOQPSKTrellisDetector(2, differantial_encoding=diff)
+    cuts = [0, 1, 2, 131, 1000, 1777, 3999, 4000]
+    bits = np.concatenate([det.detect(trip[a:b])[0] for a, b in zip(cuts[:-1], cuts[1:])])
+    assert det.i == 4000
+    assert np.array_equal(bits, g[f"trip_L2_diff{int(diff)}_bits"][:, 0])
+    with pytest.raises(ValueError):
+        det.iteration(trip[0])
+
+
 def test_count_errors():
     from waveforms_amd import _hip, device as dev
 

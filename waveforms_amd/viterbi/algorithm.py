@@ -5,7 +5,8 @@ the GPU with the detector state resident in HBM (csrc/wf_viterbi.hip,
 viterbi_iteration_kernel), any window ``length``.  ``detect`` is the batch form the
 MI355X path is built for: a whole burst of matched-filter rows in one launch
 (chunk-parallel ACS + depth-2 traceback), ``length == 2`` only, returning for every row
-exactly what ``iteration(row)[...][0]`` would.
+exactly what ``iteration(row)[...][0]`` would; it is stateful like ``iteration`` (successive
+calls continue the same burst through a device-resident carry).
 """
 from __future__ import annotations
 
@@ -39,6 +40,8 @@ class SOQPSKTrellisDetector:
         self.state_exp_term = [+1j, -1, +1, -1j]
         self._d_state = None
         self._d_io = None
+        self._d_carry = None      # batch API: [i, metrics[4], increments[8], ...] on the device
+        self._mode = None         # "iteration" or "batch" once the first call has been made
 
     # ------------------------------------------------------------------ per-symbol API
     def _ensure_state(self):
@@ -60,6 +63,9 @@ class SOQPSKTrellisDetector:
         oldest first, float64 like the reference."""
         from waveforms_amd import _hip
 
+        if self._mode == "batch":
+            raise ValueError("this detector has been driven through detect(); use one API per burst")
+        self._mode = "iteration"
         self._ensure_state()
         L = int(self.length)
         z = np.asarray(mf_outputs, dtype=np.complex128).reshape(3)
@@ -79,11 +85,18 @@ class SOQPSKTrellisDetector:
         """``mf_rows``: float64[n, 3, 2] device tensor -> (bits u8[n], symbols i8[n]) on device."""
         from waveforms_amd import device as dev
 
+        from waveforms_amd import _hip
+
         if self.length != 2:
             raise ValueError("batch detection implements the reference default length=2")
-        if self.i != 0:
-            raise ValueError("batch detection starts a fresh burst; use iteration() to continue one")
-        return dev.viterbi_detect(mf_rows, self.differential, warmup)
+        if self._mode == "iteration":
+            raise ValueError("this detector has been driven through iteration(); use one API per burst")
+        self._mode = "batch"
+        if self._d_carry is None:
+            self._d_carry = _hip.zeros(32, "float64")
+        out = dev.viterbi_detect(mf_rows, self.differential, warmup, self._d_carry)
+        self.i += int(mf_rows.shape[0])     # like iteration(): one call per row, state carried
+        return out
 
     def detect(self, mf_rows: NDArray[np.complex128], warmup: int = 0):
         """Host in / host out batch form: complex128[n, 3] -> (bits u8[n], symbols i8[n])."""

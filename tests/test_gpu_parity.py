@@ -576,3 +576,84 @@ def test_stream_graph_replay_equals_eager_chunks():
         want = st.run(ebn0, seed=5, stream_id=2)
         got = st.run_graph(ebn0, seed=5, stream_id=2)
         assert got == want and st.graph_replays == n_int and want[1] > 0
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 128, 129, 200])
+def test_tiny_bursts_every_stage(oracle, n):
+    """Ragged and minimal sizes through every kernel: PRBS, encoder, modulator (fused and
+    staged; bursts shorter than the pulse take numpy's swapped-operand length), bank, detector."""
+    from waveforms.cpm.modulate import cpm_modulate
+    from waveforms.cpm.trellis.encoder import TrellisEncoder
+    from waveforms.cpm.trellis.model import SOQPSKTrellis4x2DiffEncoded
+    from waveforms.filters.matched import MatchedFilterBank, pt_matched_filter_taps
+    from waveforms.glfsr import PNSequence
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    bits = PNSequence(23).generate(n)
+    want_bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, n)
+    assert np.array_equal(bits, want_bits)
+    sym = TrellisEncoder(SOQPSKTrellis4x2DiffEncoded)(bits)
+    assert np.array_equal(sym, oracle.fsm_encode("SOQPSKTrellis4x2DiffEncoded", want_bits)[0])
+    pulse = oracle.freq_pulse_soqpsk_tg(8)
+    t, sig = cpm_modulate(sym, 0.25, pulse, 8)
+    wt, wsig = oracle.cpm_modulate(sym, 0.25, pulse, 8)
+    assert t.shape == wt.shape and sig.shape == wsig.shape
+    np.testing.assert_allclose(sig, wsig, rtol=0, atol=1e-12)
+    noise = oracle.philox_awgn(0.5, 2, n, 0, sig.size)
+    r = sig * np.exp(-1j * np.pi / 4) + noise
+    taps = pt_matched_filter_taps(pulse, 0.25, 8)
+    rows = MatchedFilterBank(taps)(r)                               # full rate
+    want_rows = np.array([np.convolve(r, tp, mode="same") for tp in taps]).T
+    np.testing.assert_allclose(rows, want_rows, rtol=0, atol=1e-12)
+    cols = oracle.decimate_columns(r.size, 8, 2, -1)
+    if cols.size:
+        db, ds = SOQPSKTrellisDetector().detect(want_rows[cols])
+        wb, ws_ = oracle.viterbi_detect(want_rows[cols])
+        assert np.array_equal(db, wb) and np.array_equal(ds, ws_)
+
+
+def test_empty_inputs_and_error_paths(oracle):
+    from waveforms.cpm.modulate import cpm_modulate, frequency_modulate
+    from waveforms.filters.matched import MatchedFilterBank
+    from waveforms.glfsr import PNSequence
+    from waveforms.noise import PhiloxStream, generate_complex_awgn
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+    from waveforms_amd import _hip, device as dev
+
+    pulse = oracle.freq_pulse_soqpsk_tg(8)
+    # no symbols at all: the reference still returns the pi/4 carrier over max(sps, M) samples
+    t, sig = cpm_modulate(np.zeros(0, dtype=np.int8), 0.25, pulse, 8)
+    wt, wsig = oracle.cpm_modulate(np.zeros(0, dtype=np.int8), 0.25, pulse, 8)
+    assert t.shape == wt.shape == (8,) and sig.shape == wsig.shape == (65,)
+    np.testing.assert_allclose(sig, wsig, rtol=0, atol=1e-15)
+    assert PNSequence(9).generate(0).size == 0
+    assert generate_complex_awgn(1.0, 0, PhiloxStream(1)).size == 0
+    assert frequency_modulate(np.zeros(0), 8).size == 0
+    b, s_ = SOQPSKTrellisDetector().detect(np.zeros((0, 3), dtype=np.complex128))
+    assert b.size == 0 and s_.size == 0
+    c = dev.count_errors(_hip.zeros(4, "int8"), _hip.zeros(4, "int8"), _hip.zeros(4, "uint8"), _hip.zeros(4, "uint8"), 0)
+    assert c.cpu().tolist() == [0, 0]
+    bank = MatchedFilterBank(np.ones((3, 9), dtype=np.complex128))
+    with pytest.raises(ValueError):                      # input shorter than the filter
+        bank(np.ones(5, dtype=np.complex128))
+    with pytest.raises(ValueError):                      # columns past the end
+        bank(np.ones(100, dtype=np.complex128), first=0, step=8, ncols=14)
+    with pytest.raises(ValueError):
+        SOQPSKTrellisDetector(length=4).detect(np.zeros((4, 3), dtype=np.complex128))
+    with pytest.raises(KeyError):
+        PNSequence(65)
+
+
+@pytest.mark.parametrize("nsym", [100, 1000, 5000])
+def test_small_links_equal_oracle(oracle, nsym):
+    from waveforms_amd.link import SOQPSKLink
+
+    for fuse in (0, 3):
+        link = SOQPSKLink(nsym, 8, fuse=fuse)
+        link.run_block(2.0, seed=9, stream_id=4, skip_bits=12345)
+        got = link.result()
+        bits = oracle.glfsr_bits(0x420000, 0x7FFFFF, 12345 + nsym)[0][12345:]
+        noise = oracle.philox_awgn(oracle.sigma_for_ebn0(2.0, 8), 9, 4, 0, (nsym + 1) * 8)
+        res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise)
+        assert got == (res["sym_errors"], res["bit_errors"], res["compared"]) and got[1] > 0

@@ -115,38 +115,105 @@ __device__ __forceinline__ double wf_wave_incl_scan(double v)
     return v;
 }
 
-// sin / cos of 2*pi*t, t in TURNS.  The quadrant reduction is exact (scaling by 4, floor
-// and the subtraction are exact in binary floating point), so there is no Payne-Hanek
-// path and no cancellation; the residual angle in [0, pi/4] goes through the classic
-// minimax kernels (Sun fdlibm __kernel_sin / __kernel_cos coefficient sets, < 1 ulp).
-__device__ __forceinline__ void wf_sincos_turns(double t, double *sn, double *cs)
+// sin / cos of 2*pi*t: table-driven.  The turn is cut into 128 sectors; {cos, sin} at the sector
+// centres come from a 2 KB table (generated in 80-bit arithmetic, rounded once), the residual
+// angle |r| <= pi/128 goes through two short Taylor kernels (next terms: r^9/9! < 1e-20,
+// r^8/8! < 4e-18) and one complex rotation.  The sector split is exact (scaling by 128, floor
+// and the subtractions are exact in binary floating point; for a 32-bit uniform it is pure
+// integer work), so there is no Payne-Hanek path, no quadrant selects and no cancellation.
+// Absolute error < 2 ulp(1); 16 fp64 operations against 18 + 16 selects for the octant form.
+static __device__ __constant__ double2 kWfCisTab[128] = {
+    {0x1.ffd886084cd0dp-1, 0x1.92155f7a3667ep-6}, {0x1.fe9cdad01883ap-1, 0x1.2d52092ce19f6p-4},
+    {0x1.fc26470e19fd3p-1, 0x1.f564e56a9730ep-4}, {0x1.f8764fa714ba9p-1, 0x1.5e214448b3fc6p-3},
+    {0x1.f38f3ac64e589p-1, 0x1.c0b826a7e4f63p-3}, {0x1.ed740e7684963p-1, 0x1.111d262b1f677p-2},
+    {0x1.e6288ec48e112p-1, 0x1.4135c94176601p-2}, {0x1.ddb13b6ccc23cp-1, 0x1.7088530fa459fp-2},
+    {0x1.d4134d14dc93ap-1, 0x1.9ef7943a8ed8ap-2}, {0x1.c954b213411f5p-1, 0x1.cc66e9931c45ep-2},
+    {0x1.bd7c0ac6f952ap-1, 0x1.f8ba4dbf89abap-2}, {0x1.b090a58150200p-1, 0x1.11eb3541b4b23p-1},
+    {0x1.a29a7a0462782p-1, 0x1.26d054cdd12dfp-1}, {0x1.93a22499263fbp-1, 0x1.3affa292050b9p-1},
+    {0x1.83b0e0bff976ep-1, 0x1.4e6cabbe3e5e9p-1}, {0x1.72d0837efff96p-1, 0x1.610b7551d2cdfp-1},
+    {0x1.610b7551d2cdfp-1, 0x1.72d0837efff96p-1}, {0x1.4e6cabbe3e5e9p-1, 0x1.83b0e0bff976ep-1},
+    {0x1.3affa292050b9p-1, 0x1.93a22499263fbp-1}, {0x1.26d054cdd12dfp-1, 0x1.a29a7a0462782p-1},
+    {0x1.11eb3541b4b23p-1, 0x1.b090a58150200p-1}, {0x1.f8ba4dbf89abap-2, 0x1.bd7c0ac6f952ap-1},
+    {0x1.cc66e9931c45ep-2, 0x1.c954b213411f5p-1}, {0x1.9ef7943a8ed8ap-2, 0x1.d4134d14dc93ap-1},
+    {0x1.7088530fa459fp-2, 0x1.ddb13b6ccc23cp-1}, {0x1.4135c94176601p-2, 0x1.e6288ec48e112p-1},
+    {0x1.111d262b1f677p-2, 0x1.ed740e7684963p-1}, {0x1.c0b826a7e4f63p-3, 0x1.f38f3ac64e589p-1},
+    {0x1.5e214448b3fc6p-3, 0x1.f8764fa714ba9p-1}, {0x1.f564e56a9730ep-4, 0x1.fc26470e19fd3p-1},
+    {0x1.2d52092ce19f6p-4, 0x1.fe9cdad01883ap-1}, {0x1.92155f7a3667ep-6, 0x1.ffd886084cd0dp-1},
+    {-0x1.92155f7a3667ep-6, 0x1.ffd886084cd0dp-1}, {-0x1.2d52092ce19f6p-4, 0x1.fe9cdad01883ap-1},
+    {-0x1.f564e56a9730ep-4, 0x1.fc26470e19fd3p-1}, {-0x1.5e214448b3fc6p-3, 0x1.f8764fa714ba9p-1},
+    {-0x1.c0b826a7e4f63p-3, 0x1.f38f3ac64e589p-1}, {-0x1.111d262b1f677p-2, 0x1.ed740e7684963p-1},
+    {-0x1.4135c94176601p-2, 0x1.e6288ec48e112p-1}, {-0x1.7088530fa459fp-2, 0x1.ddb13b6ccc23cp-1},
+    {-0x1.9ef7943a8ed8ap-2, 0x1.d4134d14dc93ap-1}, {-0x1.cc66e9931c45ep-2, 0x1.c954b213411f5p-1},
+    {-0x1.f8ba4dbf89abap-2, 0x1.bd7c0ac6f952ap-1}, {-0x1.11eb3541b4b23p-1, 0x1.b090a58150200p-1},
+    {-0x1.26d054cdd12dfp-1, 0x1.a29a7a0462782p-1}, {-0x1.3affa292050b9p-1, 0x1.93a22499263fbp-1},
+    {-0x1.4e6cabbe3e5e9p-1, 0x1.83b0e0bff976ep-1}, {-0x1.610b7551d2cdfp-1, 0x1.72d0837efff96p-1},
+    {-0x1.72d0837efff96p-1, 0x1.610b7551d2cdfp-1}, {-0x1.83b0e0bff976ep-1, 0x1.4e6cabbe3e5e9p-1},
+    {-0x1.93a22499263fbp-1, 0x1.3affa292050b9p-1}, {-0x1.a29a7a0462782p-1, 0x1.26d054cdd12dfp-1},
+    {-0x1.b090a58150200p-1, 0x1.11eb3541b4b23p-1}, {-0x1.bd7c0ac6f952ap-1, 0x1.f8ba4dbf89abap-2},
+    {-0x1.c954b213411f5p-1, 0x1.cc66e9931c45ep-2}, {-0x1.d4134d14dc93ap-1, 0x1.9ef7943a8ed8ap-2},
+    {-0x1.ddb13b6ccc23cp-1, 0x1.7088530fa459fp-2}, {-0x1.e6288ec48e112p-1, 0x1.4135c94176601p-2},
+    {-0x1.ed740e7684963p-1, 0x1.111d262b1f677p-2}, {-0x1.f38f3ac64e589p-1, 0x1.c0b826a7e4f63p-3},
+    {-0x1.f8764fa714ba9p-1, 0x1.5e214448b3fc6p-3}, {-0x1.fc26470e19fd3p-1, 0x1.f564e56a9730ep-4},
+    {-0x1.fe9cdad01883ap-1, 0x1.2d52092ce19f6p-4}, {-0x1.ffd886084cd0dp-1, 0x1.92155f7a3667ep-6},
+    {-0x1.ffd886084cd0dp-1, -0x1.92155f7a3667ep-6}, {-0x1.fe9cdad01883ap-1, -0x1.2d52092ce19f6p-4},
+    {-0x1.fc26470e19fd3p-1, -0x1.f564e56a9730ep-4}, {-0x1.f8764fa714ba9p-1, -0x1.5e214448b3fc6p-3},
+    {-0x1.f38f3ac64e589p-1, -0x1.c0b826a7e4f63p-3}, {-0x1.ed740e7684963p-1, -0x1.111d262b1f677p-2},
+    {-0x1.e6288ec48e112p-1, -0x1.4135c94176601p-2}, {-0x1.ddb13b6ccc23cp-1, -0x1.7088530fa459fp-2},
+    {-0x1.d4134d14dc93ap-1, -0x1.9ef7943a8ed8ap-2}, {-0x1.c954b213411f5p-1, -0x1.cc66e9931c45ep-2},
+    {-0x1.bd7c0ac6f952ap-1, -0x1.f8ba4dbf89abap-2}, {-0x1.b090a58150200p-1, -0x1.11eb3541b4b23p-1},
+    {-0x1.a29a7a0462782p-1, -0x1.26d054cdd12dfp-1}, {-0x1.93a22499263fbp-1, -0x1.3affa292050b9p-1},
+    {-0x1.83b0e0bff976ep-1, -0x1.4e6cabbe3e5e9p-1}, {-0x1.72d0837efff96p-1, -0x1.610b7551d2cdfp-1},
+    {-0x1.610b7551d2cdfp-1, -0x1.72d0837efff96p-1}, {-0x1.4e6cabbe3e5e9p-1, -0x1.83b0e0bff976ep-1},
+    {-0x1.3affa292050b9p-1, -0x1.93a22499263fbp-1}, {-0x1.26d054cdd12dfp-1, -0x1.a29a7a0462782p-1},
+    {-0x1.11eb3541b4b23p-1, -0x1.b090a58150200p-1}, {-0x1.f8ba4dbf89abap-2, -0x1.bd7c0ac6f952ap-1},
+    {-0x1.cc66e9931c45ep-2, -0x1.c954b213411f5p-1}, {-0x1.9ef7943a8ed8ap-2, -0x1.d4134d14dc93ap-1},
+    {-0x1.7088530fa459fp-2, -0x1.ddb13b6ccc23cp-1}, {-0x1.4135c94176601p-2, -0x1.e6288ec48e112p-1},
+    {-0x1.111d262b1f677p-2, -0x1.ed740e7684963p-1}, {-0x1.c0b826a7e4f63p-3, -0x1.f38f3ac64e589p-1},
+    {-0x1.5e214448b3fc6p-3, -0x1.f8764fa714ba9p-1}, {-0x1.f564e56a9730ep-4, -0x1.fc26470e19fd3p-1},
+    {-0x1.2d52092ce19f6p-4, -0x1.fe9cdad01883ap-1}, {-0x1.92155f7a3667ep-6, -0x1.ffd886084cd0dp-1},
+    {0x1.92155f7a3667ep-6, -0x1.ffd886084cd0dp-1}, {0x1.2d52092ce19f6p-4, -0x1.fe9cdad01883ap-1},
+    {0x1.f564e56a9730ep-4, -0x1.fc26470e19fd3p-1}, {0x1.5e214448b3fc6p-3, -0x1.f8764fa714ba9p-1},
+    {0x1.c0b826a7e4f63p-3, -0x1.f38f3ac64e589p-1}, {0x1.111d262b1f677p-2, -0x1.ed740e7684963p-1},
+    {0x1.4135c94176601p-2, -0x1.e6288ec48e112p-1}, {0x1.7088530fa459fp-2, -0x1.ddb13b6ccc23cp-1},
+    {0x1.9ef7943a8ed8ap-2, -0x1.d4134d14dc93ap-1}, {0x1.cc66e9931c45ep-2, -0x1.c954b213411f5p-1},
+    {0x1.f8ba4dbf89abap-2, -0x1.bd7c0ac6f952ap-1}, {0x1.11eb3541b4b23p-1, -0x1.b090a58150200p-1},
+    {0x1.26d054cdd12dfp-1, -0x1.a29a7a0462782p-1}, {0x1.3affa292050b9p-1, -0x1.93a22499263fbp-1},
+    {0x1.4e6cabbe3e5e9p-1, -0x1.83b0e0bff976ep-1}, {0x1.610b7551d2cdfp-1, -0x1.72d0837efff96p-1},
+    {0x1.72d0837efff96p-1, -0x1.610b7551d2cdfp-1}, {0x1.83b0e0bff976ep-1, -0x1.4e6cabbe3e5e9p-1},
+    {0x1.93a22499263fbp-1, -0x1.3affa292050b9p-1}, {0x1.a29a7a0462782p-1, -0x1.26d054cdd12dfp-1},
+    {0x1.b090a58150200p-1, -0x1.11eb3541b4b23p-1}, {0x1.bd7c0ac6f952ap-1, -0x1.f8ba4dbf89abap-2},
+    {0x1.c954b213411f5p-1, -0x1.cc66e9931c45ep-2}, {0x1.d4134d14dc93ap-1, -0x1.9ef7943a8ed8ap-2},
+    {0x1.ddb13b6ccc23cp-1, -0x1.7088530fa459fp-2}, {0x1.e6288ec48e112p-1, -0x1.4135c94176601p-2},
+    {0x1.ed740e7684963p-1, -0x1.111d262b1f677p-2}, {0x1.f38f3ac64e589p-1, -0x1.c0b826a7e4f63p-3},
+    {0x1.f8764fa714ba9p-1, -0x1.5e214448b3fc6p-3}, {0x1.fc26470e19fd3p-1, -0x1.f564e56a9730ep-4},
+    {0x1.fe9cdad01883ap-1, -0x1.2d52092ce19f6p-4}, {0x1.ffd886084cd0dp-1, -0x1.92155f7a3667ep-6},
+};
+
+__device__ __forceinline__ void wf_cis_sector(double2 cs0, double r, double *sn, double *cs)
 {
-    const double y = t * 4.0;
-    const double q = floor(y);
-    const double f = y - q;                 // [0, 1) quarter turns, exact
-    const bool fold = f > 0.5;
-    const double g = fold ? 1.0 - f : f;    // [0, 0.5], exact
-    const double x = g * 1.57079632679489661923;  // [0, pi/4]
-    const double z = x * x;
-    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(z, ps, 2.75573137070700676789e-06);
-    ps = fma(z, ps, -1.98412698298579493134e-04);
-    ps = fma(z, ps, 8.33333333332248946124e-03);
-    ps = fma(z, ps, -1.66666666666666324348e-01);
-    ps = fma(x * z, ps, x);
-    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(z, pc, -2.75573143513906633035e-07);
-    pc = fma(z, pc, 2.48015872894767294178e-05);
-    pc = fma(z, pc, -1.38888888888741095749e-03);
-    pc = fma(z, pc, 4.16666666666666019037e-02);
-    pc = fma(z * z, pc, fma(z, -0.5, 1.0));
-    const double sq = fold ? pc : ps;       // sin / cos inside the quadrant
-    const double cq = fold ? ps : pc;
-    const int qi = (int)q & 3;
-    const double s1 = (qi & 1) ? cq : sq;
-    const double c1 = (qi & 1) ? sq : cq;
-    *sn = (qi & 2) ? -s1 : s1;
-    *cs = ((qi + 1) & 2) ? -c1 : c1;
+    const double z = r * r;
+    double ps = fma(z, -1.0 / 5040.0, 1.0 / 120.0);
+    ps = fma(z, ps, -1.0 / 6.0);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.0 / 720.0, 1.0 / 24.0);
+    pc = fma(z, pc, -0.5);
+    const double c = fma(z, pc, 1.0);
+    *cs = fma(-cs0.y, s, cs0.x * c);
+    *sn = fma(cs0.x, s, cs0.y * c);
+}
+
+__device__ __forceinline__ void wf_sincos_turns(double t, double *sn, double *cs)   // any |t| < 2^24
+{
+    const double y = t * 128.0;
+    const double fl = floor(y);
+    const double r = ((y - fl) - 0.5) * (6.28318530717958647692 / 128.0);
+    wf_cis_sector(kWfCisTab[(int)fl & 127], r, sn, cs);
+}
+
+__device__ __forceinline__ void wf_sincos_u32(uint32_t xb, double *sn, double *cs)   // t = xb * 2^-32
+{
+    const int ri = (int)(xb & 0x1FFFFFFu) - (1 << 24);
+    wf_cis_sector(kWfCisTab[xb >> 25], (double)ri * (6.28318530717958647692 * 0x1.0p-32), sn, cs);
 }
 
 // ln((xa + 1) * 2^-32) for a 32-bit word: table-driven.  m in [1, 2) from the exponent split of
@@ -240,21 +307,18 @@ __device__ __forceinline__ double wf_log_unit32(uint32_t xa)
     return fmin(fma(de, 6.93147180369123816490e-01, fma(r, p, tc.y) + de * 1.90821492927058770002e-10), 0.0);
 }
 
-// sqrt(max(a, 0)) for a normal-range double: v_rsq_f64 seed + Goldschmidt, then one residual
-// correction.  Negative inputs (a rounding-level -0.0...01 from -2 ln(1)) give 0 — without the
+// sqrt(max(a, 0)) for a normal-range double: v_rsq_f64 seed, one Goldschmidt step, then one
+// Newton correction on the exactly computed residual (< 1 ulp).  Negative inputs (a rounding-level -0.0...01 from -2 ln(1)) give 0 — without the
 // clamp, a * rsq(tiny) would turn them into ~1e133.
 __device__ __forceinline__ double wf_sqrt_pos(double a)
 {
     a = fmax(a, 0.0);
-    const double y = __builtin_amdgcn_rsq(fmax(a, 0x1.0p-1000));
+    const double y = __builtin_amdgcn_rsq(fmax(a, 0x1.0p-1000));   // relative error <= 2^-23
     double g = a * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);                                               // one Goldschmidt step: ~2^-45
     h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double dres = fma(-g, g, a);
+    const double dres = fma(-g, g, a);                              // Newton on the exact residual: ~2^-90
     return fma(dres, h, g);
 }
 
@@ -286,7 +350,6 @@ __device__ __forceinline__ wf_philox_out wf_philox4x32_10(uint32_t c0, uint32_t 
 // Box-Muller from two 32-bit words: u1 = (xa + 1) 2^-32 in (0, 1], u2 = xb 2^-32 in [0, 1).
 __device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double sigma, double *re, double *im)
 {
-    const double u2 = (double)xb * 0x1.0p-32;
 #ifdef WF_ABL_NO_LOG
     const double r = sigma * ((double)xa + 1.0) * 0x1.0p-32;
 #else
@@ -294,9 +357,9 @@ __device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double
 #endif
     double s, c;
 #ifdef WF_ABL_NO_SINCOS
-    s = u2; c = 1.0 - u2;
+    s = (double)xb * 0x1.0p-32; c = 1.0 - s;
 #else
-    wf_sincos_turns(u2, &s, &c);
+    wf_sincos_u32(xb, &s, &c);
 #endif
     *re = r * c;
     *im = r * s;

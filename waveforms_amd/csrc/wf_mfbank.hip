@@ -42,6 +42,10 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
     const int step = STEP ? STEP : P.step;
     const int pad = STEP ? (STEP % 2 == 0) : P.pad;
     const int ntaps = NTAPS ? NTAPS : P.ntaps;
+    // fast path: the taps live in LDS (broadcast ds_read_b128) — as scalar operands the 54 doubles
+    // of the 3 x 9 bank overflow the SGPR file and spill through v_writelane/v_readlane
+    __shared__ double2 s_taps[NTAPS ? NF * NTAPS : 1];
+    if (NTAPS && STEP && t < NF * NTAPS) s_taps[t] = reinterpret_cast<const double2 *>(taps)[t];
     for (int64_t blk = blockIdx.x; blk < P.nblk; blk += gridDim.x) {
         const int64_t k0 = blk * P.ob;
         // first input sample of the span: oldest sample of output k0
@@ -59,6 +63,39 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
             const int vlo = lo64 > 0 ? (lo64 < P.span ? (int)lo64 : P.span) : 0;
             const int vhi = hi64 < P.span ? (hi64 > 0 ? (int)hi64 : 0) : P.span;
             const double2 *rp = reinterpret_cast<const double2 *>(r) + ws;   // dereferenced only inside [vlo, vhi)
+#ifndef WF_ABL_NO_INTERIOR
+            if (vlo == 0 && vhi == P.span) {
+                // interior window (all but the first and last workgroup iterations of a burst): every
+                // offset is a burst sample, so there are no per-lane bounds.  The trip count is
+                // block-uniform; the two partial pairs at the window ends load from a clamped address
+                // and park their result in the dump slot behind the window.
+                const int last = P.span - 1;
+                const int dump = P.span + (pad ? P.span / step + 1 : 0);
+                const int niter = (P.span + 1 + 2 * MF_THREADS - 1) / (2 * MF_THREADS);
+                int w0 = 2 * t - odd;
+                auto ld = [&](int w) { return rp[min(max(w, 0), last)]; };
+                double2 c0 = ld(w0), c1 = ld(w0 + 1);
+                uint64_t pair = pair_lo + (uint64_t)t;                // (w0 + odd) >> 1 == t + it * MF_THREADS
+#pragma unroll 1
+                for (int it = 0; it < niter; ++it) {
+                    const double2 n0 = ld(w0 + 2 * MF_THREADS), n1 = ld(w0 + 2 * MF_THREADS + 1);
+                    double g[4];
+                    wf_gaussian_two(pair, P.stream_id, P.seed, P.sigma, g);
+                    const int w1 = w0 + 1;
+                    const int q0 = (w0 >= 0 && w0 <= last) ? w0 + (pad ? w0 / step : 0) : dump;
+                    const int q1 = (w1 <= last) ? w1 + (pad ? w1 / step : 0) : dump;
+                    s_win[q0] = make_double2(fma(c0.x, P.rot_re, fma(-c0.y, P.rot_im, g[0])),
+                                             fma(c0.x, P.rot_im, fma(c0.y, P.rot_re, g[1])));
+                    s_win[q1] = make_double2(fma(c1.x, P.rot_re, fma(-c1.y, P.rot_im, g[2])),
+                                             fma(c1.x, P.rot_im, fma(c1.y, P.rot_re, g[3])));
+                    c0 = n0;
+                    c1 = n1;
+                    w0 += 2 * MF_THREADS;
+                    pair += MF_THREADS;
+                }
+            } else
+#endif
+            {
             auto fetch = [&](int w) {
 #ifdef WF_ABL_NO_MEM   // ablation only: no global traffic
                 return make_double2((double)w, 1.0);
@@ -90,6 +127,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 }
                 c0 = n0;
                 c1 = n1;
+            }
             }
         } else {
             // all of this thread's loads are issued before the first one is consumed
@@ -126,17 +164,17 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
             const int base = t * (step + pad);
             if (NTAPS && STEP) {
                 // fully unrolled: LDS offsets and tap addresses are compile-time constants
+                // (this instantiation is dispatched only for nfilt == NF)
+                double2 x[NTAPS ? NTAPS : 1];
 #pragma unroll
-                for (int j = 0; j < NTAPS; ++j) {
-                    const double2 x = s_win[base + j + (STEP % 2 == 0 ? j / STEP : 0)];
+                for (int j = 0; j < NTAPS; ++j) x[j] = s_win[base + j + (STEP % 2 == 0 ? j / STEP : 0)];
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        if (f < P.nfilt) {
-                            const double tr = taps[2 * (f * NTAPS + (NTAPS - 1 - j))];
-                            const double ti = taps[2 * (f * NTAPS + (NTAPS - 1 - j)) + 1];
-                            ar[f] = fma(x.x, tr, fma(-x.y, ti, ar[f]));
-                            ai[f] = fma(x.x, ti, fma(x.y, tr, ai[f]));
-                        }
+                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                    for (int j = 0; j < NTAPS; ++j) {
+                        const double2 tp = s_taps[f * NTAPS + (NTAPS - 1 - j)];
+                        ar[f] = fma(x[j].x, tp.x, fma(-x[j].y, tp.y, ar[f]));
+                        ai[f] = fma(x[j].x, tp.y, fma(x[j].y, tp.x, ai[f]));
                     }
                 }
             } else {
@@ -169,7 +207,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
 #endif
 #pragma unroll
             for (int f = 0; f < NF; ++f)
-                if (f < P.nfilt) o[f] = make_double2(ar[f], ai[f]);
+                if ((NTAPS && STEP) || f < P.nfilt) o[f] = make_double2(ar[f], ai[f]);
         }
     }
 }
@@ -219,7 +257,18 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
         }
         ob = ob > 16 ? ob - 16 : ob - 1;
     }
-    const int slots = P.span + (P.pad ? P.span / step + 1 : 0);
+    if (noise && P.ob > 16) {
+        // the channel is generated in trips of 2*MF_THREADS samples: a window of 2049 samples (256
+        // columns, 9 taps, step 8) would cost a fifth trip for its last pair, and that whole trip
+        // lands on one wave.  Give up a few columns when that saves a trip.
+        auto trips = [&](int o) { return ((o - 1) * step + ntaps + 1 + 2 * MF_THREADS - 1) / (2 * MF_THREADS); };
+        int best = P.ob;
+        for (int o = P.ob; o >= P.ob - 16; --o)
+            if ((double)o / trips(o) > (double)best / trips(best)) best = o;
+        P.ob = best;
+        P.span = (best - 1) * step + ntaps;
+    }
+    const int slots = P.span + (P.pad ? P.span / step + 1 : 0) + 1;   // + the dump slot of the interior staging path
     P.nblk = (ncols + P.ob - 1) / P.ob;
     const int grid = (int)(P.nblk < 4096 ? P.nblk : 4096);
     hipStream_t s = wf_stream(stream);

@@ -103,17 +103,36 @@ __device__ __forceinline__ void wf_lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Inclusive wave64 prefix sum of doubles.
+// A double moved across lanes by DPP (two v_mov_b32_dpp): lanes without a source, or in rows
+// outside ROW_MASK, receive 0.0.  CTRL: 0x110 + n = row_shr:n, 0x142 = row_bcast:15,
+// 0x143 = row_bcast:31, 0x138 = wave_shr:1.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double wf_dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// Inclusive wave64 prefix sum of doubles, entirely in the VALU: Hillis-Steele inside each row of
+// 16 lanes (row_shr 1, 2, 4, 8), then the row totals are broadcast into the following rows
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  18 instructions and no LDS
+// round trips — as __shfl_up (ds_bpermute_b32) the same scan is a chain of 6 dependent LDS
+// accesses, which was the latency that bounded the modulator's row loop.
 __device__ __forceinline__ double wf_wave_incl_scan(double v)
 {
-    const int lane = wf_lane();
-#pragma unroll
-    for (int d = 1; d < WF_WAVE; d <<= 1) {
-        double o = __shfl_up(v, d, WF_WAVE);
-        if (lane >= d) v += o;
-    }
+    v += wf_dpp_f64<0x111, 0xf>(v);
+    v += wf_dpp_f64<0x112, 0xf>(v);
+    v += wf_dpp_f64<0x114, 0xf>(v);
+    v += wf_dpp_f64<0x118, 0xf>(v);
+    v += wf_dpp_f64<0x142, 0xa>(v);
+    v += wf_dpp_f64<0x143, 0xc>(v);
     return v;
 }
+
+// The value of the lane below (0.0 in lane 0).
+__device__ __forceinline__ double wf_wave_shr1(double v) { return wf_dpp_f64<0x138, 0xf>(v); }
 
 // sin / cos of 2*pi*t: table-driven.  The turn is cut into 128 sectors; {cos, sin} at the sector
 // centres come from a 2 KB table (generated in 80-bit arithmetic, rounded once), the residual
@@ -200,6 +219,22 @@ __device__ __forceinline__ void wf_cis_sector(double2 cs0, double r, double *sn,
     const double c = fma(z, pc, 1.0);
     *cs = fma(-cs0.y, s, cs0.x * c);
     *sn = fma(cs0.x, s, cs0.y * c);
+}
+
+// `tab` is kWfCisTab or a copy of it in LDS (wf_stage_cis_table): on gfx9-family hardware loads
+// and stores share the in-order vmcnt counter, so a table load from global memory inside a loop
+// that also stores makes every iteration wait for the previous iteration's stores to land.
+__device__ __forceinline__ void wf_sincos_sectors(const double2 *tab, double y, double *sn, double *cs)   // angle = y / 128 turns
+{
+    const double fl = floor(y);
+    const double r = ((y - fl) - 0.5) * (6.28318530717958647692 / 128.0);
+    wf_cis_sector(tab[(int)fl & 127], r, sn, cs);
+}
+
+// Copy the sector table into LDS (128 x 16 B); the caller synchronises before the first use.
+__device__ __forceinline__ void wf_stage_cis_table(double2 *lds_tab, int t, int nthreads)
+{
+    for (int k = t; k < 128; k += nthreads) lds_tab[k] = kWfCisTab[k];
 }
 
 __device__ __forceinline__ void wf_sincos_turns(double t, double *sn, double *cs)   // any |t| < 2^24

@@ -15,7 +15,9 @@
 // (wf_phase.hip), carry, mod, sincos, 16 B coalesced stores.
 #include "wf_common.h"
 
+#ifndef MOD_THREADS
 #define MOD_THREADS 256
+#endif
 #ifndef MOD_ROWS
 #define MOD_ROWS 16
 #endif
@@ -181,6 +183,9 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
 {
     extern __shared__ double s_amp[];       // window of symbol amplitudes
     __shared__ double s_tot[2 * MOD_WAVES];
+    __shared__ double2 s_xp[2 * MOD_THREADS];   // wave-private transpose: pairs per lane -> rows of 64 samples
+    __shared__ double2 s_cis[128];              // sincos sector table (LDS copy: see wf_sincos_sectors)
+    wf_stage_cis_table(s_cis, threadIdx.x, MOD_THREADS);   // the tile loop starts with a barrier
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int sps = P.sps;
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
         const int j1 = i - 1 + wrap, k1 = r1 + j1 * sps;
         tap1[i] = (j1 >= 0 && j1 < JMAX && k1 < P.ntaps) ? pulse[k1] : 0.0;
     }
+    const double sec_per_unit = 128.0 * P.inv_sps, sec_phi0 = 128.0 * P.phi0_turns;   // phase units -> 1/128 turns
     const int l_top0p1 = (q0 - cq) + JMAX;
     const int win = MOD_ROWS * sym_per_row + JMAX + 2;
     const uint64_t *Wq = reinterpret_cast<const uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
         const int64_t tile_base = tile_g * tile_len;      // global sample index
         const int64_t sym_base = tile_base / sps;
         const int64_t mp1_lo = sym_base + cq - JMAX + 1;
+        const bool full_tile = tile_base >= P.out_origin && tile_base + tile_len <= P.out_hi;
         wf_lds_barrier();
         for (int k = t; k < win; k += MOD_THREADS) s_amp[k] = mod_amp(symbols, hvec, P, mp1_lo + k - 1);
         wf_lds_barrier();
@@ -248,8 +255,7 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
 #else
             const double inc = wf_wave_incl_scan(acc0 + acc1);
 #endif
-            const double e = __shfl_up(inc, 1, WF_WAVE);
-            const double ex = lane == 0 ? 0.0 : e;
+            const double ex = wf_wave_shr1(inc);   // exclusive prefix (0 in lane 0)
             double *tot = s_tot + (u & 1) * MOD_WAVES;
             if (lane == 63) tot[wave] = inc;
             wf_lds_barrier();
@@ -259,40 +265,55 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                 if (w == wave) offw = rowtot;
                 rowtot += tot[w];
             }
+            double2 e0 = make_double2(0.0, 0.0), e1 = e0;   // samples 2t and 2t + 1 of the row
             if (active) {
-                const int64_t n = tile_base + (int64_t)u * P.rs + 2 * t;
                 const double v0 = run + (offw + ex + acc0);
                 // one exact reduction per pair; the second sample is a single frequency-pulse value
                 // further and wf_sincos_turns reduces its argument exactly anyway
-                const double ra = mod_pos_d(v0, P.sps_d, P.inv_sps);
+                // (no fix-up of a remainder that rounds to -eps or sps+eps: the sector split of the
+                // sincos below is exact for any argument)
+                const double ra = fma(-floor(v0 * P.inv_sps), P.sps_d, v0);
                 const double rb = ra + acc1;
-                double s0, c0, s1, c1;
 #ifdef WF_ABL_NO_SINCOS
-                s0 = ra; c0 = ra + 1; s1 = rb; c1 = rb + 1;
+                e0 = make_double2(ra + 1, ra); e1 = make_double2(rb + 1, rb);
 #else
-                wf_sincos_turns(fma(ra, P.inv_sps, P.phi0_turns), &s0, &c0);
-                wf_sincos_turns(fma(rb, P.inv_sps, P.phi0_turns), &s1, &c1);
+                wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
+                wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
 #endif
-#ifdef WF_ABL_CONTIG_STORE   // ablation only: right bytes, wrong places, contiguous 16 B per lane
-                {
-                    const int64_t rowb = tile_base + (int64_t)u * P.rs - P.out_origin;
-                    double2 *o = reinterpret_cast<double2 *>(out + 2 * rowb);
-                    if (rowb + P.rs <= P.out_hi - P.out_origin) {
-                        o[t] = make_double2(c0, s0);
-                        o[t + P.rs / 2] = make_double2(c1, s1);
-                    }
-                }
-#else
-                if (n >= P.out_origin) {   // n is even and so is out_origin: a pair is never split below
-                    double2 *o = reinterpret_cast<double2 *>(out + 2 * (n - P.out_origin));
-                    if (n + 1 < P.out_hi) {
-                        o[0] = make_double2(c0, s0);
-                        o[1] = make_double2(c1, s1);
-                    } else if (n < P.out_hi) {
-                        o[0] = make_double2(c0, s0);
-                    }
-                }
+            }
+            // A lane holding two adjacent samples would store 16 B at a 32 B stride (half-filled
+            // lines per instruction: 3.9 TB/s against 5.1 for contiguous rows), so the wave's 128
+            // samples are transposed through its private LDS strip: each store instruction then
+            // writes 64 consecutive samples = 1 KB.  Same wave, in-order LDS: no workgroup barrier.
+#ifdef WF_ABL_PAIR_STORE   // ablation only: 16 B stores at a 32 B lane stride
+            {
+                const int64_t n = tile_base + (int64_t)u * P.rs + 2 * t;
+                double2 *o = reinterpret_cast<double2 *>(out);
+                if (active && n >= P.out_origin && n < P.out_hi) o[n - P.out_origin] = e0;
+                if (active && n + 1 >= P.out_origin && n + 1 < P.out_hi) o[n + 1 - P.out_origin] = e1;
+            }
+            run += rowtot;
+            continue;
 #endif
+            double2 *xw = s_xp + wave * (2 * WF_WAVE);
+            xw[2 * lane] = e0;
+            xw[2 * lane + 1] = e1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double2 xa = xw[lane], xb = xw[WF_WAVE + lane];
+            const int col = wave * (2 * WF_WAVE) + lane;                       // sample column inside the row
+            const int64_t na = tile_base + (int64_t)u * P.rs + col, nb = na + WF_WAVE;
+            double2 *o = reinterpret_cast<double2 *>(out);
+#ifdef WF_ABL_NO_STORE
+            if (xa.x == 1.2345e300 && xb.y == 1.2345e300)
+#endif
+            if (full_tile) {   // block-uniform: no per-lane 64-bit window tests
+                if (col < P.rs) o[na - P.out_origin] = xa;
+                if (col + WF_WAVE < P.rs) o[nb - P.out_origin] = xb;
+            } else {
+                if (col < P.rs && na >= P.out_origin && na < P.out_hi) o[na - P.out_origin] = xa;
+                if (col + WF_WAVE < P.rs && nb >= P.out_origin && nb < P.out_hi) o[nb - P.out_origin] = xb;
             }
             run += rowtot;
         }
@@ -350,7 +371,8 @@ static int mod_launch(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols,
     WF_LAUNCH_CHECK();
     hipLaunchKernelGGL(mod_tile_scan_kernel, dim3(1), dim3(1024), 0, s, d_symbols, d_h, d_pulse, P, scratch, d_q_in, d_q_out);
     WF_LAUNCH_CHECK();
-    const int grid = (int)(P.ntiles < 2048 ? P.ntiles : 2048);
+    const int64_t max_grid = 2048 * (256 / MOD_THREADS);
+    const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
     const int sps = P.sps;
 #define MOD_LAUNCH(JM)                                                                              \
     hipLaunchKernelGGL(mod_main_kernel<JM>, dim3(grid), dim3(MOD_THREADS),                          \

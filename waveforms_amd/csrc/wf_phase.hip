@@ -109,8 +109,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
 #pragma unroll
         for (int u = 0; u < PH_ROWS; ++u) {
             const double inc = wf_wave_incl_scan(x0[u] + x1[u]);
-            double e = __shfl_up(inc, 1, WF_WAVE);
-            ex[u] = lane == 0 ? 0.0 : e;
+            ex[u] = wf_wave_shr1(inc);
             if (lane == 63) s_tot[u * PH_WAVES + wave] = inc;
         }
         wf_lds_barrier();

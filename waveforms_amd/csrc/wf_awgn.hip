@@ -17,6 +17,10 @@ __global__ __launch_bounds__(256) void awgn_kernel(const double *in, int64_t n, 
                                                     double sigma, uint64_t seed, uint64_t stream_id,
                                                     uint64_t first_index, double *out)
 {
+    __shared__ double2 s_tab[256];   // log + sincos tables: LDS, because this loop stores (see wf_tabs_lds)
+    wf_stage_tables<1, 0>(s_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const wf_tabs_lds<1, 0> tb{s_tab};
     // one thread per PAIR of absolute sample indices (2P, 2P+1): one Philox block serves both
     const uint64_t pair0 = first_index >> 1;
     const int64_t npairs = (int64_t)(((first_index + (uint64_t)n - 1) >> 1) - pair0) + 1;
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(256) void awgn_kernel(const double *in, int64_t n, 
             if (ok1) v1 = *reinterpret_cast<const double2 *>(in + 2 * (k0 + 1));
         }
         double g[4];
-        wf_gaussian_two(pair, stream_id, seed, sigma, g);
+        wf_gaussian_two(pair, stream_id, seed, sigma, tb, g);
         if (ok0)
             *reinterpret_cast<double2 *>(out + 2 * k0) =
                 make_double2(fma(v0.x, rot_re, fma(-v0.y, rot_im, g[0])), fma(v0.x, rot_im, fma(v0.y, rot_re, g[1])));
@@ -65,7 +69,7 @@ __global__ void box_muller32_kernel(const uint32_t *__restrict__ words, int64_t 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
         double re, im;
-        wf_box_muller32(words[2 * k], words[2 * k + 1], sigma, &re, &im);
+        wf_box_muller32(words[2 * k], words[2 * k + 1], sigma, wf_tabs_global{}, &re, &im);
         *reinterpret_cast<double2 *>(out + 2 * k) = make_double2(re, im);
     }
 }

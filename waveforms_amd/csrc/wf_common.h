@@ -245,11 +245,6 @@ __device__ __forceinline__ void wf_sincos_turns(double t, double *sn, double *cs
     wf_cis_sector(kWfCisTab[(int)fl & 127], r, sn, cs);
 }
 
-__device__ __forceinline__ void wf_sincos_u32(uint32_t xb, double *sn, double *cs)   // t = xb * 2^-32
-{
-    const int ri = (int)(xb & 0x1FFFFFFu) - (1 << 24);
-    wf_cis_sector(kWfCisTab[xb >> 25], (double)ri * (6.28318530717958647692 * 0x1.0p-32), sn, cs);
-}
 
 // ln((xa + 1) * 2^-32) for a 32-bit word: table-driven.  m in [1, 2) from the exponent split of
 // the exact double xa + 1; 128-entry table of {1/c_i (rounded), ln(1/that)} at the bucket
@@ -323,14 +318,35 @@ static __device__ __constant__ double2 kWfLogTab[128] = {
     {0x1.0182436517a37p-1, 0x1.5fe1edad18919p-1}, {0x1.0080402010080p-1, 0x1.61e3efda46467p-1},
 };
 
-__device__ __forceinline__ double wf_log_unit32(uint32_t xa)
+// Where the Gaussian source reads its two 128-entry tables from: the __constant__ originals
+// (vector loads through L1), or a copy in LDS with entry i at p[i * STRIDE + OFF] (log) and
+// p[(128 + i) * STRIDE + OFF] (sincos).  Kernels that also store in their main loop want LDS:
+// vmcnt is shared by loads and stores, so a global table load waits for older stores.
+struct wf_tabs_global {
+    __device__ __forceinline__ double2 log(int i) const { return kWfLogTab[i]; }
+    __device__ __forceinline__ double2 cis(int i) const { return kWfCisTab[i]; }
+};
+template <int STRIDE, int OFF>
+struct wf_tabs_lds {
+    const double2 *p;
+    __device__ __forceinline__ double2 log(int i) const { return p[i * STRIDE + OFF]; }
+    __device__ __forceinline__ double2 cis(int i) const { return p[(128 + i) * STRIDE + OFF]; }
+};
+template <int STRIDE, int OFF>
+__device__ __forceinline__ void wf_stage_tables(double2 *p, int t, int nthreads)   // caller synchronises
+{
+    for (int k = t; k < 256; k += nthreads) p[k * STRIDE + OFF] = k < 128 ? kWfLogTab[k] : kWfCisTab[k - 128];
+}
+
+template <class Tabs>
+__device__ __forceinline__ double wf_log_unit32(uint32_t xa, const Tabs &tb)
 {
     const double x = (double)xa + 1.0;                              // 1 .. 2^32, exact
     const long long ix = __double_as_longlong(x);
     const int e = (int)(ix >> 52) - (1023 + 32);
     const long long mant = ix & 0x000FFFFFFFFFFFFFll;
     const double m = __longlong_as_double(mant | 0x3FF0000000000000ll);
-    const double2 tc = kWfLogTab[(int)(mant >> 45)];
+    const double2 tc = tb.log((int)(mant >> 45));
     const double r = fma(m, tc.x, -1.0);
     double p = fma(r, -1.0 / 6.0, 0.2);
     p = fma(r, p, -0.25);
@@ -382,19 +398,27 @@ __device__ __forceinline__ wf_philox_out wf_philox4x32_10(uint32_t c0, uint32_t 
     return {c0, c1, c2, c3};
 }
 
+template <class Tabs>
+__device__ __forceinline__ void wf_sincos_u32(uint32_t xb, const Tabs &tb, double *sn, double *cs)   // t = xb * 2^-32
+{
+    const int ri = (int)(xb & 0x1FFFFFFu) - (1 << 24);
+    wf_cis_sector(tb.cis((int)(xb >> 25)), (double)ri * (6.28318530717958647692 * 0x1.0p-32), sn, cs);
+}
+
 // Box-Muller from two 32-bit words: u1 = (xa + 1) 2^-32 in (0, 1], u2 = xb 2^-32 in [0, 1).
-__device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double sigma, double *re, double *im)
+template <class Tabs>
+__device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double sigma, const Tabs &tb, double *re, double *im)
 {
 #ifdef WF_ABL_NO_LOG
     const double r = sigma * ((double)xa + 1.0) * 0x1.0p-32;
 #else
-    const double r = sigma * wf_sqrt_pos(-2.0 * wf_log_unit32(xa));
+    const double r = sigma * wf_sqrt_pos(-2.0 * wf_log_unit32(xa, tb));
 #endif
     double s, c;
 #ifdef WF_ABL_NO_SINCOS
     s = (double)xb * 0x1.0p-32; c = 1.0 - s;
 #else
-    wf_sincos_u32(xb, &s, &c);
+    wf_sincos_u32(xb, tb, &s, &c);
 #endif
     *re = r * c;
     *im = r * s;
@@ -403,8 +427,9 @@ __device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double
 // The two complex Gaussian samples with absolute indices 2*pair and 2*pair + 1: ONE
 // Philox4x32-10 block (counter = pair index, stream id; key = seed), words (x0, x1) for the
 // even sample, (x2, x3) for the odd one.  g = {re0, im0, re1, im1}.
+template <class Tabs>
 __device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_id, uint64_t seed, double sigma,
-                                                double g[4])
+                                                const Tabs &tb, double g[4])
 {
 #ifdef WF_ABL_NO_PHILOX   // ablation only: NOT a valid generator
     const wf_philox_out p = {(uint32_t)pair * 2654435761u, (uint32_t)(pair >> 7) ^ (uint32_t)seed,
@@ -413,8 +438,8 @@ __device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_i
     const wf_philox_out p = wf_philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)stream_id,
                                              (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
 #endif
-    wf_box_muller32(p.x0, p.x1, sigma, &g[0], &g[1]);
-    wf_box_muller32(p.x2, p.x3, sigma, &g[2], &g[3]);
+    wf_box_muller32(p.x0, p.x1, sigma, tb, &g[0], &g[1]);
+    wf_box_muller32(p.x2, p.x3, sigma, tb, &g[2], &g[3]);
 }
 
 __device__ __forceinline__ uint64_t wf_wave_xor_reduce(uint64_t v)

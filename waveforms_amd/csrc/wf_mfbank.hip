@@ -25,6 +25,7 @@ struct mf_params {
     int ob;    // outputs per workgroup iteration (<= MF_THREADS)
     int span;  // input samples staged per iteration
     int pad;   // 1: one pad slot every `step` samples
+    int dump;  // LDS slot that absorbs the partial pairs of the interior staging path
     int64_t nblk;
     // fused channel (NOISE instantiation): staged sample = r*rot + sigma*N(idx)
     double rot_re, rot_im, sigma;
@@ -46,6 +47,11 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
     // of the 3 x 9 bank overflow the SGPR file and spill through v_writelane/v_readlane
     __shared__ double2 s_taps[NTAPS ? NF * NTAPS : 1];
     if (NTAPS && STEP && t < NF * NTAPS) s_taps[t] = reinterpret_cast<const double2 *>(taps)[t];
+    // The fused channel of the step-8 fast path keeps the Gaussian source's two tables in the
+    // window's 256 PAD slots (slot 9 g + 8 is never written by the staging): LDS for free, and no
+    // global table loads queued behind the previous iteration's stores on vmcnt.
+    constexpr bool LDS_TABS = NOISE && STEP == 8;
+    if (LDS_TABS) wf_stage_tables<9, 8>(s_win, t, MF_THREADS);   // first use is behind the loop's barrier
     for (int64_t blk = blockIdx.x; blk < P.nblk; blk += gridDim.x) {
         const int64_t k0 = blk * P.ob;
         // first input sample of the span: oldest sample of output k0
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 // block-uniform; the two partial pairs at the window ends load from a clamped address
                 // and park their result in the dump slot behind the window.
                 const int last = P.span - 1;
-                const int dump = P.span + (pad ? P.span / step + 1 : 0);
+                const int dump = P.dump;
                 const int niter = (P.span + 1 + 2 * MF_THREADS - 1) / (2 * MF_THREADS);
                 int w0 = 2 * t - odd;
                 auto ld = [&](int w) { return rp[min(max(w, 0), last)]; };
@@ -80,7 +86,8 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 for (int it = 0; it < niter; ++it) {
                     const double2 n0 = ld(w0 + 2 * MF_THREADS), n1 = ld(w0 + 2 * MF_THREADS + 1);
                     double g[4];
-                    wf_gaussian_two(pair, P.stream_id, P.seed, P.sigma, g);
+                    if (LDS_TABS) wf_gaussian_two(pair, P.stream_id, P.seed, P.sigma, wf_tabs_lds<9, 8>{s_win}, g);
+                    else wf_gaussian_two(pair, P.stream_id, P.seed, P.sigma, wf_tabs_global{}, g);
                     const int w1 = w0 + 1;
                     const int q0 = (w0 >= 0 && w0 <= last) ? w0 + (pad ? w0 / step : 0) : dump;
                     const int q1 = (w1 <= last) ? w1 + (pad ? w1 / step : 0) : dump;
@@ -112,7 +119,11 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 const bool in0 = w0 >= vlo && w0 < vhi, in1 = w1 >= vlo && w1 < vhi;
                 double g[4] = {0.0, 0.0, 0.0, 0.0};
                 if (in0 || in1)   // the channel of wf_awgn_c128, on the fly
-                    wf_gaussian_two(pair_lo + (uint64_t)((w0 + odd) >> 1), P.stream_id, P.seed, P.sigma, g);
+                {
+                    const uint64_t pr = pair_lo + (uint64_t)((w0 + odd) >> 1);
+                    if (LDS_TABS) wf_gaussian_two(pr, P.stream_id, P.seed, P.sigma, wf_tabs_lds<9, 8>{s_win}, g);
+                    else wf_gaussian_two(pr, P.stream_id, P.seed, P.sigma, wf_tabs_global{}, g);
+                }
                 if (w0 >= 0) {
                     const double2 x = in0 ? make_double2(fma(c0.x, P.rot_re, fma(-c0.y, P.rot_im, g[0])),
                                                          fma(c0.x, P.rot_im, fma(c0.y, P.rot_re, g[1])))
@@ -268,7 +279,11 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
         P.ob = best;
         P.span = (best - 1) * step + ntaps;
     }
-    const int slots = P.span + (P.pad ? P.span / step + 1 : 0) + 1;   // + the dump slot of the interior staging path
+    // window + the dump slot of the interior staging path; the step-8 channel needs all 256 pad
+    // slots (tables), so its dump slot sits behind pad slot 255
+    P.dump = P.span + (P.pad ? P.span / step + 1 : 0);
+    if (noise && step == 8 && P.dump < 9 * 256) P.dump = 9 * 256;
+    const int slots = P.dump + 1;
     P.nblk = (ncols + P.ob - 1) / P.ob;
     const int grid = (int)(P.nblk < 4096 ? P.nblk : 4096);
     hipStream_t s = wf_stream(stream);

@@ -76,9 +76,11 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
     __shared__ double s_tot[PH_ROWS * PH_WAVES];
     __shared__ long long s_tile;
     __shared__ uint64_t s_prefix;
+    __shared__ double2 s_cis[128];   // sincos sector table in LDS (persistent store loop: see wf_sincos_sectors)
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     uint64_t *desc = scan + PH_DESC0;
+    wf_stage_cis_table(s_cis, t, PH_THREADS);   // the tile loop opens with a barrier
 
     for (long long iter_ = 0;; ++iter_) {
         (void)iter_;
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
 #ifdef WF_ABL_NO_SINCOS
             s0 = r0; c0 = r0 + 1; s1 = r1; c1 = r1 + 1;
 #else
-            wf_sincos_turns(fma(r0, P.inv_sps, P.phi0_turns), &s0, &c0);
-            wf_sincos_turns(fma(r1, P.inv_sps, P.phi0_turns), &s1, &c1);
+            wf_sincos_sectors(s_cis, fma(r0, 128.0 * P.inv_sps, 128.0 * P.phi0_turns), &s0, &c0);
+            wf_sincos_sectors(s_cis, fma(r1, 128.0 * P.inv_sps, 128.0 * P.phi0_turns), &s1, &c1);
 #endif
             if (i + 1 < P.n) {
                 double2 *o = reinterpret_cast<double2 *>(out + 2 * i);

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("write_csv")
     ap.add_argument("--nsym", type=int, required=True)
     ap.add_argument("--sps", type=int, default=8)
+    ap.add_argument("--out", default=None, help="output directory (default: profiles/)")
     a = ap.parse_args()
     stats = {}
     for r in csv.DictReader(open(a.kernel_stats)):
@@ -54,7 +55,8 @@ def main():
     out = {"tag": a.tag, "nsym": a.nsym, "sps": a.sps,
            "note": "traffic = 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE correction), medians over launches",
            "kernels": kernels}
-    path = Path(__file__).resolve().parent.parent / "profiles" / f"{a.tag}_summary.json"
+    outdir = Path(a.out) if a.out else Path(__file__).resolve().parent.parent / "profiles"
+    path = outdir / f"{a.tag}_summary.json"
     path.write_text(json.dumps(out, indent=1) + "\n")
     print(path)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["avg_ns"]):

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Profile `bench.py` on the GPU box: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in
+# their own --pmc passes (they do not fit one pass; never combined with other trace domains).
+#   tools/profile.sh <tag> [bench.py flags...]      e.g. tools/profile.sh r01_fused --fuse 3
+# Writes gpurun_out/<tag>/{kt,fetch,write}/... and profiles/<tag>_{kernel_stats.csv,summary.json,
+# bench_under_rocprof.json} (copy profiles/ back from gpurun_out/<tag>/profiles on the host).
+set -e
+tag=$1; shift
+root="$(cd "$(dirname "$0")/.." && pwd)"
+cd /tmp && export TMPDIR=/tmp && cd "$root"
+out=gpurun_out/$tag
+mkdir -p $out/profiles
+flags="--steps 5 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py $flags > $out/profiles/${tag}_bench_under_rocprof.json 2> $out/kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python3 bench.py $flags > /dev/null 2> $out/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python3 bench.py $flags > /dev/null 2> $out/write.err
+ks=$(find $out/kt -name '*kernel_stats.csv' | head -1)
+fc=$(find $out/fetch -name '*counter_collection.csv' | head -1)
+wc=$(find $out/write -name '*counter_collection.csv' | head -1)
+cp $ks $out/profiles/${tag}_kernel_stats.csv
+python3 tools/pmc_summary.py $tag $ks $fc $wc --nsym 10000000 --sps 8 --out $out/profiles
+# keep the merge-back small: the raw per-dispatch CSVs are tens of MB
+find $out -name '*counter_collection.csv' -delete; find $out -name '*kernel_trace.csv' -delete
+python3 - <<PY
+import csv
+for r in csv.DictReader(open("$out/profiles/${tag}_kernel_stats.csv")):
+    print(r["Name"][:64].ljust(64), r["Calls"].rjust(4), f'{float(r["AverageNs"])/1e3:9.2f} us', r["Percentage"])
+PY

@@ -75,9 +75,15 @@ __device__ __forceinline__ vit_comp vit_components(const double2 *__restrict__ z
     return c;
 }
 
-// one ACS stage of section COL: returns the 4 selection bits (1 = second branch won)
+// one ACS stage of section COL: second[s] = the second listed branch won state s.
+// The survivor metric is min(fa, fb): identical to the reference's `fb < fa ? fb : fa` for every
+// ordered pair (equal values differ at most in the sign of a zero, which no later compare or
+// sum can see), and one v_min_f64 instead of a compare and two 32-bit selects.  The selection
+// flags are WAVE MASKS (the ballot of the compare is the SGPR pair v_cmp writes anyway), so the
+// whole traceback below is scalar mask logic (s_and_b64 / s_or_b64 / s_xor_b64) that costs the
+// vector pipe nothing; a lane reads its own bit back with one v_cndmask (inverse ballot).
 template <int COL>
-__device__ __forceinline__ unsigned vit_acs(const double m[4], const vit_comp &q, double out[4])
+__device__ __forceinline__ void vit_acs(const double m[4], const vit_comp &q, double out[4], uint64_t second[4])
 {
     double fa[4], fb[4];
     if (COL == 0) {
@@ -91,15 +97,14 @@ __device__ __forceinline__ unsigned vit_acs(const double m[4], const vit_comp &q
         fa[2] = m[2] + q.r1; fb[2] = m[3] + q.a;
         fa[3] = m[2] + q.b;  fb[3] = m[3] + q.i1;
     }
-    unsigned sel = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const bool second = fb[s] < fa[s];
-        out[s] = second ? fb[s] : fa[s];
-        sel |= (second ? 1u : 0u) << s;
+        second[s] = __builtin_amdgcn_ballot_w64(fb[s] < fa[s]);
+        out[s] = fmin(fa[s], fb[s]);
     }
-    return sel;
 }
+
+__device__ __forceinline__ uint64_t vit_mux(uint64_t c, uint64_t x, uint64_t y) { return (c & x) | (~c & y); }
 
 // predecessor state of end state `st` in section COL: first / second branch start
 __device__ __forceinline__ int vit_pred(int col, int st, unsigned second)
@@ -111,7 +116,7 @@ __device__ __forceinline__ int vit_pred(int col, int st, unsigned second)
 struct vit_lane {
     double m0[4];
     vit_comp prev;                       // components of the previous call's row
-    uint64_t pb_lo, pb_hi, ps_lo, ps_hi;
+    uint32_t wb, ws;                     // decisions of the current group of 16 calls: 1 bit / 2 bits each
 };
 
 // One detector call k (COL = column parity of k): stage 0 commits the previous call's
@@ -119,8 +124,7 @@ struct vit_lane {
 // depth-2 traceback from the first arg-min (algorithm.py:57-101 with length = 2).
 template <int COL>
 __device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict__ zrow, bool prime, int diff,
-                                         int64_t k, int64_t a, int64_t ncalls, uint8_t *__restrict__ bits,
-                                         int8_t *__restrict__ syms)
+                                         int64_t k, int64_t a, int64_t ncalls, uint64_t *__restrict__ dec)
 {
     constexpr int PREV = COL ^ 1;
     const vit_comp now = vit_components<COL>(zrow);
@@ -131,37 +135,90 @@ __device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict_
     const double mn = fmin(fmin(L.m0[0], L.m0[1]), fmin(L.m0[2], L.m0[3]));
     const double carried[4] = {L.m0[0] - mn, L.m0[1] - mn, L.m0[2] - mn, L.m0[3] - mn};
     double ma[4], mb[4];
-    const unsigned sel0 = vit_acs<PREV>(carried, L.prev, ma);   // stage j = 0
-    const unsigned sel1 = vit_acs<COL>(ma, now, mb);            // stage j = 1
-    // np.argmin: first minimum
-    const int i01 = mb[1] < mb[0] ? 1 : 0, i23 = mb[3] < mb[2] ? 3 : 2;
-    const double v01 = mb[1] < mb[0] ? mb[1] : mb[0], v23 = mb[3] < mb[2] ? mb[3] : mb[2];
-    const int s1 = v23 < v01 ? i23 : i01;
-    const int e0 = vit_pred(COL, s1, (sel1 >> s1) & 1u);        // state after stage 0
-    const unsigned w0 = (sel0 >> e0) & 1u;                      // which branch entered e0
-    // branch of section PREV entering e0 through its first / second slot; its start state
-    const int st0 = vit_pred(PREV, e0, w0);
-    const int b = 2 * st0 + (PREV == 0 ? (e0 >> 1) : (e0 & 1));
-    const int bit = br_inp(PREV, b, diff);
-    // output symbols by branch: even {0,+2,0,-2,-2,0,+2,0}, odd {0,-2,+2,0,0,+2,-2,0} as (sym + 2) nibbles
-    constexpr unsigned kSymPlus2 = PREV == 0 ? 0x24200242u : 0x20422402u;
-    const int sym = (int)((kSymPlus2 >> (4 * b)) & 15u) - 2;
+    uint64_t n0[4], n1[4];
+    vit_acs<PREV>(carried, L.prev, ma, n0);   // stage j = 0
+    vit_acs<COL>(ma, now, mb, n1);            // stage j = 1
+    // np.argmin (first minimum) and the depth-2 traceback, as lane-mask logic.
+    //   s1 = arg-min state of stage 1 (bits s1b1 s1b0), w1 = which branch entered it
+    const uint64_t c01 = __builtin_amdgcn_ballot_w64(mb[1] < mb[0]), c23 = __builtin_amdgcn_ballot_w64(mb[3] < mb[2]);
+    const double v01 = fmin(mb[0], mb[1]), v23 = fmin(mb[2], mb[3]);
+    const uint64_t s1b1 = __builtin_amdgcn_ballot_w64(v23 < v01);
+    const uint64_t s1b0 = vit_mux(s1b1, c23, c01);
+    const uint64_t w1 = vit_mux(s1b1, vit_mux(c23, n1[3], n1[2]), vit_mux(c01, n1[1], n1[0]));
+    //   e0 = state after stage 0 = predecessor of s1 in section COL:
+    //        even (st & 1) + 2 * second, odd (st & 2) + second
+    const uint64_t e0b0 = COL == 0 ? s1b0 : w1;
+    const uint64_t e0b1 = COL == 0 ? w1 : s1b1;
+    const uint64_t w0 = vit_mux(e0b1, vit_mux(e0b0, n0[3], n0[2]), vit_mux(e0b0, n0[1], n0[0]));   // which branch entered e0
+    //   st0 = start state of that branch (predecessor of e0 in section PREV); branch index
+    //   b = 2 * st0 + (PREV == 0 ? e0 >> 1 : e0 & 1)
+    const uint64_t st0b0 = PREV == 0 ? e0b0 : w0;
+    const uint64_t st0b1 = PREV == 0 ? w0 : e0b1;
+    const uint64_t b0 = PREV == 0 ? e0b1 : e0b0, b1 = st0b0, b2 = st0b1;
+    //   input bit (br_inp): (b & 1) ^ (diff ? (PREV == 0 ? st0 >> 1 : st0 & 1) : 0)
+    const uint64_t bit_m = b0 ^ (diff ? (PREV == 0 ? st0b1 : st0b0) : 0ull);
+    //   output symbol by branch (model.py:205-258): even {0,+2,0,-2,-2,0,+2,0}, odd {0,-2,+2,0,0,+2,-2,0};
+    //   code = sym / 2 + 1: even  code&1 <=> b0 == b2, code&2 <=> b0 != b2 && b1 == b2
+    //                       odd   code&1 <=> b0 == b1, code&2 <=> b0 != b1 && b2 == b0
+    const uint64_t x02 = b0 ^ b2, x01 = b0 ^ b1, x12 = b1 ^ b2;
+    const uint64_t cd0_m = PREV == 0 ? ~x02 : ~x01;
+    const uint64_t cd1_m = PREV == 0 ? (x02 & ~x12) : (x01 & ~x02);
+    const bool bit = __builtin_amdgcn_inverse_ballot_w64(bit_m);
+    const bool cd0 = __builtin_amdgcn_inverse_ballot_w64(cd0_m), cd1 = __builtin_amdgcn_inverse_ballot_w64(cd1_m);
 #pragma unroll
     for (int s = 0; s < 4; ++s) L.m0[s] = ma[s];
     L.prev = now;
     if (k >= a) {
+        // Decisions stay on chip until the lane's chunk is done: packed here (bit c: input bit;
+        // bits 2c..2c+1: sym / 2 + 1), one 8 B word per 16 calls parked in the wave's LDS strip,
+        // expanded and stored by vit_flush after the last row has been loaded.  A global store in
+        // this loop would share vmcnt with the row prefetch and force every wait down to
+        // vmcnt(0) (mixed loads and stores complete out of order on gfx9-family counters).
         const int c = (int)(k - a) & 15;
-        const uint64_t bv = (uint64_t)(bit & 0xFF), sv = (uint64_t)(sym & 0xFF);
-        if (c < 8) { L.pb_lo |= bv << (8 * c); L.ps_lo |= sv << (8 * c); }
-        else { L.pb_hi |= bv << (8 * (c - 8)); L.ps_hi |= sv << (8 * (c - 8)); }
-        if (c == 15) {
-            *reinterpret_cast<ulonglong2 *>(bits + k - 15) = make_ulonglong2(L.pb_lo, L.pb_hi);
-            *reinterpret_cast<ulonglong2 *>(syms + k - 15) = make_ulonglong2(L.ps_lo, L.ps_hi);
-            L.pb_lo = L.pb_hi = L.ps_lo = L.ps_hi = 0;
-        } else if (k + 1 == ncalls) {  // ragged tail of the burst
-            for (int q = 0; q <= c; ++q) {
-                bits[k - c + q] = (uint8_t)(((q < 8 ? L.pb_lo : L.pb_hi) >> (8 * (q & 7))) & 0xFF);
-                syms[k - c + q] = (int8_t)(((q < 8 ? L.ps_lo : L.ps_hi) >> (8 * (q & 7))) & 0xFF);
+        L.wb |= (bit ? 1u : 0u) << c;
+        L.ws |= ((cd0 ? 1u : 0u) | (cd1 ? 2u : 0u)) << (2 * c);
+        if (c == 15 || k + 1 == ncalls) {
+            dec[(int)(k - a) >> 4] = (uint64_t)L.wb | ((uint64_t)L.ws << 32);
+            L.wb = L.ws = 0;
+        }
+    }
+}
+
+// Expand the packed decisions of one lane (calls [a, a + n)) and store them: 16 B per group of 16.
+__device__ __forceinline__ uint64_t vit_spread_bits8(uint32_t x)    // 8 bits -> 8 bytes of 0 / 1, LSB first
+{
+    const uint64_t t = ((uint64_t)(x & 0xFF) * 0x0101010101010101ull) & 0x8040201008040201ull;
+    return ((t + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+}
+
+__device__ __forceinline__ uint64_t vit_spread_syms8(uint32_t x)    // 8 two-bit codes -> 8 bytes of -2 / 0 / +2
+{
+    uint64_t t = ((uint64_t)(x & 0xFFFF) | ((uint64_t)(x & 0xFFFF) << 24)) & 0x000000FF000000FFull;
+    t = (t | (t << 12)) & 0x000F000F000F000Full;
+    t = (t | (t << 6)) & 0x0303030303030303ull;
+    const uint64_t v = t << 1;                                       // 0, 2, 4 per byte; + 0xFE (mod 256) = -2, 0, +2
+    return ((v & 0x7F7F7F7F7F7F7F7Full) + 0x7E7E7E7E7E7E7E7Eull) ^ ((v ^ 0xFEFEFEFEFEFEFEFEull) & 0x8080808080808080ull);
+}
+
+template <int CH>
+__device__ __forceinline__ void vit_flush(const uint64_t *__restrict__ dec, int64_t a, int64_t ncalls,
+                                          uint8_t *__restrict__ bits, int8_t *__restrict__ syms)
+{
+#pragma unroll
+    for (int gq = 0; gq < CH / 16; ++gq) {
+        const int64_t k0 = a + 16 * gq;
+        if (k0 >= ncalls) break;
+        const uint64_t w = dec[gq];
+        const uint32_t wb = (uint32_t)w, ws = (uint32_t)(w >> 32);
+        const uint64_t b_lo = vit_spread_bits8(wb), b_hi = vit_spread_bits8(wb >> 8);
+        const uint64_t s_lo = vit_spread_syms8(ws), s_hi = vit_spread_syms8(ws >> 16);
+        if (k0 + 16 <= ncalls) {
+            *reinterpret_cast<ulonglong2 *>(bits + k0) = make_ulonglong2(b_lo, b_hi);
+            *reinterpret_cast<ulonglong2 *>(syms + k0) = make_ulonglong2(s_lo, s_hi);
+        } else {   // ragged tail of the burst
+            for (int q = 0; k0 + q < ncalls; ++q) {
+                bits[k0 + q] = (uint8_t)(((q < 8 ? b_lo : b_hi) >> (8 * (q & 7))) & 0xFF);
+                syms[k0 + q] = (int8_t)(((q < 8 ? s_lo : s_hi) >> (8 * (q & 7))) & 0xFF);
             }
         }
     }
@@ -200,13 +257,24 @@ __device__ __forceinline__ void vit_comp_to_inc(const vit_comp &c, int col, doub
 // while the current one is being decoded.  Steps are decoded in (even, odd) column pairs
 // so only two ACS bodies are live at a time.
 #define VIT_S 4
+#define VIT_DEPTH 3   // batches of cooperative loads in flight per wave (register sets pend0..2)
 #define VIT_PIECES (3 * VIT_S)        // 16-byte pieces per lane-segment
 #define VIT_LANE_SLOTS (VIT_PIECES + 1)
+
+// 16 B load as a VALUE: assigning `dst[u] = ptr[i]` for the double2 class type lowers to a memcpy
+// into the private array, which then stays in scratch memory instead of registers.
+__device__ __forceinline__ double2 vit_ld16(const double2 *p)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = *reinterpret_cast<const v2d *>(p);
+    return make_double2(v.x, v.y);
+}
 
 template <int CH, int PAR0>   // PAR0: column parity of step 0's call index
 __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf, int64_t ncalls, int diff, int warmup,
                                                    uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
-                                                   double *__restrict__ state, int64_t i0, double2 (*s_rows)[WF_WAVE * VIT_LANE_SLOTS])
+                                                   double *__restrict__ state, int64_t i0, double2 (*s_rows)[WF_WAVE * VIT_LANE_SLOTS],
+                                                   uint64_t *__restrict__ s_dec)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t g0 = ((int64_t)blockIdx.x * (VIT_THREADS / WF_WAVE) + wave) * WF_WAVE;  // first lane of the wave
@@ -216,6 +284,7 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     const int nbatch = (nsteps + VIT_S - 1) / VIT_S;
     const double2 *rows = reinterpret_cast<const double2 *>(mf);
     double2 *tile = s_rows[wave];
+    uint64_t *dec = s_dec + (wave * WF_WAVE + lane) * (CH / 16 + 1);   // + 1: odd 8 B stride, conflict-free
 
     // cooperative piece p = u*64 + lane  ->  (segment = lane of the wave it belongs to, piece index).
     // Everything per-lane is 32-bit and batch-invariant; the batch only moves a wave-uniform base.
@@ -229,24 +298,34 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
         sgw[u] = (sg << 8) | (p - sg * VIT_PIECES);
     }
     const int64_t g0u = __builtin_amdgcn_readfirstlane((int)(g0 >> 6)) * (int64_t)WF_WAVE;   // wave-uniform copy of g0
-    auto fetch = [&](int b, double2 dst[VIT_PIECES]) {
+    // Rows outside [0, ncalls) exist only around the first and last chunk of a burst and are never
+    // decoded (vit_step is skipped for them), so their loads are merely redirected to a valid
+    // address: a wave-uniform test picks the unclamped form for every interior batch.
+    auto fetch = [&](int b, double2 dst[VIT_PIECES]) __attribute__((always_inline)) {
         const int64_t rb = g0u * CH - warmup - 1 + (int64_t)b * VIT_S;   // first row of the batch (uniform)
-        const int64_t lo64 = -rb, hi64 = ncalls - rb;                     // valid rrel range [lo, hi)
-        const int lo = lo64 < -(1 << 30) ? -(1 << 30) : (lo64 > (1 << 30) ? (1 << 30) : (int)lo64);
-        const int hi = hi64 < -(1 << 30) ? -(1 << 30) : (hi64 > (1 << 30) ? (1 << 30) : (int)hi64);
         const double2 *basep = rows + 3 * rb;
-#pragma unroll
-        for (int u = 0; u < VIT_PIECES; ++u) {
-            const int sg = sgw[u] >> 8, wi = sgw[u] & 255;
-            const int rrel = sg * CH + wi / 3;          // row relative to the wave's first row of the batch
 #ifdef WF_ABL_NO_MEM   // ablation only
-            dst[u] = make_double2((double)(rrel & 7) - 3.5, (double)(wi & 3) - 1.0);
+#pragma unroll
+        for (int u = 0; u < VIT_PIECES; ++u) dst[u] = make_double2((double)(sgw[u] & 7) - 3.5, (double)(sgw[u] & 3) - 1.0);
 #else
-            dst[u] = (rrel >= lo && rrel < hi) ? basep[3 * CH * sg + wi] : make_double2(0.0, 0.0);
-#endif
+        if (rb >= 0 && rb + (int64_t)(WF_WAVE - 1) * CH + VIT_S <= ncalls) {
+#pragma unroll
+            for (int u = 0; u < VIT_PIECES; ++u) dst[u] = vit_ld16(basep + 3 * CH * (sgw[u] >> 8) + (sgw[u] & 255));
+        } else {
+            const int64_t lo64 = -rb, hi64 = ncalls - 1 - rb;             // valid rrel range [lo, hi]
+            const int lo = lo64 < -(1 << 30) ? -(1 << 30) : (lo64 > (1 << 30) ? (1 << 30) : (int)lo64);
+            const int hi = hi64 < -(1 << 30) ? -(1 << 30) : (hi64 > (1 << 30) ? (1 << 30) : (int)hi64);
+#pragma unroll
+            for (int u = 0; u < VIT_PIECES; ++u) {
+                const int sg = sgw[u] >> 8, wi = sgw[u] & 255;
+                const int rrel = sg * CH + wi / 3;      // row relative to the wave's first row of the batch
+                const int rc = min(max(rrel, lo), hi);
+                dst[u] = vit_ld16(basep + 3 * rc + (wi - 3 * (wi / 3)));
+            }
         }
+#endif
     };
-    auto stash = [&](const double2 src[VIT_PIECES]) {
+    auto stash = [&](const double2 src[VIT_PIECES]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < VIT_PIECES; ++u) tile[(sgw[u] >> 8) * VIT_LANE_SLOTS + (sgw[u] & 255)] = src[u];
     };
@@ -255,35 +334,54 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
 #pragma unroll
     for (int k = 0; k < 4; ++k) L.m0[k] = 0.0;
     L.prev.r1 = L.prev.i1 = L.prev.a = L.prev.b = 0.0;
-    L.pb_lo = L.pb_hi = L.ps_lo = L.ps_hi = 0;
+    L.wb = L.ws = 0;
     if (state && a == 0) {   // the lane that starts the burst continues the carried detector
 #pragma unroll
         for (int k = 0; k < 4; ++k) L.m0[k] = state[1 + k];
         L.prev = vit_comp_from_inc(state + 5, (int)((i0 - 1) & 1));
     }
-    double2 pend[VIT_PIECES];
-    fetch(0, pend);
-    stash(pend);
-    wf_lds_barrier();
+    // The tile is wave-private and LDS executes a wave's accesses in order, so the loop needs no
+    // workgroup barrier at all: only the loads gate it.  One batch of lookahead left a wave
+    // waiting a full memory round trip (~4 us under load) per 4 decoded steps, with ~1 wave per
+    // SIMD resident -> 207 us for 176 steps.  VIT_DEPTH batches are kept in flight in registers
+    // instead (VIT_DEPTH x 12 x 16 B per lane; the register file is nearly empty at this occupancy).
+    double2 pend0[VIT_PIECES], pend1[VIT_PIECES], pend2[VIT_PIECES];   // VIT_DEPTH = 3 register sets
+    // Every round issues exactly one batch of loads, unconditionally (past the last batch it
+    // re-reads that batch: L2 hits, results unused).  With a conditional refill the compiler must
+    // assume the path on which nothing was issued behind a register set and waits with vmcnt(0).
+    const int last_b = nbatch - 1;
+    fetch(0, pend0);
+    fetch(min(1, last_b), pend1);
+    fetch(min(2, last_b), pend2);
     const int64_t kbase = a - warmup - 1;
-    for (int b = 0; b < nbatch; ++b) {
-        if (b + 1 < nbatch) fetch(b + 1, pend);          // in flight during the decode below
+    auto round = [&](int b, double2 (&pd)[VIT_PIECES]) __attribute__((always_inline)) {
+        stash(pd);                                           // waits for batch b only (loads return in order)
+        fetch(min(b + VIT_DEPTH, last_b), pd);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (live) {
 #pragma unroll 1
             for (int jj = 0; jj < VIT_S; jj += 2) {
                 const int j = b * VIT_S + jj;
-                const int64_t k = kbase + j;              // call index of the even step
+                const int64_t k = kbase + j;                  // call index of the even step
                 const double2 *zr = tile + lane * VIT_LANE_SLOTS + 3 * jj;
                 if (j < nsteps && k >= 0 && k < ncalls)
-                    vit_step<PAR0>(L, zr, j == 0, diff, k, a, ncalls, bits, syms);
+                    vit_step<PAR0>(L, zr, j == 0, diff, k, a, ncalls, dec);
                 if (j + 1 < nsteps && k + 1 >= 0 && k + 1 < ncalls)
-                    vit_step<PAR0 ^ 1>(L, zr + 3, false, diff, k + 1, a, ncalls, bits, syms);
+                    vit_step<PAR0 ^ 1>(L, zr + 3, false, diff, k + 1, a, ncalls, dec);
             }
         }
-        wf_lds_barrier();                                  // batch b fully consumed
-        if (b + 1 < nbatch) stash(pend);
-        wf_lds_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // batch b consumed before the next stash
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int b0 = 0; b0 < nbatch; b0 += VIT_DEPTH) {   // rounds past nbatch decode nothing (j >= nsteps)
+        round(b0, pend0);
+        round(b0 + 1, pend1);
+        round(b0 + 2, pend2);
     }
+    if (live) vit_flush<CH>(dec, a, ncalls, bits, syms);   // same lane wrote the strip: in-order LDS, no barrier
     if (state && live && a + CH >= ncalls) {
         // the lane that owns the last call hands the detector state on (streaming).  Written
         // to the second half of the carry block; viterbi_carry_commit_kernel moves it.
@@ -297,19 +395,17 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
 #ifndef VIT_MIN_WAVES
 #define VIT_MIN_WAVES 1
 #endif
-#ifndef VIT_LONG_CH
-#define VIT_LONG_CH 128
-#endif
 template <int CH>
 __global__ __launch_bounds__(VIT_THREADS, VIT_MIN_WAVES) void viterbi_batch_kernel(const double *__restrict__ mf, int64_t ncalls,
                                                                      int diff, int warmup, uint8_t *__restrict__ bits,
                                                                      int8_t *__restrict__ syms, double *__restrict__ state)
 {
     __shared__ double2 s_rows[VIT_THREADS / WF_WAVE][WF_WAVE * VIT_LANE_SLOTS];
+    __shared__ uint64_t s_dec[VIT_THREADS * (CH / 16 + 1)];   // packed decisions, one strip per lane
     const int64_t i0 = state ? (int64_t)state[0] : 0;
     // call index of step 0 is lane_start - warmup - 1 with lane_start a multiple of CH (even)
-    if ((i0 - warmup - 1) & 1) viterbi_batch_body<CH, 1>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows);
-    else viterbi_batch_body<CH, 0>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows);
+    if ((i0 - warmup - 1) & 1) viterbi_batch_body<CH, 1>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
+    else viterbi_batch_body<CH, 0>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
 }
 
 __global__ void viterbi_carry_commit_kernel(double *state)
@@ -330,19 +426,21 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     WF_HIP(hipSetDevice(ctx->device));
     if (warmup == 0) warmup = VIT_DEFAULT_WARMUP;
     if (warmup > 4096) warmup = 4096;
-    // long bursts: 128 calls per lane (warm-up re-reads 37 % instead of 75 %); short ones
-    // keep 64 so that enough lanes exist to fill the chip
-    const int ch = ncalls >= (1 << 22) ? VIT_LONG_CH : 64;
+    // Calls per lane: the warm-up re-reads 48 / CH of the rows (75 % at 64, 37 % at 128, 19 % at
+    // 256) but every lane walks CH + 48 dependent steps, so CH grows only while the burst still
+    // yields about one wave per SIMD (1024 SIMDs x 64 lanes).
+    const int ch = ncalls >= (3 << 22) ? 256 : ncalls >= (3 << 20) ? 128 : 64;
     const int64_t nthreads = (ncalls + ch - 1) / ch;
     const int64_t nblocks = (nthreads + VIT_THREADS - 1) / VIT_THREADS;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
     hipStream_t s = wf_stream(stream);
-    if (ch == VIT_LONG_CH)
-        hipLaunchKernelGGL(viterbi_batch_kernel<VIT_LONG_CH>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
-                           ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
-    else
-        hipLaunchKernelGGL(viterbi_batch_kernel<64>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri,
-                           ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
+#define VIT_LAUNCH(CHV)                                                                                      \
+    hipLaunchKernelGGL(viterbi_batch_kernel<CHV>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri, \
+                       ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state)
+    if (ch == 256) VIT_LAUNCH(256);
+    else if (ch == 128) VIT_LAUNCH(128);
+    else VIT_LAUNCH(64);
+#undef VIT_LAUNCH
     WF_LAUNCH_CHECK();
     if (d_state) {
         hipLaunchKernelGGL(viterbi_carry_commit_kernel, dim3(1), dim3(64), 0, s, d_state);

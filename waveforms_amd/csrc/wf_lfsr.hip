@@ -4,12 +4,15 @@
 //
 // One step of the register is the linear map T over GF(2)^64:
 //   T e_0 = mask, T e_c = e_{c-1}.
-// The context caches T^(2^j), j = 0..63 (column form) per mask; block b jumps to
-// position skip + b*2^16 with one wave doing matrix-vector products in parallel
-// (lane c holds column c, XOR-reduce over the wave), then every thread jumps a
-// further t*256 steps with the 8 matrices T^(2^8..2^15) staged in LDS and emits 256
-// bits.  Bits are re-packed through LDS so that global stores are 16 B per lane,
-// fully coalesced.
+// The context caches, per mask, T^(2^j), j = 0..63 and T^(256 t), t = 0..255 (column form).
+// Block b jumps to position skip + b*2^16 with one wave doing matrix-vector products in
+// parallel (lane c holds column c, XOR-reduce by DPP, result read back as a scalar); every
+// thread then jumps a further t*256 steps with ONE product against its own T^(256 t) (the
+// columns selected by the set bits of the block state, coalesced loads) and emits 256 bits,
+// in a 32-bit register when the degree allows.  Bits are re-packed through LDS so that global
+// stores are 16 B per lane, fully coalesced.
+#include <vector>
+
 #include "wf_common.h"
 
 #define LFSR_THREADS 256
@@ -38,8 +41,19 @@ static wf_lfsr_tables *get_tables(wf_ctx *ctx, uint64_t mask)
     for (int c = 1; c < 64; ++c) t->host[0][c] = 1ull << (c - 1);
     for (int j = 1; j < 64; ++j)
         for (int c = 0; c < 64; ++c) t->host[j][c] = host_matvec(t->host[j - 1], t->host[j - 1][c]);
-    if (hipMalloc(&t->dev, sizeof(t->host)) != hipSuccess ||
-        hipMemcpy(t->dev, t->host, sizeof(t->host), hipMemcpyHostToDevice) != hipSuccess) {
+    // thread-jump table behind the 64 x 64 words: TJ[c][t] = column c of T^(256 t)
+    std::vector<uint64_t> tj((size_t)64 * LFSR_THREADS);
+    {
+        uint64_t cur[64];
+        for (int c = 0; c < 64; ++c) cur[c] = 1ull << c;                       // T^0
+        for (int th = 0; th < LFSR_THREADS; ++th) {
+            for (int c = 0; c < 64; ++c) tj[(size_t)c * LFSR_THREADS + th] = cur[c];
+            for (int c = 0; c < 64; ++c) cur[c] = host_matvec(t->host[LFSR_LOG2_BPT], cur[c]);   // T^256 * (.)
+        }
+    }
+    if (hipMalloc(&t->dev, sizeof(t->host) + tj.size() * sizeof(uint64_t)) != hipSuccess ||
+        hipMemcpy(t->dev, t->host, sizeof(t->host), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t->dev + 64 * 64, tj.data(), tj.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
         delete t;
         return nullptr;
     }
@@ -52,6 +66,25 @@ static uint64_t host_jump(const wf_lfsr_tables *t, uint64_t state, uint64_t step
     for (int j = 0; j < 64; ++j)
         if ((steps >> j) & 1) state = host_matvec(t->host[j], state);
     return state;
+}
+
+// XOR of a 64-bit value over the wave, returned as a wave-uniform scalar: row_shr 1, 2, 4, 8, the
+// row totals pushed down by row_bcast:15 / :31, lane 63 read back (no LDS round trips, unlike the
+// __shfl_xor butterfly — this product sits in a serial chain of up to 64).
+__device__ __forceinline__ uint64_t lfsr_wave_xor(uint64_t v)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#define LFSR_DPP_STEP(CTRL, RM)                                                      \
+    lo ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, RM, 0xf, false);   \
+    hi ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, RM, 0xf, false)
+    LFSR_DPP_STEP(0x111, 0xf);
+    LFSR_DPP_STEP(0x112, 0xf);
+    LFSR_DPP_STEP(0x114, 0xf);
+    LFSR_DPP_STEP(0x118, 0xf);
+    LFSR_DPP_STEP(0x142, 0xa);
+    LFSR_DPP_STEP(0x143, 0xc);
+#undef LFSR_DPP_STEP
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
 }
 
 __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__restrict__ jump,
@@ -83,32 +116,45 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
         for (int j = 0; j < 64; ++j) {
             if ((pos0 >> j) & 1) {  // wave-uniform
                 const uint64_t col = s_tab[j][lane];
-                s = wf_wave_xor_reduce(((s >> lane) & 1) ? col : 0ull);
+                s = lfsr_wave_xor(((s >> lane) & 1) ? col : 0ull);
             }
         }
         if (t == 0) s_base = s;
     }
     __syncthreads();
-    const uint64_t (*s_mat)[64] = &s_tab[LFSR_LOG2_BPT];   // T^(2^8) .. T^(2^15): thread t jumps t * 2^8 further
-
-    uint64_t s = s_base;
+    // thread t: T^(256 t) * base — XOR of the columns picked by the set bits of the (block-uniform)
+    // base state; the loads are coalesced over t
+    const uint64_t base = s_base;
+    const uint64_t *tj = jump + 64 * 64;
+    uint64_t s = 0;
+    for (int c = 0; c < degree; ++c)
+        if ((base >> c) & 1) s ^= tj[c * LFSR_THREADS + t];
+    if (degree <= 32) {
+        uint32_t s32 = (uint32_t)s;
+        const uint32_t m32 = (uint32_t)mask;
 #pragma unroll 1
-    for (int b = 0; b < 8; ++b) {
-        uint64_t y = 0;
-#pragma unroll 8
-        for (int c = 0; c < degree; ++c) y ^= ((s >> c) & 1) ? s_mat[b][c] : 0ull;   // bits >= degree are zero
-        s = ((t >> b) & 1) ? y : s;
-    }
-#pragma unroll 1
-    for (int wi = 0; wi < LFSR_WORDS; ++wi) {
-        uint64_t w = 0;
-#pragma unroll 16
-        for (int k = 0; k < 64; ++k) {
-            const uint64_t bit = s & 1;
-            s = (s >> 1) ^ (mask & (0 - bit));
-            w |= bit << k;
+        for (int wi = 0; wi < 2 * LFSR_WORDS; ++wi) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const uint32_t bit = s32 & 1u;
+                s32 = (s32 >> 1) ^ (m32 & (0u - bit));
+                w |= bit << k;
+            }
+            reinterpret_cast<uint32_t *>(s_words)[t * 2 * LFSR_WORDS + wi] = w;
         }
-        s_words[t * LFSR_WORDS + wi] = w;
+    } else {
+#pragma unroll 1
+        for (int wi = 0; wi < LFSR_WORDS; ++wi) {
+            uint64_t w = 0;
+#pragma unroll 16
+            for (int k = 0; k < 64; ++k) {
+                const uint64_t bit = s & 1;
+                s = (s >> 1) ^ (mask & (0 - bit));
+                w |= bit << k;
+            }
+            s_words[t * LFSR_WORDS + wi] = w;
+        }
     }
     __syncthreads();
 

@@ -24,6 +24,8 @@
 #define MOD_WAVES (MOD_THREADS / WF_WAVE)
 #define MOD_MASK ((1ull << 62) - 1)
 #define MOD_MAX_PART 40
+#define MOD_SCAN_TAPS 2048   // taps staged in LDS by the carry kernel
+#define MOD_SCAN_PER 16      // tiles per thread the carry kernel keeps in registers
 
 struct mod_params {
     int64_t nsym, out_len, ntiles;
@@ -74,7 +76,22 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_tile_sums_kernel(const int8_t
     if (j >= P.ntiles) return;
     const int64_t lo = (P.tile_lo + j - 1) * P.spt - P.dsh;
     double acc = 0.0;
-    for (int k = lane; k < P.spt; k += WF_WAVE) acc += mod_amp(symbols, hvec, P, lo + k);
+    const int64_t l0 = lo - P.sym_origin;
+    if (P.nh == 1 && lo >= 0 && lo + P.spt <= P.nsym && l0 >= 0 && l0 + P.spt <= P.nloc) {
+        // interior tile, single modulation index (wave-uniform test): 8 symbols per lane and trip
+        // from one unaligned 8 B load, no per-symbol bounds or index arithmetic
+        const double h0 = hvec[0];
+        const int8_t *sp = symbols + l0;
+        int k = 8 * lane;
+        for (; k + 8 <= P.spt; k += 8 * WF_WAVE) {
+            const uint64_t w = *reinterpret_cast<const uint64_t *>(sp + k);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += (double)(int8_t)(w >> (8 * q)) * h0;
+        }
+        for (int q = 0; k + q < P.spt && q < 8; ++q) acc += (double)sp[k + q] * h0;   // spt not a multiple of 8
+    } else {
+        for (int k = lane; k < P.spt; k += WF_WAVE) acc += mod_amp(symbols, hvec, P, lo + k);
+    }
 #pragma unroll
     for (int d = WF_WAVE / 2; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, WF_WAVE);
     if (lane == 0) scratch[MOD_OFF_P + j] = acc;
@@ -90,7 +107,17 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
 {
     __shared__ double s_T, s_K0;
     __shared__ uint64_t s_part[1024 / WF_WAVE];
+    __shared__ double s_pulse[MOD_SCAN_TAPS];
     const int t = threadIdx.x;
+    // the serial pass below reads one tap per trip: from global memory that is a dependent
+    // ~0.3 us load each (20 us for the 65-tap SOQPSK pulse), so the taps are staged first
+    const bool staged = P.ntaps <= MOD_SCAN_TAPS;
+    if (staged)
+        for (int k = t; k < P.ntaps; k += 1024) s_pulse[k] = pulse[k];
+    // ... and so are the amplitudes of the few symbols whose pulse starts before sample 0
+    __shared__ double s_head[MOD_MAX_PART + 1];
+    if (t >= 1 && t <= MOD_MAX_PART) s_head[t] = (t <= P.nhead && t <= P.nsym) ? mod_amp(symbols, hvec, P, t - 1) : 0.0;
+    __syncthreads();
     if (t == 0) {
         // Gcum at the few indices needed, by one sequential pass over the taps
         // idx_l = ntaps - 1 + R - (l+1)*sps, R = (c - ntaps) mod sps   (partial symbols)
@@ -105,14 +132,15 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
         int num = P.ntaps - 1 + R, num_q = num / P.sps, num_r = num - num_q * P.sps;
         int hn = P.c - 1, hn_q = hn >= 0 ? hn / P.sps : 0, hn_r = hn >= 0 ? hn - hn_q * P.sps : 0;
         for (int k = 0; k < P.ntaps; ++k) {
-            run += pulse[k];
+            run += staged ? s_pulse[k] : pulse[k];
             if (num > 0 && num_r == 0) {
                 const int l = num_q - 1;
                 if (l >= 0 && l < P.npart) scratch[MOD_OFF_GPART + l] = run;
             }
             if (hn > 0 && hn_r == 0) {
                 const int64_t mp1 = hn_q;
-                if (mp1 >= 1 && mp1 <= P.nhead && mp1 <= P.nsym) k0 += mod_amp(symbols, hvec, P, mp1 - 1) * run;
+                if (mp1 >= 1 && mp1 <= P.nhead && mp1 <= P.nsym)
+                    k0 += (mp1 <= MOD_MAX_PART ? s_head[mp1] : mod_amp(symbols, hvec, P, mp1 - 1)) * run;
             }
             --num;
             if (--num_r < 0) { num_r = P.sps - 1; --num_q; }
@@ -140,8 +168,26 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
         if (carried && j == 0) return 0;
         return fixed_raw(j);
     };
+    // Each thread owns `per` consecutive tiles.  Up to MOD_SCAN_PER of them are fetched with one
+    // batch of independent loads and kept in registers for both passes; a serial
+    // `run += fixed(j)` loop pays a full memory round trip per tile, twice.
+    const bool batched = per <= MOD_SCAN_PER;
+    uint64_t fx[MOD_SCAN_PER];
     uint64_t run = 0;
-    for (int64_t j = j0; j < j1; ++j) run += fixed(j);
+    if (batched) {
+        double pv[MOD_SCAN_PER];
+#pragma unroll
+        for (int i = 0; i < MOD_SCAN_PER; ++i) pv[i] = j0 + i < j1 ? Pj[j0 + i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < MOD_SCAN_PER; ++i) {
+            fx[i] = 0;
+            if (j0 + i < j1 && !(carried && j0 + i == 0))
+                fx[i] = (uint64_t)(mod_pos_d(T * pv[i], P.sps_d, P.inv_sps) * P.inv_sps * 0x1.0p62) & MOD_MASK;
+            run += fx[i];
+        }
+    } else {
+        for (int64_t j = j0; j < j1; ++j) run += fixed(j);
+    }
     // block-wide exclusive scan of the per-thread sums (u64, wraps mod 2^64 — only the low
     // 62 bits are kept): wave shuffles, then the 16 wave totals through LDS
     const int lane = t & 63, wave = t >> 6;
@@ -158,12 +204,27 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
     run = base + inc - run;   // exclusive prefix of this thread
     uint64_t exported = 0;
     bool have = false;
-    for (int64_t j = j0; j < j1; ++j) {
-        run += fixed(j);
-        Wq[j] = run & MOD_MASK;
-        if (j == P.q_out_tile) {
-            exported = run & MOD_MASK;
-            have = true;
+    if (batched) {
+#pragma unroll
+        for (int i = 0; i < MOD_SCAN_PER; ++i) {
+            const int64_t j = j0 + i;
+            if (j < j1) {
+                run += fx[i];
+                Wq[j] = run & MOD_MASK;
+                if (j == P.q_out_tile) {
+                    exported = run & MOD_MASK;
+                    have = true;
+                }
+            }
+        }
+    } else {
+        for (int64_t j = j0; j < j1; ++j) {
+            run += fixed(j);
+            Wq[j] = run & MOD_MASK;
+            if (j == P.q_out_tile) {
+                exported = run & MOD_MASK;
+                have = true;
+            }
         }
     }
     // q_in and q_out may be the same word: every read of q_in happened before this barrier

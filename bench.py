@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 # stage -> kernel that dominates it (names as rocprofv3 prints them)
 STAGE_KERNEL = {"fir": "fir_kernel<9>", "phase": "phase_kernel", "modulate": "mod_main_kernel<9>",
                 "awgn": "awgn_kernel", "mfbank": "mf_bank_kernel<3, false, 8, 9>", "awgn+mfbank": "mf_bank_kernel<3, true, 8, 9>",
-                "viterbi": "viterbi_batch_kernel<128>", "count": "count_errors_kernel", "prbs": "lfsr_kernel",
+                "viterbi": "viterbi_batch_kernel<128, false>", "count": "count_errors_kernel", "prbs": "lfsr_kernel",
                 "encode": "enc_reduce_kernel"}
 
 
@@ -87,9 +87,9 @@ def main() -> None:
     ap.add_argument("--sps", type=int, default=8)
     ap.add_argument("--ebn0", type=float, default=10.0)
     ap.add_argument("--detector", default="PT")
-    ap.add_argument("--fuse", type=int, default=3,
+    ap.add_argument("--fuse", type=int, default=7,
                     help="bit 0: fused modulator (FIR + phase scan in one pass); bit 1: AWGN inside the MF bank; "
-                         "0 = every stage its own kernel")
+                         "bit 2: detector-packed 32 B rows between bank and detector; 0 = every stage its own kernel")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent trial blocks in flight on separate HIP streams (own workspace + context each)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 24)
@@ -180,6 +180,12 @@ def main() -> None:
     if args.fuse & 2:   # noisy samples never materialise: clean c128 in, 3 c128 per symbol out
         acc["awgn+mfbank"] = acc.pop("mfbank") + acc.pop("awgn")
         bps["awgn+mfbank"] = bps["mfbank"]
+    packed = links[0].row_bytes == 32
+    if packed:          # detector-packed rows: 4 doubles per symbol between the bank and the detector
+        bps["awgn+mfbank"] = 16 * args.sps + 32
+        bps["viterbi"] = 32 + 2
+        STAGE_KERNEL["awgn+mfbank"] = "mf_bank_kernel<3, true, 8, 9, true>"
+        STAGE_KERNEL["viterbi"] = "viterbi_batch_kernel<128, true>"
     stages = {}
     for name, ms in acc.items():
         gb = bps[name] * args.nsym / 1e9

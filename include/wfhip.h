@@ -219,7 +219,10 @@ typedef struct {
     int warmup;             /* Viterbi chunk warm-up, 0 = default                     */
     int fuse;               /* bit 0: fused modulator (wf_cpm_modulate_c128) instead   */
                             /* of the FIR + phase-scan stage kernels; bit 1: AWGN      */
-                            /* inside the MF bank (wf_awgn_mf_bank_c128)               */
+                            /* inside the MF bank (wf_awgn_mf_bank_c128); bit 2 (with  */
+                            /* bit 1, 3 x 9-tap bank, sps 8): the bank writes only the */
+                            /* 4 real components per call the 4-state detector reads   */
+                            /* ({Re z1, Im z1, Re|Im z0, Im|Re z2}: 32 B rows, not 48) */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
                             /* around every stage into that slot (wf_link_stage_ms)   */
 } wf_link_config;
@@ -235,7 +238,8 @@ int wf_link_stage_ms(wf_ctx *ctx, int event_slot, float *h_ms);
 
 /* Workspace offsets of a wf_link_run block, for callers that want the intermediates:
  * info8 = {ncols, 0, off(detected bits), off(detected symbols), off(signal), 0,
- *          signal samples, off(MF rows)} (offsets in bytes into the workspace). */
+ *          signal samples, off(MF rows)} (offsets in bytes into the workspace; with fuse bit 2
+ *          in effect the MF rows area holds 4 doubles per call). */
 int wf_link_layout(const wf_link_config *cfg, int64_t *info8);
 
 /* ---- streaming link (continuous stream in chunks) -------------------------------

@@ -477,7 +477,7 @@ def test_fused_channel_and_count_equal_stage_kernels(oracle):
     assert np.array_equal(_hip.to_host(b), _hip.to_host(b2)) and np.array_equal(_hip.to_host(s_), _hip.to_host(s2))
 
 
-@pytest.mark.parametrize("fuse", [0, 3])
+@pytest.mark.parametrize("fuse", [0, 3, 7])
 @pytest.mark.parametrize("detector,nsym", [("PT", 1 << 15), ("PAM", 1 << 15), ("PT", 100_000)])
 def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
     """wf_link_run (all stages chained in HBM, unfused and fused forms) vs the oracle chain
@@ -499,7 +499,8 @@ def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
 
 
 # ------------------------------------------------------------------ streaming (config 5)
-@pytest.mark.parametrize("detector,fuse,chunk", [("PT", 3, 1 << 16), ("PAM", 3, 1 << 15), ("PT", 1, 3 << 14)])
+@pytest.mark.parametrize("detector,fuse,chunk", [("PT", 3, 1 << 16), ("PAM", 3, 1 << 15), ("PT", 1, 3 << 14),
+                                                 ("PT", 7, 1 << 16), ("PAM", 7, 1 << 15)])
 def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
     """wf_link_stream_chunk over a stream == wf_link_run over the whole burst: identical
     modulated samples, matched-filter rows, decisions and error counts."""
@@ -520,7 +521,9 @@ def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
         calls = lay["calls"]
         want_bits = ws[lay["off_bits"]:lay["off_bits"] + calls].clone()
         want_syms = ws[lay["off_syms"]:lay["off_syms"] + calls].clone()
-        want_mf = ws[lay["off_mf"]:lay["off_mf"] + calls * 48].clone()
+        rb = one.row_bytes            # 48, or 32 with detector-packed rows (fuse bit 2 in effect)
+        assert rb == st.row_bytes == (32 if fuse == 7 and detector == "PT" else 48)
+        want_mf = ws[lay["off_mf"]:lay["off_mf"] + calls * rb].clone()
         st.reset()
         seen = 0
         for c in range(st.nchunks):
@@ -528,7 +531,7 @@ def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
             info = st.chunk_info(c)
             k0, n = info["first_call"], info["calls"]
             w = st.workspace
-            assert torch.equal(w[info["off_mf"]:info["off_mf"] + n * 48], want_mf[k0 * 48:(k0 + n) * 48]), c
+            assert torch.equal(w[info["off_mf"]:info["off_mf"] + n * rb], want_mf[k0 * rb:(k0 + n) * rb]), c
             assert torch.equal(w[info["off_bits"]:info["off_bits"] + n], want_bits[k0:k0 + n]), c
             assert torch.equal(w[info["off_syms"]:info["off_syms"] + n], want_syms[k0:k0 + n]), c
             seen += n
@@ -649,7 +652,7 @@ def test_empty_inputs_and_error_paths(oracle):
 def test_small_links_equal_oracle(oracle, nsym):
     from waveforms_amd.link import SOQPSKLink
 
-    for fuse in (0, 3):
+    for fuse in (0, 3, 7):
         link = SOQPSKLink(nsym, 8, fuse=fuse)
         link.run_block(2.0, seed=9, stream_id=4, skip_bits=12345)
         got = link.result()
@@ -657,3 +660,34 @@ def test_small_links_equal_oracle(oracle, nsym):
         noise = oracle.philox_awgn(oracle.sigma_for_ebn0(2.0, 8), 9, 4, 0, (nsym + 1) * 8)
         res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise)
         assert got == (res["sym_errors"], res["bit_errors"], res["compared"]) and got[1] > 0
+
+
+@pytest.mark.parametrize("differential", [True, False])
+def test_packed_rows_equal_full_rows(differential):
+    """fuse bit 2: the 32 B detector-packed rows are exactly the 4 components of the 48 B rows the
+    detector reads (even calls: Re z0, Im z2; odd calls: Im z0, Re z2), and the decisions and error
+    counts are identical."""
+    from waveforms_amd.link import SOQPSKLink
+
+    nsym = (1 << 18) + 77
+    full = SOQPSKLink(nsym, 8, fuse=3, differential=differential)
+    pack = SOQPSKLink(nsym, 8, fuse=7, differential=differential)
+    assert full.row_bytes == 48 and pack.row_bytes == 32
+    for link in (full, pack):
+        link.run_block(4.0, seed=11, stream_id=2, skip_bits=999)
+    assert full.result() == pack.result() and full.result()[1] > 0
+    lf, lp = full.layout(), pack.layout()
+    calls = lf["calls"]
+    rows = full.workspace[lf["off_mf"]:lf["off_mf"] + calls * 48].view(torch_f64()).reshape(calls, 6).cpu().numpy()
+    got = pack.workspace[lp["off_mf"]:lp["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+    odd = (np.arange(calls) & 1).astype(bool)
+    want = np.stack([rows[:, 2], rows[:, 3], np.where(odd, rows[:, 1], rows[:, 0]), np.where(odd, rows[:, 4], rows[:, 5])], axis=1)
+    assert np.array_equal(got, want)
+    for key in ("off_bits", "off_syms"):
+        assert np.array_equal(full.workspace[lf[key]:lf[key] + calls].cpu().numpy(), pack.workspace[lp[key]:lp[key] + calls].cpu().numpy())
+
+
+def torch_f64():
+    import torch
+
+    return torch.float64

@@ -72,7 +72,10 @@ int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state,
 int wf_awgn_mf_bank_dyn(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,
                         double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
                         const uint64_t *d_dyn_index, const double *d_taps_ri, int nfilt, int ntaps, int64_t first,
-                        int step, int64_t ncols, double *d_out_ri, void *stream);
+                        int step, int64_t ncols, double *d_out_ri, void *stream, int pack_par0 = -1);
+// wf_viterbi4_detect over detector-packed rows (4 doubles per call, see mf_bank_kernel PACK)
+int wf_viterbi4_detect_packed(wf_ctx *ctx, const double *d_rows4, int64_t ncalls, int differential, int warmup,
+                              uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream);
 int wf_cpm_modulate_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total,
                            const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
                            int64_t tile_lo, int64_t ntiles, double *d_out_ri, int64_t out_origin,

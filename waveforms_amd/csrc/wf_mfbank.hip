@@ -31,9 +31,13 @@ struct mf_params {
     double rot_re, rot_im, sigma;
     uint64_t seed, stream_id, first_index;
     const uint64_t *dyn_index;   // optional device addend to first_index (graph replay of a stream)
+    int pack_par0;               // PACK instantiation: parity of the detector call index of column 0
 };
 
-template <int NF, bool NOISE, int STEP, int NTAPS>   // STEP / NTAPS: compile-time fast path (0 = take P.step / P.ntaps)
+// PACK (3-filter bank only): write the detector-packed row {Re z1, Im z1, a, b} — the 4 of the 6
+// real components the 4-state detector reads from a row (wf_viterbi.hip: (a, b) = (Re z0, Im z2)
+// on even calls, (Im z0, Re z2) on odd ones) — 32 B per symbol instead of 48.
+template <int NF, bool NOISE, int STEP, int NTAPS, bool PACK = false>   // STEP / NTAPS: compile-time fast path (0 = take P.step / P.ntaps)
 __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__restrict__ r,
                                                               const double *__restrict__ taps,
                                                               double *__restrict__ out, mf_params P)
@@ -212,6 +216,13 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                     }
                 }
             }
+            if (PACK) {
+                const bool odd_call = ((P.pack_par0 + (int)(k & 1)) & 1) != 0;
+                double2 *o = reinterpret_cast<double2 *>(out + 4 * k);
+                o[0] = make_double2(ar[1], ai[1]);
+                o[1] = make_double2(odd_call ? ai[0] : ar[0], odd_call ? ar[NF - 1] : ai[NF - 1]);
+                continue;
+            }
             double2 *o = reinterpret_cast<double2 *>(out + 2 * (k * P.nfilt));
 #ifdef WF_ABL_NO_MEM
             if (ar[0] == 1.2345e300)
@@ -226,7 +237,8 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
 static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_taps_ri, int nfilt,
                           int ntaps, int64_t first, int step, int64_t ncols, double *d_out_ri, void *stream,
                           bool noise, double rot_re, double rot_im, double sigma, uint64_t seed,
-                          uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index = nullptr)
+                          uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index = nullptr,
+                          int pack_par0 = -1)
 {
     WF_REQUIRE(ctx && d_r_ri && d_taps_ri, "wf_mf_bank_c128: NULL argument");
     WF_REQUIRE(nfilt >= 1 && nfilt <= 8 && ntaps >= 1 && step >= 1 && ncols >= 0 && first >= 0,
@@ -255,6 +267,9 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     P.stream_id = stream_id;
     P.first_index = first_index;
     P.dyn_index = d_dyn_index;
+    P.pack_par0 = pack_par0 & 1;
+    WF_REQUIRE(pack_par0 < 0 || (noise && step == 8 && nfilt == 3 && ntaps == 9),
+               "wf_awgn_mf_bank: packed rows exist for the fused 3 x 9-tap, step-8 bank only");
     // slots(ob) = (ob-1)*step + ntaps + pad*(that/step + 1) <= MF_LDS_SLOTS
     int ob = MF_THREADS;
     for (;;) {
@@ -290,7 +305,8 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     const size_t lds = (size_t)slots * sizeof(double2);
     using kern_t = void (*)(const double *, const double *, double *, mf_params);
     kern_t k;
-    if (step == 8 && nfilt == 3 && ntaps == 9) k = noise ? mf_bank_kernel<3, true, 8, 9> : mf_bank_kernel<3, false, 8, 9>;
+    if (pack_par0 >= 0) k = mf_bank_kernel<3, true, 8, 9, true>;
+    else if (step == 8 && nfilt == 3 && ntaps == 9) k = noise ? mf_bank_kernel<3, true, 8, 9> : mf_bank_kernel<3, false, 8, 9>;
     else if (step == 8 && nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 8, 0> : mf_bank_kernel<3, false, 8, 0>;
     else if (nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 0, 0> : mf_bank_kernel<3, false, 0, 0>;
     else k = noise ? mf_bank_kernel<8, true, 0, 0> : mf_bank_kernel<8, false, 0, 0>;
@@ -320,11 +336,12 @@ extern "C" int wf_awgn_mf_bank_c128(wf_ctx *ctx, const double *d_signal_ri, int6
 
 // Internal: fused channel + bank whose noise counter is first_index + *d_dyn_index (read on
 // the device), for the graph-replayed steady state of the streaming link.
+// pack_par0 >= 0: detector-packed rows (32 B), pack_par0 = parity of the call index of column 0.
 int wf_awgn_mf_bank_dyn(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,
                         double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
                         const uint64_t *d_dyn_index, const double *d_taps_ri, int nfilt, int ntaps, int64_t first,
-                        int step, int64_t ncols, double *d_out_ri, void *stream)
+                        int step, int64_t ncols, double *d_out_ri, void *stream, int pack_par0)
 {
     return mf_bank_launch(ctx, d_signal_ri, nsamp, d_taps_ri, nfilt, ntaps, first, step, ncols, d_out_ri, stream, true,
-                          rot_re, rot_im, sigma, seed, stream_id, first_index, d_dyn_index);
+                          rot_re, rot_im, sigma, seed, stream_id, first_index, d_dyn_index, pack_par0);
 }

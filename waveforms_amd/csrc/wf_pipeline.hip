@@ -62,6 +62,13 @@ static link_layout make_layout(int64_t nsym, int sps, int ntaps, int nfilt, int 
     return L;
 }
 
+// fuse bit 2: the fused channel + bank writes detector-packed rows (4 doubles per call instead of
+// 3 complex) and the detector reads those.  Exists for the 3 x 9-tap bank at 8 samples per symbol.
+static bool link_packed_rows(const wf_link_config *cfg)
+{
+    return (cfg->fuse & 4) && (cfg->fuse & 2) && cfg->sps == 8 && cfg->mf_ntaps == 9 && cfg->mf_nfilt == 3;
+}
+
 extern "C" int64_t wf_link_workspace_bytes(const wf_link_config *cfg)
 {
     if (!cfg || cfg->nsym < 1 || cfg->sps < 1) return -1;
@@ -144,8 +151,12 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     if (m > cfg->nsym) m = cfg->nsym;
     if (m < 0) m = 0;
     const bool fused_count = false;
+    const bool packed = fused_chan && link_packed_rows(cfg);
     if (L.ncols > 0) {
-        if (fused_chan)
+        if (packed)   // detector-packed rows: 4 doubles per call (call index of column 0 is 0: even)
+            rc = wf_awgn_mf_bank_dyn(ctx, sig, L.npts, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id, 0, nullptr,
+                                     cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, L.first, cfg->sps, L.ncols, mf, stream, 0);
+        else if (fused_chan)
             rc = wf_awgn_mf_bank_c128(ctx, sig, L.npts, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id, 0,
                                       cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, L.first, cfg->sps, L.ncols, mf, stream);
         else
@@ -156,6 +167,8 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
         if (fused_count)
             rc = wf_viterbi4_detect_count(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, bits, syms,
                                           length, m, d_counts, stream);
+        else if (packed)
+            rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream);
         else
             rc = wf_viterbi4_detect(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream);
         if (rc) return rc;
@@ -370,10 +383,12 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
     const double rot_re = cos(-M_PI / 4), rot_im = sin(-M_PI / 4);
     const int64_t first_local = S.first + S.k_lo * cfg->sps - S.out_origin;
     WF_REQUIRE(!steady || (cfg->fuse & 2), "wf_link_stream_steady needs the fused channel (fuse bit 1)");
+    const bool packed = link_packed_rows(cfg);
     if (cfg->fuse & 2) {
         rc = wf_awgn_mf_bank_dyn(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
                                  (uint64_t)S.out_origin, steady ? dyn + 1 : nullptr, cfg->d_mf_taps, cfg->mf_nfilt,
-                                 cfg->mf_ntaps, first_local, cfg->sps, S.ncols, mf, stream);
+                                 cfg->mf_ntaps, first_local, cfg->sps, S.ncols, mf, stream,
+                                 packed ? (int)(S.k_lo & 1) : -1);
     } else {
         if ((rc = wf_awgn_c128(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
                                (uint64_t)S.out_origin, sig, stream))) return rc;
@@ -381,7 +396,11 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
                              mf, stream);
     }
     if (rc) return rc;
-    if ((rc = wf_viterbi4_detect(ctx, mf, S.ncols, cfg->differential, cfg->warmup, dbits, dsyms, vit_state, stream))) return rc;
+    if (packed)
+        rc = wf_viterbi4_detect_packed(ctx, mf, S.ncols, cfg->differential, cfg->warmup, dbits, dsyms, vit_state, stream);
+    else
+        rc = wf_viterbi4_detect(ctx, mf, S.ncols, cfg->differential, cfg->warmup, dbits, dsyms, vit_state, stream);
+    if (rc) return rc;
     // decision of call k is compared with symbol k - length (examples/soqpsk_detection.py:201-209)
     const int64_t j0 = S.k_lo >= length ? 0 : length - S.k_lo;
     int64_t ncmp = S.ncols - j0;

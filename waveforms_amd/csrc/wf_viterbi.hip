@@ -64,10 +64,17 @@ struct vit_comp {
     double r1, i1, a, b;
 };
 
-template <int COL>
+template <int COL, bool PACKED>
 __device__ __forceinline__ vit_comp vit_components(const double2 *__restrict__ z)
 {
     vit_comp c;
+    if (PACKED) {   // row = {r1, i1, a, b}: the bank already picked the section's components
+        c.r1 = z[0].x;
+        c.i1 = z[0].y;
+        c.a = z[1].x;
+        c.b = z[1].y;
+        return c;
+    }
     c.r1 = z[1].x;
     c.i1 = z[1].y;
     c.a = COL == 0 ? z[0].x : z[0].y;
@@ -122,12 +129,12 @@ struct vit_lane {
 // One detector call k (COL = column parity of k): stage 0 commits the previous call's
 // increments from the min-normalised carried metrics, stage 1 looks one symbol ahead,
 // depth-2 traceback from the first arg-min (algorithm.py:57-101 with length = 2).
-template <int COL>
+template <int COL, bool PACKED>
 __device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict__ zrow, bool prime, int diff,
                                          int64_t k, int64_t a, int64_t ncalls, uint64_t *__restrict__ dec)
 {
     constexpr int PREV = COL ^ 1;
-    const vit_comp now = vit_components<COL>(zrow);
+    const vit_comp now = vit_components<COL, PACKED>(zrow);
     if (prime) {   // priming row: exact components of the call before the warm-up
         L.prev = now;
         return;
@@ -258,8 +265,9 @@ __device__ __forceinline__ void vit_comp_to_inc(const vit_comp &c, int col, doub
 // so only two ACS bodies are live at a time.
 #define VIT_S 4
 #define VIT_DEPTH 3   // batches of cooperative loads in flight per wave (register sets pend0..2)
-#define VIT_PIECES (3 * VIT_S)        // 16-byte pieces per lane-segment
-#define VIT_LANE_SLOTS (VIT_PIECES + 1)
+#define VIT_PIECES_RW(RW) ((RW) * VIT_S)   // 16-byte pieces per lane-segment, RW = double2 per row (3, packed: 2)
+#define VIT_PIECES (3 * VIT_S)
+#define VIT_LANE_SLOTS (VIT_PIECES + 1)     // LDS slots per lane as allocated (odd count: conflict-free ds_read_b128)
 
 // 16 B load as a VALUE: assigning `dst[u] = ptr[i]` for the double2 class type lowers to a memcpy
 // into the private array, which then stays in scratch memory instead of registers.
@@ -270,12 +278,15 @@ __device__ __forceinline__ double2 vit_ld16(const double2 *p)
     return make_double2(v.x, v.y);
 }
 
-template <int CH, int PAR0>   // PAR0: column parity of step 0's call index
+template <int CH, int PAR0, bool PACKED>   // PAR0: column parity of step 0's call index; PACKED: 32 B rows
 __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf, int64_t ncalls, int diff, int warmup,
                                                    uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
                                                    double *__restrict__ state, int64_t i0, double2 (*s_rows)[WF_WAVE * VIT_LANE_SLOTS],
                                                    uint64_t *__restrict__ s_dec)
 {
+    constexpr int RW = PACKED ? 2 : 3;                 // double2 per row
+    constexpr int NP = VIT_PIECES_RW(RW);             // 16-byte pieces per lane-segment and batch
+    constexpr int LS = NP + 1;                         // LDS slots per lane (odd: conflict-free)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t g0 = ((int64_t)blockIdx.x * (VIT_THREADS / WF_WAVE) + wave) * WF_WAVE;  // first lane of the wave
     const int64_t a = (g0 + lane) * CH;
@@ -290,44 +301,44 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     // Everything per-lane is 32-bit and batch-invariant; the batch only moves a wave-uniform base.
     // (segment, piece) of this lane's u-th cooperative piece, packed; LDS slot, row and global
     // offset are derived from it where needed (keeps 24 registers out of the loop)
-    int sgw[VIT_PIECES];
+    int sgw[NP];
 #pragma unroll
-    for (int u = 0; u < VIT_PIECES; ++u) {
+    for (int u = 0; u < NP; ++u) {
         const int p = u * WF_WAVE + lane;
-        const int sg = p / VIT_PIECES;
-        sgw[u] = (sg << 8) | (p - sg * VIT_PIECES);
+        const int sg = p / NP;
+        sgw[u] = (sg << 8) | (p - sg * NP);
     }
     const int64_t g0u = __builtin_amdgcn_readfirstlane((int)(g0 >> 6)) * (int64_t)WF_WAVE;   // wave-uniform copy of g0
     // Rows outside [0, ncalls) exist only around the first and last chunk of a burst and are never
     // decoded (vit_step is skipped for them), so their loads are merely redirected to a valid
     // address: a wave-uniform test picks the unclamped form for every interior batch.
-    auto fetch = [&](int b, double2 dst[VIT_PIECES]) __attribute__((always_inline)) {
+    auto fetch = [&](int b, double2 dst[NP]) __attribute__((always_inline)) {
         const int64_t rb = g0u * CH - warmup - 1 + (int64_t)b * VIT_S;   // first row of the batch (uniform)
-        const double2 *basep = rows + 3 * rb;
+        const double2 *basep = rows + RW * rb;
 #ifdef WF_ABL_NO_MEM   // ablation only
 #pragma unroll
-        for (int u = 0; u < VIT_PIECES; ++u) dst[u] = make_double2((double)(sgw[u] & 7) - 3.5, (double)(sgw[u] & 3) - 1.0);
+        for (int u = 0; u < NP; ++u) dst[u] = make_double2((double)(sgw[u] & 7) - 3.5, (double)(sgw[u] & 3) - 1.0);
 #else
         if (rb >= 0 && rb + (int64_t)(WF_WAVE - 1) * CH + VIT_S <= ncalls) {
 #pragma unroll
-            for (int u = 0; u < VIT_PIECES; ++u) dst[u] = vit_ld16(basep + 3 * CH * (sgw[u] >> 8) + (sgw[u] & 255));
+            for (int u = 0; u < NP; ++u) dst[u] = vit_ld16(basep + RW * CH * (sgw[u] >> 8) + (sgw[u] & 255));
         } else {
             const int64_t lo64 = -rb, hi64 = ncalls - 1 - rb;             // valid rrel range [lo, hi]
             const int lo = lo64 < -(1 << 30) ? -(1 << 30) : (lo64 > (1 << 30) ? (1 << 30) : (int)lo64);
             const int hi = hi64 < -(1 << 30) ? -(1 << 30) : (hi64 > (1 << 30) ? (1 << 30) : (int)hi64);
 #pragma unroll
-            for (int u = 0; u < VIT_PIECES; ++u) {
+            for (int u = 0; u < NP; ++u) {
                 const int sg = sgw[u] >> 8, wi = sgw[u] & 255;
-                const int rrel = sg * CH + wi / 3;      // row relative to the wave's first row of the batch
+                const int rrel = sg * CH + wi / RW;     // row relative to the wave's first row of the batch
                 const int rc = min(max(rrel, lo), hi);
-                dst[u] = vit_ld16(basep + 3 * rc + (wi - 3 * (wi / 3)));
+                dst[u] = vit_ld16(basep + RW * rc + (wi - RW * (wi / RW)));
             }
         }
 #endif
     };
-    auto stash = [&](const double2 src[VIT_PIECES]) __attribute__((always_inline)) {
+    auto stash = [&](const double2 src[NP]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < VIT_PIECES; ++u) tile[(sgw[u] >> 8) * VIT_LANE_SLOTS + (sgw[u] & 255)] = src[u];
+        for (int u = 0; u < NP; ++u) tile[(sgw[u] >> 8) * LS + (sgw[u] & 255)] = src[u];
     };
 
     vit_lane L;
@@ -345,7 +356,7 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     // waiting a full memory round trip (~4 us under load) per 4 decoded steps, with ~1 wave per
     // SIMD resident -> 207 us for 176 steps.  VIT_DEPTH batches are kept in flight in registers
     // instead (VIT_DEPTH x 12 x 16 B per lane; the register file is nearly empty at this occupancy).
-    double2 pend0[VIT_PIECES], pend1[VIT_PIECES], pend2[VIT_PIECES];   // VIT_DEPTH = 3 register sets
+    double2 pend0[NP], pend1[NP], pend2[NP];   // VIT_DEPTH = 3 register sets
     // Every round issues exactly one batch of loads, unconditionally (past the last batch it
     // re-reads that batch: L2 hits, results unused).  With a conditional refill the compiler must
     // assume the path on which nothing was issued behind a register set and waits with vmcnt(0).
@@ -354,7 +365,7 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     fetch(min(1, last_b), pend1);
     fetch(min(2, last_b), pend2);
     const int64_t kbase = a - warmup - 1;
-    auto round = [&](int b, double2 (&pd)[VIT_PIECES]) __attribute__((always_inline)) {
+    auto round = [&](int b, double2 (&pd)[NP]) __attribute__((always_inline)) {
         stash(pd);                                           // waits for batch b only (loads return in order)
         fetch(min(b + VIT_DEPTH, last_b), pd);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -365,11 +376,11 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
             for (int jj = 0; jj < VIT_S; jj += 2) {
                 const int j = b * VIT_S + jj;
                 const int64_t k = kbase + j;                  // call index of the even step
-                const double2 *zr = tile + lane * VIT_LANE_SLOTS + 3 * jj;
+                const double2 *zr = tile + lane * LS + RW * jj;
                 if (j < nsteps && k >= 0 && k < ncalls)
-                    vit_step<PAR0>(L, zr, j == 0, diff, k, a, ncalls, dec);
+                    vit_step<PAR0, PACKED>(L, zr, j == 0, diff, k, a, ncalls, dec);
                 if (j + 1 < nsteps && k + 1 >= 0 && k + 1 < ncalls)
-                    vit_step<PAR0 ^ 1>(L, zr + 3, false, diff, k + 1, a, ncalls, dec);
+                    vit_step<PAR0 ^ 1, PACKED>(L, zr + RW, false, diff, k + 1, a, ncalls, dec);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -395,7 +406,7 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
 #ifndef VIT_MIN_WAVES
 #define VIT_MIN_WAVES 1
 #endif
-template <int CH>
+template <int CH, bool PACKED = false>
 __global__ __launch_bounds__(VIT_THREADS, VIT_MIN_WAVES) void viterbi_batch_kernel(const double *__restrict__ mf, int64_t ncalls,
                                                                      int diff, int warmup, uint8_t *__restrict__ bits,
                                                                      int8_t *__restrict__ syms, double *__restrict__ state)
@@ -404,8 +415,8 @@ __global__ __launch_bounds__(VIT_THREADS, VIT_MIN_WAVES) void viterbi_batch_kern
     __shared__ uint64_t s_dec[VIT_THREADS * (CH / 16 + 1)];   // packed decisions, one strip per lane
     const int64_t i0 = state ? (int64_t)state[0] : 0;
     // call index of step 0 is lane_start - warmup - 1 with lane_start a multiple of CH (even)
-    if ((i0 - warmup - 1) & 1) viterbi_batch_body<CH, 1>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
-    else viterbi_batch_body<CH, 0>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
+    if ((i0 - warmup - 1) & 1) viterbi_batch_body<CH, 1, PACKED>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
+    else viterbi_batch_body<CH, 0, PACKED>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
 }
 
 __global__ void viterbi_carry_commit_kernel(double *state)
@@ -415,7 +426,7 @@ __global__ void viterbi_carry_commit_kernel(double *state)
 }
 
 static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential, int warmup,
-                          uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream)
+                          uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream, bool packed = false)
 {
     WF_REQUIRE(ctx && ncalls >= 0 && warmup >= 0, "wf_viterbi4_detect: bad argument");
     if (ncalls == 0) return WF_OK;
@@ -434,12 +445,18 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     const int64_t nblocks = (nthreads + VIT_THREADS - 1) / VIT_THREADS;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
     hipStream_t s = wf_stream(stream);
-#define VIT_LAUNCH(CHV)                                                                                      \
-    hipLaunchKernelGGL(viterbi_batch_kernel<CHV>, dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri, \
+#define VIT_LAUNCH(CHV, PK)                                                                                      \
+    hipLaunchKernelGGL((viterbi_batch_kernel<CHV, PK>), dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri, \
                        ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state)
-    if (ch == 256) VIT_LAUNCH(256);
-    else if (ch == 128) VIT_LAUNCH(128);
-    else VIT_LAUNCH(64);
+    if (packed) {
+        if (ch == 256) VIT_LAUNCH(256, true);
+        else if (ch == 128) VIT_LAUNCH(128, true);
+        else VIT_LAUNCH(64, true);
+    } else {
+        if (ch == 256) VIT_LAUNCH(256, false);
+        else if (ch == 128) VIT_LAUNCH(128, false);
+        else VIT_LAUNCH(64, false);
+    }
 #undef VIT_LAUNCH
     WF_LAUNCH_CHECK();
     if (d_state) {
@@ -454,6 +471,12 @@ extern "C" int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t nc
                                   void *stream)
 {
     return viterbi_launch(ctx, d_mf_ri, ncalls, differential, warmup, d_bits, d_syms, d_state, stream);
+}
+
+int wf_viterbi4_detect_packed(wf_ctx *ctx, const double *d_rows4, int64_t ncalls, int differential, int warmup,
+                              uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream)
+{
+    return viterbi_launch(ctx, d_rows4, ncalls, differential, warmup, d_bits, d_syms, d_state, stream, true);
 }
 
 extern "C" int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,

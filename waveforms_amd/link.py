@@ -35,7 +35,7 @@ class SOQPSKLink:
 
     def _configure(self, nsym: int, sps: int = 8, pulse=None, mod_index: float = 0.25, detector: str = "PT",
                    pn_degree: int = 23, differential: bool = True, timing_offset: int | None = None,
-                   warmup: int = 0, fuse: int = 3, private_ctx: bool = False) -> None:
+                   warmup: int = 0, fuse: int = 7, private_ctx: bool = False) -> None:
         self.nsym, self.sps = int(nsym), int(sps)
         # a link that runs on its own stream next to other links needs its own scratch
         self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()
@@ -64,6 +64,14 @@ class SOQPSKLink:
         cfg.event_slot = -1
         cfg.fuse = int(fuse)
         self.cfg = cfg
+
+    @property
+    def row_bytes(self) -> int:
+        """Bytes per matched-filter row in the workspace: 48 (3 complex128), or 32 when fuse bit 2 is
+        in effect (detector-packed rows; 3 x 9-tap bank at 8 samples per symbol with the fused channel)."""
+        c = self.cfg
+        packed = (c.fuse & 4) and (c.fuse & 2) and c.sps == 8 and c.mf_ntaps == 9 and c.mf_nfilt == 3
+        return 32 if packed else 16 * c.mf_nfilt
 
     def layout(self) -> dict:
         """Byte offsets of the intermediates inside ``self.workspace``."""
@@ -110,6 +118,8 @@ class SOQPSKStream:
     Neighbouring context is re-generated as a halo or carried in a 512-byte device block;
     decisions and error counts equal a one-shot :class:`SOQPSKLink` over the whole stream,
     while HBM use is that of one chunk."""
+
+    row_bytes = SOQPSKLink.row_bytes   # same rule: it reads self.cfg only
 
     def __init__(self, total_symbols: int, chunk_symbols: int, sps: int = 8, **kw) -> None:
         # reuse the link's configuration (taps, pulse, PRBS ...) without its one-shot workspace

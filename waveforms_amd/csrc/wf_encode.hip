@@ -20,6 +20,11 @@ struct enc_params {
     int col0;  // i0 % columns
     int state0;
     int64_t nsym;
+    // SMALL trellises (<= 4 states, <= 16 table entries — the SOQPSK 4x2 pair): both tables ride in
+    // registers, 2 bits per next-state entry and one byte per output symbol.  From LDS the 16
+    // entries sit in 4 banks and 64 lanes of random lookups serialise on them.
+    uint32_t next2;
+    uint64_t out_lo, out_hi;
 };
 
 __device__ __forceinline__ uint64_t map_identity()
@@ -46,6 +51,42 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d)
     return (uint64_t)__shfl_up((unsigned long long)v, d, WF_WAVE);
 }
 
+// Value of the lane `CTRL` says (DPP), identity map where there is none.  Only the words that
+// hold states < NS travel.
+template <int NS, int CTRL, int RM>
+__device__ __forceinline__ uint64_t map_dpp(uint64_t v)
+{
+    const uint64_t id = map_identity();
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)id, (int)(uint32_t)v, CTRL, RM, 0xf, false);
+    uint32_t hi = (uint32_t)(id >> 32);
+    if (NS > 8) hi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)(uint32_t)(v >> 32), CTRL, RM, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Inclusive wave scan of maps in lane order (compose earlier lanes first): Hillis-Steele inside
+// rows of 16 lanes, then the row totals are pushed into the following rows.  VALU only.
+template <int NS>
+__device__ __forceinline__ uint64_t map_wave_scan(uint64_t inc)
+{
+    inc = map_compose<NS>(map_dpp<NS, 0x111, 0xf>(inc), inc);
+    inc = map_compose<NS>(map_dpp<NS, 0x112, 0xf>(inc), inc);
+    inc = map_compose<NS>(map_dpp<NS, 0x114, 0xf>(inc), inc);
+    inc = map_compose<NS>(map_dpp<NS, 0x118, 0xf>(inc), inc);
+    inc = map_compose<NS>(map_dpp<NS, 0x142, 0xa>(inc), inc);
+    inc = map_compose<NS>(map_dpp<NS, 0x143, 0xc>(inc), inc);
+    return inc;
+}
+
+// 8 bytes of 0 / 1 -> 8 nibbles (byte k -> nibble k)
+__device__ __forceinline__ uint32_t bytes_to_nibbles(uint64_t x)
+{
+    uint64_t t = x & 0x0101010101010101ull;
+    t = (t | (t >> 4)) & 0x0011001100110011ull;
+    t = (t | (t >> 8)) & 0x0000111100001111ull;
+    t = (t | (t >> 16)) & 0x0000000011111111ull;
+    return (uint32_t)t;
+}
+
 // Gather the input values of this thread's 16 symbols (4 bits each) into one u64.
 __device__ __forceinline__ uint64_t load_inputs(const uint8_t *__restrict__ bits, int64_t sym0,
                                                 int64_t nsym, int card, int *nvalid)
@@ -55,6 +96,10 @@ __device__ __forceinline__ uint64_t load_inputs(const uint8_t *__restrict__ bits
     *nvalid = nv;
     uint64_t packed = 0;
     const uint8_t *p = bits + sym0 * card;
+    if (nv == ENC_SYM_PER_THREAD && card == 1) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+        return (uint64_t)bytes_to_nibbles(v.x) | ((uint64_t)bytes_to_nibbles(v.y) << 32);
+    }
     if (nv == ENC_SYM_PER_THREAD) {
         // card * 16 bytes, 16-byte aligned (sym0 is a multiple of 16)
         for (int q = 0; q < card; ++q) {
@@ -76,7 +121,7 @@ __device__ __forceinline__ uint64_t load_inputs(const uint8_t *__restrict__ bits
 }
 
 // Kernel A: per-thread maps, block-exclusive prefix maps, block aggregates.
-template <int NS>
+template <int NS, bool SMALL>
 __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
     const uint8_t *__restrict__ bits, const uint8_t *__restrict__ tab_next, enc_params P,
     uint64_t *__restrict__ thread_excl, uint64_t *__restrict__ block_agg)
@@ -84,8 +129,27 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
     __shared__ uint8_t s_next[1024];
     __shared__ uint64_t s_wave[ENC_THREADS / WF_WAVE];
     const int t = threadIdx.x;
-    const int tabn = P.columns * P.states * P.ninp;
-    for (int k = t; k < tabn; k += ENC_THREADS) s_next[k] = tab_next[k];
+    __shared__ uint8_t s_T[SMALL ? 1024 : 4];
+    if (!SMALL) {
+        const int tabn = P.columns * P.states * P.ninp;
+        for (int k = t; k < tabn; k += ENC_THREADS) s_next[k] = tab_next[k];
+    } else {
+        // SMALL: a run's map fits 8 bits (4 states x 2 bits) and a symbol has <= 4 (column, input)
+        // kinds, so "compose the run so far with one more symbol" is a 1 KB table: ONE byte lookup
+        // per symbol instead of walking every start state.
+        for (int e = t; e < 1024; e += ENC_THREADS) {
+            const int cur = e >> 2, sel = e & 3;
+            const int col = sel / P.ninp, inp = sel - col * P.ninp;
+            int r = 0;
+            for (int s0 = 0; s0 < 4; ++s0) {
+                const int st = (cur >> (2 * s0)) & 3;
+                const int idx = (col * P.states + st) * P.ninp + inp;
+                const int nx = (st < P.states && col < P.columns) ? (int)((P.next2 >> (2 * idx)) & 3u) : st;
+                r |= nx << (2 * s0);
+            }
+            s_T[e] = (uint8_t)r;
+        }
+    }
     __syncthreads();
 
     const int64_t gthread = (int64_t)blockIdx.x * ENC_THREADS + t;
@@ -95,6 +159,17 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
     const int colstart = (int)((P.col0 + sym0) % P.columns);
 
     uint64_t m = 0;
+    if (SMALL) {
+        int cur = 0xE4, col = colstart;   // identity: state s -> s
+        const uint32_t ilo = (uint32_t)inps, ihi = (uint32_t)(inps >> 32);
+        for (int k = 0; k < nv; ++k) {
+            const int inp = (int)(((k < 8 ? ilo : ihi) >> (4 * (k & 7))) & 15u);
+            cur = s_T[cur * 4 + col * P.ninp + inp];
+            col = col + 1 == P.columns ? 0 : col + 1;
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < 4; ++s0) m |= (uint64_t)((cur >> (2 * s0)) & 3) << (4 * s0);
+    } else
 #pragma unroll
     for (int s0 = 0; s0 < NS; ++s0) {
         int st = s0;
@@ -102,7 +177,8 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
             int col = colstart;
             for (int k = 0; k < nv; ++k) {
                 const int inp = (int)((inps >> (4 * k)) & 15ull);
-                st = s_next[(col * P.states + st) * P.ninp + inp];
+                const int idx = (col * P.states + st) * P.ninp + inp;
+                st = SMALL ? (int)((P.next2 >> (2 * idx)) & 3u) : (int)s_next[idx];
                 col = col + 1 == P.columns ? 0 : col + 1;
             }
         }
@@ -110,15 +186,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_reduce_kernel(
     }
     // wave inclusive scan (compose in thread order)
     const int lane = t & 63, wave = t >> 6;
-    uint64_t inc = m;
-#pragma unroll
-    for (int d = 1; d < WF_WAVE; d <<= 1) {
-        const uint64_t o = shfl_up_u64(inc, d);
-        if (lane >= d) inc = map_compose<NS>(o, inc);
-    }
+    const uint64_t inc = map_wave_scan<NS>(m);
     if (lane == 63) s_wave[wave] = inc;
-    uint64_t excl = shfl_up_u64(inc, 1);
-    if (lane == 0) excl = map_identity();
+    const uint64_t excl = map_dpp<NS, 0x138, 0xf>(inc);   // wave_shr:1, identity into lane 0
     __syncthreads();
     uint64_t pre = map_identity();
     for (int w = 0; w < wave; ++w) pre = map_compose<NS>(pre, s_wave[w]);
@@ -141,15 +211,9 @@ __global__ __launch_bounds__(ENC_SCAN_THREADS) void enc_block_scan_kernel(const 
     const int b0 = min(nblocks, t * per), b1 = min(nblocks, b0 + per);
     uint64_t run = map_identity();
     for (int b = b0; b < b1; ++b) run = map_compose<NS>(run, block_agg[b]);
-    uint64_t inc = run;
-#pragma unroll
-    for (int d = 1; d < WF_WAVE; d <<= 1) {
-        const uint64_t o = shfl_up_u64(inc, d);
-        if (lane >= d) inc = map_compose<NS>(o, inc);
-    }
+    const uint64_t inc = map_wave_scan<NS>(run);
     if (lane == 63) s_wave[wave] = inc;
-    uint64_t excl = shfl_up_u64(inc, 1);
-    if (lane == 0) excl = map_identity();
+    uint64_t excl = map_dpp<NS, 0x138, 0xf>(inc);
     __syncthreads();
     uint64_t pre = map_identity();
     for (int w = 0; w < wave; ++w) pre = map_compose<NS>(pre, s_wave[w]);
@@ -162,6 +226,7 @@ __global__ __launch_bounds__(ENC_SCAN_THREADS) void enc_block_scan_kernel(const 
 }
 
 // Kernel C: emit symbols.
+template <bool SMALL>
 __global__ __launch_bounds__(ENC_THREADS) void enc_emit_kernel(
     const uint8_t *__restrict__ bits, const uint8_t *__restrict__ tab_next,
     const int8_t *__restrict__ tab_out, enc_params P, const uint64_t *__restrict__ thread_excl,
@@ -171,12 +236,14 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_emit_kernel(
     __shared__ uint8_t s_next[1024];
     __shared__ int8_t s_out[1024];
     const int t = threadIdx.x;
-    const int tabn = P.columns * P.states * P.ninp;
-    for (int k = t; k < tabn; k += ENC_THREADS) {
-        s_next[k] = tab_next[k];
-        s_out[k] = tab_out[k];
+    if (!SMALL) {
+        const int tabn = P.columns * P.states * P.ninp;
+        for (int k = t; k < tabn; k += ENC_THREADS) {
+            s_next[k] = tab_next[k];
+            s_out[k] = tab_out[k];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int64_t gthread = (int64_t)blockIdx.x * ENC_THREADS + t;
     const int64_t sym0 = gthread * ENC_SYM_PER_THREAD;
     int nv;
@@ -189,9 +256,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_emit_kernel(
     for (int k = 0; k < nv; ++k) {
         const int inp = (int)((inps >> (4 * k)) & 15ull);
         const int idx = (col * P.states + st) * P.ninp + inp;
-        const uint64_t o = (uint8_t)s_out[idx];
+        const uint64_t o = SMALL ? (((idx < 8 ? P.out_lo : P.out_hi) >> (8 * (idx & 7))) & 0xFFull) : (uint64_t)(uint8_t)s_out[idx];
         if (k < 8) lo |= o << (8 * k); else hi |= o << (8 * (k - 8));
-        st = s_next[idx];
+        st = SMALL ? (int)((P.next2 >> (2 * idx)) & 3u) : (int)s_next[idx];
         col = col + 1 == P.columns ? 0 : col + 1;
     }
     if (nv == ENC_SYM_PER_THREAD) {
@@ -248,10 +315,16 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
         ctx->tables_cached = tabn;
         WF_HIP(hipMemcpyAsync(ctx->d_tables, ctx->h_tables_cache, 2048, hipMemcpyHostToDevice, s));
     }
-    enc_params P{columns, states, card, ninp, (int)(i0 % columns), state0, nsym};
-#define ENC_A(NS) hipLaunchKernelGGL(enc_reduce_kernel<NS>, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits, \
-                                    ctx->d_tables, P, thread_excl, block_agg)
-    if (states <= 4) ENC_A(4); else if (states <= 8) ENC_A(8); else ENC_A(16);
+    enc_params P{columns, states, card, ninp, (int)(i0 % columns), state0, nsym, 0u, 0ull, 0ull};
+    const bool small = states <= 4 && tabn <= 16 && columns * ninp <= 4;
+    if (small)
+        for (int k = 0; k < tabn; ++k) {
+            P.next2 |= (uint32_t)(h_next[k] & 3) << (2 * k);
+            (k < 8 ? P.out_lo : P.out_hi) |= (uint64_t)(uint8_t)h_out[k] << (8 * (k & 7));
+        }
+#define ENC_A(NS, SM) hipLaunchKernelGGL((enc_reduce_kernel<NS, SM>), dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits, \
+                                        ctx->d_tables, P, thread_excl, block_agg)
+    if (small) ENC_A(4, true); else if (states <= 4) ENC_A(4, false); else if (states <= 8) ENC_A(8, false); else ENC_A(16, false);
 #undef ENC_A
     WF_LAUNCH_CHECK();
     WF_REQUIRE(!d_state_at || (at_index >= 0 && at_index <= nsym && at_index % ENC_SYM_PER_THREAD == 0),
@@ -261,9 +334,14 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
     if (states <= 4) ENC_B(4); else if (states <= 8) ENC_B(8); else ENC_B(16);
 #undef ENC_B
     WF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(enc_emit_kernel, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
-                       ctx->d_tables, reinterpret_cast<const int8_t *>(ctx->d_tables + 1024), P,
-                       thread_excl, block_state, d_symbols, ctx->d_small, d_state_at, at_index);
+    if (small)
+        hipLaunchKernelGGL(enc_emit_kernel<true>, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
+                           ctx->d_tables, reinterpret_cast<const int8_t *>(ctx->d_tables + 1024), P,
+                           thread_excl, block_state, d_symbols, ctx->d_small, d_state_at, at_index);
+    else
+        hipLaunchKernelGGL(enc_emit_kernel<false>, dim3((unsigned)nblocks), dim3(ENC_THREADS), 0, s, d_bits,
+                           ctx->d_tables, reinterpret_cast<const int8_t *>(ctx->d_tables + 1024), P,
+                           thread_excl, block_state, d_symbols, ctx->d_small, d_state_at, at_index);
     WF_LAUNCH_CHECK();
     if (h_state_out) {
         WF_HIP(hipMemcpyAsync(ctx->h_small, ctx->d_small, sizeof(int), hipMemcpyDeviceToHost, s));

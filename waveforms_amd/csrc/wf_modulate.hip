@@ -118,21 +118,51 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
     __shared__ double s_head[MOD_MAX_PART + 1];
     if (t >= 1 && t <= MOD_MAX_PART) s_head[t] = (t <= P.nhead && t <= P.nsym) ? mod_amp(symbols, hvec, P, t - 1) : 0.0;
     __syncthreads();
-    if (t == 0) {
-        // Gcum at the few indices needed, by one sequential pass over the taps
-        // idx_l = ntaps - 1 + R - (l+1)*sps, R = (c - ntaps) mod sps   (partial symbols)
-        // head:  c - 1 - mp1*sps, mp1 = 1..nhead
+    if (staged) {
+        // Gcum = running sum of the taps, in place in LDS: wave 0 scans 64 taps per trip (DPP) and
+        // carries the total; the few entries the tile carries need are then gathered in parallel.
+        // (A serial `run += pulse[k]` walk by one lane cost ~5 us of dependent LDS reads.)
+        if (t < WF_WAVE) {
+            double carry = 0.0;
+            for (int k0 = 0; k0 < P.ntaps; k0 += WF_WAVE) {
+                const int k = k0 + t;
+                const double inc = wf_wave_incl_scan(k < P.ntaps ? s_pulse[k] : 0.0) + carry;
+                if (k < P.ntaps) s_pulse[k] = inc;
+                carry = __shfl(inc, WF_WAVE - 1, WF_WAVE);
+            }
+        }
+        __syncthreads();
+        int R = (P.c - P.ntaps) % P.sps;
+        if (R < 0) R += P.sps;
+        if (t < MOD_MAX_PART) {
+            // idx_l = ntaps - 1 + R - (l+1)*sps  (partial symbols at a tile edge)
+            const int idx = P.ntaps - 1 + R - (t + 1) * P.sps;
+            scratch[MOD_OFF_GPART + t] = (t < P.npart && idx >= 0 && idx < P.ntaps) ? s_pulse[idx] : 0.0;
+        }
+        if (t == 0) {
+            // head truncation: symbols whose pulse starts before sample 0, tap index c - 1 - mp1*sps
+            double k0 = 0.0;
+            for (int mp1 = 1; mp1 <= P.nhead && mp1 <= P.nsym; ++mp1) {
+                const int idx = P.c - 1 - mp1 * P.sps;
+                if (idx >= 0 && idx < P.ntaps)
+                    k0 += (mp1 <= MOD_MAX_PART ? s_head[mp1] : mod_amp(symbols, hvec, P, mp1 - 1)) * s_pulse[idx];
+            }
+            const double T = s_pulse[P.ntaps - 1];
+            scratch[0] = T;
+            scratch[1] = k0;
+            s_T = T;
+            s_K0 = k0;
+        }
+    } else if (t == 0) {
+        // very long pulses: one sequential pass over the taps in global memory
         int R = (P.c - P.ntaps) % P.sps;
         if (R < 0) R += P.sps;
         double run = 0.0, k0 = 0.0;
         for (int l = 0; l < MOD_MAX_PART; ++l) scratch[MOD_OFF_GPART + l] = 0.0;
-        // num = ntaps - 1 + R - k hits (l+1)*sps at the partial-symbol taps, hn = c - 1 - k hits
-        // mp1*sps at the head-correction taps; both count down with k, so their remainders and
-        // quotients are tracked incrementally (no division in this serial loop)
         int num = P.ntaps - 1 + R, num_q = num / P.sps, num_r = num - num_q * P.sps;
         int hn = P.c - 1, hn_q = hn >= 0 ? hn / P.sps : 0, hn_r = hn >= 0 ? hn - hn_q * P.sps : 0;
         for (int k = 0; k < P.ntaps; ++k) {
-            run += staged ? s_pulse[k] : pulse[k];
+            run += pulse[k];
             if (num > 0 && num_r == 0) {
                 const int l = num_q - 1;
                 if (l >= 0 && l < P.npart) scratch[MOD_OFF_GPART + l] = run;

@@ -240,14 +240,6 @@ __device__ __forceinline__ void wf_stage_cis_table(double2 *lds_tab, int t, int 
     for (int k = t; k < 128; k += nthreads) lds_tab[k] = kWfCisTab[k];
 }
 
-__device__ __forceinline__ void wf_sincos_turns(double t, double *sn, double *cs)   // any |t| < 2^24
-{
-    const double y = t * 128.0;
-    const double fl = floor(y);
-    const double r = ((y - fl) - 0.5) * (6.28318530717958647692 / 128.0);
-    wf_cis_sector(kWfCisTab[(int)fl & 127], r, sn, cs);
-}
-
 
 // ln((xa + 1) * 2^-32) for a 32-bit word: table-driven.  m in [1, 2) from the exponent split of
 // the exact double xa + 1; 128-entry table of {1/c_i (rounded), ln(1/that)} at the bucket
@@ -443,13 +435,6 @@ __device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_i
 #endif
     wf_box_muller32(p.x0, p.x1, sigma, tb, &g[0], &g[1]);
     wf_box_muller32(p.x2, p.x3, sigma, tb, &g[2], &g[3]);
-}
-
-__device__ __forceinline__ uint64_t wf_wave_xor_reduce(uint64_t v)
-{
-#pragma unroll
-    for (int d = WF_WAVE / 2; d >= 1; d >>= 1) v ^= __shfl_xor(v, d, WF_WAVE);
-    return v;
 }
 
 __device__ __forceinline__ long long wf_wave_sum_i64(long long v)

@@ -46,11 +46,6 @@ __device__ __forceinline__ uint64_t map_compose(uint64_t f, uint64_t g)
     return h;
 }
 
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d)
-{
-    return (uint64_t)__shfl_up((unsigned long long)v, d, WF_WAVE);
-}
-
 // Value of the lane `CTRL` says (DPP), identity map where there is none.  Only the words that
 // hold states < NS travel.
 template <int NS, int CTRL, int RM>

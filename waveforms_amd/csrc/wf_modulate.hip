@@ -359,10 +359,9 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
             double2 e0 = make_double2(0.0, 0.0), e1 = e0;   // samples 2t and 2t + 1 of the row
             if (active) {
                 const double v0 = run + (offw + ex + acc0);
-                // one exact reduction per pair; the second sample is a single frequency-pulse value
-                // further and wf_sincos_turns reduces its argument exactly anyway
-                // (no fix-up of a remainder that rounds to -eps or sps+eps: the sector split of the
-                // sincos below is exact for any argument)
+                // one reduction mod sps per pair (the second sample is a single frequency-pulse value
+                // further); a remainder that rounds to -eps or sps+eps needs no fix-up because the
+                // sector split of wf_sincos_sectors is exact for any argument
                 const double ra = fma(-floor(v0 * P.inv_sps), P.sps_d, v0);
                 const double rb = ra + acc1;
 #ifdef WF_ABL_NO_SINCOS

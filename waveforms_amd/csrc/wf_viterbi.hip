@@ -21,7 +21,7 @@
 #include "wf_common.h"
 
 #define VIT_THREADS 256
-#define VIT_DEFAULT_WARMUP 47   // + 1 priming row + 64 output rows = 28 batches of 4
+#define VIT_DEFAULT_WARMUP 47   // + 1 priming row: 48 rows = 12 batches of 4 before the first output row
 #define VIT_MAX_LEN 64
 
 // Branch b of column c: start = b >> 1; ends / output-symbol index (0: -2, 1: 0, 2: +2):
@@ -112,13 +112,6 @@ __device__ __forceinline__ void vit_acs(const double m[4], const vit_comp &q, do
 }
 
 __device__ __forceinline__ uint64_t vit_mux(uint64_t c, uint64_t x, uint64_t y) { return (c & x) | (~c & y); }
-
-// predecessor state of end state `st` in section COL: first / second branch start
-__device__ __forceinline__ int vit_pred(int col, int st, unsigned second)
-{
-    // even: (0,2) (1,3) (0,2) (1,3); odd: (0,1) (0,1) (2,3) (2,3)
-    return col == 0 ? (st & 1) + 2 * (int)second : (st & 2) + (int)second;
-}
 
 struct vit_lane {
     double m0[4];
@@ -255,14 +248,14 @@ __device__ __forceinline__ void vit_comp_to_inc(const vit_comp &c, int col, doub
 
 // Batch kernel.  Lane g owns calls [g*CH, (g+1)*CH) and walks rows g*CH - W - 1 ... (one
 // priming row for the exact previous increments, W warm-up rows, CH output rows).  Rows are
-// 48 B each and a lane's rows are contiguous, so per-lane loads would touch 64 different
-// cache lines per instruction and thrash L1 (measured 2.4x HBM over-fetch).  Instead each
-// wave stages VIT_S rows of all its 64 lanes per batch with COOPERATIVE loads — 12 lanes
-// cover one lane-segment of 192 B, every 16 B piece of every cache line is fetched once —
-// into a wave-private LDS tile (13 slots of 16 B per lane: the odd slot count makes the
-// per-lane ds_read_b128 conflict-free), with the next batch's global loads in flight
-// while the current one is being decoded.  Steps are decoded in (even, odd) column pairs
-// so only two ACS bodies are live at a time.
+// 48 B each (32 B when the bank packed them) and a lane's rows are contiguous, so per-lane
+// loads would touch 64 different cache lines per instruction and thrash L1 (measured 2.4x HBM
+// over-fetch).  Instead each wave stages VIT_S rows of all its 64 lanes per batch with
+// COOPERATIVE loads — consecutive lanes cover one lane-segment of VIT_S rows, every 16 B piece
+// of every cache line is fetched once — into a wave-private LDS tile (an odd number of 16 B
+// slots per lane makes the per-lane ds_read_b128 conflict-free), with VIT_DEPTH batches of
+// global loads in flight while the current one is being decoded.  Steps are decoded in
+// (even, odd) column pairs so only two ACS bodies are live at a time.
 #define VIT_S 4
 #define VIT_DEPTH 3   // batches of cooperative loads in flight per wave (register sets pend0..2)
 #define VIT_PIECES_RW(RW) ((RW) * VIT_S)   // 16-byte pieces per lane-segment, RW = double2 per row (3, packed: 2)

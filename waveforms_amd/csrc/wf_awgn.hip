@@ -21,27 +21,50 @@ __global__ __launch_bounds__(256) void awgn_kernel(const double *in, int64_t n, 
     wf_stage_tables<1, 0>(s_tab, threadIdx.x, blockDim.x);
     __syncthreads();
     const wf_tabs_lds<1, 0> tb{s_tab};
-    // one thread per PAIR of absolute sample indices (2P, 2P+1): one Philox block serves both
+    // one thread per PAIR of absolute sample indices (2P, 2P+1): one Philox block serves both.
+    // A wave covers 128 consecutive samples; they travel between HBM and the lanes through a
+    // wave-private LDS strip so that every load / store instruction touches 64 consecutive
+    // samples (1 KB) — a lane moving its own pair directly issues 16 B accesses at a 32 B stride,
+    // which wrote 1.56 GB for a 1.28 GB burst (half-filled lines per instruction).
+    __shared__ double2 s_xp[2 * 256];
+    const int lane = threadIdx.x & 63;
+    double2 *xw = s_xp + (threadIdx.x >> 6) * (2 * WF_WAVE);
     const uint64_t pair0 = first_index >> 1;
     const int64_t npairs = (int64_t)(((first_index + (uint64_t)n - 1) >> 1) - pair0) + 1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += stride) {
-        const uint64_t pair = pair0 + (uint64_t)q;
-        const int64_t k0 = (int64_t)(2 * pair - first_index);   // local index of the even sample (may be -1)
-        double2 v0 = make_double2(0.0, 0.0), v1 = v0;
-        const bool ok0 = k0 >= 0, ok1 = k0 + 1 < n;
-        if (in) {
-            if (ok0) v0 = *reinterpret_cast<const double2 *>(in + 2 * k0);
-            if (ok1) v1 = *reinterpret_cast<const double2 *>(in + 2 * (k0 + 1));
+    const int64_t q0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);      // first pair of this wave
+    const double2 *in2 = reinterpret_cast<const double2 *>(in);
+    double2 *out2 = reinterpret_cast<double2 *>(out);
+    for (int64_t qw = q0; qw < npairs; qw += stride) {
+        const uint64_t pair = pair0 + (uint64_t)(qw + lane);
+        const int64_t kb = (int64_t)(2 * (pair0 + (uint64_t)qw) - first_index);   // local index of the wave's first sample (may be -1)
+        const int64_t ka = kb + lane, kc = ka + WF_WAVE;
+        const bool oka = ka >= 0 && ka < n, okc = kc >= 0 && kc < n;
+        double2 va = make_double2(0.0, 0.0), vc = va;
+        if (in2) {
+            if (oka) va = in2[ka];
+            if (okc) vc = in2[kc];
         }
+        xw[lane] = va;
+        xw[WF_WAVE + lane] = vc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double2 v0 = xw[2 * lane], v1 = xw[2 * lane + 1];
         double g[4];
         wf_gaussian_two(pair, stream_id, seed, sigma, tb, g);
-        if (ok0)
-            *reinterpret_cast<double2 *>(out + 2 * k0) =
-                make_double2(fma(v0.x, rot_re, fma(-v0.y, rot_im, g[0])), fma(v0.x, rot_im, fma(v0.y, rot_re, g[1])));
-        if (ok1)
-            *reinterpret_cast<double2 *>(out + 2 * (k0 + 1)) =
-                make_double2(fma(v1.x, rot_re, fma(-v1.y, rot_im, g[2])), fma(v1.x, rot_im, fma(v1.y, rot_re, g[3])));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // every lane has read its pair before the strip is reused
+        xw[2 * lane] = make_double2(fma(v0.x, rot_re, fma(-v0.y, rot_im, g[0])), fma(v0.x, rot_im, fma(v0.y, rot_re, g[1])));
+        xw[2 * lane + 1] = make_double2(fma(v1.x, rot_re, fma(-v1.y, rot_im, g[2])), fma(v1.x, rot_im, fma(v1.y, rot_re, g[3])));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double2 ra = xw[lane], rc = xw[WF_WAVE + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (oka) out2[ka] = ra;
+        if (okc) out2[kc] = rc;
     }
 }
 

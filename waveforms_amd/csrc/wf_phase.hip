@@ -77,6 +77,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
     __shared__ long long s_tile;
     __shared__ uint64_t s_prefix;
     __shared__ double2 s_cis[128];   // sincos sector table in LDS (persistent store loop: see wf_sincos_sectors)
+    __shared__ double2 s_xp[2 * PH_THREADS];   // wave-private strips for the store transpose
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     uint64_t *desc = scan + PH_DESC0;
@@ -194,13 +195,23 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
             wf_sincos_sectors(s_cis, fma(r0, 128.0 * P.inv_sps, 128.0 * P.phi0_turns), &s0, &c0);
             wf_sincos_sectors(s_cis, fma(r1, 128.0 * P.inv_sps, 128.0 * P.phi0_turns), &s1, &c1);
 #endif
-            if (i + 1 < P.n) {
-                double2 *o = reinterpret_cast<double2 *>(out + 2 * i);
-                o[0] = make_double2(c0, s0);
-                o[1] = make_double2(c1, s1);
-            } else if (i < P.n) {
-                *reinterpret_cast<double2 *>(out + 2 * i) = make_double2(c0, s0);
-            }
+            // wave-private transpose (as in wf_modulate.hip): a lane holding two adjacent samples
+            // would store 16 B at a 32 B stride; this way every store instruction writes 64
+            // consecutive samples
+            (void)i;
+            double2 *xw = s_xp + wave * (2 * WF_WAVE);
+            xw[2 * lane] = make_double2(c0, s0);
+            xw[2 * lane + 1] = make_double2(c1, s1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double2 xa = xw[lane], xb = xw[WF_WAVE + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // strip read before the next row overwrites it
+            const int64_t na = base + u * PH_ROW + wave * (2 * WF_WAVE) + lane, nb = na + WF_WAVE;
+            double2 *o = reinterpret_cast<double2 *>(out);
+            if (na < P.n) o[na] = xa;
+            if (nb < P.n) o[nb] = xb;
         }
     }
 }

@@ -1,3 +1,5 @@
+"""Write bandwidth a plain fill reaches on this GPU for a buffer the size of one bench block of
+complex128 samples (1.28 GB): the store floor the modulator is compared with in DESIGN.md."""
 import torch
 n=80_000_008
 x=torch.empty((n,2),dtype=torch.float64,device='cuda')

@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 # stage -> kernel that dominates it (names as rocprofv3 prints them)
 STAGE_KERNEL = {"fir": "fir_kernel<9>", "phase": "phase_kernel", "modulate": "mod_main_kernel<9>",
                 "awgn": "awgn_kernel", "mfbank": "mf_bank_kernel<3, false, 8, 9>", "awgn+mfbank": "mf_bank_kernel<3, true, 8, 9>",
-                "viterbi": "viterbi_batch_kernel<128, false>", "count": "count_errors_kernel", "prbs": "lfsr_kernel",
+                "viterbi": "viterbi_batch_kernel<false>", "count": "count_errors_kernel", "prbs": "lfsr_kernel",
                 "encode": "enc_reduce_kernel"}
 
 
@@ -185,7 +185,7 @@ def main() -> None:
         bps["awgn+mfbank"] = 16 * args.sps + 32
         bps["viterbi"] = 32 + 2
         STAGE_KERNEL["awgn+mfbank"] = "mf_bank_kernel<3, true, 8, 9, true>"
-        STAGE_KERNEL["viterbi"] = "viterbi_batch_kernel<128, true>"
+        STAGE_KERNEL["viterbi"] = "viterbi_batch_kernel<true>"
     stages = {}
     for name, ms in acc.items():
         gb = bps[name] * args.nsym / 1e9

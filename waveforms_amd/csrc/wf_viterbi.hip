@@ -200,12 +200,10 @@ __device__ __forceinline__ uint64_t vit_spread_syms8(uint32_t x)    // 8 two-bit
     return ((v & 0x7F7F7F7F7F7F7F7Full) + 0x7E7E7E7E7E7E7E7Eull) ^ ((v ^ 0xFEFEFEFEFEFEFEFEull) & 0x8080808080808080ull);
 }
 
-template <int CH>
-__device__ __forceinline__ void vit_flush(const uint64_t *__restrict__ dec, int64_t a, int64_t ncalls,
+__device__ __forceinline__ void vit_flush(const uint64_t *__restrict__ dec, int ch, int64_t a, int64_t ncalls,
                                           uint8_t *__restrict__ bits, int8_t *__restrict__ syms)
 {
-#pragma unroll
-    for (int gq = 0; gq < CH / 16; ++gq) {
+    for (int gq = 0; gq < ch / 16; ++gq) {
         const int64_t k0 = a + 16 * gq;
         if (k0 >= ncalls) break;
         const uint64_t w = dec[gq];
@@ -271,8 +269,8 @@ __device__ __forceinline__ double2 vit_ld16(const double2 *p)
     return make_double2(v.x, v.y);
 }
 
-template <int CH, int PAR0, bool PACKED>   // PAR0: column parity of step 0's call index; PACKED: 32 B rows
-__device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf, int64_t ncalls, int diff, int warmup,
+template <int PAR0, bool PACKED>   // PAR0: column parity of step 0's call index; PACKED: 32 B rows
+__device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf, int64_t ncalls, int CH, int diff, int warmup,
                                                    uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
                                                    double *__restrict__ state, int64_t i0, double2 (*s_rows)[WF_WAVE * VIT_LANE_SLOTS],
                                                    uint64_t *__restrict__ s_dec)
@@ -385,7 +383,7 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
         round(b0 + 1, pend1);
         round(b0 + 2, pend2);
     }
-    if (live) vit_flush<CH>(dec, a, ncalls, bits, syms);   // same lane wrote the strip: in-order LDS, no barrier
+    if (live) vit_flush(dec, CH, a, ncalls, bits, syms);   // same lane wrote the strip: in-order LDS, no barrier
     if (state && live && a + CH >= ncalls) {
         // the lane that owns the last call hands the detector state on (streaming).  Written
         // to the second half of the carry block; viterbi_carry_commit_kernel moves it.
@@ -399,17 +397,17 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
 #ifndef VIT_MIN_WAVES
 #define VIT_MIN_WAVES 1
 #endif
-template <int CH, bool PACKED = false>
+template <bool PACKED>
 __global__ __launch_bounds__(VIT_THREADS, VIT_MIN_WAVES) void viterbi_batch_kernel(const double *__restrict__ mf, int64_t ncalls,
-                                                                     int diff, int warmup, uint8_t *__restrict__ bits,
+                                                                     int ch, int diff, int warmup, uint8_t *__restrict__ bits,
                                                                      int8_t *__restrict__ syms, double *__restrict__ state)
 {
     __shared__ double2 s_rows[VIT_THREADS / WF_WAVE][WF_WAVE * VIT_LANE_SLOTS];
-    __shared__ uint64_t s_dec[VIT_THREADS * (CH / 16 + 1)];   // packed decisions, one strip per lane
+    extern __shared__ uint64_t s_dec[];   // packed decisions, one strip of ch / 16 + 1 words per lane
     const int64_t i0 = state ? (int64_t)state[0] : 0;
-    // call index of step 0 is lane_start - warmup - 1 with lane_start a multiple of CH (even)
-    if ((i0 - warmup - 1) & 1) viterbi_batch_body<CH, 1, PACKED>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
-    else viterbi_batch_body<CH, 0, PACKED>(mf, ncalls, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
+    // call index of step 0 is lane_start - warmup - 1 with lane_start a multiple of ch (even)
+    if ((i0 - warmup - 1) & 1) viterbi_batch_body<1, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
+    else viterbi_batch_body<0, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
 }
 
 __global__ void viterbi_carry_commit_kernel(double *state)
@@ -430,27 +428,35 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     WF_HIP(hipSetDevice(ctx->device));
     if (warmup == 0) warmup = VIT_DEFAULT_WARMUP;
     if (warmup > 4096) warmup = 4096;
-    // Calls per lane: the warm-up re-reads 48 / CH of the rows (75 % at 64, 37 % at 128, 19 % at
-    // 256) but every lane walks CH + 48 dependent steps, so CH grows only while the burst still
-    // yields about one wave per SIMD (1024 SIMDs x 64 lanes).
-    const int ch = ncalls >= (3 << 22) ? 256 : ncalls >= (3 << 20) ? 128 : 64;
+    // Calls per lane (a multiple of 16).  The kernel holds 3 batches of row loads in registers and
+    // runs ONE wave per SIMD, so a launch of more than 256 workgroups (one per CU) would need a
+    // second round: the chunk is the smallest that fits the burst into 256 workgroups — every lane
+    // walks ch + 48 dependent steps, so smaller is faster, and the warm-up re-reads 48 / ch of the
+    // rows.  (1e7 calls: ch = 160, 0.112 ms; at 128 the 306 workgroups took 0.134 ms.)  Very long
+    // bursts cap at 512 (decision strips in LDS) and take several rounds.
+    int ch = (int)((ncalls + 65535) / 65536);
+    ch = (ch + 15) / 16 * 16;
+    if (ch < 32) ch = 32;
+    if (ch > 512) ch = 512;
+#ifdef VIT_FORCE_CH
+    ch = VIT_FORCE_CH;
+#endif
     const int64_t nthreads = (ncalls + ch - 1) / ch;
     const int64_t nblocks = (nthreads + VIT_THREADS - 1) / VIT_THREADS;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
     hipStream_t s = wf_stream(stream);
-#define VIT_LAUNCH(CHV, PK)                                                                                      \
-    hipLaunchKernelGGL((viterbi_batch_kernel<CHV, PK>), dim3((unsigned)nblocks), dim3(VIT_THREADS), 0, s, d_mf_ri, \
-                       ncalls, differential ? 1 : 0, warmup, d_bits, d_syms, d_state)
-    if (packed) {
-        if (ch == 256) VIT_LAUNCH(256, true);
-        else if (ch == 128) VIT_LAUNCH(128, true);
-        else VIT_LAUNCH(64, true);
-    } else {
-        if (ch == 256) VIT_LAUNCH(256, false);
-        else if (ch == 128) VIT_LAUNCH(128, false);
-        else VIT_LAUNCH(64, false);
+    const size_t lds = (size_t)VIT_THREADS * (ch / 16 + 1) * sizeof(uint64_t);
+    if (lds > 32 * 1024) {
+        const void *kfn = packed ? reinterpret_cast<const void *>(viterbi_batch_kernel<true>)
+                                 : reinterpret_cast<const void *>(viterbi_batch_kernel<false>);
+        WF_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-#undef VIT_LAUNCH
+    if (packed)
+        hipLaunchKernelGGL(viterbi_batch_kernel<true>, dim3((unsigned)nblocks), dim3(VIT_THREADS), lds, s, d_mf_ri, ncalls, ch,
+                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
+    else
+        hipLaunchKernelGGL(viterbi_batch_kernel<false>, dim3((unsigned)nblocks), dim3(VIT_THREADS), lds, s, d_mf_ri, ncalls, ch,
+                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
     WF_LAUNCH_CHECK();
     if (d_state) {
         hipLaunchKernelGGL(viterbi_carry_commit_kernel, dim3(1), dim3(64), 0, s, d_state);

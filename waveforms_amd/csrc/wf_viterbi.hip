@@ -255,7 +255,9 @@ __device__ __forceinline__ void vit_comp_to_inc(const vit_comp &c, int col, doub
 // global loads in flight while the current one is being decoded.  Steps are decoded in
 // (even, odd) column pairs so only two ACS bodies are live at a time.
 #define VIT_S 4
-#define VIT_DEPTH 3   // batches of cooperative loads in flight per wave (register sets pend0..2)
+#ifndef VIT_DEPTH
+#define VIT_DEPTH 3   // batches of cooperative loads in flight per wave (register sets pend0..2); 2 or 3
+#endif
 #define VIT_PIECES_RW(RW) ((RW) * VIT_S)   // 16-byte pieces per lane-segment, RW = double2 per row (3, packed: 2)
 #define VIT_PIECES (3 * VIT_S)
 #define VIT_LANE_SLOTS (VIT_PIECES + 1)     // LDS slots per lane as allocated (odd count: conflict-free ds_read_b128)
@@ -347,14 +349,20 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     // waiting a full memory round trip (~4 us under load) per 4 decoded steps, with ~1 wave per
     // SIMD resident -> 207 us for 176 steps.  VIT_DEPTH batches are kept in flight in registers
     // instead (VIT_DEPTH x 12 x 16 B per lane; the register file is nearly empty at this occupancy).
-    double2 pend0[NP], pend1[NP], pend2[NP];   // VIT_DEPTH = 3 register sets
+#if VIT_DEPTH == 3
+    double2 pend0[NP], pend1[NP], pend2[NP];
+#else
+    double2 pend0[NP], pend1[NP];
+#endif
     // Every round issues exactly one batch of loads, unconditionally (past the last batch it
     // re-reads that batch: L2 hits, results unused).  With a conditional refill the compiler must
     // assume the path on which nothing was issued behind a register set and waits with vmcnt(0).
     const int last_b = nbatch - 1;
     fetch(0, pend0);
     fetch(min(1, last_b), pend1);
+#if VIT_DEPTH == 3
     fetch(min(2, last_b), pend2);
+#endif
     const int64_t kbase = a - warmup - 1;
     auto round = [&](int b, double2 (&pd)[NP]) __attribute__((always_inline)) {
         stash(pd);                                           // waits for batch b only (loads return in order)
@@ -381,7 +389,9 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     for (int b0 = 0; b0 < nbatch; b0 += VIT_DEPTH) {   // rounds past nbatch decode nothing (j >= nsteps)
         round(b0, pend0);
         round(b0 + 1, pend1);
+#if VIT_DEPTH == 3
         round(b0 + 2, pend2);
+#endif
     }
     if (live) vit_flush(dec, CH, a, ncalls, bits, syms);   // same lane wrote the strip: in-order LDS, no barrier
     if (state && live && a + CH >= ncalls) {

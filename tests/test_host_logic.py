@@ -204,3 +204,21 @@ def test_sweep_sharding_and_reduce_gloo_world2():
     blocks = np.arange(5).sum()
     want = [[100 * p * 5 + blocks, 10 * p * 5 + blocks, 5000] for p in range(3)]
     assert got[0] == want and got[1] == want
+
+
+def test_link_row_bytes_rule():
+    """Host mirror of wf_pipeline.hip:link_packed_rows — which link configurations carry
+    detector-packed 32 B rows (needs no GPU: it reads the configuration only)."""
+    from waveforms_amd import _hip
+    from waveforms_amd.link import SOQPSKLink
+
+    def rb(fuse, sps=8, ntaps=9, nfilt=3):
+        link = SOQPSKLink.__new__(SOQPSKLink)
+        cfg = _hip.LinkConfig()
+        cfg.fuse, cfg.sps, cfg.mf_ntaps, cfg.mf_nfilt = fuse, sps, ntaps, nfilt
+        link.cfg = cfg
+        return link.row_bytes
+
+    assert rb(7) == 32 and rb(6) == 32
+    assert rb(3) == 48 and rb(0) == 48 and rb(5) == 48      # bit 2 needs the fused channel (bit 1)
+    assert rb(7, sps=4) == 48 and rb(7, ntaps=17) == 48     # only the 3 x 9-tap bank at 8 samples per symbol

@@ -10,8 +10,11 @@
 // 16 B loads (each received sample is read from HBM once), then every thread owns one
 // output column and runs the taps out of LDS.  For an even `step` one 16 B pad slot per
 // `step` samples makes the ds_read_b128 column accesses bank-conflict free; taps are
-// wave-uniform (scalar loads).  128 B read + nfilt*16 B written per symbol at sps = 8:
-// HBM-bound for the 9-tap PT bank.
+// wave-uniform (broadcast LDS reads in the 3 x 9 fast path, scalar loads otherwise).
+// 128 B read + nfilt*16 B written per symbol at sps = 8: HBM-bound for the 9-tap PT bank.
+// NOISE instantiations apply the channel (derotation + Philox AWGN, wf_awgn.hip) while
+// staging — then the kernel is bound by the vector pipe — and PACK writes the 32 B
+// detector-packed row instead of 3 complex outputs.
 #include "wf_common.h"
 
 #define MF_THREADS 256

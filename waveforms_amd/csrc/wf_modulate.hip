@@ -11,8 +11,8 @@
 // Two tiny kernels build T*S at tile granularity (exact modular accumulation in 62-bit
 // fixed point, like wf_phase.hip); the main kernel then handles every tile
 // independently: symbol amplitudes of the tile in LDS, per-thread tap phases in
-// registers (wf_fir.hip), in-tile fp64 scan by wave shuffles + LDS wave totals
-// (wf_phase.hip), carry, mod, sincos, 16 B coalesced stores.
+// registers (wf_fir.hip), in-tile fp64 scan by DPP + LDS wave totals (wf_phase.hip),
+// carry, mod, table sincos (LDS), wave-transposed stores of 64 consecutive samples.
 #include "wf_common.h"
 
 #ifndef MOD_THREADS

@@ -6,7 +6,7 @@
 //
 // Single-pass chained prefix scan ("decoupled look-back"): the input is read once
 // and the output written once (8 B + 16 B per sample — the HBM roofline of this
-// stage).  Tiles of 2048 samples are claimed through an atomic ticket, so every
+// stage).  Tiles of 4096 samples are claimed through an atomic ticket, so every
 // predecessor of a tile is already running when it starts.  Only the accumulated
 // phase MODULO sps matters, so a tile's aggregate is published as a 62-bit
 // fixed-point fraction of a revolution with a 2-bit status in ONE 64-bit word

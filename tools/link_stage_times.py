@@ -1,7 +1,10 @@
 """Per-stage HIP-event times of the fused link at bench size, optionally with another build of the\nlibrary:  python tools/link_stage_times.py [path/to/libwfhip.so|'' [nsym [fuse]]]  (used by tools/ablate_link.sh)."""
-import sys, torch
-sys.path.insert(0, '/root/repo')
+import sys
 from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from waveforms_amd import _hip
 if len(sys.argv) > 1 and sys.argv[1]:
     _hip._LIB_PATH = Path(sys.argv[1]).resolve()

@@ -92,6 +92,8 @@ def main() -> None:
                          "bit 2: detector-packed 32 B rows between bank and detector; 0 = every stage its own kernel")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent trial blocks in flight on separate HIP streams (own workspace + context each)")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="record the per-stage HIP events on every E-th timed step only (the last step always)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -129,12 +131,17 @@ def main() -> None:
     slots = 64
     assert args.steps >= 1
 
+    every = max(1, args.event_every)
+
+    def instrumented(k: int) -> bool:
+        return k % every == every - 1 or k == args.steps - 1
+
     def step(k: int, timed: bool) -> None:
         # every (rank, step) is its own trial block: distinct PRBS segment and Philox subsequence
         block = k * world + rank
         with torch.cuda.stream(streams[k % nstreams]):
             links[k % nstreams].run_block(args.ebn0, seed=1, stream_id=block & 0xFFFFFFFF, skip_bits=(block % 4096) * args.nsym,
-                                          event_slot=(k % slots) if timed else -1)
+                                          event_slot=(k % slots) if timed and instrumented(k) else -1)
 
     def fence() -> None:
         if dist is not None:
@@ -167,11 +174,11 @@ def main() -> None:
     se, be, compared = (int(v) for v in counts.cpu().tolist())
 
     # per-stage kernel time from the HIP events recorded inside the timed region
-    n_ev = min(args.steps, slots)
+    ev_steps = [k for k in range(max(0, args.steps - slots), args.steps) if instrumented(k)]
     acc = {}
-    for k in range(args.steps - n_ev, args.steps):
+    for k in ev_steps:
         for name, ms in links[k % nstreams].stage_ms(k % slots).items():
-            acc[name] = acc.get(name, 0.0) + ms / n_ev
+            acc[name] = acc.get(name, 0.0) + ms / len(ev_steps)
     bps = stage_bytes_per_symbol(args.sps)
     if args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
         acc["modulate"] = acc.pop("fir")

@@ -1,4 +1,8 @@
-"""Per-stage HIP-event times of the fused link at bench size, optionally with another build of the\nlibrary:  python tools/link_stage_times.py [path/to/libwfhip.so|'' [nsym [fuse]]]  (used by tools/ablate_link.sh)."""
+"""Per-stage HIP-event times of the fused link at bench size, optionally with another build of the
+library (used by tools/ablate_link.sh):
+
+    python tools/link_stage_times.py [path/to/libwfhip.so | '' [nsym [fuse]]]
+"""
 import sys
 from pathlib import Path
 

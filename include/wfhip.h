@@ -165,6 +165,14 @@ int wf_awgn_mf_bank_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, 
 int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
                        int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
                        void *stream);
+/* The batch detector is chunk-parallel: every lane re-derives the path metrics over `warmup` rows
+ * before its chunk.  Each launch verifies on the device that the metrics a chunk started from are
+ * bitwise the metrics the previous chunk ended with — the condition under which all decisions are
+ * those of the sequential SOQPSKTrellisDetector — and counts the chunks for which that failed.
+ * *h_count = that counter since the last reset (synchronises `stream`); 0 means every batch call
+ * since then reproduced the sequential detector exactly.  Non-zero: re-run with a larger `warmup`. */
+int wf_viterbi4_unmerged(wf_ctx *ctx, int64_t *h_count, int reset, void *stream);
+
 /* wf_viterbi4_detect + wf_count_errors in one call (fresh detector): decision k is
  * compared with reference element k - skip for 0 <= k - skip < ncompare
  * (examples/soqpsk_detection.py:201-209: skip = length); counts are ADDED to d_counts[0..1]. */

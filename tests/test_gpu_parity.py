@@ -725,3 +725,30 @@ def test_link_full_size_fuse_modes_agree(nsym):
     assert m == nsym - 3                  # ncols - length: the example's min_size (examples/soqpsk_detection.py:204)
     ber = be / m
     assert 5.5e-4 < ber < 8.0e-4          # reference at 10 dB: 6.8e-4 (tests/golden/ber_golden*.csv)
+
+
+def test_detector_reports_and_repairs_unmerged_chunks(oracle):
+    """The chunk-parallel kernel proves its own output: every launch checks that each chunk started
+    from bitwise the metrics its predecessor ended with.  Ordinary inputs never trip it; rows built
+    so that survivors cannot merge inside the warm-up do, and detect() then repeats the call with a
+    longer warm-up until the result IS the sequential detector's."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+    from waveforms_amd import _hip, device as dev
+
+    n = 300_000
+    rng = np.random.default_rng(11)
+    ordinary = (rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3)))
+    ordinary[:, 1] += np.where(rng.integers(0, 2, n) > 0, 1.5, -1.5)
+    dev.viterbi_unmerged(reset=True)
+    dev.viterbi_detect(_hip.to_device(ordinary))
+    assert dev.viterbi_unmerged(reset=True) == 0
+
+    # a warm-up of one row cannot reach the true metrics on noisy data: the launch must say so ...
+    noisy = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    dev.viterbi_detect(_hip.to_device(noisy), warmup=1)
+    assert dev.viterbi_unmerged(reset=True) > 0
+    # ... and detect() must notice and repeat the call with a longer warm-up until the output is proven
+    got_b, got_s = SOQPSKTrellisDetector().detect(noisy, warmup=1)
+    want_b, want_s = oracle.viterbi_detect(noisy)
+    assert np.array_equal(got_b, want_b) and np.array_equal(got_s, want_s)
+    assert dev.viterbi_unmerged(reset=True) == 0

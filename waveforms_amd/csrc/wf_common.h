@@ -57,6 +57,9 @@ struct wf_ctx {
     std::map<uint64_t, wf_lfsr_tables *> lfsr;
     double *d_mod_scratch = nullptr;  // fused modulator: constants, tile sums, tile carries
     size_t mod_scratch_words = 0;
+    double *d_vit_edge = nullptr;     // chunk-parallel detector: per-wave start / end metrics (8 doubles each)
+    size_t vit_edge_words = 0;
+    unsigned long long *d_vit_unmerged = nullptr;   // chunks whose warm-up did not reach the true path metrics
     hipEvent_t *events = nullptr;  // WF_LINK_EVENT_SLOTS x (WF_LINK_STAGES + 1), created lazily
 };
 
@@ -65,6 +68,7 @@ static inline hipStream_t wf_stream(void *s) { return reinterpret_cast<hipStream
 int wf_ctx_reserve_scan(wf_ctx *ctx, size_t words);
 int wf_ctx_reserve_fsm(wf_ctx *ctx, size_t words);
 int wf_ctx_reserve_mod(wf_ctx *ctx, size_t words);
+int wf_ctx_reserve_vit(wf_ctx *ctx, size_t words);
 
 // Internal (not exported) forms with device-resident carries, used by the streaming link.
 int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,

@@ -30,6 +30,8 @@ extern "C" int wf_ctx_create(int device, wf_ctx **out)
     WF_HIP(hipMemset(c->d_fault, 0, 64));
     WF_HIP(hipHostMalloc(&c->h_fault, 64, hipHostMallocDefault));
     WF_HIP(hipMalloc(&c->d_tables, 4096));
+    WF_HIP(hipMalloc(&c->d_vit_unmerged, sizeof(unsigned long long)));
+    WF_HIP(hipMemset(c->d_vit_unmerged, 0, sizeof(unsigned long long)));
     WF_HIP(hipMalloc(&c->d_small, 256));
     WF_HIP(hipHostMalloc(&c->h_small, 256, hipHostMallocDefault));
     *out = c;
@@ -54,6 +56,8 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
     if (c->d_scan) (void)hipFree(c->d_scan);
     if (c->d_fsm_scratch) (void)hipFree(c->d_fsm_scratch);
     if (c->d_mod_scratch) (void)hipFree(c->d_mod_scratch);
+    if (c->d_vit_edge) (void)hipFree(c->d_vit_edge);
+    if (c->d_vit_unmerged) (void)hipFree(c->d_vit_unmerged);
     if (c->d_fault) (void)hipFree(c->d_fault);
     if (c->h_fault) (void)hipHostFree(c->h_fault);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -116,5 +120,18 @@ int wf_ctx_reserve_mod(wf_ctx *c, size_t words)
     while (cap < words) cap *= 2;
     WF_HIP(hipMalloc(&c->d_mod_scratch, cap * sizeof(double)));
     c->mod_scratch_words = cap;
+    return WF_OK;
+}
+
+int wf_ctx_reserve_vit(wf_ctx *c, size_t words)
+{
+    if (words <= c->vit_edge_words) return WF_OK;
+    WF_HIP(hipDeviceSynchronize());
+    if (c->d_vit_edge) WF_HIP(hipFree(c->d_vit_edge));
+    c->d_vit_edge = nullptr;
+    size_t cap = c->vit_edge_words ? c->vit_edge_words : (1 << 14);
+    while (cap < words) cap *= 2;
+    WF_HIP(hipMalloc(&c->d_vit_edge, cap * sizeof(double)));
+    c->vit_edge_words = cap;
     return WF_OK;
 }

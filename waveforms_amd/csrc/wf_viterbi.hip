@@ -117,6 +117,7 @@ struct vit_lane {
     double m0[4];
     vit_comp prev;                       // components of the previous call's row
     uint32_t wb, ws;                     // decisions of the current group of 16 calls: 1 bit / 2 bits each
+    double ms[4];                        // metrics the warm-up arrived at, just before the lane's first own call
 };
 
 // One detector call k (COL = column parity of k): stage 0 commits the previous call's
@@ -222,6 +223,12 @@ __device__ __forceinline__ void vit_flush(const uint64_t *__restrict__ dec, int 
     }
 }
 
+__device__ __forceinline__ void vit_save_start(vit_lane &L)
+{
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) L.ms[s4] = L.m0[s4];
+}
+
 // Carry block <-> lane state.  The block keeps the reference's shape (8 branch increments of
 // the last call); section `col` of that call tells which components they hold.
 __device__ __forceinline__ vit_comp vit_comp_from_inc(const double *inc, int col)
@@ -275,7 +282,8 @@ template <int PAR0, bool PACKED>   // PAR0: column parity of step 0's call index
 __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf, int64_t ncalls, int CH, int diff, int warmup,
                                                    uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
                                                    double *__restrict__ state, int64_t i0, double2 (*s_rows)[WF_WAVE * VIT_LANE_SLOTS],
-                                                   uint64_t *__restrict__ s_dec)
+                                                   uint64_t *__restrict__ s_dec, double *__restrict__ edge,
+                                                   unsigned long long *__restrict__ unmerged)
 {
     constexpr int RW = PACKED ? 2 : 3;                 // double2 per row
     constexpr int NP = VIT_PIECES_RW(RW);             // 16-byte pieces per lane-segment and batch
@@ -376,8 +384,10 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
                 const int j = b * VIT_S + jj;
                 const int64_t k = kbase + j;                  // call index of the even step
                 const double2 *zr = tile + lane * LS + RW * jj;
+                if (j == warmup + 1) vit_save_start(L);       // wave-uniform: the next step is call a
                 if (j < nsteps && k >= 0 && k < ncalls)
                     vit_step<PAR0, PACKED>(L, zr, j == 0, diff, k, a, ncalls, dec);
+                if (j + 1 == warmup + 1) vit_save_start(L);
                 if (j + 1 < nsteps && k + 1 >= 0 && k + 1 < ncalls)
                     vit_step<PAR0 ^ 1, PACKED>(L, zr + RW, false, diff, k + 1, a, ncalls, dec);
             }
@@ -394,6 +404,30 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
 #endif
     }
     if (live) vit_flush(dec, CH, a, ncalls, bits, syms);   // same lane wrote the strip: in-order LDS, no barrier
+    // Proof obligation of the chunk-parallel form: the metrics a lane's warm-up arrived at must be
+    // BITWISE the metrics its predecessor ended with (then every later compare is the sequential
+    // detector's).  Inside a wave the predecessor's end state is one DPP shift away; the first lane
+    // of a wave and the last lane of the previous one meet in `edge` (viterbi_verify_kernel).
+    // Mismatches only count up `unmerged`; callers re-run with a longer warm-up (it never happened
+    // in any test or sweep, down to 0 dB and on unstructured random rows).
+    if (edge) {
+        bool bad = false;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const double pe = wf_wave_shr1(L.m0[s4]);
+            bad |= __double_as_longlong(pe) != __double_as_longlong(L.ms[s4]);
+        }
+        bad = bad && live && lane > 0;
+        const unsigned long long nb = __builtin_amdgcn_ballot_w64(bad);
+        if (nb && lane == 0) atomicAdd(unmerged, (unsigned long long)__popcll(nb));
+        double *e = edge + 8 * (g0 >> 6);
+        if (live && lane == 0)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) e[s4] = L.ms[s4];
+        if (live && lane == WF_WAVE - 1)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) e[4 + s4] = L.m0[s4];
+    }
     if (state && live && a + CH >= ncalls) {
         // the lane that owns the last call hands the detector state on (streaming).  Written
         // to the second half of the carry block; viterbi_carry_commit_kernel moves it.
@@ -410,14 +444,26 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
 template <bool PACKED>
 __global__ __launch_bounds__(VIT_THREADS, VIT_MIN_WAVES) void viterbi_batch_kernel(const double *__restrict__ mf, int64_t ncalls,
                                                                      int ch, int diff, int warmup, uint8_t *__restrict__ bits,
-                                                                     int8_t *__restrict__ syms, double *__restrict__ state)
+                                                                     int8_t *__restrict__ syms, double *__restrict__ state,
+                                                                     double *__restrict__ edge, unsigned long long *__restrict__ unmerged)
 {
     __shared__ double2 s_rows[VIT_THREADS / WF_WAVE][WF_WAVE * VIT_LANE_SLOTS];
     extern __shared__ uint64_t s_dec[];   // packed decisions, one strip of ch / 16 + 1 words per lane
     const int64_t i0 = state ? (int64_t)state[0] : 0;
     // call index of step 0 is lane_start - warmup - 1 with lane_start a multiple of ch (even)
-    if ((i0 - warmup - 1) & 1) viterbi_batch_body<1, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
-    else viterbi_batch_body<0, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec);
+    if ((i0 - warmup - 1) & 1) viterbi_batch_body<1, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec, edge, unmerged);
+    else viterbi_batch_body<0, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec, edge, unmerged);
+}
+
+// Wave w's first lane against wave w-1's last lane (see the end of viterbi_batch_body).
+__global__ void viterbi_verify_kernel(const double *__restrict__ edge, int64_t nwaves, unsigned long long *__restrict__ unmerged)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (w >= nwaves) return;
+    bool bad = false;
+    for (int s4 = 0; s4 < 4; ++s4)
+        bad |= __double_as_longlong(edge[8 * w + s4]) != __double_as_longlong(edge[8 * (w - 1) + 4 + s4]);
+    if (bad) atomicAdd(unmerged, 1ull);
 }
 
 __global__ void viterbi_carry_commit_kernel(double *state)
@@ -456,6 +502,10 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
     hipStream_t s = wf_stream(stream);
     const size_t lds = (size_t)VIT_THREADS * (ch / 16 + 1) * sizeof(uint64_t);
+    const int64_t nwaves_live = (nthreads + WF_WAVE - 1) / WF_WAVE;     // waves that own at least one call
+    int rcv = wf_ctx_reserve_vit(ctx, (size_t)nwaves_live * 8);
+    if (rcv) return rcv;
+    double *edge = ctx->d_vit_edge;
     if (lds > 32 * 1024) {
         const void *kfn = packed ? reinterpret_cast<const void *>(viterbi_batch_kernel<true>)
                                  : reinterpret_cast<const void *>(viterbi_batch_kernel<false>);
@@ -463,11 +513,16 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     }
     if (packed)
         hipLaunchKernelGGL(viterbi_batch_kernel<true>, dim3((unsigned)nblocks), dim3(VIT_THREADS), lds, s, d_mf_ri, ncalls, ch,
-                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
+                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state, edge, ctx->d_vit_unmerged);
     else
         hipLaunchKernelGGL(viterbi_batch_kernel<false>, dim3((unsigned)nblocks), dim3(VIT_THREADS), lds, s, d_mf_ri, ncalls, ch,
-                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state);
+                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state, edge, ctx->d_vit_unmerged);
     WF_LAUNCH_CHECK();
+    if (nwaves_live > 1) {
+        hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((nwaves_live - 1 + 255) / 256)), dim3(256), 0, s, edge,
+                           nwaves_live, ctx->d_vit_unmerged);
+        WF_LAUNCH_CHECK();
+    }
     if (d_state) {
         hipLaunchKernelGGL(viterbi_carry_commit_kernel, dim3(1), dim3(64), 0, s, d_state);
         WF_LAUNCH_CHECK();
@@ -480,6 +535,19 @@ extern "C" int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t nc
                                   void *stream)
 {
     return viterbi_launch(ctx, d_mf_ri, ncalls, differential, warmup, d_bits, d_syms, d_state, stream);
+}
+
+extern "C" int wf_viterbi4_unmerged(wf_ctx *ctx, int64_t *h_count, int reset, void *stream)
+{
+    WF_REQUIRE(ctx && h_count, "wf_viterbi4_unmerged: NULL argument");
+    WF_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = wf_stream(stream);
+    unsigned long long v = 0;
+    WF_HIP(hipMemcpyAsync(&v, ctx->d_vit_unmerged, sizeof(v), hipMemcpyDeviceToHost, s));
+    WF_HIP(hipStreamSynchronize(s));
+    if (reset && v) WF_HIP(hipMemsetAsync(ctx->d_vit_unmerged, 0, sizeof(v), s));
+    *h_count = (int64_t)v;
+    return WF_OK;
 }
 
 int wf_viterbi4_detect_packed(wf_ctx *ctx, const double *d_rows4, int64_t ncalls, int differential, int warmup,

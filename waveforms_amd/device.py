@@ -168,6 +168,15 @@ def viterbi_detect(mf_rows, differential: bool = True, warmup: int = 0, state=No
     return bits[:ncalls], syms[:ncalls]
 
 
+def viterbi_unmerged(reset: bool = True, ctx=None) -> int:
+    """Chunks of the batch detector whose warm-up did not arrive at the true path metrics since the
+    last reset (``wf_viterbi4_unmerged``; synchronises).  0 = every batch call reproduced the
+    sequential detector bit for bit."""
+    n = ctypes.c_int64(0)
+    _hip.check(_hip.lib().wf_viterbi4_unmerged(ctx if ctx is not None else _hip.ctx(), ctypes.byref(n), int(reset), _hip.stream()))
+    return int(n.value)
+
+
 def count_errors(det_syms, ref_syms, det_bits, ref_bits, m: int, counts=None):
     """K11: counts[0] += symbol errors, counts[1] += bit errors over the first m elements."""
     if counts is None:

@@ -106,8 +106,16 @@ class SOQPSKLink:
         self.compared += m.value
 
     def result(self) -> tuple[int, int, int]:
-        """(symbol errors, bit errors, symbols compared) — synchronises."""
+        """(symbol errors, bit errors, symbols compared) — synchronises.  Raises if the detector
+        reported a chunk whose warm-up had not reached the true path metrics (the counts would then
+        not be provably those of the sequential detector): re-run with a larger ``warmup``."""
         _hip.check(_hip.lib().wf_ctx_check(self._ctx, _hip.stream()))
+        from waveforms_amd import device as dev
+
+        unmerged = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
+        if unmerged:
+            raise RuntimeError(f"{unmerged} detector chunk(s) did not merge with the sequential path within the "
+                               f"warm-up; construct the link with a larger warmup= (current {self.cfg.warmup or 47})")
         se, be = (int(v) for v in self.counts.cpu().tolist())
         return se, be, self.compared
 
@@ -209,6 +217,5 @@ class SOQPSKStream:
         return self.result()
 
     def result(self) -> tuple[int, int, int]:
-        _hip.check(_hip.lib().wf_ctx_check(self._ctx, _hip.stream()))
-        se, be = (int(v) for v in self.counts.cpu().tolist())
-        return se, be, self.compared
+        """Like :meth:`SOQPSKLink.result` (raises if a detector chunk did not merge)."""
+        return SOQPSKLink.result(self)

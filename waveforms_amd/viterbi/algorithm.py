@@ -94,8 +94,20 @@ class SOQPSKTrellisDetector:
         self._mode = "batch"
         if self._d_carry is None:
             self._d_carry = _hip.zeros(32, "float64")
-        out = dev.viterbi_detect(mf_rows, self.differential, warmup, self._d_carry)
-        self.i += int(mf_rows.shape[0])     # like iteration(): one call per row, state carried
+        # The kernel is chunk-parallel; it reports chunks whose warm-up did not reach the true path
+        # metrics (none in practice).  Such a call is repeated from the same carried state with a
+        # longer warm-up until it is provably the sequential detector's output.
+        n = int(mf_rows.shape[0])
+        carry0 = self._d_carry.clone()
+        dev.viterbi_unmerged(reset=True)
+        w = warmup
+        while True:
+            out = dev.viterbi_detect(mf_rows, self.differential, w, self._d_carry)
+            if dev.viterbi_unmerged(reset=True) == 0 or w >= 4096:
+                break
+            w = max(2 * w, 256)
+            self._d_carry.copy_(carry0)
+        self.i += n                         # like iteration(): one call per row, state carried
         return out
 
     def detect(self, mf_rows: NDArray[np.complex128], warmup: int = 0):

@@ -357,12 +357,12 @@ __device__ __forceinline__ double wf_log_unit32(uint32_t xa, const Tabs &tb)
     return fmin(fma(de, 6.93147180369123816490e-01, fma(r, p, tc.y) + de * 1.90821492927058770002e-10), 0.0);
 }
 
-// sqrt(max(a, 0)) for a normal-range double: v_rsq_f64 seed, one Goldschmidt step, then one
-// Newton correction on the exactly computed residual (< 1 ulp).  Negative inputs (a rounding-level -0.0...01 from -2 ln(1)) give 0 — without the
-// clamp, a * rsq(tiny) would turn them into ~1e133.
-__device__ __forceinline__ double wf_sqrt_pos(double a)
+// sqrt(a) for a normal-range double a >= +0: v_rsq_f64 seed, one Goldschmidt step, then one
+// Newton correction on the exactly computed residual (< 1 ulp).  a = 0 gives 0 (the seed's
+// argument is floored).  The caller must not pass a negative a: -2 ln(u) for u = 1 once rounded
+// to -4e-19 and a * rsq(tiny) turned it into 1e133 — wf_log_unit32 clamps its result to <= 0.
+__device__ __forceinline__ double wf_sqrt_pos(double a)   // a >= +0.0 (the caller's log is clamped to <= 0)
 {
-    a = fmax(a, 0.0);
     const double y = __builtin_amdgcn_rsq(fmax(a, 0x1.0p-1000));   // relative error <= 2^-23
     double g = a * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);

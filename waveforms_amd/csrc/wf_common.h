@@ -113,12 +113,15 @@ __device__ __forceinline__ void wf_lds_barrier()
 // A double moved across lanes by DPP (two v_mov_b32_dpp): lanes without a source, or in rows
 // outside ROW_MASK, receive 0.0.  CTRL: 0x110 + n = row_shr:n, 0x142 = row_bcast:15,
 // 0x143 = row_bcast:31, 0x138 = wave_shr:1.
+// With every row enabled, bound_ctrl lets the hardware supply the zeros (no register has to be
+// cleared first); with a row mask the untouched rows keep the zero passed as `old`.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double wf_dpp_f64(double v)
 {
+    constexpr bool BC = ROW_MASK == 0xf;
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, BC);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, BC);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 

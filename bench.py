@@ -36,7 +36,7 @@ def stage_bytes_per_symbol(sps: int, nfilt: int = 3) -> dict:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 
 # stage -> kernel that dominates it (names as rocprofv3 prints them)
-STAGE_KERNEL = {"fir": "fir_kernel<9>", "phase": "phase_kernel", "modulate": "mod_main_kernel<9>",
+STAGE_KERNEL = {"fir": "fir_kernel<9>", "phase": "phase_kernel", "modulate": "mod_main_kernel<9, true>",
                 "awgn": "awgn_kernel", "mfbank": "mf_bank_kernel<3, false, 8, 9>", "awgn+mfbank": "mf_bank_kernel<3, true, 8, 9>",
                 "viterbi": "viterbi_batch_kernel<false>", "count": "count_errors_kernel", "prbs": "lfsr_kernel",
                 "encode": "enc_reduce_kernel"}

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
 #ifndef MOD_MIN_WAVES
 #define MOD_MIN_WAVES 1
 #endif
-template <int JMAX>
+// FULLROW: the row is exactly 2 * MOD_THREADS samples (sps divides 512: every thread is active and
+// every column is in the row), so the per-lane activity tests and their zero fills drop out.
+template <int JMAX, bool FULLROW>
 __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(const int8_t *__restrict__ symbols,
                                                                 const double *__restrict__ hvec,
                                                                 const double *__restrict__ pulse,
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int sps = P.sps;
-    const bool active = 2 * t < P.rs;
+    const bool active = FULLROW || 2 * t < P.rs;
     const int tile_len = MOD_ROWS * P.rs;
     const int sym_per_row = P.rs / sps;
     const int cq = P.c / sps;
@@ -399,11 +401,11 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
             if (xa.x == 1.2345e300 && xb.y == 1.2345e300)
 #endif
             if (full_tile) {   // block-uniform: no per-lane 64-bit window tests
-                if (col < P.rs) o[na - P.out_origin] = xa;
-                if (col + WF_WAVE < P.rs) o[nb - P.out_origin] = xb;
+                if (FULLROW || col < P.rs) o[na - P.out_origin] = xa;
+                if (FULLROW || col + WF_WAVE < P.rs) o[nb - P.out_origin] = xb;
             } else {
-                if (col < P.rs && na >= P.out_origin && na < P.out_hi) o[na - P.out_origin] = xa;
-                if (col + WF_WAVE < P.rs && nb >= P.out_origin && nb < P.out_hi) o[nb - P.out_origin] = xb;
+                if ((FULLROW || col < P.rs) && na >= P.out_origin && na < P.out_hi) o[na - P.out_origin] = xa;
+                if ((FULLROW || col + WF_WAVE < P.rs) && nb >= P.out_origin && nb < P.out_hi) o[nb - P.out_origin] = xb;
             }
             run += rowtot;
         }
@@ -464,10 +466,16 @@ static int mod_launch(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols,
     const int64_t max_grid = 2048 * (256 / MOD_THREADS);
     const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
     const int sps = P.sps;
-#define MOD_LAUNCH(JM)                                                                              \
-    hipLaunchKernelGGL(mod_main_kernel<JM>, dim3(grid), dim3(MOD_THREADS),                          \
-                       (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2) * sizeof(double), s, d_symbols, d_h, \
-                       d_pulse, scratch, d_out_ri, P)
+#define MOD_LAUNCH(JM)                                                                                   \
+    do {                                                                                                 \
+        const size_t lds = (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2) * sizeof(double);                  \
+        if (P.rs == 2 * MOD_THREADS)                                                                     \
+            hipLaunchKernelGGL((mod_main_kernel<JM, true>), dim3(grid), dim3(MOD_THREADS), lds, s, d_symbols, d_h, \
+                               d_pulse, scratch, d_out_ri, P);                                           \
+        else                                                                                             \
+            hipLaunchKernelGGL((mod_main_kernel<JM, false>), dim3(grid), dim3(MOD_THREADS), lds, s, d_symbols, d_h, \
+                               d_pulse, scratch, d_out_ri, P);                                           \
+    } while (0)
     if (J <= 4) MOD_LAUNCH(4);
     else if (J <= 9) MOD_LAUNCH(9);
     else if (J <= 17) MOD_LAUNCH(17);

@@ -4,11 +4,11 @@
 //
 // One step of the register is the linear map T over GF(2)^64:
 //   T e_0 = mask, T e_c = e_{c-1}.
-// The context caches, per mask, T^(2^j), j = 0..63 and T^(256 t), t = 0..255 (column form).
-// Block b jumps to position skip + b*2^16 with one wave doing matrix-vector products in
+// The context caches, per mask, T^(2^j), j = 0..63 and T^(B t), t = 0..255, B = bits per thread
+// (128; column form).  Block b jumps to position skip + b*256*B with one wave doing matrix-vector products in
 // parallel (lane c holds column c, XOR-reduce by DPP, result read back as a scalar); every
-// thread then jumps a further t*256 steps with ONE product against its own T^(256 t) (the
-// columns selected by the set bits of the block state, coalesced loads) and emits 256 bits,
+// thread then jumps a further t*B steps with ONE product against its own T^(B t) (the
+// columns selected by the set bits of the block state, coalesced loads) and emits B bits,
 // in a 32-bit register when the degree allows.  Bits are re-packed through LDS so that global
 // stores are 16 B per lane, fully coalesced.
 #include <vector>
@@ -16,10 +16,12 @@
 #include "wf_common.h"
 
 #define LFSR_THREADS 256
-#define LFSR_WORDS 4                                               // 64-bit words per thread
-#define LFSR_BITS_PER_THREAD (64 * LFSR_WORDS)                     // 2^8
-#define LFSR_LOG2_BPT 8
-#define LFSR_BITS_PER_BLOCK (LFSR_THREADS * LFSR_BITS_PER_THREAD)  // 2^16
+#ifndef LFSR_WORDS
+#define LFSR_WORDS 2                                               // 64-bit words per thread (1, 2 or 4)
+#endif
+#define LFSR_BITS_PER_THREAD (64 * LFSR_WORDS)
+#define LFSR_LOG2_BPT (LFSR_WORDS == 4 ? 8 : LFSR_WORDS == 2 ? 7 : 6)
+#define LFSR_BITS_PER_BLOCK (LFSR_THREADS * LFSR_BITS_PER_THREAD)
 
 static inline uint64_t host_matvec(const uint64_t *cols, uint64_t v)
 {
@@ -41,14 +43,14 @@ static wf_lfsr_tables *get_tables(wf_ctx *ctx, uint64_t mask)
     for (int c = 1; c < 64; ++c) t->host[0][c] = 1ull << (c - 1);
     for (int j = 1; j < 64; ++j)
         for (int c = 0; c < 64; ++c) t->host[j][c] = host_matvec(t->host[j - 1], t->host[j - 1][c]);
-    // thread-jump table behind the 64 x 64 words: TJ[c][t] = column c of T^(256 t)
+    // thread-jump table behind the 64 x 64 words: TJ[c][t] = column c of T^(B t), B = bits per thread
     std::vector<uint64_t> tj((size_t)64 * LFSR_THREADS);
     {
         uint64_t cur[64];
         for (int c = 0; c < 64; ++c) cur[c] = 1ull << c;                       // T^0
         for (int th = 0; th < LFSR_THREADS; ++th) {
             for (int c = 0; c < 64; ++c) tj[(size_t)c * LFSR_THREADS + th] = cur[c];
-            for (int c = 0; c < 64; ++c) cur[c] = host_matvec(t->host[LFSR_LOG2_BPT], cur[c]);   // T^256 * (.)
+            for (int c = 0; c < 64; ++c) cur[c] = host_matvec(t->host[LFSR_LOG2_BPT], cur[c]);   // T^B * (.)
         }
     }
     if (hipMalloc(&t->dev, sizeof(t->host) + tj.size() * sizeof(uint64_t)) != hipSuccess ||
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
         if (t == 0) s_base = s;
     }
     __syncthreads();
-    // thread t: T^(256 t) * base — XOR of the columns picked by the set bits of the (block-uniform)
+    // thread t: T^(B t) * base — XOR of the columns picked by the set bits of the (block-uniform)
     // base state; the loads are coalesced over t
     const uint64_t base = s_base;
     const uint64_t *tj = jump + 64 * 64;

@@ -110,6 +110,23 @@ __device__ __forceinline__ void wf_lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// 16 B accesses with the non-temporal hint, for the 1.28 GB of baseband samples the modulator
+// writes once and the next kernel reads once: the lines do not linger in L2 as dirty data.
+// Measured inside the link: modulator 0.297 -> 0.284 ms and the channel kernel that reads those
+// samples 0.408 -> 0.391 ms.  (The same hint on the bank's row stores, on its sample loads and on
+// the detector's row loads changed nothing.)
+typedef double wf_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wf_store16_nt(double2 *p, double2 v)
+{
+    wf_v2d t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<wf_v2d *>(p));
+}
+__device__ __forceinline__ double2 wf_load16_nt(const double2 *p)
+{
+    const wf_v2d t = __builtin_nontemporal_load(reinterpret_cast<const wf_v2d *>(p));
+    return make_double2(t.x, t.y);
+}
+
 // A double moved across lanes by DPP (two v_mov_b32_dpp): lanes without a source, or in rows
 // outside ROW_MASK, receive 0.0.  CTRL: 0x110 + n = row_shr:n, 0x142 = row_bcast:15,
 // 0x143 = row_bcast:31, 0x138 = wave_shr:1.

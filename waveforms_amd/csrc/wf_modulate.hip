@@ -401,11 +401,11 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
             if (xa.x == 1.2345e300 && xb.y == 1.2345e300)
 #endif
             if (full_tile) {   // block-uniform: no per-lane 64-bit window tests
-                if (FULLROW || col < P.rs) o[na - P.out_origin] = xa;
-                if (FULLROW || col + WF_WAVE < P.rs) o[nb - P.out_origin] = xb;
+                if (FULLROW || col < P.rs) wf_store16_nt(o + (na - P.out_origin), xa);
+                if (FULLROW || col + WF_WAVE < P.rs) wf_store16_nt(o + (nb - P.out_origin), xb);
             } else {
-                if ((FULLROW || col < P.rs) && na >= P.out_origin && na < P.out_hi) o[na - P.out_origin] = xa;
-                if ((FULLROW || col + WF_WAVE < P.rs) && nb >= P.out_origin && nb < P.out_hi) o[nb - P.out_origin] = xb;
+                if ((FULLROW || col < P.rs) && na >= P.out_origin && na < P.out_hi) wf_store16_nt(o + (na - P.out_origin), xa);
+                if ((FULLROW || col + WF_WAVE < P.rs) && nb >= P.out_origin && nb < P.out_hi) wf_store16_nt(o + (nb - P.out_origin), xb);
             }
             run += rowtot;
         }

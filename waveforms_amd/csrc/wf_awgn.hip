@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void awgn_kernel(const double *in, int64_t n, 
         const double2 ra = xw[lane], rc = xw[WF_WAVE + lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (oka) out2[ka] = ra;
-        if (okc) out2[kc] = rc;
+        if (oka) wf_store16_nt(out2 + ka, ra);   // streamed once, read once by the next kernel
+        if (okc) wf_store16_nt(out2 + kc, rc);
     }
 }
 

@@ -88,7 +88,9 @@ __global__ __launch_bounds__(FIR_THREADS) void fir_kernel(const int8_t *__restri
                     acc1 = fma(tap1[i], v, acc1);
                 }
                 if (n + 1 < P.out_len) {
-                    *reinterpret_cast<double2 *>(out + n) = make_double2(acc0, acc1);
+                    // non-temporal: the phase scan that reads this next runs 5 % faster when these
+                    // lines are not left dirty in L2 (this kernel itself 2 % slower)
+                    wf_store16_nt(reinterpret_cast<double2 *>(out + n), make_double2(acc0, acc1));
                 } else if (n < P.out_len) {
                     out[n] = acc0;
                 }

@@ -210,8 +210,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const double *__restr
             __builtin_amdgcn_wave_barrier();   // strip read before the next row overwrites it
             const int64_t na = base + u * PH_ROW + wave * (2 * WF_WAVE) + lane, nb = na + WF_WAVE;
             double2 *o = reinterpret_cast<double2 *>(out);
-            if (na < P.n) o[na] = xa;
-            if (nb < P.n) o[nb] = xb;
+            if (na < P.n) wf_store16_nt(o + na, xa);   // streamed once, read once by the next kernel
+            if (nb < P.n) wf_store16_nt(o + nb, xb);
         }
     }
 }

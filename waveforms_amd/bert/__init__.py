@@ -74,6 +74,11 @@ def gpu_block_runner(plan: SweepPlan):
 
     def finish() -> np.ndarray:
         _hip.device_check()
+        from waveforms_amd import device as dev
+
+        unmerged = dev.viterbi_unmerged(reset=True)
+        if unmerged:   # the detector could not prove some chunk equal to the sequential detector
+            raise RuntimeError(f"{unmerged} detector chunk(s) did not merge within the warm-up; raise SweepPlan/link warmup")
         out = np.zeros((npts, 3), dtype=np.int64)
         out[:, :2] = table.cpu().numpy()
         out[:, 2] = compared

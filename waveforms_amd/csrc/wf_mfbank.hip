@@ -29,6 +29,7 @@ struct mf_params {
     int span;  // input samples staged per iteration
     int pad;   // 1: one pad slot every `step` samples
     int dump;  // LDS slot that absorbs the partial pairs of the interior staging path
+    int taps_slot;   // step-8, any-length bank: LDS slot of the tap copy [NF][ntaps] (rows >= nfilt zero)
     int64_t nblk;
     // fused channel (NOISE instantiation): staged sample = r*rot + sigma*N(idx)
     double rot_re, rot_im, sigma;
@@ -66,6 +67,15 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
     // The fused channel of the step-8 fast path keeps the Gaussian source's two tables in the
     // window's 256 PAD slots (slot 9 g + 8 is never written by the staging): LDS for free, and no
     // global table loads queued behind the previous iteration's stores on vmcnt.
+    // Long banks at step 8 (the 73-tap PAM bank): the taps are copied behind the window once per
+    // workgroup and read back as broadcasts; as scalar loads inside the tap loop every trip waited
+    // for three dependent s_loads (fused channel + PAM bank: 1.12 ms).
+    constexpr bool LONG8 = STEP == 8 && NTAPS == 0;
+    if (LONG8) {
+        double2 *lt = s_win + P.taps_slot;
+        for (int k = t; k < NF * ntaps; k += MF_THREADS)
+            lt[k] = k < P.nfilt * ntaps ? reinterpret_cast<const double2 *>(taps)[k] : make_double2(0.0, 0.0);
+    }
     constexpr bool LDS_TABS = NOISE && STEP == 8;
     if (LDS_TABS) wf_stage_tables<9, 8>(s_win, t, MF_THREADS);   // first use is behind the loop's barrier
     for (int64_t blk = blockIdx.x; blk < P.nblk; blk += gridDim.x) {
@@ -227,6 +237,32 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                         ai[f] = fma(x[j].x, tp.y, fma(x[j].y, tp.x, ai[f]));
                     }
                 }
+            } else if (LONG8) {
+                const double2 *lt = s_win + P.taps_slot;
+                const int ng = ntaps >> 3;
+                for (int g = 0; g < ng; ++g) {
+                    const double2 *xw = s_win + base + 9 * g;          // 8 samples, then one pad slot
+                    const double2 *tg = lt + (ntaps - 1 - 8 * g);      // tap of sample 8 g, going down
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const double2 x = xw[r];
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const double2 tp = tg[f * ntaps - r];
+                            ar[f] = fma(x.x, tp.x, fma(-x.y, tp.y, ar[f]));
+                            ai[f] = fma(x.x, tp.y, fma(x.y, tp.x, ai[f]));
+                        }
+                    }
+                }
+                for (int j = 8 * ng; j < ntaps; ++j) {                 // ntaps % 8 trailing taps
+                    const double2 x = s_win[base + j + (j >> 3)];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const double2 tp = lt[f * ntaps + (ntaps - 1 - j)];
+                        ar[f] = fma(x.x, tp.x, fma(-x.y, tp.y, ar[f]));
+                        ai[f] = fma(x.x, tp.y, fma(x.y, tp.x, ai[f]));
+                    }
+                }
             } else {
                 int extra = 0, jm = 0;
 #ifdef WF_ABL_NO_MAC
@@ -333,7 +369,9 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     // slots (tables), so its dump slot sits behind pad slot 255
     P.dump = P.span + (P.pad ? P.span / step + 1 : 0);
     if (noise && step == 8 && P.dump < 9 * 256) P.dump = 9 * 256;
-    const int slots = P.dump + 1;
+    P.taps_slot = P.dump + 1;
+    const bool long8 = step == 8 && nfilt <= 3 && !(nfilt == 3 && ntaps == 9);
+    const int slots = P.dump + 1 + (long8 ? 3 * ntaps : 0);
     P.nblk = (ncols + P.ob - 1) / P.ob;
     const int grid = (int)(P.nblk < 4096 ? P.nblk : 4096);
     hipStream_t s = wf_stream(stream);

@@ -191,7 +191,8 @@ def main() -> None:
     if packed:          # detector-packed rows: 4 doubles per symbol between the bank and the detector
         bps["awgn+mfbank"] = 16 * args.sps + 32
         bps["viterbi"] = 32 + 2
-        STAGE_KERNEL["awgn+mfbank"] = "mf_bank_kernel<3, true, 8, 9, true>"
+        STAGE_KERNEL["awgn+mfbank"] = ("mf_bank_kernel<3, true, 8, 9, true>" if links[0].cfg.mf_ntaps == 9
+                                       else "mf_bank_kernel<3, true, 8, 0, true>")
         STAGE_KERNEL["viterbi"] = "viterbi_batch_kernel<true>"
     stages = {}
     for name, ms in acc.items():

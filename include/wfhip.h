@@ -228,7 +228,7 @@ typedef struct {
     int fuse;               /* bit 0: fused modulator (wf_cpm_modulate_c128) instead   */
                             /* of the FIR + phase-scan stage kernels; bit 1: AWGN      */
                             /* inside the MF bank (wf_awgn_mf_bank_c128); bit 2 (with  */
-                            /* bit 1, 3 x 9-tap bank, sps 8): the bank writes only the */
+                            /* bit 1, 3-filter bank, sps 8): the bank writes only the  */
                             /* 4 real components per call the 4-state detector reads   */
                             /* ({Re z1, Im z1, Re|Im z0, Im|Re z2}: 32 B rows, not 48) */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */

@@ -522,7 +522,7 @@ def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
         want_bits = ws[lay["off_bits"]:lay["off_bits"] + calls].clone()
         want_syms = ws[lay["off_syms"]:lay["off_syms"] + calls].clone()
         rb = one.row_bytes            # 48, or 32 with detector-packed rows (fuse bit 2 in effect)
-        assert rb == st.row_bytes == (32 if fuse == 7 and detector == "PT" else 48)
+        assert rb == st.row_bytes == (32 if fuse == 7 else 48)
         want_mf = ws[lay["off_mf"]:lay["off_mf"] + calls * rb].clone()
         st.reset()
         seen = 0

@@ -221,4 +221,5 @@ def test_link_row_bytes_rule():
 
     assert rb(7) == 32 and rb(6) == 32
     assert rb(3) == 48 and rb(0) == 48 and rb(5) == 48      # bit 2 needs the fused channel (bit 1)
-    assert rb(7, sps=4) == 48 and rb(7, ntaps=17) == 48     # only the 3 x 9-tap bank at 8 samples per symbol
+    assert rb(7, sps=4) == 48 and rb(7, nfilt=1) == 16          # 3-filter banks at 8 samples per symbol only
+    assert rb(7, ntaps=73) == 32                                # any tap count (the PAM bank)

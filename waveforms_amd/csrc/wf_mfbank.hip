@@ -339,8 +339,8 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     P.first_index = first_index;
     P.dyn_index = d_dyn_index;
     P.pack_par0 = pack_par0 & 1;
-    WF_REQUIRE(pack_par0 < 0 || (noise && step == 8 && nfilt == 3 && ntaps == 9),
-               "wf_awgn_mf_bank: packed rows exist for the fused 3 x 9-tap, step-8 bank only");
+    WF_REQUIRE(pack_par0 < 0 || (noise && step == 8 && nfilt == 3),
+               "wf_awgn_mf_bank: packed rows exist for the fused 3-filter, step-8 bank only");
     // slots(ob) = (ob-1)*step + ntaps + pad*(that/step + 1) <= MF_LDS_SLOTS
     int ob = MF_THREADS;
     for (;;) {
@@ -370,7 +370,7 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     P.dump = P.span + (P.pad ? P.span / step + 1 : 0);
     if (noise && step == 8 && P.dump < 9 * 256) P.dump = 9 * 256;
     P.taps_slot = P.dump + 1;
-    const bool long8 = step == 8 && nfilt <= 3 && !(nfilt == 3 && ntaps == 9);
+    const bool long8 = step == 8 && nfilt <= 3 && !(nfilt == 3 && ntaps == 9);   // the <3, *, 8, 0> instantiations
     const int slots = P.dump + 1 + (long8 ? 3 * ntaps : 0);
     P.nblk = (ncols + P.ob - 1) / P.ob;
     const int grid = (int)(P.nblk < 4096 ? P.nblk : 4096);
@@ -378,7 +378,7 @@ static int mf_bank_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, cons
     const size_t lds = (size_t)slots * sizeof(double2);
     using kern_t = void (*)(const double *, const double *, double *, mf_params);
     kern_t k;
-    if (pack_par0 >= 0) k = mf_bank_kernel<3, true, 8, 9, true>;
+    if (pack_par0 >= 0) k = ntaps == 9 ? mf_bank_kernel<3, true, 8, 9, true> : mf_bank_kernel<3, true, 8, 0, true>;
     else if (step == 8 && nfilt == 3 && ntaps == 9) k = noise ? mf_bank_kernel<3, true, 8, 9> : mf_bank_kernel<3, false, 8, 9>;
     else if (step == 8 && nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 8, 0> : mf_bank_kernel<3, false, 8, 0>;
     else if (nfilt <= 3) k = noise ? mf_bank_kernel<3, true, 0, 0> : mf_bank_kernel<3, false, 0, 0>;

@@ -63,10 +63,10 @@ static link_layout make_layout(int64_t nsym, int sps, int ntaps, int nfilt, int 
 }
 
 // fuse bit 2: the fused channel + bank writes detector-packed rows (4 doubles per call instead of
-// 3 complex) and the detector reads those.  Exists for the 3 x 9-tap bank at 8 samples per symbol.
+// 3 complex) and the detector reads those.  Exists for 3-filter banks at 8 samples per symbol.
 static bool link_packed_rows(const wf_link_config *cfg)
 {
-    return (cfg->fuse & 4) && (cfg->fuse & 2) && cfg->sps == 8 && cfg->mf_ntaps == 9 && cfg->mf_nfilt == 3;
+    return (cfg->fuse & 4) && (cfg->fuse & 2) && cfg->sps == 8 && cfg->mf_nfilt == 3;
 }
 
 extern "C" int64_t wf_link_workspace_bytes(const wf_link_config *cfg)

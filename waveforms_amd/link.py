@@ -68,9 +68,9 @@ class SOQPSKLink:
     @property
     def row_bytes(self) -> int:
         """Bytes per matched-filter row in the workspace: 48 (3 complex128), or 32 when fuse bit 2 is
-        in effect (detector-packed rows; 3 x 9-tap bank at 8 samples per symbol with the fused channel)."""
+        in effect (detector-packed rows; 3-filter bank at 8 samples per symbol with the fused channel)."""
         c = self.cfg
-        packed = (c.fuse & 4) and (c.fuse & 2) and c.sps == 8 and c.mf_ntaps == 9 and c.mf_nfilt == 3
+        packed = (c.fuse & 4) and (c.fuse & 2) and c.sps == 8 and c.mf_nfilt == 3
         return 32 if packed else 16 * c.mf_nfilt
 
     def layout(self) -> dict:

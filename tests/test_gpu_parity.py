@@ -752,3 +752,22 @@ def test_detector_reports_and_repairs_unmerged_chunks(oracle):
     want_b, want_s = oracle.viterbi_detect(noisy)
     assert np.array_equal(got_b, want_b) and np.array_equal(got_s, want_s)
     assert dev.viterbi_unmerged(reset=True) == 0
+
+
+@pytest.mark.parametrize("sps,detector", [(4, "PT"), (10, "PT"), (6, "PAM"), (16, "PT")])
+def test_link_other_sample_rates_equal_oracle(oracle, sps, detector):
+    """The link away from the tuned 8-samples-per-symbol path (generic bank and staging kernels,
+    unpacked rows) still equals the oracle chain count for count."""
+    from waveforms_amd.link import SOQPSKLink
+
+    nsym = 30_000
+    for fuse in (0, 7):
+        link = SOQPSKLink(nsym, sps, detector=detector, fuse=fuse)
+        assert link.row_bytes == (32 if sps == 8 and fuse == 7 else 48)
+        link.run_block(5.0, seed=21, stream_id=3, skip_bits=777)
+        got = link.result()
+        bits = oracle.glfsr_bits(0x420000, 0x7FFFFF, 777 + nsym)[0][777:]
+        noise = oracle.philox_awgn(oracle.sigma_for_ebn0(5.0, sps), 21, 3, 0, (nsym + 1) * sps)
+        res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(sps), 0.25, sps, None, noise=noise,
+                                   detector=detector, timing_offset=-1 if detector == "PT" else 0)
+        assert got == (res["sym_errors"], res["bit_errors"], res["compared"]) and got[1] > 0

@@ -211,7 +211,7 @@ def main() -> None:
     if rank == 0:
         total_sym = args.steps * args.nsym * world
         out = {
-            "metric": "SOQPSK-TG Msym/s mod+Viterbi-detect @8sps",
+            "metric": f"SOQPSK-TG Msym/s mod+Viterbi-detect @{args.sps}sps",   # BASELINE's metric at the default sps = 8
             "value": round(total_sym / elapsed / 1e6, 2), "unit": "Msym/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -771,3 +771,43 @@ def test_link_other_sample_rates_equal_oracle(oracle, sps, detector):
         res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(sps), 0.25, sps, None, noise=noise,
                                    detector=detector, timing_offset=-1 if detector == "PT" else 0)
         assert got == (res["sym_errors"], res["bit_errors"], res["compared"]) and got[1] > 0
+
+
+def test_cabi_rejects_bad_arguments_without_touching_the_device():
+    """Every entry point validates shapes, sizes and alignment on the host and returns a status (the
+    Python mirror raises) — a kernel is never launched on operands it was not written for."""
+    import ctypes
+
+    import torch
+
+    from waveforms_amd import _hip, device as dev
+
+    lib, ctx, st = _hip.lib(), _hip.ctx(), _hip.stream()
+    buf = _hip.zeros(4096, "float64")
+    odd = buf.data_ptr() + 8                                   # 8-byte aligned, not 16
+    taps = _hip.zeros((3, 9, 2), "float64")
+
+    def rc_of(name, *args):
+        return getattr(lib, name)(*args)
+
+    # misaligned complex buffers
+    assert rc_of("wf_mf_bank_c128", ctx, odd, 100, taps.data_ptr(), 3, 9, 0, 8, 5, buf.data_ptr(), st) < 0
+    assert rc_of("wf_awgn_c128", ctx, odd, 100, 1.0, 0.0, 1.0, 1, 0, 0, buf.data_ptr(), st) < 0
+    # shapes the kernels do not cover
+    assert rc_of("wf_mf_bank_c128", ctx, buf.data_ptr(), 100, taps.data_ptr(), 9, 9, 0, 8, 5, buf.data_ptr(), st) < 0   # nfilt 9
+    assert rc_of("wf_mf_bank_c128", ctx, buf.data_ptr(), 5, taps.data_ptr(), 3, 9, 0, 8, 1, buf.data_ptr(), st) < 0     # input < taps
+    assert rc_of("wf_mf_bank_c128", ctx, buf.data_ptr(), 100, taps.data_ptr(), 3, 9, 0, 8, 14, buf.data_ptr(), st) < 0  # columns past the end
+    assert rc_of("wf_viterbi4_detect", ctx, None, 10, 1, 0, buf.data_ptr(), buf.data_ptr(), None, st) < 0              # NULL rows
+    assert rc_of("wf_lfsr_generate", ctx, 70, 1, 1, 0, buf.data_ptr(), 10, None, st) == -2                              # KeyError class
+    assert rc_of("wf_lfsr_generate", ctx, 9, 0x110, 0x1FF, 0, odd + 1, 10, None, st) < 0                                # unaligned bits
+    assert rc_of("wf_cpm_modulate_c128", ctx, buf.data_ptr(), 10, buf.data_ptr(), 1, buf.data_ptr(), 9, 1, 0.0, buf.data_ptr(), st) == -1  # sps 1: ValueError class
+    assert rc_of("wf_phase_cexp_f64", ctx, buf.data_ptr(), -1, 8, 0.0, 0.0, buf.data_ptr(), None, st) < 0
+    n = ctypes.c_int64(0)
+    assert rc_of("wf_viterbi4_unmerged", ctx, None, 0, st) < 0
+    assert lib.wf_last_error_string().decode() != ""
+    # the Python mirror turns those into exceptions
+    with pytest.raises((ValueError, RuntimeError)):
+        dev.mf_bank(buf[:200].view(-1, 2), taps, 0, 8, 1000)
+    torch.cuda.synchronize()
+    _hip.device_check()                                       # nothing faulted
+    assert rc_of("wf_viterbi4_unmerged", ctx, ctypes.byref(n), 0, st) == 0

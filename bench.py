@@ -59,23 +59,75 @@ def measured_traffic(stage: str, nsym: int, sps: int):
     return best
 
 
-def cpu_baseline(sps: int, ebn0: float, nsym: int) -> dict:
-    """The oracle (CPU port of the reference algorithm: C loops + numpy) timed on one host
-    core over a bounded sample of the same workload."""
+def _cpu_pool_ready(_):
+    import oracle
+
+    oracle.build_c_oracle()
+    return os.getpid()
+
+
+def _cpu_trial(job):
+    """One independent trial block on one host core: own PRBS segment, own PCG64 noise stream."""
+    kind, idx, nsym, sps, ebn0 = job
     import numpy as np
 
     import oracle
 
-    oracle.build_c_oracle()
     t0 = time.perf_counter()
-    bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, nsym)
-    rng = np.random.Generator(np.random.PCG64(seed=1))
-    res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(sps), 0.25, sps,
-                               oracle.sigma_for_ebn0(ebn0, sps), rng=rng)
-    dt = time.perf_counter() - t0
-    return {"value": round(nsym / dt / 1e6, 4), "unit": "Msym/s", "cores": 1, "kind": "port",
-            "sample": f"{nsym} PN23 symbols of the same SOQPSK-TG @{sps}sps chain (oracle: C loops + numpy, "
-                      f"PCG64 noise), {dt:.1f} s, bit errors {res['bit_errors']}/{res['compared']}"}
+    state = ((idx + 1) * 2654435761) & 0x7FFFFF or 1
+    rng = np.random.Generator(np.random.PCG64(seed=1 + idx))
+    pulse, sigma = oracle.freq_pulse_soqpsk_tg(sps), oracle.sigma_for_ebn0(ebn0, sps)
+    if kind == "port":      # compiled / vectorised restatement (C loops + numpy)
+        bits, _ = oracle.glfsr_bits(0x420000, state, nsym)
+        res = oracle.detection_run(bits, pulse, 0.25, sps, sigma, rng=rng)
+    else:                   # the reference's execution form: interpreted per-symbol / per-sample loops
+        from oracle import faithful_loops as fl
+
+        bits, _ = fl.lfsr_bits_loop(0x420000, state, nsym)
+        res = fl.detection_run_loop(bits, pulse, 0.25, sps, sigma, rng)
+    return nsym, time.perf_counter() - t0, res["bit_errors"], res["compared"]
+
+
+def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int) -> dict:
+    """The oracle timed on the host cores of this box, one process per core on independent trial
+    blocks, in two forms: `port` = the CPU port of the reference algorithm (C loops +
+    numpy), and `faithful_loop` = the reference's own execution form (interpreted per-symbol
+    detector and per-sample modulator loops, oracle/faithful_loops.py).  Outside the timed region."""
+    import multiprocessing as mp
+
+    host_cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host_cores
+    cores = max(1, min(usable, 16))          # the CPU share of a one-GPU box is 16 cores
+    ctx = mp.get_context("spawn")            # never fork a process that has initialised HIP
+    out = {}
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_pool_ready, range(cores), chunksize=1)     # imports + C build outside the clock
+        for kind, n in (("port", nsym_port), ("faithful_loop", nsym_loop)):
+            one = _cpu_trial_timed(pool, [(kind, 0, n, sps, ebn0)])
+            many = _cpu_trial_timed(pool, [(kind, 1 + k, n, sps, ebn0) for k in range(cores)])
+            out[kind] = {"value": round(many["rate"], 4), "unit": "Msym/s", "cores": cores,
+                         "single_core": round(one["rate"], 4),
+                         "sample": f"{cores} independent blocks of {n} PN23 symbols, one process per core, "
+                                   f"{many['wall']:.1f} s wall (1 block on 1 core: {one['wall']:.1f} s); "
+                                   f"bit errors {many['bit_errors']}/{many['compared']}"}
+    return {"value": out["port"]["value"], "unit": "Msym/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+            "single_core": out["port"]["single_core"],
+            "sample": "same SOQPSK-TG @%dsps chain, Eb/N0 %.1f dB, oracle C loops + numpy, PCG64 noise: %s"
+                      % (sps, ebn0, out["port"]["sample"]),
+            "faithful_loop": {**out["faithful_loop"], "kind": "port",
+                              "note": "the reference's execution form (interpreted per-symbol Viterbi, per-sample phase loop, "
+                                      "full-rate np.convolve bank): what the reference costs on these cores"}}
+
+
+def _cpu_trial_timed(pool, jobs) -> dict:
+    t0 = time.perf_counter()
+    res = pool.map(_cpu_trial, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    return {"rate": sum(r[0] for r in res) / wall / 1e6, "wall": wall,
+            "bit_errors": sum(r[2] for r in res), "compared": sum(r[3] for r in res)}
 
 
 def main() -> None:
@@ -94,31 +146,24 @@ def main() -> None:
                     help="independent trial blocks in flight on separate HIP streams (own workspace + context each)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the per-stage HIP events on every E-th timed step only (the last step always)")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 24)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="symbols per core, compiled port")
+    ap.add_argument("--cpu-loop-sample", type=int, default=1 << 14, help="symbols per core, faithful-loop form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    from waveforms_amd.bert import init_ranks, spawn_ranks
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as child processes, before
+        # anything here has touched the GPU; rank 0 prints the JSON line on the inherited stdout
+        raise SystemExit(spawn_ranks(str(Path(__file__).resolve()), args.gpus, sys.argv[1:]))
     import torch
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
+    if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     # Rehearsal switch for a 1-GPU box: WF_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses
     # gloo for the two collectives, so the N > 1 code path can be exercised without N GPUs.
-    rehearsal = os.environ.get("WF_BENCH_REHEARSAL") == "1"
-    torch.cuda.set_device(0 if rehearsal else local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    coll_dev = "cpu" if rehearsal else "cuda"
+    rank, world, dist, coll_dev = init_ranks(rehearsal=os.environ.get("WF_BENCH_REHEARSAL") == "1")
 
     from waveforms_amd import _hip
     from waveforms_amd.link import SOQPSKLink
@@ -231,7 +276,7 @@ def main() -> None:
             "stages": stages,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

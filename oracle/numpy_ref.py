@@ -30,17 +30,22 @@ _lib = None
 
 
 def build_c_oracle(force: bool = False) -> Path:
-    """Compile ``wf_oracle.c`` with gcc (building the checker is not using it)."""
-    src = _HERE / "wf_oracle.c"
-    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
-        _SO.parent.mkdir(exist_ok=True)
-        tmp = _SO.with_suffix(f".{os.getpid()}.tmp")
+    """Compile the C restatements with gcc (building the checker is not using it).
+    WF_ORACLE_SANITIZE=1 (tools/sanitize.py, CPU box): an AddressSanitizer + UBSan build in its
+    own file; the process must then run with gcc's libasan preloaded."""
+    srcs = [_HERE / "wf_oracle.c"] + ([_HERE / "cpm_oracle.c"] if (_HERE / "cpm_oracle.c").exists() else [])
+    san = os.environ.get("WF_ORACLE_SANITIZE") == "1"
+    so = _SO.with_name("libwforacle_san.so") if san else _SO
+    if force or not so.exists() or so.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
+        so.parent.mkdir(exist_ok=True)
+        tmp = so.with_suffix(f".{os.getpid()}.tmp")
         # -ffp-contract=off: no fused multiply-adds, the reference's numpy/libm do none.
+        opt = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if san else ["-O2"]
         subprocess.check_call(
-            ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", str(tmp), str(src), "-lm"]
+            ["gcc", *opt, "-ffp-contract=off", "-fPIC", "-shared", "-o", str(tmp), *map(str, srcs), "-lm"]
         )
-        os.replace(tmp, _SO)
-    return _SO
+        os.replace(tmp, so)
+    return so
 
 
 def _c():

@@ -51,8 +51,8 @@ def test_golden_curve_is_monotone_and_crosses_targets():
 @pytest.mark.parametrize("detector", ["PT", "PAM"])
 def test_gpu_ber_curve_within_0p05_db_of_reference(detector):
     """Blocks of 2^17 symbols like the reference runs (same edge effects), 2^27 symbols per
-    point on the GPU (its sampling noise is then negligible); the tolerance is 0.05 dB plus
-    three standard deviations of the REFERENCE curve's own Poisson noise at the crossing."""
+    point on the GPU (its sampling noise is then negligible); the tolerance is the plain 0.05 dB
+    BASELINE.json states."""
     from ber_sweep import golden_curve
 
     from waveforms.bert import SweepPlan, ber_sweep, ebn0_at_ber
@@ -75,4 +75,8 @@ def test_gpu_ber_curve_within_0p05_db_of_reference(detector):
         sig_db = (1 / np.log(10)) / np.sqrt(min(gerr[j - 1], gerr[j])) / slope
         print(f"{detector} BER {target:g}: GPU {mine:.3f} dB, reference {ref:.3f} dB, delta {mine - ref:+.3f} dB "
               f"(reference 1-sigma {sig_db:.3f} dB)")
-        assert abs(mine - ref) <= 0.05 + 3 * sig_db
+        # the stated bar, outright: both curves are deterministic (fixed seeds, committed reference
+        # counts), so this is not a statistical acceptance test; the reference's own 1-sigma at the
+        # crossing (0.007 - 0.015 dB with the 4.4e7 reference symbols per point committed for
+        # 10 - 12 dB) is printed above for the reader, not added to the tolerance
+        assert abs(mine - ref) <= 0.05

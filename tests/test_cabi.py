@@ -47,6 +47,28 @@ def test_binding_table_matches_header(built_lib):
     assert lib.wf_link_workspace_bytes(ctypes.byref(cfg)) > 1000 * 8 * 24
 
 
+def test_geometry_entry_points_reject_out_of_range_sps(built_lib):
+    """sps = 0 and sps = 600 used to divide by zero on the host (SIGFPE) inside the fused
+    modulator's geometry; every exported way in now returns a status instead."""
+    from waveforms_amd import _hip
+
+    lib = _hip.lib()
+    tl, spt, nt = ctypes.c_int64(7), ctypes.c_int64(7), ctypes.c_int64(7)
+    for sps in (0, 1, 257, 600, -3):
+        assert lib.wf_mod_tile_geometry(sps, 65, 100000, ctypes.byref(tl), ctypes.byref(spt), ctypes.byref(nt)) == _hip.WF_ERR_VALUE
+        assert (tl.value, spt.value, nt.value) == (0, 0, 0)
+        cfg = _hip.LinkConfig()
+        cfg.nsym, cfg.sps, cfg.ntaps, cfg.mf_nfilt, cfg.mf_ntaps, cfg.timing_offset = 1 << 20, sps, 65, 3, 9, -1
+        assert lib.wf_link_stream_workspace_bytes(ctypes.byref(cfg), 1 << 16) == -1
+        info = (ctypes.c_int64 * 8)()
+        assert lib.wf_link_stream_layout(ctypes.byref(cfg), 1 << 16, 0, info) == _hip.WF_ERR_VALUE
+        assert lib.wf_link_stream_interior(ctypes.byref(cfg), 1 << 16, 1) == 0
+    assert lib.wf_mod_tile_geometry(8, 0, 100000, None, None, None) == _hip.WF_ERR_VALUE
+    assert lib.wf_mod_tile_geometry(8, 65, 0, None, None, None) == _hip.WF_ERR_VALUE
+    assert lib.wf_mod_tile_geometry(8, 65, 100000, ctypes.byref(tl), ctypes.byref(spt), ctypes.byref(nt)) == 0
+    assert (tl.value, spt.value) == (8192, 1024) and nt.value == 98
+
+
 def test_link_config_layout_matches_c(tmp_path):
     """ctypes mirror of wf_link_config == what a C compiler lays out from the header."""
     import subprocess

@@ -581,6 +581,43 @@ def test_stream_graph_replay_equals_eager_chunks():
         assert got == want and st.graph_replays == n_int and want[1] > 0
 
 
+def test_stream_config4_full_size_1e9_symbols():
+    """BASELINE configs[4] at its real size: a 1e9-symbol continuous stream (PN31) in chunks of
+    2^22 symbols.  Size-independent properties: the error counts do not depend on the chunking
+    (2^22 vs 3 * 2^21 symbols per chunk) nor on eager launches vs hipGraph replay of the steady
+    state, every symbol is compared exactly once, and the BER sits on the reference's curve."""
+    from waveforms_amd.link import SOQPSKStream
+
+    total = 1_000_000_000
+    a = SOQPSKStream(total, 1 << 22, 8, pn_degree=31)
+    want = a.run(10.0, seed=1, stream_id=4)
+    assert a.nchunks == 239 and want[2] == total - 3        # ncols - length compared, like the one-shot link
+    got_graph = a.run_graph(10.0, seed=1, stream_id=4)
+    assert got_graph == want and a.graph_replays == a.interior_chunks() >= 236
+    del a
+    b = SOQPSKStream(total, 3 << 21, 8, pn_degree=31)
+    assert b.nchunks == 159 and b.run(10.0, seed=1, stream_id=4) == want
+    assert 6.4e-4 < want[1] / want[2] < 7.2e-4               # reference at 10 dB: 6.6e-4 .. 6.8e-4
+
+
+def test_link_full_size_equals_oracle_chain_1e7(oracle):
+    """BASELINE configs[1] at full size, once, against the oracle itself (not only fuse-level
+    agreement): 1e7 PN23 symbols through the default fused link (fuse = 7) == oracle.detection_run
+    fed the same Philox noise, count for count."""
+    from waveforms_amd.link import SOQPSKLink
+
+    nsym = 10_000_000
+    link = SOQPSKLink(nsym, 8, fuse=7)
+    link.run_block(10.0, seed=1, stream_id=0)
+    got = link.result()
+    del link
+    bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, nsym)
+    noise = oracle.philox_awgn(oracle.sigma_for_ebn0(10.0, 8), 1, 0, 0, (nsym + 1) * 8)
+    res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise)
+    assert got == (res["sym_errors"], res["bit_errors"], res["compared"])
+    assert res["bit_errors"] > 5000
+
+
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 128, 129, 200])
 def test_tiny_bursts_every_stage(oracle, n):

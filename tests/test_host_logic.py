@@ -1,7 +1,11 @@
 """Host-side logic of the product package (tap design, trellis model, alias import,
 sweep sharding) against the reference-generated goldens.  CPU only."""
+from pathlib import Path
+
 import numpy as np
 import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
 
 TRELLIS_NAMES = ["SOQPSKTrellis8x1", "SOQPSKTrellis4x2", "SOQPSKTrellis4x2DiffEncoded",
                  "SimpleTrellis2", "SimpleTrellis4"]
@@ -204,6 +208,39 @@ def test_sweep_sharding_and_reduce_gloo_world2():
     blocks = np.arange(5).sum()
     want = [[100 * p * 5 + blocks, 10 * p * 5 + blocks, 5000] for p in range(3)]
     assert got[0] == want and got[1] == want
+
+
+def test_spawn_ranks_starts_children_and_relays_rank0(tmp_path):
+    """`python bench.py --gpus N` without torchrun: spawn_ranks starts the N ranks as child
+    processes (torch.distributed.run, loopback rendezvous) and rank 0's line comes back on the
+    inherited stdout.  Here the ranks are tests/_rank_probe.py with the stand-in block runner."""
+    import json
+    import subprocess
+    import sys
+
+    code = ("import sys; from waveforms_amd.bert import spawn_ranks; "
+            f"sys.exit(spawn_ranks({str(ROOT / 'tests' / '_rank_probe.py')!r}, 2, ['--blocks', '5']))")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    got = json.loads(line)
+    blocks = int(np.arange(5).sum())
+    assert got["world"] == 2
+    assert got["counts"] == [[100 * p * 5 + blocks, 10 * p * 5 + blocks, 5000] for p in range(3)]
+    # a failing rank is the caller's exit status
+    code = ("import sys; from waveforms_amd.bert import spawn_ranks; "
+            f"sys.exit(spawn_ranks({str(ROOT / 'tests' / '_rank_probe.py')!r}, 2, ['--no-such-flag']))")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
+def test_bench_gpus_n_self_launches_without_torchrun():
+    """bench.py / tools/ber_sweep.py no longer exit with 'launch with torchrun': with --gpus N > 1
+    and no WORLD_SIZE they go through spawn_ranks before importing torch."""
+    for name in ("bench.py", "tools/ber_sweep.py"):
+        src = (ROOT / name).read_text()
+        assert "spawn_ranks(" in src and "launch with torchrun" not in src
+        assert src.index("spawn_ranks(") < src.index("import torch\n"), name
 
 
 def test_link_row_bytes_rule():

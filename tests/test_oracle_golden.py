@@ -266,3 +266,42 @@ def test_timing_offset_scan(oracle, golden):
                                        detector=kind, timing_offset=off)
             assert [res["sym_errors"], res["bit_errors"], res["compared"]] == scan[str(off)][kind], (off, kind)
     assert min(scan, key=lambda o: scan[o]["PT"][1]) == "-1" and min(scan, key=lambda o: scan[o]["PAM"][1]) == "0"
+
+
+# ------------------------------------------------------------------ faithful-loop form (bench cpu_baseline)
+def test_faithful_loops_detector_on_random_triplets(oracle, golden):
+    """oracle/faithful_loops.py keeps the reference's interpreted per-symbol form; pinned on the
+    same reference outputs as the compiled oracle (ties, normalisation, traceback, any length)."""
+    from oracle import faithful_loops as fl
+
+    g = golden("detect")
+    for length, diff, n in ((2, True, 4000), (2, False, 1500), (4, True, 1500), (6, False, 1500)):
+        det = fl.DetectorLoop(length, diff)
+        got = [det.iteration(z) for z in g["triplets"][:n]]
+        assert np.array_equal(np.array([b for b, _ in got]), g[f"trip_L{length}_diff{int(diff)}_bits"][:n])
+        assert np.array_equal(np.array([s for _, s in got]), g[f"trip_L{length}_diff{int(diff)}_syms"][:n])
+
+
+def test_faithful_loops_chain_reproduces_reference_counts(oracle, golden):
+    from oracle import faithful_loops as fl
+
+    bits9, st = fl.lfsr_bits_loop(oracle.lfsr_mask(9), (1 << 9) - 1, 511)
+    assert st == (1 << 9) - 1 and np.array_equal(bits9, oracle.pn_sequence(9))
+    g = golden("detect")
+    sym, i, state = fl.fsm_encode_loop("SOQPSKTrellis4x2DiffEncoded", g["pn9_bits"])
+    assert np.array_equal(sym, g["pn9_tg8__symbols"]) and i == 512
+    with pytest.raises(ValueError):
+        fl.fsm_encode_loop("SimpleTrellis4", np.zeros(5, dtype=np.uint8))
+    assert np.array_equal(fl.fsm_encode_loop("SimpleTrellis4", g["pn9_bits"])[0], oracle.fsm_encode("SimpleTrellis4", g["pn9_bits"])[0])
+    pulse = oracle.freq_pulse_soqpsk_tg(8)
+    sig = fl.cpm_modulate_loop(sym, 0.25, pulse, 8)
+    np.testing.assert_allclose(sig * np.exp(-1j * np.pi / 4) + g["pn9_tg8__noise"], g["pn9_tg8__received"], rtol=0, atol=1e-15)
+    # BASELINE.md section 2: PN15 + pad bit, sps 8, Eb/N0 10 dB, seed 1, PT detector -> 16 errors of 32765
+    e = golden("e2e.json")
+    res = fl.detection_run_loop(pn_padded(oracle, 15)[:4096], pulse, 0.25, 8, float(np.sqrt(0.4)),
+                                np.random.Generator(np.random.PCG64(seed=1)))
+    ref = oracle.detection_run(pn_padded(oracle, 15)[:4096], pulse, 0.25, 8, float(np.sqrt(0.4)),
+                               rng=np.random.Generator(np.random.PCG64(seed=1)))
+    assert (res["sym_errors"], res["bit_errors"], res["compared"]) == (ref["sym_errors"], ref["bit_errors"], ref["compared"])
+    assert np.array_equal(res["det_bits"], ref["det_bits"][2:].astype(np.uint8))
+    assert e["sps8_10dB_TG_PT"][2] == 32765

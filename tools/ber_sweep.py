@@ -1,6 +1,7 @@
 """SOQPSK-TG BER sweep on the device-resident link (BASELINE config 4).
 
     python tools/ber_sweep.py [--ebn0 0:12] [--symbols-per-point 1e8] [--block 4194304] [--detector PT]
+    python tools/ber_sweep.py --gpus 8 ...          (starts the 8 ranks itself, as child processes)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/ber_sweep.py ...
 
 Independent trial blocks are dealt round-robin to the ranks; the only collective is one
@@ -47,21 +48,22 @@ def main():
     ap.add_argument("--block", type=int, default=1 << 22)
     ap.add_argument("--detector", default="PT")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=0, help="N > 1 without torchrun: start N ranks as child processes")
+    ap.add_argument("--json-out", default=None, help="rank 0 also writes its result object to this file")
     a = ap.parse_args()
     lo, hi = (int(v) for v in a.ebn0.split(":"))
     ebn0 = list(range(lo, hi + 1))
 
+    from waveforms_amd.bert import SweepPlan, ber_sweep, ber_table, ebn0_at_ber, init_ranks, spawn_ranks
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python tools/ber_sweep.py --gpus N`: the ranks are child processes of this one,
+        # started before anything here has touched the GPU
+        raise SystemExit(spawn_ranks(str(Path(__file__).resolve()), a.gpus, sys.argv[1:]))
     import torch
 
-    from waveforms_amd.bert import SweepPlan, ber_sweep, ber_table, dist_env, ebn0_at_ber
-
-    rank, world, local = dist_env()
-    torch.cuda.set_device(local)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    # WF_BENCH_REHEARSAL=1: every rank on cuda:0, gloo collectives (N > 1 on a one-GPU box)
+    rank, world, dist, _ = init_ranks(rehearsal=os.environ.get("WF_BENCH_REHEARSAL") == "1")
     blocks = max(1, int(round(a.symbols_per_point / a.block)))
     plan = SweepPlan(ebn0_db=ebn0, blocks_per_point=blocks, nsym=a.block, seed=a.seed, detector=a.detector)
     torch.cuda.synchronize()
@@ -85,7 +87,10 @@ def main():
                     out[f"delta_db_vs_reference_at_{target:g}"] = round(mine - ebn0_at_ber(ge, gb, target), 4)
             except ValueError:
                 pass
+        out["counts"] = [[int(v) for v in row] for row in counts]
         print(json.dumps(out))
+        if a.json_out:
+            Path(a.json_out).write_text(json.dumps(out) + "\n")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -14,7 +14,11 @@ from pathlib import Path
 
 import numpy as np
 
-_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwfhip.so"
+import os
+
+# WF_HIP_LIBRARY: load another build of the same C ABI (tools/sanitize.py points it at the
+# host-sanitized build on the CPU box).  Not a fallback: a missing file still raises.
+_LIB_PATH = Path(os.environ.get("WF_HIP_LIBRARY") or Path(__file__).resolve().parent / "csrc" / "libwfhip.so")
 
 WF_ERR_VALUE, WF_ERR_KEY, WF_ERR_HIP, WF_ERR_DEVICE, WF_ERR_NOMEM = -1, -2, -3, -4, -5
 
@@ -143,6 +147,16 @@ def new_ctx() -> int:
     out = c_void_p()
     check(lib().wf_ctx_create(require_device(), ctypes.byref(out)))
     return out.value
+
+
+def free_ctx(handle) -> None:
+    """Destroy a context made by :func:`new_ctx` (synchronises the device).  Safe at interpreter
+    shutdown: does nothing once the library handle is gone."""
+    if handle and _lib is not None:
+        try:
+            _lib.wf_ctx_destroy(handle)
+        except Exception:   # noqa: BLE001 - best effort in __del__ paths
+            pass
 
 
 def stream() -> int:

@@ -48,6 +48,48 @@ def dist_env() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", 0)))
 
 
+def spawn_ranks(script: str, ngpus: int, argv: Sequence[str]) -> int:
+    """Start ``ngpus`` rank processes of ``script`` (one per GPU) under ``torch.distributed.run``
+    as CHILD processes and return their exit status.  For entry points that were started as a
+    plain ``python script --gpus N`` with no rendezvous in the environment.  The caller must not
+    have touched the GPU: the parent only waits (a process that has initialised HIP must never
+    be replaced by exec on these machines, and is never needed here); the ranks' stdout is
+    inherited, so rank 0's result line is the caller's."""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:   # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(ngpus)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_ranks(rehearsal: bool = False):
+    """Join the job's process group (if WORLD_SIZE > 1) and select this rank's GPU.  Returns
+    (rank, world, dist-or-None, device for collectives).  ``rehearsal``: every rank on cuda:0 and
+    gloo for the collectives, so the N > 1 path can be exercised on a one-GPU box."""
+    import torch
+
+    rank, world, local = dist_env()
+    torch.cuda.set_device(0 if rehearsal else local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return rank, world, dist, ("cpu" if rehearsal else "cuda")
+
+
 def gpu_block_runner(plan: SweepPlan):
     """Default runner: a device-resident SOQPSKLink; returns (run(point, block), finish())."""
     from waveforms_amd import _hip

@@ -279,6 +279,9 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
     const int tabn = columns * states * ninp;
     WF_REQUIRE(tabn <= 1024, "wf_fsm_encode: trellis table too large (%d)", tabn);
     WF_REQUIRE(state0 >= 0 && state0 < states && i0 >= 0, "wf_fsm_encode: bad i/state");
+    // a next-state entry outside the trellis would index the state maps / LDS tables out of bounds
+    for (int k = 0; k < tabn; ++k)
+        WF_REQUIRE(h_next[k] < states, "wf_fsm_encode: next-state table entry %d is %d (states %d)", k, (int)h_next[k], states);
     if (nbits % card) {
         wf_set_error("Input length must be a multiple of FSM cardinality.");
         return WF_ERR_VALUE;
@@ -308,7 +311,10 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
         memcpy(ctx->h_tables_cache, h_next, tabn);
         memcpy(ctx->h_tables_cache + 1024, h_out, tabn);
         ctx->tables_cached = tabn;
+        // The cache is per context, the upload is ordered on this call's stream only: a later call
+        // with the same tables on ANOTHER stream skips the upload, so it must already have landed.
         WF_HIP(hipMemcpyAsync(ctx->d_tables, ctx->h_tables_cache, 2048, hipMemcpyHostToDevice, s));
+        WF_HIP(hipStreamSynchronize(s));
     }
     enc_params P{columns, states, card, ninp, (int)(i0 % columns), state0, nsym, 0u, 0ull, 0ull};
     const bool small = states <= 4 && tabn <= 16 && columns * ninp <= 4;

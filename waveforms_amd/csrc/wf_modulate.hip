@@ -417,6 +417,14 @@ static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 // Geometry shared by the one-shot entry point and the streaming link.
 static bool mod_setup(mod_params &P, int64_t nsym, int nh, int ntaps, int sps, double phi0)
 {
+    // outside 2 <= sps <= 256 the row length below is 0 (or the lcm divides by 0): not a
+    // configuration of the fused kernel.  P is left in a defined state for callers that read it.
+    if (sps < 2 || sps > 256 || ntaps < 1 || nsym < 1 || nh < 1) {
+        P = mod_params{};
+        P.sps = sps;
+        P.ntaps = ntaps;
+        return false;
+    }
     const int64_t npts = (nsym + 1) * (int64_t)sps;
     const int J = (ntaps + sps - 1) / sps;
     P.nsym = nsym;
@@ -532,6 +540,14 @@ extern "C" int wf_mod_tile_geometry(int sps, int ntaps, int64_t nsym_total, int6
 {
     mod_params P;
     const bool ok = mod_setup(P, nsym_total, 1, ntaps, sps, 0.0);
+    if (sps < 2 || sps > 256 || ntaps < 1 || nsym_total < 1) {
+        wf_set_error("wf_mod_tile_geometry: sps %d ntaps %d nsym %lld outside 2 <= sps <= 256, ntaps >= 1, nsym >= 1",
+                     sps, ntaps, (long long)nsym_total);
+        if (tile_len) *tile_len = 0;
+        if (sym_per_tile) *sym_per_tile = 0;
+        if (ntiles_total) *ntiles_total = 0;
+        return WF_ERR_VALUE;
+    }
     if (tile_len) *tile_len = (int64_t)MOD_ROWS * P.rs;
     if (sym_per_tile) *sym_per_tile = P.spt;
     if (ntiles_total) *ntiles_total = P.ntiles;

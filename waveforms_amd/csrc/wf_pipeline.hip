@@ -224,6 +224,10 @@ static stream_layout make_stream_layout(const wf_link_config *cfg, int64_t B, in
     stream_layout S;
     const int length = 2;
     S.N = cfg->nsym; S.B = B; S.c = c;
+    if (cfg->sps < 2 || cfg->sps > 256 || cfg->ntaps < 1 || cfg->nsym < 1 || cfg->mf_ntaps < 1) {
+        S = stream_layout{};   // everything zero, ok = false: nothing below may divide by sps / spt
+        return S;
+    }
     S.ok = wf_mod_tile_geometry(cfg->sps, cfg->ntaps, cfg->nsym, &S.tile_len, &S.spt, &S.ntiles_total) == 0;
     S.halo = round_up(S.spt + 48, 16);
     S.npts = wf_fir_out_len(S.N, cfg->sps, cfg->ntaps);

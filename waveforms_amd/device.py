@@ -157,12 +157,13 @@ def viterbi_detect_count(mf_rows, ref_bits, ref_syms, skip: int, ncompare: int, 
     return bits[:ncalls], syms[:ncalls]
 
 
-def viterbi_detect(mf_rows, differential: bool = True, warmup: int = 0, state=None):
-    """K8-K10 (length 2) -> (bits u8[ncalls], symbols i8[ncalls]) on device."""
+def viterbi_detect(mf_rows, differential: bool = True, warmup: int = 0, state=None, ctx=None):
+    """K8-K10 (length 2) -> (bits u8[ncalls], symbols i8[ncalls]) on device.  ``ctx``: a private
+    wf_ctx (own scratch and own unmerged-chunk counter) instead of the device's shared one."""
     ncalls = int(mf_rows.shape[0])
     bits = _hip.empty(ncalls + 16, "uint8")
     syms = _hip.empty(ncalls + 16, "int8")
-    _hip.check(_hip.lib().wf_viterbi4_detect(_hip.ctx(), _hip.ptr(mf_rows), ncalls, int(bool(differential)),
+    _hip.check(_hip.lib().wf_viterbi4_detect(ctx if ctx is not None else _hip.ctx(), _hip.ptr(mf_rows), ncalls, int(bool(differential)),
                                              warmup, _hip.ptr(bits), _hip.ptr(syms), _hip.ptr(state),
                                              _hip.stream()))
     return bits[:ncalls], syms[:ncalls]

@@ -39,6 +39,7 @@ class SOQPSKLink:
         self.nsym, self.sps = int(nsym), int(sps)
         # a link that runs on its own stream next to other links needs its own scratch
         self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()
+        self._owns_ctx = bool(private_ctx)
         pulse = freq_pulse_soqpsk_tg(sps) if pulse is None else np.asarray(pulse, dtype=np.float64)
         if detector == "PT":
             taps = pt_matched_filter_taps(pulse, mod_index, sps)
@@ -64,6 +65,11 @@ class SOQPSKLink:
         cfg.event_slot = -1
         cfg.fuse = int(fuse)
         self.cfg = cfg
+
+    def __del__(self):
+        if getattr(self, "_owns_ctx", False):
+            _hip.free_ctx(self._ctx)
+            self._owns_ctx = False
 
     @property
     def row_bytes(self) -> int:

@@ -41,7 +41,15 @@ class SOQPSKTrellisDetector:
         self._d_state = None
         self._d_io = None
         self._d_carry = None      # batch API: [i, metrics[4], increments[8], ...] on the device
+        self._ctx = None          # batch API: private wf_ctx (own proof counter), created on first use
         self._mode = None         # "iteration" or "batch" once the first call has been made
+
+    def __del__(self):
+        if getattr(self, "_ctx", None) is not None:
+            from waveforms_amd import _hip
+
+            _hip.free_ctx(self._ctx)
+            self._ctx = None
 
     # ------------------------------------------------------------------ per-symbol API
     def _ensure_state(self):
@@ -97,14 +105,24 @@ class SOQPSKTrellisDetector:
         # The kernel is chunk-parallel; it reports chunks whose warm-up did not reach the true path
         # metrics (none in practice).  Such a call is repeated from the same carried state with a
         # longer warm-up until it is provably the sequential detector's output.
+        # The proof counter lives in the wf_ctx: the detector owns a private context so that neither
+        # its reads-with-reset nor its repair runs can disturb (or be disturbed by) a SOQPSKLink or
+        # a BER sweep that shares the device's default context.
+        if self._ctx is None:
+            self._ctx = _hip.new_ctx()
         n = int(mf_rows.shape[0])
         carry0 = self._d_carry.clone()
-        dev.viterbi_unmerged(reset=True)
+        dev.viterbi_unmerged(reset=True, ctx=self._ctx)
         w = warmup
         while True:
-            out = dev.viterbi_detect(mf_rows, self.differential, w, self._d_carry)
-            if dev.viterbi_unmerged(reset=True) == 0 or w >= 4096:
+            out = dev.viterbi_detect(mf_rows, self.differential, w, self._d_carry, ctx=self._ctx)
+            unmerged = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
+            if unmerged == 0:
                 break
+            if w >= 4096:   # the library clamps the warm-up there: nothing longer can be tried
+                self._d_carry.copy_(carry0)
+                raise RuntimeError(f"{unmerged} detector chunk(s) still differ from the sequential detector with a "
+                                   f"warm-up of {w} rows; no decisions are returned")
             w = max(2 * w, 256)
             self._d_carry.copy_(carry0)
         self.i += n                         # like iteration(): one call per row, state carried

@@ -281,6 +281,82 @@ int wf_link_stream_steady(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_
                           void *d_workspace, int64_t workspace_bytes, int64_t *d_counts, int64_t *h_compared,
                           void *stream);
 
+/* ---- generic CPM trellis detector (ARTM multi-h, PCM/FM) ---------------------------
+ * The reference has NO detector for these waveforms — only their modulator side
+ * (waveforms/cpm/multih/pulse_filters.py:11-23, precoder.py:9-23, waveforms/cpm/pcmfm/) and the
+ * state-space theory (notes/cpm/cpm.md:52-140, N_S = p M^(L-1)).  These entry points implement the
+ * detector DEFINED by oracle/cpm_oracle.c (sequential, build-defined): tilted-phase states of
+ * notes/cpm/cpm.md:100-140, pulse-truncation matched filters in the manner of
+ * examples/soqpsk_detection.py:134-156, and the conventions of waveforms/viterbi/algorithm.py:57-98
+ * (increment Re(rotation * mf) minimised, strict '<', first arg-min, min-normalised metrics, one
+ * decision per call from the best state).
+ *
+ * State = (phase class v mod NC, the Lp-1 previous symbols); NC < p carries the phase index per
+ * survivor.  At most 16 states: NC * M^(Lp-1) <= 16; M in {2, 4}; nh in {1, 2}; Lp in 1..3. */
+typedef struct {
+    int M;          /* alphabet size: alpha = 2 U - (M - 1), U = 0 .. M-1                      */
+    int p;          /* modulation indices K[i] / p, symbol m uses K[m % nh]                    */
+    int nh;
+    int K[2];
+    int Lp;         /* symbols per matched filter (pulse truncation length)                    */
+    int NC;         /* phase classes in the trellis state (divides p)                          */
+    int D;          /* decision delay: call n decides symbol n - D + 1;  D * log2(M) <= 64     */
+} wf_cpm_detector_config;
+
+/* Matched-filter rows: row n, filter f = sum_k r[start0 + n*sps + k] * conj(T[n % nh][f][k]),
+ * k < ntm.  d_templates: nh x nfilt x ntm complex128 (nfilt = M^Lp, index f = u_0 + M u_1 + ...),
+ * d_rows: ncalls x nfilt complex128.  Samples outside [0, nsamp) count as zero. */
+int wf_cpm_mf_rows_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_templates_ri, int nh,
+                        int nfilt, int ntm, int64_t start0, int sps, int64_t ncalls, double *d_rows_ri,
+                        void *stream);
+
+/* The detector over ncalls rows.  d_rot_cs: 2p pairs (cos, sin)(pi r / p) (caller-computed so that
+ * oracle and device rotate with the same doubles).  d_decisions[k] (uint8) = the U decided at call
+ * k, i.e. of symbol n0 + k - D + 1 (n0 = calls already made on d_state; entries with
+ * n0 + k < D - 1 are written as 0).  Chunk-parallel like wf_viterbi4_detect: each 16-lane group
+ * re-derives metrics, phase indices and decision registers over `warmup` rows (0 = default) and
+ * every launch verifies bitwise that a chunk started from what its predecessor ended with
+ * (wf_viterbi4_unmerged counts failures).  d_state (WF_CPM_STATE_BYTES, zeroed = fresh detector,
+ * may be NULL) carries the detector across calls. */
+#define WF_CPM_STATE_BYTES 1024
+int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs,
+                          const double *d_rows_ri, int64_t ncalls, int warmup, uint8_t *d_decisions,
+                          void *d_state, void *stream);
+
+/* Symbol and bit errors of decided U against transmitted symbols alpha (int8):
+ * d_counts[0] += #(U != (alpha + M - 1)/2), d_counts[1] += popcount(U ^ (alpha + M - 1)/2)
+ * (the reference's mappers are natural binary: waveforms/cpm/multih/precoder.py:22-23). */
+int wf_cpm_count_errors(wf_ctx *ctx, const uint8_t *d_decided_u, const int8_t *d_ref_alpha, int M, int64_t m,
+                        int64_t *d_counts, void *stream);
+
+/* Device-resident link for these waveforms (one bench step / trial block):
+ * PRBS -> mapper (wf_symbol_map kind) -> cpm_modulate -> *exp(-j pi/4) + AWGN -> matched-filter
+ * rows -> detector -> error count over symbols [skip_head, ncalls - D].  Stage events as in
+ * wf_link_run (slots: prbs, map, modulate, -, awgn, mfbank, viterbi, count). */
+typedef struct {
+    int64_t nsym;
+    int sps;
+    int degree;
+    uint64_t mask, state, skip;
+    int mapper_kind;          /* 1: MultiHSymbolMapper (2 bits/symbol), 2: PCMFMSymbolMapper       */
+    wf_cpm_detector_config det;
+    const double *d_h;        /* device: nh modulation indices K[i]/p as doubles                  */
+    const double *d_pulse;    /* device: frequency pulse                                          */
+    int ntaps;
+    const double *d_templates; /* device: nh x M^Lp x (sps+1) complex128                           */
+    const double *d_rot_cs;   /* device: 2p x (cos, sin)                                          */
+    double sigma;
+    uint64_t seed, stream_id;
+    int warmup;
+    int skip_head;            /* leading symbols excluded from the comparison (start transient)   */
+    int event_slot;
+} wf_cpm_link_config;
+int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg);
+int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
+                    int64_t *d_counts, int64_t *h_compared, void *stream);
+/* info8 = {ncalls, start0, off(decisions), off(symbols alpha), off(signal), 0, signal samples, off(rows)} */
+int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ def test_two_ranks_through_the_real_block_runner_equal_one_rank():
     assert one["world"] == 1 and two["world"] == 2
     assert one["counts"] == two["counts"]
     c = np.array(one["counts"])
-    assert (c[:, 2] == 3 * (262144 - 2)).all()          # every block compared nsym - length symbols
+    assert (c[:, 2] == 3 * (262144 - 3)).all()          # every block compares ncols - length = nsym - 3 symbols
     assert c[0, 1] > c[1, 1] > c[2, 1] > 0               # BER falls with Eb/N0 (0, 4, 8 dB)
 
 
@@ -42,7 +42,7 @@ def test_bench_gpus_2_without_torchrun_rehearsal():
     out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--nsym", "1000000",
                 "--no-cpu-baseline"], {"WF_BENCH_REHEARSAL": "1"})
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
-    assert out["ber"]["symbols"] == 2 * 3 * (1000000 - 2)
+    assert out["ber"]["symbols"] == 2 * 3 * (1000000 - 3)
     assert out["value"] > 0 and "roofline" in out
 
 

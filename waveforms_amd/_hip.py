@@ -61,7 +61,30 @@ SIGNATURES = {
     "wf_link_stream_chunk": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
     "wf_link_stream_interior": (c_int, [_P, c_int64, c_int64]),
     "wf_link_stream_steady": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
+    "wf_cpm_mf_rows_c128": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
+    "wf_cpm_viterbi_detect": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
+    "wf_cpm_count_errors": (c_int, [_P, _P, _P, c_int, c_int64, _P, _P]),
+    "wf_cpm_link_workspace_bytes": (c_int64, [_P]),
+    "wf_cpm_link_run": (c_int, [_P, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
+    "wf_cpm_link_layout": (c_int, [_P, POINTER(c_int64)]),
 }
+
+
+class CPMDetectorConfig(ctypes.Structure):
+    """wf_cpm_detector_config of include/wfhip.h."""
+
+    _fields_ = [("M", c_int), ("p", c_int), ("nh", c_int), ("K", c_int * 2), ("Lp", c_int), ("NC", c_int), ("D", c_int)]
+
+
+class CPMLinkConfig(ctypes.Structure):
+    """wf_cpm_link_config of include/wfhip.h."""
+
+    _fields_ = [
+        ("nsym", c_int64), ("sps", c_int), ("degree", c_int), ("mask", c_uint64), ("state", c_uint64), ("skip", c_uint64),
+        ("mapper_kind", c_int), ("det", CPMDetectorConfig), ("d_h", c_void_p), ("d_pulse", c_void_p), ("ntaps", c_int),
+        ("d_templates", c_void_p), ("d_rot_cs", c_void_p), ("sigma", c_double), ("seed", c_uint64), ("stream_id", c_uint64),
+        ("warmup", c_int), ("skip_head", c_int), ("event_slot", c_int),
+    ]
 
 
 class LinkConfig(ctypes.Structure):

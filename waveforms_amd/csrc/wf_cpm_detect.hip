@@ -1,0 +1,701 @@
+// wf_cpm_detect.hip — generic CPM trellis detector (ARTM multi-h CPM, PCM/FM): matched-filter
+// rows, chunk-parallel Viterbi, error count, and the device-resident link built from them.
+//
+// mcdiarmid/waveforms has no detector for these waveforms (only their modulators:
+// waveforms/cpm/multih/*, waveforms/cpm/pcmfm/*, and the theory of notes/cpm/cpm.md:52-140), so
+// the algorithm is the one DEFINED by cpm_oracle.c (the sequential statement kept with the tests), which follows the conventions of the
+// reference's one detector (waveforms/viterbi/algorithm.py:57-98: increment Re(rotation * mf)
+// minimised, strict '<' / first listed branch on ties, first arg-min, min-normalised metrics, one
+// decision per call from the best state) on the tilted-phase trellis of notes/cpm/cpm.md:100-140
+// with pulse-truncation matched filters in the manner of examples/soqpsk_detection.py:134-156.
+// The kernels here reproduce that sequential detector bit for bit.
+//
+// Mapping.  A trellis of <= 16 states lives in one DPP ROW: lane = state, 16 lanes = one detector,
+// 4 detectors (chunks of consecutive calls) per wave.  Per call every state lane
+//   - rotates its M matched-filter outputs by its survivor's phase (table in LDS), forms the M
+//     candidate metrics and drops each into the slot of the end state it leads to (LDS exchange:
+//     the trellis permutation is data-independent, slots are precomputed on the host),
+//   - reads back its own M incoming candidates, selects with strict '<' in list order, fetches the
+//     winner's phase index and decision register with ds_bpermute,
+//   - joins a 16-lane all-reduce (DPP row_ror) for the min-normalisation; the lane whose
+//     normalised metric is exactly 0.0 (first such lane) is the best state and emits the decision.
+// Chunks start `warmup` calls early from a fresh detector and every launch PROVES that each chunk
+// began from bitwise the (metric, phase index, decision register) its predecessor ended with, as
+// wf_viterbi.hip does for the 4-state SOQPSK detector.
+#include <string.h>
+
+#include "wf_common.h"
+
+#define CPM_THREADS 256
+#define CPM_WAVES (CPM_THREADS / WF_WAVE)
+#define CPM_GROUPS 4            // 16-lane detectors per wave
+#define CPM_TB 4                // calls per staged batch of rows
+#define CPM_DEFAULT_WARMUP 128
+
+struct cpm_tables {
+    // variant kv: 0 / 1 = the symbol leaving the window uses K[0] / K[1]; 2 = it is a virtual
+    // pre-start symbol (no phase).  dest[kv][s][u] = 4 * end_state + slot of branch (s, u);
+    // info[kv][e][j] = src | u << 4 | ((K * u_old) mod p) << 8 for slot j of end state e.
+    uint8_t dest[3][16][4];
+    uint16_t info[3][16][4];
+};
+
+struct cpm_vit_params {
+    int M, lgM, p, nh, K0, K1, Lp, NC, D, S, NF;
+    int CH, W;
+    int64_t ncalls;
+    int rows_off, xch_off, dec_off, wave_bytes, rot_off;   // dynamic LDS layout (bytes)
+    cpm_tables T;
+};
+
+static int cpm_ksum_mod(int nh, int K0, int K1, int p, int64_t m)   // sum of K over symbols 0 .. m-1, mod 2p
+{
+    if (m <= 0) return 0;
+    const int per = nh == 2 ? K0 + K1 : K0;
+    int64_t acc = (m / nh) % (2 * p) * per;
+    if (nh == 2 && (m & 1)) acc += K0;
+    return (int)(acc % (2 * p));
+}
+
+__device__ __forceinline__ int cpm_tilt_at(const cpm_vit_params &P, int64_t n)   // (M-1) * sum K over symbols 0 .. n-Lp, mod 2p
+{
+    const int64_t m = n - P.Lp + 1;
+    if (m <= 0) return 0;
+    const int per = P.nh == 2 ? P.K0 + P.K1 : P.K0;
+    int64_t acc = (m / P.nh) % (2 * P.p) * per;
+    if (P.nh == 2 && (m & 1)) acc += P.K0;
+    return (int)(((int64_t)(P.M - 1) * (acc % (2 * P.p))) % (2 * P.p));
+}
+
+// all-reduce min over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1)
+__device__ __forceinline__ double cpm_row_min(double v)
+{
+    v = fmin(v, wf_dpp_f64<0x128, 0xf>(v));
+    v = fmin(v, wf_dpp_f64<0x124, 0xf>(v));
+    v = fmin(v, wf_dpp_f64<0x122, 0xf>(v));
+    v = fmin(v, wf_dpp_f64<0x121, 0xf>(v));
+    return v;
+}
+
+__device__ __forceinline__ double cpm_bperm_f64(int byte_addr, double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)b);
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ uint64_t cpm_bperm_u64(int byte_addr, uint64_t v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)v);
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(v >> 32));
+    return ((uint64_t)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// 16 B load as a VALUE (a double2 class assignment into a private array lowers to a memcpy and
+// keeps the array in scratch)
+__device__ __forceinline__ double2 vit_ld16_c(const double2 *p)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = *reinterpret_cast<const v2d *>(p);
+    return make_double2(v.x, v.y);
+}
+
+__device__ __forceinline__ void cpm_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Device-resident detector state (WF_CPM_STATE_BYTES): words 0..63 current, 64..127 staging.
+//   [0] calls made (as int64), [1..16] metrics (double), [17..32] phase indices (int64),
+//   [33..48] decision registers (uint64)
+#define CPM_ST_N 0
+#define CPM_ST_M 1
+#define CPM_ST_V 17
+#define CPM_ST_H 33
+#define CPM_ST_STAGE 64
+
+// edge buffer per wave: [0] group 0's start state, [1] group 3's end state; 16 lanes x 3 words each
+#define CPM_EDGE_WORDS (2 * 16 * 3)
+
+template <int M_, int LP_>
+__global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 *__restrict__ rows,
+                                                                  const double2 *__restrict__ rot_cs,
+                                                                  uint8_t *__restrict__ out, uint64_t *__restrict__ state,
+                                                                  uint64_t *__restrict__ edge,
+                                                                  unsigned long long *__restrict__ unmerged,
+                                                                  cpm_vit_params P)
+{
+    constexpr int M = M_;
+    constexpr int LGM = M_ == 4 ? 2 : 1;
+    constexpr int NF = LP_ == 1 ? M_ : (LP_ == 2 ? M_ * M_ : M_ * M_ * M_);
+    constexpr int PIECES = CPM_TB * NF;                       // 16 B pieces per group and batch
+    constexpr int PL = PIECES >= 16 ? PIECES / 16 : 1;        // pieces per lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, s = lane & 15;
+    const bool active = s < P.S;
+    const int corr = s / P.NC;
+    char *wbase = smem + wave * P.wave_bytes;
+    double2 *rowbuf = reinterpret_cast<double2 *>(wbase + P.rows_off) + g * PIECES;
+    double *xch = reinterpret_cast<double *>(wbase + P.xch_off);      // [64 lanes][4 slots] + 1 dump slot
+    uint8_t *dec = reinterpret_cast<uint8_t *>(wbase + P.dec_off) + g * P.CH;
+    double2 *rot = reinterpret_cast<double2 *>(smem + P.rot_off);
+    for (int k = threadIdx.x; k < 2 * P.p; k += CPM_THREADS) rot[k] = rot_cs[k];
+    __syncthreads();
+
+    const int64_t n0 = state ? (int64_t)state[CPM_ST_N] : 0;          // calls made before this launch
+    const int64_t chunk = ((int64_t)blockIdx.x * CPM_WAVES + wave) * CPM_GROUPS + g;
+    const int64_t k_first = chunk * P.CH;                             // first own call (local index)
+    const bool live = k_first < P.ncalls;
+    const int T = P.W + P.CH;
+
+    // per-lane slices of the branch tables (three variants of the leaving symbol's K)
+    uint32_t dsel[3], ilo[3], ihi[3];
+#pragma unroll
+    for (int kv = 0; kv < 3; ++kv) {
+        dsel[kv] = *reinterpret_cast<const uint32_t *>(&P.T.dest[kv][s][0]);
+        ilo[kv] = *reinterpret_cast<const uint32_t *>(&P.T.info[kv][s][0]);
+        ihi[kv] = *reinterpret_cast<const uint32_t *>(&P.T.info[kv][s][2]);
+    }
+
+    // detector registers of this state
+    double m = active ? 0.0 : INFINITY;
+    int v = s % P.NC;
+    uint64_t hist = 0;
+    if (state && chunk == 0 && n0 > 0) {                               // continue the carried detector
+        m = active ? __longlong_as_double((long long)state[CPM_ST_M + s]) : INFINITY;
+        v = (int)state[CPM_ST_V + s];
+        hist = state[CPM_ST_H + s];
+    }
+    const int64_t k_start = chunk == 0 ? 0 : k_first - P.W;            // first call this group really runs
+    int tilt = cpm_tilt_at(P, n0 + k_start);
+    double ms_m = m;
+    int ms_v = v;
+    uint64_t ms_h = hist;
+
+    // cooperative row fetch: piece q = s + 16 i of the batch's CPM_TB * NF pieces
+    auto fetch = [&](int b, double2 (&dst)[PL]) __attribute__((always_inline)) {
+        const int64_t kb = k_first - P.W + (int64_t)b * CPM_TB;        // local call of the batch's first row
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const int q = s + 16 * i;
+            int64_t row = kb + q / NF;
+            row = row < 0 ? 0 : (row >= P.ncalls ? P.ncalls - 1 : row);   // never decoded when clamped
+            const int qq = q < PIECES ? q : 0;
+            dst[i] = vit_ld16_c(rows + row * NF + (qq - (qq / NF) * NF));
+        }
+    };
+    double2 pend[PL];
+    const int nbatch = T / CPM_TB;
+    fetch(0, pend);
+    for (int b = 0; b < nbatch; ++b) {
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const int q = s + 16 * i;
+            if (q < PIECES) rowbuf[q] = pend[i];
+        }
+        fetch(b + 1 < nbatch ? b + 1 : b, pend);                        // always one batch in flight
+        cpm_wave_sync();
+#pragma unroll 1
+        for (int tt = 0; tt < CPM_TB; ++tt) {
+            const int t = b * CPM_TB + tt;
+            const int64_t k = k_first - P.W + t;                        // local call index of this group
+            const int64_t n = n0 + k;                                   // global call index
+            const bool valid = live && k >= 0 && k < P.ncalls;
+            if (t == P.W) {                                             // the next call is the chunk's first own one
+                ms_m = m;
+                ms_v = v;
+                ms_h = hist;
+            }
+            const int64_t m_old = n - LP_ + 1;
+            const int kv = m_old < 0 ? 2 : (P.nh == 2 ? (int)(m_old & 1) : 0);
+            const int K_old = kv == 2 ? 0 : (kv ? P.K1 : P.K0);
+            const uint32_t dsl = kv == 0 ? dsel[0] : (kv == 1 ? dsel[1] : dsel[2]);
+            const uint32_t il = kv == 0 ? ilo[0] : (kv == 1 ? ilo[1] : ilo[2]);
+            const uint32_t ih = kv == 0 ? ihi[0] : (kv == 1 ? ihi[1] : ihi[2]);
+            int r = 2 * v - tilt;
+            r += r < 0 ? 2 * P.p : 0;
+            const double2 cs = rot[r];
+            const double2 *zrow = rowbuf + tt * NF + M * corr;
+#pragma unroll
+            for (int u = 0; u < M; ++u) {
+                const double2 z = zrow[u];
+                const double inc = -fma(cs.x, z.x, cs.y * z.y);         // -Re(e^{-j theta} Z)
+                const double cand = m + inc;
+                const int slot = (int)((dsl >> (8 * u)) & 0xFFu);
+                xch[active ? (g * 64 + slot) : 256] = cand;             // 256 = the wave's dump slot
+            }
+            cpm_wave_sync();
+            double c[M];
+            if constexpr (M == 4) {
+                const double2 a0 = *reinterpret_cast<const double2 *>(xch + lane * 4);
+                const double2 a1 = *reinterpret_cast<const double2 *>(xch + lane * 4 + 2);
+                c[0] = a0.x; c[1] = a0.y; c[M - 2] = a1.x; c[M - 1] = a1.y;
+            } else {
+                const double2 a0 = *reinterpret_cast<const double2 *>(xch + lane * 4);
+                c[0] = a0.x; c[1] = a0.y;
+            }
+            double best = c[0];
+            int w = 0;
+#pragma unroll
+            for (int j = 1; j < M; ++j) {
+                const bool lt = c[j] < best;                           // strict '<': the first listed branch keeps a tie
+                best = lt ? c[j] : best;
+                w = lt ? j : w;
+            }
+            const uint32_t pair = (w & 2) ? ih : il;
+            const uint32_t inf = (w & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+            const int src = (int)(inf & 15u), u_new = (int)((inf >> 4) & 3u), incmod = (int)((inf >> 8) & 63u);
+            const int baddr = ((lane & 48) | src) << 2;
+            int nv = __builtin_amdgcn_ds_bpermute(baddr, v) + incmod;
+            nv -= nv >= P.p ? P.p : 0;
+            const uint64_t nh_ = (cpm_bperm_u64(baddr, hist) << LGM) | (uint64_t)u_new;
+            double nm = active ? best : INFINITY;
+            nm -= cpm_row_min(nm);                                      // the minimum becomes exactly 0.0
+            if (valid) {
+                m = nm;
+                v = nv;
+                hist = nh_;
+                tilt += (M - 1) * K_old;
+                tilt -= tilt >= 2 * P.p ? 2 * P.p : 0;
+                if (t >= P.W) {
+                    // np.argmin: the first state whose metric is the minimum
+                    const unsigned long long zero = __builtin_amdgcn_ballot_w64(active && nm == 0.0);
+                    const unsigned long long below = zero & ((1ull << lane) - 1ull) & (0xFFFFull << (lane & 48));
+                    if (active && nm == 0.0 && below == 0ull)
+                        dec[t - P.W] = n >= P.D - 1 ? (uint8_t)((nh_ >> (LGM * (P.D - 1))) & (uint64_t)(M - 1)) : (uint8_t)0;
+                }
+            }
+            // (the next call's candidate writes follow this call's candidate reads in program
+            //  order; a wave's LDS accesses execute in order)
+        }
+        cpm_wave_sync();                                                // batch consumed before the next stash
+    }
+    // flush decisions: 16 B per lane and 256 calls
+    if (live) {
+        for (int i = 0; i < P.CH / 256; ++i) {
+            const int off = 16 * (s + 16 * i);
+            const int64_t k = k_first + off;
+            if (k + 16 <= P.ncalls) {
+                *reinterpret_cast<uint4 *>(out + k) = *reinterpret_cast<const uint4 *>(dec + off);
+            } else {
+                for (int q = 0; q < 16 && k + q < P.ncalls; ++q) out[k + q] = dec[off + q];
+            }
+        }
+    }
+    // proof: this chunk started from bitwise what its predecessor ended with
+    {
+        const int pa = ((lane - 16) & 63) << 2;
+        const double pm = cpm_bperm_f64(pa, m);
+        const int pv = __builtin_amdgcn_ds_bpermute(pa, v);
+        const uint64_t ph = cpm_bperm_u64(pa, hist);
+        // only the D decisions still inside the register can reach an output
+        const uint64_t hmask = LGM * P.D >= 64 ? ~0ull : ((1ull << (LGM * P.D)) - 1ull);
+        bool bad = __double_as_longlong(pm) != __double_as_longlong(ms_m) || pv != ms_v || ((ph ^ ms_h) & hmask) != 0ull;
+        bad = bad && live && active && g > 0;
+        const unsigned long long nb = __builtin_amdgcn_ballot_w64(bad);
+        if (nb && lane == 0) atomicAdd(unmerged, 1ull);
+        uint64_t *e = edge + ((int64_t)blockIdx.x * CPM_WAVES + wave) * CPM_EDGE_WORDS;
+        if (g == 0 && live && s < 16) {
+            e[3 * s] = (uint64_t)__double_as_longlong(ms_m);
+            e[3 * s + 1] = (uint64_t)(int64_t)ms_v;
+            e[3 * s + 2] = ms_h;
+        }
+        if (g == CPM_GROUPS - 1) {
+            // a chunk that is not live leaves an all-ones marker: viterbi verify skips it
+            e[48 + 3 * s] = live ? (uint64_t)__double_as_longlong(m) : ~0ull;
+            e[48 + 3 * s + 1] = (uint64_t)(int64_t)v;
+            e[48 + 3 * s + 2] = hist;
+        }
+    }
+    if (state && live && k_first + P.CH >= P.ncalls) {                 // the group that owns the last call
+        state[CPM_ST_STAGE + CPM_ST_N] = (uint64_t)(n0 + P.ncalls);
+        state[CPM_ST_STAGE + CPM_ST_M + s] = (uint64_t)__double_as_longlong(m);
+        state[CPM_ST_STAGE + CPM_ST_V + s] = (uint64_t)(int64_t)v;
+        state[CPM_ST_STAGE + CPM_ST_H + s] = hist;
+    }
+}
+
+// Wave w's first chunk against wave w-1's last one (see the end of cpm_viterbi_kernel).
+__global__ void cpm_verify_kernel(const uint64_t *__restrict__ edge, int64_t nwaves, int S, uint64_t hmask,
+                                  unsigned long long *__restrict__ unmerged)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (w >= nwaves) return;
+    const uint64_t *a = edge + w * CPM_EDGE_WORDS, *b = edge + (w - 1) * CPM_EDGE_WORDS + 48;
+    bool bad = false;
+    for (int s = 0; s < S; ++s)
+        bad |= a[3 * s] != b[3 * s] || a[3 * s + 1] != b[3 * s + 1] || ((a[3 * s + 2] ^ b[3 * s + 2]) & hmask) != 0ull;
+    if (bad) atomicAdd(unmerged, 1ull);
+}
+
+__global__ void cpm_carry_commit_kernel(uint64_t *state)
+{
+    const int t = threadIdx.x;
+    if (t < 64) state[t] = state[CPM_ST_STAGE + t];
+}
+
+// Host: the trellis permutation.  Branches are enumerated exactly like cpm_oracle.c (the sequential statement kept with the tests)
+// (start state ascending, then input ascending), so slot j of an end state is the j-th listed
+// branch into it and strict '<' over slots 0, 1, ... reproduces that statement's tie-break.
+static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
+{
+    const int M = d->M, Lp = d->Lp, NC = d->NC, p = d->p;
+    WF_REQUIRE((M == 2 || M == 4) && Lp >= 1 && Lp <= 3 && (d->nh == 1 || d->nh == 2) && p >= 1 && p <= 64 && NC >= 1 &&
+                   p % NC == 0 && d->D >= 1,
+               "wf_cpm: unsupported detector (M %d Lp %d nh %d p %d NC %d D %d)", M, Lp, d->nh, p, NC, d->D);
+    const int lgM = M == 4 ? 2 : 1;
+    WF_REQUIRE(d->D * lgM <= 64, "wf_cpm: decision delay %d does not fit the 64-bit decision register", d->D);
+    int ncorr = 1, msub = 1, NF = 1;
+    for (int i = 1; i < Lp; ++i) ncorr *= M;
+    for (int i = 2; i < Lp; ++i) msub *= M;
+    for (int i = 0; i < Lp; ++i) NF *= M;
+    const int S = NC * ncorr;
+    WF_REQUIRE(S <= 16, "wf_cpm: %d states (at most 16 = one DPP row)", S);
+    for (int i = 0; i < d->nh; ++i) WF_REQUIRE(d->K[i] >= 0 && d->K[i] < p, "wf_cpm: K[%d] = %d outside [0, p)", i, d->K[i]);
+    P.M = M; P.lgM = lgM; P.p = p; P.nh = d->nh; P.K0 = d->K[0]; P.K1 = d->nh == 2 ? d->K[1] : d->K[0];
+    P.Lp = Lp; P.NC = NC; P.D = d->D; P.S = S; P.NF = NF;
+    memset(&P.T, 0xFF, sizeof P.T);
+    for (int kv = 0; kv < 3; ++kv) {
+        const int K_old = kv == 2 ? 0 : (kv == 1 ? P.K1 : P.K0);
+        int fill[16] = {0};
+        for (int s = 0; s < S; ++s) {
+            const int cls = s % NC, corr = s / NC;
+            for (int u = 0; u < M; ++u) {
+                const int u_old = Lp == 1 ? u : corr / msub;
+                const int corr2 = Lp == 1 ? 0 : u + M * (corr % msub);
+                const int inc = (K_old * u_old) % p;
+                const int s2 = (cls + inc) % NC + NC * corr2;      // (v + inc) mod p mod NC == (cls + inc) mod NC: NC | p
+                const int j = fill[s2]++;
+                WF_REQUIRE(j < M, "wf_cpm: internal: more than M branches into a state");
+                P.T.dest[kv][s][u] = (uint8_t)(4 * s2 + j);
+                P.T.info[kv][s2][j] = (uint16_t)(s | (u << 4) | (inc << 8));
+            }
+        }
+        for (int s = 0; s < S; ++s) WF_REQUIRE(fill[s] == M, "wf_cpm: internal: state %d has %d incoming branches", s, fill[s]);
+    }
+    return WF_OK;
+}
+
+extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs,
+                                     const double *d_rows_ri, int64_t ncalls, int warmup, uint8_t *d_decisions,
+                                     void *d_state, void *stream)
+{
+    WF_REQUIRE(ctx && det && ncalls >= 0 && warmup >= 0, "wf_cpm_viterbi_detect: bad argument");
+    cpm_vit_params P;
+    int rc = cpm_build_tables(det, P);
+    if (rc) return rc;
+    if (ncalls == 0) return WF_OK;
+    WF_REQUIRE(d_rot_cs && d_rows_ri && d_decisions, "wf_cpm_viterbi_detect: NULL device pointer");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_rows_ri) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_decisions) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(d_rot_cs) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
+               "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
+    WF_HIP(hipSetDevice(ctx->device));
+    // calls per chunk: 256 for short bursts, 512 once that still fills the chip several times over
+    P.CH = ncalls >= (1 << 22) ? 512 : 256;
+    int W = warmup ? warmup : CPM_DEFAULT_WARMUP;
+    W = (W + CPM_TB - 1) / CPM_TB * CPM_TB;
+    if (W > 4096) W = 4096;
+    while (P.CH < W) P.CH *= 2;                                    // a chunk's warm-up never reaches before call 0 of the burst
+    P.W = W;
+    P.ncalls = ncalls;
+    const int pieces = CPM_TB * P.NF;
+    P.rows_off = 0;
+    P.xch_off = CPM_GROUPS * pieces * 16;
+    P.dec_off = P.xch_off + (64 * 4 + 2) * 8;
+    P.wave_bytes = (P.dec_off + CPM_GROUPS * P.CH + 15) / 16 * 16;
+    P.rot_off = CPM_WAVES * P.wave_bytes;
+    const size_t lds = (size_t)P.rot_off + (size_t)2 * P.p * 16;
+    WF_REQUIRE(lds <= 160 * 1024, "wf_cpm_viterbi_detect: chunk of %d calls does not fit LDS", P.CH);
+    const int64_t nchunks = (ncalls + P.CH - 1) / P.CH;
+    const int64_t nwaves = (nchunks + CPM_GROUPS - 1) / CPM_GROUPS;
+    const int64_t nblocks = (nwaves + CPM_WAVES - 1) / CPM_WAVES;
+    WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_viterbi_detect: burst too long for one launch");
+    rc = wf_ctx_reserve_vit(ctx, (size_t)nblocks * CPM_WAVES * CPM_EDGE_WORDS);
+    if (rc) return rc;
+    uint64_t *edge = reinterpret_cast<uint64_t *>(ctx->d_vit_edge);
+    hipStream_t s = wf_stream(stream);
+    using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params);
+    kern_t k = nullptr;
+    if (P.M == 4) k = P.Lp == 1 ? cpm_viterbi_kernel<4, 1> : (P.Lp == 2 ? cpm_viterbi_kernel<4, 2> : cpm_viterbi_kernel<4, 3>);
+    else k = P.Lp == 1 ? cpm_viterbi_kernel<2, 1> : (P.Lp == 2 ? cpm_viterbi_kernel<2, 2> : cpm_viterbi_kernel<2, 3>);
+    if (lds > 48 * 1024)
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(CPM_THREADS), lds, s, reinterpret_cast<const double2 *>(d_rows_ri),
+                       reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
+                       ctx->d_vit_unmerged, P);
+    WF_LAUNCH_CHECK();
+    if (nwaves > 1) {
+        const uint64_t hmask = P.lgM * P.D >= 64 ? ~0ull : ((1ull << (P.lgM * P.D)) - 1ull);
+        hipLaunchKernelGGL(cpm_verify_kernel, dim3((unsigned)((nwaves - 1 + 255) / 256)), dim3(256), 0, s, edge, nwaves, P.S,
+                           hmask, ctx->d_vit_unmerged);
+        WF_LAUNCH_CHECK();
+    }
+    if (d_state) {
+        hipLaunchKernelGGL(cpm_carry_commit_kernel, dim3(1), dim3(64), 0, s, static_cast<uint64_t *>(d_state));
+        WF_LAUNCH_CHECK();
+    }
+    return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Matched-filter rows: row n, filter f = sum_k r[start0 + n sps + k] * conj(T[n % nh][f][k]).
+// A workgroup stages the samples of CPM_MF_SYMS consecutive symbols in LDS (each sample is read
+// from HBM once); thread t owns filter f = t % NF for the symbols sub, sub + 256/NF, ...; its
+// templates for both columns stay in registers (NTM = 9: the sps = 8 case), or come from an LDS
+// copy (any length).  Accumulation order is that of cpm_oracle.c (the sequential statement kept with the tests):orc_cpm_mf_rows.
+#define CPM_MF_SYMS 256
+
+struct cpm_mf_params {
+    int64_t nsamp, start0, ncalls;
+    int sps, ntm, nh;
+};
+
+template <int NF, int NTM>
+__global__ __launch_bounds__(256) void cpm_mf_rows_kernel(const double2 *__restrict__ r, const double2 *__restrict__ templ,
+                                                            double2 *__restrict__ out, cpm_mf_params P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *s_r = reinterpret_cast<double2 *>(smem);
+    const int ntm = NTM ? NTM : P.ntm;
+    const int span = CPM_MF_SYMS * P.sps + ntm;                       // samples staged per block (last ones overlap the next block)
+    double2 *s_t = s_r + span;                                        // generic path: nh x NF x ntm templates
+    const int t = threadIdx.x;
+    const int f = t % NF, sub = t / NF;
+    constexpr int SUBS = 256 / NF;
+    double2 tap[2][NTM ? NTM : 1];
+    if (NTM) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < NTM; ++k) tap[c][k] = templ[((c < P.nh ? c : 0) * NF + f) * NTM + k];
+    } else {
+        for (int k = t; k < P.nh * NF * ntm; k += 256) s_t[k] = templ[k];
+    }
+    const int64_t nblk = (P.ncalls + CPM_MF_SYMS - 1) / CPM_MF_SYMS;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t nb = blk * CPM_MF_SYMS;
+        const int64_t s0 = P.start0 + nb * P.sps;
+        __syncthreads();
+        for (int i = t; i < span; i += 256) {
+            const int64_t a = s0 + i;
+            s_r[i] = (a >= 0 && a < P.nsamp) ? wf_load16_nt(r + a) : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        for (int sym = sub; sym < CPM_MF_SYMS; sym += SUBS) {
+            const int64_t n = nb + sym;
+            if (n >= P.ncalls) break;
+            const int c = (int)(n % P.nh);
+            const double2 *x = s_r + sym * P.sps;
+            double zr = 0.0, zi = 0.0;
+            if (NTM) {
+#pragma unroll
+                for (int k = 0; k < NTM; ++k) {
+                    const double2 xv = x[k];
+                    const double2 tp = c ? tap[1][k] : tap[0][k];
+                    zr = fma(xv.x, tp.x, fma(xv.y, tp.y, zr));
+                    zi = fma(xv.y, tp.x, fma(-xv.x, tp.y, zi));
+                }
+            } else {
+                const double2 *tp = s_t + (c * NF + f) * ntm;
+                for (int k = 0; k < ntm; ++k) {
+                    const double2 xv = x[k];
+                    zr = fma(xv.x, tp[k].x, fma(xv.y, tp[k].y, zr));
+                    zi = fma(xv.y, tp[k].x, fma(-xv.x, tp[k].y, zi));
+                }
+            }
+            out[n * NF + f] = make_double2(zr, zi);
+        }
+    }
+}
+
+extern "C" int wf_cpm_mf_rows_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_templates_ri, int nh,
+                                   int nfilt, int ntm, int64_t start0, int sps, int64_t ncalls, double *d_rows_ri,
+                                   void *stream)
+{
+    WF_REQUIRE(ctx && nsamp >= 0 && ncalls >= 0, "wf_cpm_mf_rows_c128: bad argument");
+    WF_REQUIRE((nh == 1 || nh == 2) && ntm >= 1 && ntm <= 257 && sps >= 1 && sps <= 256,
+               "wf_cpm_mf_rows_c128: nh %d ntm %d sps %d", nh, ntm, sps);
+    WF_REQUIRE(nfilt == 2 || nfilt == 4 || nfilt == 8 || nfilt == 16 || nfilt == 64,
+               "wf_cpm_mf_rows_c128: %d filters per symbol (M^Lp with M in {2, 4}, Lp <= 3)", nfilt);
+    if (ncalls == 0) return WF_OK;
+    WF_REQUIRE(d_r_ri && d_templates_ri && d_rows_ri, "wf_cpm_mf_rows_c128: NULL device pointer");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_r_ri) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_rows_ri) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(d_templates_ri) & 15) == 0,
+               "wf_cpm_mf_rows_c128: device pointers must be 16-byte aligned");
+    WF_HIP(hipSetDevice(ctx->device));
+    cpm_mf_params P{nsamp, start0, ncalls, sps, ntm, nh};
+    const bool fast = ntm == 9;
+    const size_t lds = ((size_t)CPM_MF_SYMS * sps + ntm + (fast ? 0 : (size_t)nh * nfilt * ntm)) * sizeof(double2);
+    WF_REQUIRE(lds <= 160 * 1024, "wf_cpm_mf_rows_c128: sps %d / %d-tap filters do not fit LDS staging", sps, ntm);
+    const int64_t nblk = (ncalls + CPM_MF_SYMS - 1) / CPM_MF_SYMS;
+    const int grid = (int)(nblk < 8192 ? nblk : 8192);
+    using kern_t = void (*)(const double2 *, const double2 *, double2 *, cpm_mf_params);
+    kern_t k;
+    switch (nfilt) {
+    case 2: k = fast ? cpm_mf_rows_kernel<2, 9> : cpm_mf_rows_kernel<2, 0>; break;
+    case 4: k = fast ? cpm_mf_rows_kernel<4, 9> : cpm_mf_rows_kernel<4, 0>; break;
+    case 8: k = fast ? cpm_mf_rows_kernel<8, 9> : cpm_mf_rows_kernel<8, 0>; break;
+    case 16: k = fast ? cpm_mf_rows_kernel<16, 9> : cpm_mf_rows_kernel<16, 0>; break;
+    default: k = fast ? cpm_mf_rows_kernel<64, 9> : cpm_mf_rows_kernel<64, 0>; break;
+    }
+    if (lds > 48 * 1024)
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, wf_stream(stream), reinterpret_cast<const double2 *>(d_r_ri),
+                       reinterpret_cast<const double2 *>(d_templates_ri), reinterpret_cast<double2 *>(d_rows_ri), P);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void cpm_count_kernel(const uint8_t *__restrict__ dec, const int8_t *__restrict__ alpha, int M, int64_t m,
+                                 unsigned long long *__restrict__ counts)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    long long se = 0, be = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+        const int u = ((int)alpha[k] + (M - 1)) >> 1;
+        const int x = (int)dec[k] ^ u;
+        se += x != 0;
+        be += __popc(x);
+    }
+    se = wf_wave_sum_i64(se);
+    be = wf_wave_sum_i64(be);
+    if ((threadIdx.x & 63) == 0 && (se | be)) {
+        atomicAdd(counts, (unsigned long long)se);
+        atomicAdd(counts + 1, (unsigned long long)be);
+    }
+}
+
+extern "C" int wf_cpm_count_errors(wf_ctx *ctx, const uint8_t *d_decided_u, const int8_t *d_ref_alpha, int M, int64_t m,
+                                   int64_t *d_counts, void *stream)
+{
+    WF_REQUIRE(ctx && (M == 2 || M == 4) && m >= 0 && d_counts, "wf_cpm_count_errors: bad argument");
+    if (m == 0) return WF_OK;
+    WF_REQUIRE(d_decided_u && d_ref_alpha, "wf_cpm_count_errors: NULL device pointer");
+    WF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(cpm_count_kernel, dim3(wf_grid_for(m, 256 * 16, 512)), dim3(256), 0, wf_stream(stream), d_decided_u,
+                       d_ref_alpha, M, m, reinterpret_cast<unsigned long long *>(d_counts));
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Device-resident link for multi-h CPM / PCM/FM: the SOQPSK link's structure (wf_pipeline.hip)
+// with the mapper, the multi-index modulator and the generic detector.
+struct cpm_link_layout {
+    int64_t nsym, nbits, npts, ncalls, start0;
+    int ntm, nfilt, bps;
+    size_t off_bits, off_syms, off_sig, off_rows, off_dec, total;
+};
+
+static inline int64_t cpm_round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+static bool cpm_make_layout(const wf_cpm_link_config *cfg, cpm_link_layout &L)
+{
+    if (!cfg || cfg->nsym < 1 || cfg->sps < 2 || cfg->sps > 256 || cfg->ntaps < 1) return false;
+    if (cfg->mapper_kind != 1 && cfg->mapper_kind != 2) return false;
+    const wf_cpm_detector_config &d = cfg->det;
+    if ((d.M != 2 && d.M != 4) || d.Lp < 1 || d.Lp > 3) return false;
+    L.bps = cfg->mapper_kind == 1 ? 2 : 1;
+    if ((L.bps == 2) != (d.M == 4)) return false;
+    L.nsym = cfg->nsym;
+    L.nbits = cfg->nsym * L.bps;
+    L.npts = wf_fir_out_len(cfg->nsym, cfg->sps, cfg->ntaps);
+    L.ntm = cfg->sps + 1;
+    // cpm_detect.py:cpm_geometry of the test-side statement
+    const int c = (cfg->ntaps - 1) / 2;
+    const int span = (cfg->ntaps - 1) - d.Lp * cfg->sps;
+    const int o = span >= 0 ? span / 2 : -((-span + 1) / 2);          // floor division
+    if (o < -(cfg->sps / 2)) return false;
+    L.start0 = cfg->sps - c + o;
+    int64_t nc = (L.npts - L.ntm - L.start0) / cfg->sps + 1;
+    if (L.npts - L.ntm - L.start0 < 0) nc = 0;
+    L.ncalls = nc < cfg->nsym ? nc : cfg->nsym;
+    L.nfilt = 1;
+    for (int i = 0; i < d.Lp; ++i) L.nfilt *= d.M;
+    size_t o_ = 0;
+    L.off_bits = o_; o_ += (size_t)cpm_round_up(L.nbits + 16, 256);
+    L.off_syms = o_; o_ += (size_t)cpm_round_up(L.nsym + 16, 256);
+    L.off_sig = o_;  o_ += (size_t)cpm_round_up(L.npts * 16, 256);
+    L.off_rows = o_; o_ += (size_t)cpm_round_up(L.ncalls * L.nfilt * 16, 256);
+    L.off_dec = o_;  o_ += (size_t)cpm_round_up(L.ncalls + 16, 256);
+    L.total = o_;
+    return true;
+}
+
+extern "C" int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg)
+{
+    cpm_link_layout L;
+    return cpm_make_layout(cfg, L) ? (int64_t)L.total : -1;
+}
+
+extern "C" int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8)
+{
+    cpm_link_layout L;
+    if (!info8 || !cpm_make_layout(cfg, L)) return WF_ERR_VALUE;
+    info8[0] = L.ncalls; info8[1] = L.start0; info8[2] = (int64_t)L.off_dec; info8[3] = (int64_t)L.off_syms;
+    info8[4] = (int64_t)L.off_sig; info8[5] = 0; info8[6] = L.npts; info8[7] = (int64_t)L.off_rows;
+    return WF_OK;
+}
+
+extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
+                               int64_t *d_counts, int64_t *h_compared, void *stream)
+{
+    WF_REQUIRE(ctx && cfg && d_workspace && d_counts, "wf_cpm_link_run: NULL argument");
+    cpm_link_layout L;
+    WF_REQUIRE(cpm_make_layout(cfg, L), "wf_cpm_link_run: bad configuration");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_workspace) & 255) == 0, "wf_cpm_link_run: workspace must be 256-byte aligned");
+    WF_REQUIRE((int64_t)L.total <= workspace_bytes, "wf_cpm_link_run: workspace too small (%lld < %lld)",
+               (long long)workspace_bytes, (long long)L.total);
+    WF_REQUIRE(cfg->d_h && cfg->d_pulse && cfg->d_templates && cfg->d_rot_cs, "wf_cpm_link_run: NULL table pointer");
+    char *w = static_cast<char *>(d_workspace);
+    uint8_t *bits = reinterpret_cast<uint8_t *>(w + L.off_bits);
+    int8_t *syms = reinterpret_cast<int8_t *>(w + L.off_syms);
+    double *sig = reinterpret_cast<double *>(w + L.off_sig);
+    double *rows = reinterpret_cast<double *>(w + L.off_rows);
+    uint8_t *dec = reinterpret_cast<uint8_t *>(w + L.off_dec);
+    hipEvent_t *ev = nullptr;
+    if (cfg->event_slot >= 0) {
+        WF_REQUIRE(cfg->event_slot < WF_LINK_EVENT_SLOTS, "wf_cpm_link_run: event_slot %d", cfg->event_slot);
+        if (!ctx->events) {
+            ctx->events = new hipEvent_t[WF_LINK_EVENT_SLOTS * (WF_LINK_STAGES + 1)];
+            for (int k = 0; k < WF_LINK_EVENT_SLOTS * (WF_LINK_STAGES + 1); ++k) WF_HIP(hipEventCreate(&ctx->events[k]));
+        }
+        ev = ctx->events + cfg->event_slot * (WF_LINK_STAGES + 1);
+    }
+#define MARK(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(stream))); } while (0)
+    int rc;
+    MARK(0);
+    if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, L.nbits, nullptr, stream))) return rc;
+    MARK(1);
+    // MultiHSymbolMapper on an even number of bits leaves its parity at 0 (precoder.py:22)
+    if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, L.nbits, 0, 0, 0, syms, stream))) return rc;
+    MARK(2);
+    rc = wf_cpm_modulate_c128(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, sig, stream);
+    if (rc < 0) return rc;
+    WF_REQUIRE(rc == 0, "wf_cpm_link_run: burst / pulse outside the fused modulator (%lld symbols, %d taps)",
+               (long long)cfg->nsym, cfg->ntaps);
+    MARK(3);
+    MARK(4);
+    if ((rc = wf_awgn_c128(ctx, sig, L.npts, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, sig, stream))) return rc;
+    MARK(5);
+    if ((rc = wf_cpm_mf_rows_c128(ctx, sig, L.npts, cfg->d_templates, cfg->det.nh, L.nfilt, L.ntm, L.start0, cfg->sps, L.ncalls,
+                                  rows, stream))) return rc;
+    MARK(6);
+    if ((rc = wf_cpm_viterbi_detect(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, stream))) return rc;
+    MARK(7);
+    // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] are compared
+    const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;
+    int64_t m = L.ncalls - cfg->det.D + 1 - skip;
+    if (m < 0) m = 0;
+    if (m > 0)
+        if ((rc = wf_cpm_count_errors(ctx, dec + skip + cfg->det.D - 1, syms + skip, cfg->det.M, m, d_counts, stream))) return rc;
+    MARK(8);
+#undef MARK
+    if (h_compared) *h_compared = m;
+    return WF_OK;
+}

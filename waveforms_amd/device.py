@@ -195,3 +195,22 @@ def decimation(size: int, sps: int, length: int, timing_offset: int):
     ncols = (limit - first + sps - 1) // sps if limit > first else 0
     return first, ncols
 
+
+
+def cpm_mf_rows(received, templates, start0: int, sps: int, ncalls: int):
+    """Generic CPM detector front end -> rows f64[ncalls, nfilt, 2]; templates f64[nh, nfilt, ntm, 2]."""
+    nsamp = int(received.shape[0])
+    nh, nfilt, ntm = (int(v) for v in templates.shape[:3])
+    out = _hip.empty((max(ncalls, 0), nfilt, 2), "float64")
+    _hip.check(_hip.lib().wf_cpm_mf_rows_c128(_hip.ctx(), _hip.ptr(received), nsamp, _hip.ptr(templates), nh, nfilt, ntm,
+                                              start0, sps, ncalls, _hip.ptr(out), _hip.stream()))
+    return out
+
+
+def cpm_count_errors(decided_u, ref_alpha, M: int, m: int, counts=None):
+    """counts[0] += symbol errors, counts[1] += bit errors of decided U against transmitted alpha."""
+    if counts is None:
+        counts = _hip.zeros(2, "int64")
+    _hip.check(_hip.lib().wf_cpm_count_errors(_hip.ctx(), _hip.ptr(decided_u), _hip.ptr(ref_alpha), M, m, _hip.ptr(counts),
+                                              _hip.stream()))
+    return counts

@@ -225,3 +225,85 @@ class SOQPSKStream:
     def result(self) -> tuple[int, int, int]:
         """Like :meth:`SOQPSKLink.result` (raises if a detector chunk did not merge)."""
         return SOQPSKLink.result(self)
+
+
+class CPMLink:
+    """Device-resident link for the waveforms served by the generic CPM trellis detector
+    (``wf_cpm_link_run``): PRBS -> mapper -> cpm_modulate -> AWGN -> matched-filter rows ->
+    detector -> error count.  ``waveform``: "multih" (ARTM multi-h CPM, BASELINE configs[2]) or
+    "pcmfm"."""
+
+    STAGES = ("prbs", "map", "modulate", "-", "awgn", "mfbank", "viterbi", "count")
+
+    def __init__(self, nsym: int, sps: int = 8, waveform: str = "multih", spec=None, pn_degree: int = 23, warmup: int = 0,
+                 skip_head: int = 64, private_ctx: bool = False) -> None:
+        from .viterbi import cpm
+
+        if waveform == "multih":
+            from .cpm.multih import freq_pulse_multih_irig
+
+            pulse, kind, spec = freq_pulse_multih_irig(sps), 1, spec or cpm.ARTM_16
+        elif waveform == "pcmfm":
+            from .cpm.pcmfm import freq_pulse_pcmfm
+
+            pulse, kind, spec = freq_pulse_pcmfm(sps), 2, spec or cpm.PCMFM_10
+        else:
+            raise ValueError(f"unknown waveform {waveform!r}")
+        self.nsym, self.sps, self.spec, self.waveform = int(nsym), int(sps), spec, waveform
+        self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()
+        self._owns_ctx = bool(private_ctx)
+        self._d_h = _hip.to_device(spec.mod_index)
+        self._d_pulse = _hip.to_device(np.asarray(pulse, dtype=np.float64))
+        self._d_templates = _hip.to_device(cpm.matched_filter_templates(pulse, sps, spec))
+        self._d_rot = _hip.to_device(cpm.rotation_table(spec))
+        cfg = _hip.CPMLinkConfig()
+        cfg.nsym, cfg.sps = self.nsym, self.sps
+        cfg.degree, cfg.mask, cfg.state, cfg.skip = pn_degree, generate_mask(pn_degree), (1 << pn_degree) - 1, 0
+        cfg.mapper_kind, cfg.det = kind, spec.c_config()
+        cfg.d_h, cfg.d_pulse, cfg.ntaps = self._d_h.data_ptr(), self._d_pulse.data_ptr(), int(np.asarray(pulse).size)
+        cfg.d_templates, cfg.d_rot_cs = self._d_templates.data_ptr(), self._d_rot.data_ptr()
+        cfg.sigma, cfg.seed, cfg.stream_id = 0.0, 1, 0
+        cfg.warmup, cfg.skip_head, cfg.event_slot = warmup, skip_head, -1
+        self.cfg = cfg
+        self.workspace_bytes = _hip.lib().wf_cpm_link_workspace_bytes(ctypes.byref(cfg))
+        if self.workspace_bytes < 0:
+            raise ValueError("invalid link configuration")
+        self.workspace = _hip.empty(self.workspace_bytes, "uint8")
+        self.counts = _hip.zeros(2, "int64")
+        self.compared = 0
+
+    def __del__(self):
+        if getattr(self, "_owns_ctx", False):
+            _hip.free_ctx(self._ctx)
+            self._owns_ctx = False
+
+    def layout(self) -> dict:
+        info = (ctypes.c_int64 * 8)()
+        _hip.check(_hip.lib().wf_cpm_link_layout(ctypes.byref(self.cfg), info))
+        keys = ("calls", "start0", "off_decisions", "off_syms", "off_signal", "_", "signal_len", "off_rows")
+        return dict(zip(keys, (int(v) for v in info)))
+
+    def reset_counts(self) -> None:
+        self.counts.zero_()
+        self.compared = 0
+
+    def stage_ms(self, event_slot: int) -> dict[str, float]:
+        buf = (ctypes.c_float * len(self.STAGES))()
+        _hip.check(_hip.lib().wf_link_stage_ms(self._ctx, event_slot, buf))
+        return {k: float(v) for k, v in zip(self.STAGES, buf) if k != "-"}
+
+    def run_block(self, ebn0_db: float | None, seed: int = 1, stream_id: int = 0, skip_bits: int = 0, event_slot: int = -1) -> None:
+        """Queue one trial block; ``ebn0_db=None`` = no noise."""
+        from .viterbi.cpm import sigma_for_ebn0 as cpm_sigma
+
+        c = self.cfg
+        c.sigma = 0.0 if ebn0_db is None else cpm_sigma(ebn0_db, self.sps, self.spec.bits_per_symbol)
+        c.seed, c.stream_id, c.skip, c.event_slot = seed, stream_id, skip_bits, event_slot
+        m = ctypes.c_int64(0)
+        _hip.check(_hip.lib().wf_cpm_link_run(self._ctx, ctypes.byref(c), self.workspace.data_ptr(), self.workspace_bytes,
+                                              self.counts.data_ptr(), ctypes.byref(m), _hip.stream()))
+        self.compared += m.value
+
+    def result(self) -> tuple[int, int, int]:
+        """(symbol errors, bit errors, symbols compared); raises if a detector chunk was not proven."""
+        return SOQPSKLink.result(self)

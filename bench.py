@@ -77,7 +77,14 @@ def _cpu_trial(job):
     state = ((idx + 1) * 2654435761) & 0x7FFFFF or 1
     rng = np.random.Generator(np.random.PCG64(seed=1 + idx))
     pulse, sigma = oracle.freq_pulse_soqpsk_tg(sps), oracle.sigma_for_ebn0(ebn0, sps)
-    if kind == "port":      # compiled / vectorised restatement (C loops + numpy)
+    if kind.startswith("cpm:"):   # generic CPM detector chain (build-defined; no reference form exists)
+        waveform = kind[4:]
+        spec = oracle.ARTM_16 if waveform == "multih" else oracle.PCMFM_SPEC
+        bits, _ = oracle.glfsr_bits(0x420000, state, nsym * spec.lgM)
+        sym = oracle.multih_mapper(bits)[0] if waveform == "multih" else oracle.pcmfm_mapper(bits)
+        pulse = oracle.freq_pulse_multih_irig(sps) if waveform == "multih" else oracle.freq_pulse_pcmfm(sps)
+        res = oracle.cpm_detection_run(sym, pulse, sps, spec, sigma=oracle.cpm_sigma_for_ebn0(ebn0, sps, spec.lgM), rng=rng)
+    elif kind == "port":      # compiled / vectorised restatement (C loops + numpy)
         bits, _ = oracle.glfsr_bits(0x420000, state, nsym)
         res = oracle.detection_run(bits, pulse, 0.25, sps, sigma, rng=rng)
     else:                   # the reference's execution form: interpreted per-symbol / per-sample loops
@@ -88,7 +95,7 @@ def _cpu_trial(job):
     return nsym, time.perf_counter() - t0, res["bit_errors"], res["compared"]
 
 
-def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int) -> dict:
+def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int, waveform: str = "soqpsk") -> dict:
     """The oracle timed on the host cores of this box, one process per core on independent trial
     blocks, in two forms: `port` = the CPU port of the reference algorithm (C loops +
     numpy), and `faithful_loop` = the reference's own execution form (interpreted per-symbol
@@ -105,7 +112,8 @@ def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int) -> dict:
     out = {}
     with ctx.Pool(cores) as pool:
         pool.map(_cpu_pool_ready, range(cores), chunksize=1)     # imports + C build outside the clock
-        for kind, n in (("port", nsym_port), ("faithful_loop", nsym_loop)):
+        kinds = (("port", nsym_port), ("faithful_loop", nsym_loop)) if waveform == "soqpsk" else ((f"cpm:{waveform}", nsym_port // 2),)
+        for kind, n in kinds:
             one = _cpu_trial_timed(pool, [(kind, 0, n, sps, ebn0)])
             many = _cpu_trial_timed(pool, [(kind, 1 + k, n, sps, ebn0) for k in range(cores)])
             out[kind] = {"value": round(many["rate"], 4), "unit": "Msym/s", "cores": cores,
@@ -113,6 +121,11 @@ def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int) -> dict:
                          "sample": f"{cores} independent blocks of {n} PN23 symbols, one process per core, "
                                    f"{many['wall']:.1f} s wall (1 block on 1 core: {one['wall']:.1f} s); "
                                    f"bit errors {many['bit_errors']}/{many['compared']}"}
+    if waveform != "soqpsk":
+        o = out[f"cpm:{waveform}"]
+        return {**o, "host_cores": host_cores, "kind": "port",
+                "sample": f"same {waveform} @{sps}sps chain, Eb/N0 {ebn0:.1f} dB, sequential C detector + numpy (the reference has no "
+                          f"detector for this waveform: build-defined oracle), PCG64 noise: {o['sample']}"}
     return {"value": out["port"]["value"], "unit": "Msym/s", "cores": cores, "host_cores": host_cores, "kind": "port",
             "single_core": out["port"]["single_core"],
             "sample": "same SOQPSK-TG @%dsps chain, Eb/N0 %.1f dB, oracle C loops + numpy, PCG64 noise: %s"
@@ -139,6 +152,9 @@ def main() -> None:
     ap.add_argument("--sps", type=int, default=8)
     ap.add_argument("--ebn0", type=float, default=10.0)
     ap.add_argument("--detector", default="PT")
+    ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"],
+                    help="soqpsk: BASELINE configs[1] (the headline metric); multih: configs[2], ARTM multi-h CPM through the "
+                         "16-state generic CPM trellis detector; pcmfm: PCM/FM through the same detector family")
     ap.add_argument("--fuse", type=int, default=7,
                     help="bit 0: fused modulator (FIR + phase scan in one pass); bit 1: AWGN inside the MF bank; "
                          "bit 2: detector-packed 32 B rows between bank and detector; 0 = every stage its own kernel")
@@ -169,8 +185,16 @@ def main() -> None:
     from waveforms_amd.link import SOQPSKLink
 
     nstreams = max(1, args.streams)
-    links = [SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse, private_ctx=nstreams > 1)
-             for _ in range(nstreams)]
+    cpm = args.waveform != "soqpsk"
+    if cpm:
+        from waveforms_amd.link import CPMLink
+
+        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1) for _ in range(nstreams)]
+        bits_per_sym = links[0].spec.bits_per_symbol
+    else:
+        links = [SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse, private_ctx=nstreams > 1)
+                 for _ in range(nstreams)]
+        bits_per_sym = 1
     streams = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
     link = links[0]
     slots = 64
@@ -185,7 +209,8 @@ def main() -> None:
         # every (rank, step) is its own trial block: distinct PRBS segment and Philox subsequence
         block = k * world + rank
         with torch.cuda.stream(streams[k % nstreams]):
-            links[k % nstreams].run_block(args.ebn0, seed=1, stream_id=block & 0xFFFFFFFF, skip_bits=(block % 4096) * args.nsym,
+            links[k % nstreams].run_block(args.ebn0, seed=1, stream_id=block & 0xFFFFFFFF,
+                                          skip_bits=(block % 4096) * args.nsym * bits_per_sym,
                                           event_slot=(k % slots) if timed and instrumented(k) else -1)
 
     def fence() -> None:
@@ -225,14 +250,22 @@ def main() -> None:
         for name, ms in links[k % nstreams].stage_ms(k % slots).items():
             acc[name] = acc.get(name, 0.0) + ms / len(ev_steps)
     bps = stage_bytes_per_symbol(args.sps)
-    if args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
+    if cpm:
+        nf = links[0].spec.nfilt
+        # bits -> symbols -> c128 samples -> noisy samples in place -> nf complex rows -> one decision byte
+        bps = {"prbs": bits_per_sym, "map": bits_per_sym + 1, "modulate": 1 + 16 * args.sps, "awgn": 32 * args.sps,
+               "mfbank": 16 * args.sps + 16 * nf, "viterbi": 16 * nf + 1, "count": 2}
+        STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}>",
+                             "viterbi": f"cpm_viterbi_kernel<{links[0].spec.M}, {links[0].spec.Lp}>", "map": "symbol_map_kernel",
+                             "modulate": "mod_main_kernel<4, true>"})
+    if not cpm and args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
         acc["modulate"] = acc.pop("fir")
         acc.pop("phase", None)
         bps["modulate"] = 1 + 16 * args.sps
-    if args.fuse & 2:   # noisy samples never materialise: clean c128 in, 3 c128 per symbol out
+    if not cpm and args.fuse & 2:   # noisy samples never materialise: clean c128 in, 3 c128 per symbol out
         acc["awgn+mfbank"] = acc.pop("mfbank") + acc.pop("awgn")
         bps["awgn+mfbank"] = bps["mfbank"]
-    packed = links[0].row_bytes == 32
+    packed = not cpm and links[0].row_bytes == 32
     if packed:          # detector-packed rows: 4 doubles per symbol between the bank and the detector
         bps["awgn+mfbank"] = 16 * args.sps + 32
         bps["viterbi"] = 32 + 2
@@ -256,19 +289,25 @@ def main() -> None:
     if rank == 0:
         total_sym = args.steps * args.nsym * world
         out = {
-            "metric": f"SOQPSK-TG Msym/s mod+Viterbi-detect @{args.sps}sps",   # BASELINE's metric at the default sps = 8
+            "metric": (f"SOQPSK-TG Msym/s mod+Viterbi-detect @{args.sps}sps" if not cpm else    # BASELINE's metric at the default sps = 8
+                       f"{'ARTM multi-h CPM' if args.waveform == 'multih' else 'PCM/FM'} Msym/s mod+{links[0].spec.nstates}-state-Viterbi-detect @{args.sps}sps"),
             "value": round(total_sym / elapsed / 1e6, 2), "unit": "Msym/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"SOQPSK-TG {args.nsym:.0e} symbols @{args.sps} sps, modulate + AWGN + "
-                                   f"{args.detector} matched filter + 4-state Viterbi detect (BASELINE configs[1])",
+            "config": {"workload": (f"SOQPSK-TG {args.nsym:.0e} symbols @{args.sps} sps, modulate + AWGN + "
+                                    f"{args.detector} matched filter + 4-state Viterbi detect (BASELINE configs[1])" if not cpm else
+                                    f"{'Multi-h ARTM CPM (IRIG106 Tier II)' if args.waveform == 'multih' else 'PCM/FM'} {args.nsym:.0e} symbols "
+                                    f"@{args.sps} sps, modulate + AWGN + {links[0].spec.nfilt} matched filters ({links[0].spec.Lp}-symbol pulse "
+                                    f"truncation) + {links[0].spec.nstates}-state trellis detect"
+                                    + (" (BASELINE configs[2])" if args.waveform == "multih" else "")),
+                       "waveform": args.waveform,
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
-                       "fuse": args.fuse, "streams": nstreams, "parallelism": f"independent trial blocks x{world}"},
+                       "fuse": None if cpm else args.fuse, "streams": nstreams, "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
-                    "ber": be / max(compared, 1),
+                    "ber": be / max(compared * bits_per_sym, 1),
                     # link.result() raises otherwise: every detector chunk started from bitwise the
                     # metrics of the sequential detector (device-side check in every launch)
                     "detector_chunks_unproven": 0},
@@ -276,7 +315,7 @@ def main() -> None:
             "stages": stages,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample)
+            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample, args.waveform)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

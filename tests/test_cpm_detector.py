@@ -224,7 +224,7 @@ def test_gpu_cpm_link_equals_oracle_chain(oracle, waveform, nsym):
     spec = oracle.ARTM_16 if waveform == "multih" else oracle.PCMFM_SPEC
     pulse = oracle.freq_pulse_multih_irig(SPS) if waveform == "multih" else oracle.freq_pulse_pcmfm(SPS)
     bps = spec.lgM
-    for ebn0, block in ((5.0, 0), (8.0, 3)):
+    for ebn0, block in ((4.0, 0), (7.0, 3)):
         link.reset_counts()
         link.run_block(ebn0, seed=1, stream_id=block, skip_bits=block * nsym * bps)
         se, be, m = link.result()
@@ -235,14 +235,15 @@ def test_gpu_cpm_link_equals_oracle_chain(oracle, waveform, nsym):
         x = (res["decisions"] ^ res["truth"])[64:]
         assert m == x.size == res["compared"] - 64
         assert (se, be) == (int(np.count_nonzero(x)), int(np.unpackbits(x[:, None], axis=1).sum()))
-        assert be > 0 or nsym < 1000
+        assert be > 0 or nsym < 1000 or ebn0 > 5.0
 
 
 @pytest.mark.gpu
 def test_gpu_multih_full_size_noiseless_and_ber(oracle):
     """BASELINE configs[2] at full size (1e7 quaternary symbols = 2e7 PN23 bits): no noise -> zero
     errors; at 10 dB the BER sits where the sequential oracle puts this 16-state design
-    (1.7e-4, oracle run of 4e5 bits) and above the minimum-distance bound."""
+    (2.4e-4 .. 3.5e-4 over 8e6-bit oracle runs: error events come in long bursts, so the estimate
+    is noisy) and above the minimum-distance bound."""
     from waveforms_amd.link import CPMLink
 
     link = CPMLink(10_000_000, SPS, waveform="multih")
@@ -254,4 +255,4 @@ def test_gpu_multih_full_size_noiseless_and_ber(oracle):
     se, be, m = link.result()
     ber = be / (2 * m)
     q = 0.5 * math.erfc(math.sqrt(1.2957 * 10.0) / math.sqrt(2))
-    assert q < ber < 3.5e-4, (ber, q)
+    assert q < ber < 5e-4, (ber, q)

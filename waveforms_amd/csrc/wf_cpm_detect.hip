@@ -396,7 +396,10 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     WF_HIP(hipSetDevice(ctx->device));
     // calls per chunk: 256 for short bursts, 512 once that still fills the chip several times over
     P.CH = ncalls >= (1 << 22) ? 512 : 256;
-    int W = warmup ? warmup : CPM_DEFAULT_WARMUP;
+    // default warm-up: the D calls that refill the decision register plus the merge depth of the
+    // trellis — measured: 1e8 ARTM calls (M = 4) with 128 never tripped the proof, binary PCM/FM
+    // (one bit per call, slower merges) needed more than 128 on 5 chunks of 2e5
+    int W = warmup ? warmup : (det->M == 2 ? 3 * CPM_DEFAULT_WARMUP : CPM_DEFAULT_WARMUP);
     W = (W + CPM_TB - 1) / CPM_TB * CPM_TB;
     if (W > 4096) W = 4096;
     while (P.CH < W) P.CH *= 2;                                    // a chunk's warm-up never reaches before call 0 of the burst

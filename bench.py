@@ -155,9 +155,10 @@ def main() -> None:
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"],
                     help="soqpsk: BASELINE configs[1] (the headline metric); multih: configs[2], ARTM multi-h CPM through the "
                          "16-state generic CPM trellis detector; pcmfm: PCM/FM through the same detector family")
-    ap.add_argument("--fuse", type=int, default=7,
+    ap.add_argument("--fuse", type=int, default=15,
                     help="bit 0: fused modulator (FIR + phase scan in one pass); bit 1: AWGN inside the MF bank; "
-                         "bit 2: detector-packed 32 B rows between bank and detector; 0 = every stage its own kernel")
+                         "bit 2: detector-packed 32 B rows between bank and detector; bit 3: modulator + channel + bank in one "
+                         "kernel (no baseband samples in HBM); 0 = every stage its own kernel")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent trial blocks in flight on separate HIP streams (own workspace + context each)")
     ap.add_argument("--event-every", type=int, default=4,
@@ -258,14 +259,23 @@ def main() -> None:
         STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}>",
                              "viterbi": f"cpm_viterbi_kernel<{links[0].spec.M}, {links[0].spec.Lp}>", "map": "symbol_map_kernel",
                              "modulate": "mod_main_kernel<4, true>"})
-    if not cpm and args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
+    one_kernel = not cpm and (args.fuse & 15) == 15 and links[0].row_bytes == 32 and links[0].cfg.mf_ntaps == 9 and args.sps == 8
+    if one_kernel:      # fuse bit 3: the "fir" slot times modulator + channel + bank; symbols in, packed rows out
+        acc["mod+awgn+mfbank"] = acc.pop("fir")
+        for k in ("phase", "awgn", "mfbank"):
+            acc.pop(k, None)
+        bps["mod+awgn+mfbank"] = 1 + 32
+        bps["viterbi"] = 32 + 2
+        STAGE_KERNEL["mod+awgn+mfbank"] = "mod_chan_bank_kernel<9>"
+        STAGE_KERNEL["viterbi"] = "viterbi_batch_kernel<true>"
+    elif not cpm and args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
         acc["modulate"] = acc.pop("fir")
         acc.pop("phase", None)
         bps["modulate"] = 1 + 16 * args.sps
-    if not cpm and args.fuse & 2:   # noisy samples never materialise: clean c128 in, 3 c128 per symbol out
+    if not cpm and not one_kernel and args.fuse & 2:   # noisy samples never materialise: clean c128 in, 3 c128 per symbol out
         acc["awgn+mfbank"] = acc.pop("mfbank") + acc.pop("awgn")
         bps["awgn+mfbank"] = bps["mfbank"]
-    packed = not cpm and links[0].row_bytes == 32
+    packed = not cpm and not one_kernel and links[0].row_bytes == 32
     if packed:          # detector-packed rows: 4 doubles per symbol between the bank and the detector
         bps["awgn+mfbank"] = 16 * args.sps + 32
         bps["viterbi"] = 32 + 2

@@ -230,7 +230,11 @@ typedef struct {
                             /* inside the MF bank (wf_awgn_mf_bank_c128); bit 2 (with  */
                             /* bit 1, 3-filter bank, sps 8): the bank writes only the  */
                             /* 4 real components per call the 4-state detector reads   */
-                            /* ({Re z1, Im z1, Re|Im z0, Im|Re z2}: 32 B rows, not 48) */
+                            /* ({Re z1, Im z1, Re|Im z0, Im|Re z2}: 32 B rows, not 48);  */
+                            /* bit 3 (with bits 0-2, 9-tap bank): modulator, channel and */
+                            /* bank in ONE kernel — the baseband samples never reach HBM */
+                            /* (rows bit-identical to bits 0-2; falls back to them when  */
+                            /* the pulse is outside the kernel: > 9 symbols, sps != 8)   */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
                             /* around every stage into that slot (wf_link_stage_ms)   */
 } wf_link_config;

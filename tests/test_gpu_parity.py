@@ -477,7 +477,7 @@ def test_fused_channel_and_count_equal_stage_kernels(oracle):
     assert np.array_equal(_hip.to_host(b), _hip.to_host(b2)) and np.array_equal(_hip.to_host(s_), _hip.to_host(s2))
 
 
-@pytest.mark.parametrize("fuse", [0, 3, 7])
+@pytest.mark.parametrize("fuse", [0, 3, 7, 15])
 @pytest.mark.parametrize("detector,nsym", [("PT", 1 << 15), ("PAM", 1 << 15), ("PT", 100_000)])
 def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
     """wf_link_run (all stages chained in HBM, unfused and fused forms) vs the oracle chain
@@ -730,6 +730,62 @@ def torch_f64():
     return torch.float64
 
 
+@pytest.mark.parametrize("nsym,pulse_name,differential", [((1 << 18) + 77, "tg", True), (1024 * 5, "tg", False), (1024 * 3 + 1, "mil", True),
+                                                          (70_001, "tg", True), (1500, "tg", True), (1023, "mil", False)])
+def test_fused_modulator_channel_bank_rows_bit_identical(oracle, nsym, pulse_name, differential):
+    """fuse bit 3: modulator + channel + pulse-truncation bank in ONE kernel (the clean baseband
+    samples never reach HBM).  Its detector-packed rows are bit for bit those of fuse = 7
+    (modulator kernel -> channel + bank kernel), so decisions and counts are identical too —
+    across tile edges (8192 samples), at both ends of the burst, for bursts shorter than a tile,
+    and for the one-symbol MIL pulse."""
+    from waveforms_amd.link import SOQPSKLink
+
+    pulse = oracle.freq_pulse_soqpsk_tg(8) if pulse_name == "tg" else oracle.freq_pulse_soqpsk_mil(8)
+    ref = SOQPSKLink(nsym, 8, fuse=7, differential=differential, pulse=pulse)
+    fus = SOQPSKLink(nsym, 8, fuse=15, differential=differential, pulse=pulse)
+    assert ref.row_bytes == fus.row_bytes == 32
+    for ebn0, sid in ((3.0, 5), (9.0, 1 << 33)):
+        for link in (ref, fus):
+            link.reset_counts()
+            link.run_block(ebn0, seed=7, stream_id=sid, skip_bits=123)
+        assert ref.result() == fus.result()
+        lr, lf = ref.layout(), fus.layout()
+        calls = lr["calls"]
+        a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+        b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+        bad = np.nonzero((a.view(np.int64) != b.view(np.int64)).any(axis=1))[0]
+        assert bad.size == 0, (bad[:10], a[bad[:3]], b[bad[:3]])
+        for key in ("off_bits", "off_syms"):
+            assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
+    assert ref.result()[1] >= 0
+
+
+def test_fused_all_other_timing_offsets_and_generic_taps(oracle):
+    """The one-kernel link for every decimation phase (window start anywhere in the symbol) and for
+    a 3 x 9 bank WITHOUT the pulse-truncation symmetry (generic MAC path): rows == fuse 7."""
+    from waveforms_amd import _hip
+    from waveforms_amd.link import SOQPSKLink
+
+    nsym = 40_000
+    for off in range(-4, 4):
+        ref = SOQPSKLink(nsym, 8, fuse=7, timing_offset=off)
+        fus = SOQPSKLink(nsym, 8, fuse=15, timing_offset=off)
+        if off == 2:      # break the symmetry: arbitrary taps
+            rng = np.random.default_rng(3)
+            taps = _hip.to_device((rng.standard_normal((3, 9)) + 1j * rng.standard_normal((3, 9))))
+            for link in (ref, fus):
+                link._d_taps = taps
+                link.cfg.d_mf_taps = taps.data_ptr()
+        for link in (ref, fus):
+            link.run_block(6.0, seed=2, stream_id=off & 7)
+        assert ref.result() == fus.result(), off
+        lr, lf = ref.layout(), fus.layout()
+        calls = lr["calls"]
+        a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+        b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+        assert np.array_equal(a.view(np.int64), b.view(np.int64)), off
+
+
 # ------------------------------------------------------------------ full-size / long-burst paths
 def test_detector_long_burst_ch256(oracle):
     """Bursts of >= 3 * 2^22 calls take 256 calls per lane (the third chunk length): decisions of
@@ -752,12 +808,12 @@ def test_link_full_size_fuse_modes_agree(nsym):
     from waveforms_amd.link import SOQPSKLink
 
     results = {}
-    for fuse in (0, 3, 7):
+    for fuse in (0, 3, 7, 15):
         link = SOQPSKLink(nsym, 8, fuse=fuse)
         link.run_block(10.0, seed=1, stream_id=0)
         results[fuse] = link.result()
         del link
-    assert results[0] == results[3] == results[7]
+    assert results[0] == results[3] == results[7] == results[15]
     se, be, m = results[7]
     assert m == nsym - 3                  # ncols - length: the example's min_size (examples/soqpsk_detection.py:204)
     ber = be / m

@@ -13,6 +13,8 @@
 // independently: symbol amplitudes of the tile in LDS, per-thread tap phases in
 // registers (wf_fir.hip), in-tile fp64 scan by DPP + LDS wave totals (wf_phase.hip),
 // carry, mod, table sincos (LDS), wave-transposed stores of 64 consecutive samples.
+#include <stdlib.h>
+
 #include "wf_common.h"
 
 #ifndef MOD_THREADS
@@ -412,6 +414,270 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused modulator + channel + pulse-truncation bank (link `fuse` bit 3).  The body of
+// mod_main_kernel<JMAX, true> (row length 512 = 64 symbols at sps 8) with its output stage
+// replaced: instead of storing the 1.28 GB of clean baseband samples to HBM for the channel
+// kernel to read back (2.56 GB of the 3.3 GB a link step moves), every thread applies the
+// channel of wf_awgn_c128 to its two samples (one Philox block per thread and row) and parks
+// them in a 2-row LDS ring laid out like mf_bank_kernel's window; the 64 detector columns whose
+// 9-sample window starts in row u-1 are then taken from the ring by ALL 256 threads — a quad
+// per column, one real sum chain per lane (the A, B, C, D of the pulse-truncation bank's shared
+// sums; z1 = the plain sums) — and leave as the detector-packed 32 B row, 8 B per lane.
+// Arithmetic and its order are those of mod_main_kernel, awgn / mf_bank_kernel<3,true,8,9,true>:
+// the rows are bit-identical to fuse = 7.
+//   Tile edge: the last column of a tile looks up to 8 samples into the next tile.  The first
+// row of a tile is computed from the tile's own analytic carry, so wave 0 recomputes exactly
+// those samples of tile + 1 (same expressions as that tile's row 0) — no hand-off between
+// workgroups.  Column 0 of the burst looks at samples before sample 0: zeros (row -1 of tile 0).
+struct mcb_params {
+    double rot_re, rot_im, sigma;
+    uint64_t seed, stream_id, pair0;     // pair0 = first_index / 2 (first_index even)
+    int64_t ncols;
+    int kshift;       // floor((first - 4) / 8): column k's window starts at sample 8 (k + kshift) + d
+    int d;            // (first - 4) mod 8
+    int pack_par0;
+};
+
+#define MCB_RING 1024                        // samples: 2 rows of 512
+#define MCB_SLOTS (MCB_RING + MCB_RING / 8 + 16)  // one pad slot per 8 samples (conflict-free column reads) + the wrap copy
+
+template <int CTRL>
+__device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm broadcast of lane CTRL & 3 of each quad
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+template <int JMAX>
+__global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols,
+                                                                     const double *__restrict__ hvec,
+                                                                     const double *__restrict__ pulse,
+                                                                     const double *__restrict__ scratch,
+                                                                     const double *__restrict__ mf_taps,
+                                                                     double *__restrict__ rows, mod_params P, mcb_params Q)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    const int win = MOD_ROWS * 64 + JMAX + 2;
+    double *s_amp = s_dyn;                                                       // window of symbol amplitudes
+    double2 *s_ring = reinterpret_cast<double2 *>(s_dyn + ((win + 1) & ~1));     // noisy samples, 4 rows
+    __shared__ double s_tot[2 * MOD_WAVES];
+    __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
+    __shared__ double2 s_taps[27];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    static_assert(MOD_WAVES == 4, "the row-total prefix below is written out for 4 waves");
+    wf_stage_tables<1, 0>(s_tab, t, MOD_THREADS);
+    if (t < 27) s_taps[t] = reinterpret_cast<const double2 *>(mf_taps)[t];
+    const double2 *s_cis = s_tab + 128;
+    const wf_tabs_lds<1, 0> tb{s_tab};
+    // pulse-truncation structure of the bank (block-uniform, read straight from global memory):
+    // filter 1 all ones, filter 2 = conj(filter 0)
+    bool sym_taps = true;
+    {
+        const double2 *tg = reinterpret_cast<const double2 *>(mf_taps);
+        for (int j = 0; j < 9; ++j) {
+            const double2 t0 = tg[j], t1 = tg[9 + j], t2 = tg[18 + j];
+            sym_taps = sym_taps && t1.x == 1.0 && t1.y == 0.0 && t2.x == t0.x && t2.y == -t0.y;
+        }
+    }
+    const int sps = 8;
+    const int sym_per_row = 64;
+    const int tile_len = MOD_ROWS * 512;
+    const int cq = P.c / sps;
+    const int q0 = (2 * t + P.c) / sps;
+    const int r0 = (2 * t + P.c) - q0 * sps;
+    const int wrap = (r0 + 1 == sps) ? 1 : 0;
+    const int r1 = wrap ? 0 : r0 + 1;
+    double tap0[JMAX + 1], tap1[JMAX + 1];
+#pragma unroll
+    for (int i = 0; i <= JMAX; ++i) {
+        const int j0 = i - 1, k0 = r0 + j0 * sps;
+        tap0[i] = (j0 >= 0 && k0 < P.ntaps) ? pulse[k0] : 0.0;
+        const int j1 = i - 1 + wrap, k1 = r1 + j1 * sps;
+        tap1[i] = (j1 >= 0 && j1 < JMAX && k1 < P.ntaps) ? pulse[k1] : 0.0;
+    }
+    const double sec_per_unit = 128.0 * P.inv_sps, sec_phi0 = 128.0 * P.phi0_turns;
+    const int l_top0p1 = (q0 - cq) + JMAX;
+    const uint64_t *Wq = reinterpret_cast<const uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
+    const double *Gpart = scratch + MOD_OFF_GPART;
+    // bank: quad per column, one sum chain per lane
+    const int mq = t >> 2, mp = t & 3;
+    // per-part tap component, in LDS (as registers they cost a fifth wave per SIMD):
+    //   A: Re x * Re tap | B: Im x * Im tap | C: Re x * Im tap | D: Im x * Re tap
+    __shared__ double s_tapc[4 * 9];
+    __shared__ double2 s_halo[8];
+    if (t < 36) {
+        const double2 tp = reinterpret_cast<const double2 *>(mf_taps)[8 - t % 9];
+        s_tapc[t] = (t / 9 == 0 || t / 9 == 3) ? tp.x : tp.y;
+    }
+    const double *tapc = s_tapc + 9 * mp;
+    const double *ring_d = reinterpret_cast<const double *>(s_ring);
+
+    for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const int64_t tile_base = tile * tile_len;
+        const int64_t sym_base = tile_base / sps;
+        const int64_t mp1_lo = sym_base + cq - JMAX + 1;
+        const bool full_tile = tile_base + tile_len <= P.out_len;
+        // columns this tile may store, relative to its first symbol (32-bit tests per row)
+        const int64_t klo64 = -sym_base, khi64 = Q.ncols - sym_base;
+        const int klo = klo64 < -(1 << 20) ? -(1 << 20) : (int)klo64, khi = khi64 > (1 << 20) ? (1 << 20) : (int)khi64;
+        wf_lds_barrier();                                     // previous tile's columns are done with the ring
+        for (int k = t; k < win; k += MOD_THREADS) s_amp[k] = mod_amp(symbols, hvec, P, mp1_lo + k - 1);
+        if (tile == 0)                                        // samples before the burst (row -1): ring row 3 and the group before it
+            for (int k = t; k < 512 + 64 + 9; k += MOD_THREADS) s_ring[(MCB_RING / 512 - 1) * 576 - 9 + k] = make_double2(0.0, 0.0);
+        wf_lds_barrier();
+        double run = 0.0;
+        const int lpart = (int)((sym_base - P.dsh + 1) - mp1_lo);
+        if (tile > 0) {
+            run = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
+            double part = 0.0;
+            for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + l], Gpart[l], part);
+            run += part;
+        }
+        // the first 8 samples of the NEXT tile (lanes 0..3 of wave 0), by that tile's own row-0 expressions
+        if (wave == 0 && lane < 4) s_halo[2 * lane] = s_halo[2 * lane + 1] = make_double2(0.0, 0.0);
+        if (wave == 0 && tile + 1 < P.ntiles) {
+            double2 h0 = make_double2(0.0, 0.0), h1 = h0;
+            double runn = (double)Wq[tile + 1] * 0x1.0p-62 * P.sps_d;
+            double part = 0.0;
+            for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + MOD_ROWS * sym_per_row + l], Gpart[l], part);
+            runn += part;
+            double acc0 = 0.0, acc1 = 0.0;
+            const double *a = &s_amp[l_top0p1 + MOD_ROWS * sym_per_row];
+#pragma unroll
+            for (int i = 0; i <= JMAX; ++i) {
+                const double v = lane < 4 ? a[-i] : 0.0;
+                acc0 = fma(tap0[i], v, acc0);
+                acc1 = fma(tap1[i], v, acc1);
+            }
+            const double inc = wf_wave_incl_scan(acc0 + acc1);
+            const double ex = wf_wave_shr1(inc);
+            const double offw = 0.0;
+            const double v0 = runn + (offw + ex + acc0);
+            const double ra = fma(-floor(v0 * P.inv_sps), P.sps_d, v0);
+            const double rb = ra + acc1;
+            double2 e0, e1;
+            wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
+            wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
+            const int64_t n0 = tile_base + tile_len + 2 * lane;
+            double g[4];
+            wf_gaussian_two(Q.pair0 + (uint64_t)(n0 >> 1), Q.stream_id, Q.seed, Q.sigma, tb, g);
+            if (n0 < P.out_len) h0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
+            if (n0 + 1 < P.out_len) h1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
+            if (lane < 4) {                                   // parked until row 15 has been consumed (same wave reads it back)
+                s_halo[2 * lane] = h0;
+                s_halo[2 * lane + 1] = h1;
+            }
+        }
+        // The ring is indexed by i' = (sample - d) mod 2048, d = offset of the window starts inside
+        // the symbol grid: every window then starts on a pad-group boundary (8 samples + 1 pad slot),
+        // so its 9 samples sit at CONSTANT slot offsets 0..7 and 9 from the group's first slot —
+        // no per-tap index arithmetic.  Index 2048 (= 0 one turn later) has its own slot: the one
+        // window that ends there reads the copy.
+        // the 64 columns whose window starts in row `rho` of this tile (rho = -1 .. 15)
+        auto bank_row = [&](int rho) __attribute__((always_inline)) {
+            const int kr = 64 * rho + mq - Q.kshift;                    // column index relative to the tile's first symbol
+            const int64_t k = sym_base + kr;
+            const bool k_ok = kr >= klo && kr < khi;
+            const int grp = (64 * rho + mq) & (MCB_RING / 8 - 1);       // pad group of the window start
+            const bool odd = ((Q.pack_par0 + kr + (int)(sym_base & 1)) & 1) != 0;
+            if (sym_taps) {
+                const double *xb = ring_d + 2 * (9 * grp) + (mp & 1);
+                double S = 0.0, U = 0.0;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const double x = xb[2 * (j < 8 ? j : 9)];
+                    S = fma(x, tapc[j], S);
+                    U += x;
+                }
+                const double A = mcb_quad_bcast<0x00>(S), B = mcb_quad_bcast<0x55>(S);
+                const double C = mcb_quad_bcast<0xAA>(S), D = mcb_quad_bcast<0xFF>(S);
+                const double va = odd ? C + D : A - B;                    // Im z0 | Re z0
+                const double vb = odd ? A + B : D - C;                    // Re z2 | Im z2
+                const double val = mp < 2 ? U : (mp == 2 ? va : vb);
+                if (k_ok) rows[4 * k + mp] = val;
+            } else {
+                // any 3 x 9 bank: lane p keeps the one chain of the packed row it stores
+                const int f = mp < 2 ? 1 : (mp == 2 ? 0 : 2);
+                const bool imag = mp == 1 || (mp == 2 && odd) || (mp == 3 && !odd);
+                const double2 *xb = s_ring + 9 * grp;
+                double acc = 0.0;
+#pragma unroll 1
+                for (int j = 0; j < 9; ++j) {
+                    const double2 x = xb[j < 8 ? j : 9];
+                    const double2 tp = s_taps[f * 9 + (8 - j)];
+                    acc = imag ? fma(x.x, tp.y, fma(x.y, tp.x, acc)) : fma(x.x, tp.x, fma(-x.y, tp.y, acc));
+                }
+                if (k_ok) rows[4 * k + mp] = acc;
+            }
+        };
+#pragma unroll 2
+        for (int u = 0; u < MOD_ROWS; ++u) {
+            double acc0 = 0.0, acc1 = 0.0;
+            {
+                const double *a = &s_amp[l_top0p1 + u * sym_per_row];
+#pragma unroll
+                for (int i = 0; i <= JMAX; ++i) {
+                    const double v = a[-i];
+                    acc0 = fma(tap0[i], v, acc0);
+                    acc1 = fma(tap1[i], v, acc1);
+                }
+            }
+            const double inc = wf_wave_incl_scan(acc0 + acc1);
+            const double ex = wf_wave_shr1(inc);
+            double *tot = s_tot + (u & 1) * MOD_WAVES;
+            if (lane == 63) tot[wave] = inc;
+            wf_lds_barrier();
+            // same sums in the same order as mod_main_kernel's loop (0.0 + t0 == t0)
+            const double t0_ = tot[0], p1_ = t0_ + tot[1], p2_ = p1_ + tot[2], rowtot = p2_ + tot[3];
+            const double offw = wave_u == 0 ? 0.0 : (wave_u == 1 ? t0_ : (wave_u == 2 ? p1_ : p2_));
+            const double v0 = run + (offw + ex + acc0);
+            const double ra = fma(-floor(v0 * P.inv_sps), P.sps_d, v0);
+            const double rb = ra + acc1;
+            double2 e0, e1;
+            wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
+            wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
+            // channel (wf_awgn_c128): derotate + Philox AWGN, one block per thread and row
+            const int64_t n0 = tile_base + (int64_t)u * 512 + 2 * t;
+            double g[4];
+            wf_gaussian_two(Q.pair0 + (uint64_t)(n0 >> 1), Q.stream_id, Q.seed, Q.sigma, tb, g);
+            double2 x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
+            double2 x1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
+            if (!full_tile) {                                   // (tile-uniform) samples past the end of the burst are zeros to the bank
+                if (n0 >= P.out_len) x0 = make_double2(0.0, 0.0);
+                if (n0 + 1 >= P.out_len) x1 = make_double2(0.0, 0.0);
+            }
+            const int ia = ((u << 9) + 2 * t - Q.d) & (MCB_RING - 1), ib = (ia + 1) & (MCB_RING - 1);
+            s_ring[ia + (ia >> 3)] = x0;
+            s_ring[ib + (ib >> 3)] = x1;
+            if (ia == 0) s_ring[MCB_RING + MCB_RING / 8] = x0;  // index 2048: read by the window that ends the ring
+            if (ib == 0) s_ring[MCB_RING + MCB_RING / 8] = x1;
+            // Two-row ring: row u is complete after this barrier, and the next write into the ring
+            // (row u + 1, behind the NEXT row's first barrier) comes after every wave has left
+            // bank_row(u - 1) — one more barrier per row than a four-row ring, 18 KB less LDS
+            // (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
+            wf_lds_barrier();
+            if (u >= 1 || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);
+            run += rowtot;
+        }
+        wf_lds_barrier();                                     // every wave is done with row 14
+        if (wave == 0 && lane < 4) {                          // row 16's first 8 samples
+            const int ia = (2 * lane - Q.d) & (MCB_RING - 1), ib = (ia + 1) & (MCB_RING - 1);
+            const double2 h0 = s_halo[2 * lane], h1 = s_halo[2 * lane + 1];
+            s_ring[ia + (ia >> 3)] = h0;
+            s_ring[ib + (ib >> 3)] = h1;
+            if (ia == 0) s_ring[MCB_RING + MCB_RING / 8] = h0;
+            if (ib == 0) s_ring[MCB_RING + MCB_RING / 8] = h1;
+        }
+        wf_lds_barrier();
+        bank_row(MOD_ROWS - 1);
+    }
+}
+
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
 // Geometry shared by the one-shot entry point and the streaming link.
@@ -457,10 +723,10 @@ static bool mod_setup(mod_params &P, int64_t nsym, int nh, int ntaps, int sps, d
     return npts >= ntaps && J <= 33 && P.npart <= MOD_MAX_PART && P.spt >= P.dsh + J + P.nhead + 2;
 }
 
-static int mod_launch(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols, const double *d_h,
-                      const double *d_pulse, double *d_out_ri, const uint64_t *d_q_in, uint64_t *d_q_out, void *stream)
+// The two carry kernels (tile sums, tile scan) into the context's scratch.
+static int mod_launch_carries(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols, const double *d_h,
+                              const double *d_pulse, const uint64_t *d_q_in, uint64_t *d_q_out, void *stream)
 {
-    const int J = (P.ntaps + P.sps - 1) / P.sps;
     hipStream_t s = wf_stream(stream);
     const size_t words = (size_t)MOD_OFF_P + 2 * (size_t)P.ntiles + 8;
     int rc = wf_ctx_reserve_mod(ctx, words);
@@ -471,6 +737,17 @@ static int mod_launch(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols,
     WF_LAUNCH_CHECK();
     hipLaunchKernelGGL(mod_tile_scan_kernel, dim3(1), dim3(1024), 0, s, d_symbols, d_h, d_pulse, P, scratch, d_q_in, d_q_out);
     WF_LAUNCH_CHECK();
+    return WF_OK;
+}
+
+static int mod_launch(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols, const double *d_h,
+                      const double *d_pulse, double *d_out_ri, const uint64_t *d_q_in, uint64_t *d_q_out, void *stream)
+{
+    const int J = (P.ntaps + P.sps - 1) / P.sps;
+    hipStream_t s = wf_stream(stream);
+    int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, d_q_in, d_q_out, stream);
+    if (rc) return rc;
+    double *scratch = ctx->d_mod_scratch;
     const int64_t max_grid = 2048 * (256 / MOD_THREADS);
     const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
     const int sps = P.sps;
@@ -507,6 +784,50 @@ extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_
     mod_params P;
     if (!mod_setup(P, nsym, nh, ntaps, sps, phi0)) return 1;  // caller falls back to the two stage kernels
     return mod_launch(ctx, P, d_symbols, d_h, d_pulse, d_out_ri, nullptr, nullptr, stream);
+}
+
+// Fused modulator + channel + 3 x 9 bank with detector-packed rows (link fuse bit 3; internal).
+// Returns 1 — not an error — when the configuration is outside the fused kernel (the caller then
+// runs the separate kernels): needs sps 8, a pulse of at most 9 symbols inside the fused
+// modulator's envelope, an even first noise index.
+int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
+                            const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
+                            double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
+                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream)
+{
+    WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_mf_taps && d_rows4, "wf_mod_chan_bank_packed: NULL argument");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_rows4) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_mf_taps) & 15) == 0,
+               "wf_mod_chan_bank_packed: device pointers must be 16-byte aligned");
+    mod_params P;
+    if (sps != 8 || (first_index & 1) || first < 0 || first >= 8 || ncols < 1) return 1;
+    if (!mod_setup(P, nsym, nh, ntaps, sps, phi0) || P.rs != 2 * MOD_THREADS) return 1;
+    const int J = (ntaps + sps - 1) / sps;
+    if (J > 9) return 1;
+    WF_REQUIRE(first + (ncols - 1) * 8 < P.out_len, "wf_mod_chan_bank_packed: columns run past the burst");
+    WF_HIP(hipSetDevice(ctx->device));
+    int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, nullptr, nullptr, stream);
+    if (rc) return rc;
+    mcb_params Q;
+    Q.rot_re = rot_re; Q.rot_im = rot_im; Q.sigma = sigma;
+    Q.seed = seed; Q.stream_id = stream_id; Q.pair0 = first_index >> 1;
+    Q.ncols = ncols;
+    Q.kshift = first >= 4 ? 0 : -1;
+    Q.d = (int)((first - 4 + 8) & 7);
+    Q.pack_par0 = pack_par0 & 1;
+    const int JM = J <= 4 ? 4 : 9;
+    const int win = MOD_ROWS * 64 + JM + 2;
+    size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)MCB_SLOTS * sizeof(double2);
+    if (const char *pad = getenv("WF_MCB_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
+    const int64_t max_grid = 2048;
+    const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
+    using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
+    kern_t k = JM == 4 ? mod_chan_bank_kernel<4> : mod_chan_bank_kernel<9>;
+    if (lds > 48 * 1024)
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(MOD_THREADS), lds, wf_stream(stream), d_symbols, d_h, d_pulse, ctx->d_mod_scratch, d_mf_taps,
+                       d_rows4, P, Q);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
 }
 
 // Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total

@@ -125,6 +125,29 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     MARK(1);
     if ((rc = wf_fsm_encode(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, cfg->nsym, 0, 0, syms, nullptr, stream))) return rc;
     MARK(2);
+    // fuse bit 3 (with bits 1 and 2 in effect): modulator, channel and bank in ONE kernel — the clean
+    // baseband samples never exist in HBM.  Outside that kernel's envelope the bits below apply.
+    bool fused_all = false;
+    if ((cfg->fuse & 8) && (cfg->fuse & 1) && link_packed_rows(cfg) && cfg->mf_ntaps == 9 && L.ncols > 0) {
+        rc = wf_mod_chan_bank_packed(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_mf_taps,
+                                     cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, L.first, L.ncols, 0,
+                                     mf, stream);
+        if (rc < 0) return rc;
+        fused_all = rc == 0;
+    }
+    if (fused_all) {
+        MARK(3); MARK(4); MARK(5); MARK(6);   // the "fir" slot times the whole fused kernel
+        if ((rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream))) return rc;
+        MARK(7);
+        int64_t m_ = L.ncols - length;
+        if (m_ > cfg->nsym) m_ = cfg->nsym;
+        if (m_ < 0) m_ = 0;
+        if (m_ > 0)
+            if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, stream))) return rc;
+        MARK(8);
+        if (h_compared) *h_compared = m_;
+        return WF_OK;
+    }
     bool fused_mod = false;
     if (cfg->fuse & 1) {
         rc = wf_cpm_modulate_c128(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, sig, stream);

@@ -35,7 +35,7 @@ class SOQPSKLink:
 
     def _configure(self, nsym: int, sps: int = 8, pulse=None, mod_index: float = 0.25, detector: str = "PT",
                    pn_degree: int = 23, differential: bool = True, timing_offset: int | None = None,
-                   warmup: int = 0, fuse: int = 7, private_ctx: bool = False) -> None:
+                   warmup: int = 0, fuse: int = 15, private_ctx: bool = False) -> None:
         self.nsym, self.sps = int(nsym), int(sps)
         # a link that runs on its own stream next to other links needs its own scratch
         self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()

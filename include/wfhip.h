@@ -189,6 +189,12 @@ int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int differenti
                           const double *d_mf3_ri, double *d_bits_out, double *d_syms_out,
                           void *stream);
 
+/* The same call with HOST operands (h_mf3: 3 complex128; outputs `length` doubles each), for the
+ * reference's per-symbol loop (examples/soqpsk_detection.py:189-198): one launch + one stream
+ * synchronise through pinned, device-mapped staging owned by the context.  Synchronous. */
+int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length, int differential,
+                               const double *h_mf3_ri, double *h_bits_out, double *h_syms_out, void *stream);
+
 /* ---- K11: error counting ------------------------------------------------------
  * examples/soqpsk_detection.py:200-209: number of j < m with
  * det_syms[j] != ref_syms[j] and with det_bits[j] != ref_bits[j]; the two counts

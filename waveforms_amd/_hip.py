@@ -50,6 +50,7 @@ SIGNATURES = {
     "wf_viterbi4_detect": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "wf_viterbi4_state_bytes": (c_int64, [c_int]),
     "wf_viterbi4_iteration": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "wf_viterbi4_iteration_host": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
     "wf_count_errors": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P]),
     "wf_link_workspace_bytes": (c_int64, [_P]),
     "wf_link_run": (c_int, [_P, _P, _P, c_int64, _P, POINTER(c_int64), _P]),

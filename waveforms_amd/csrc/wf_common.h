@@ -61,6 +61,8 @@ struct wf_ctx {
     size_t vit_edge_words = 0;
     unsigned long long *d_vit_unmerged = nullptr;   // chunks whose warm-up did not reach the true path metrics
     hipEvent_t *events = nullptr;  // WF_LINK_EVENT_SLOTS x (WF_LINK_STAGES + 1), created lazily
+    double *h_iter = nullptr;      // per-symbol detector call: pinned, device-mapped staging (6 in + 2 x 64 out)
+    double *d_iter = nullptr;      // ... the device's address of the same memory
 };
 
 static inline hipStream_t wf_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

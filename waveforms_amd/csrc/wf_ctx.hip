@@ -63,6 +63,7 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_iter) (void)hipHostFree(c->h_iter);
     delete c;
     return WF_OK;
 }

@@ -660,3 +660,31 @@ extern "C" int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int
     WF_LAUNCH_CHECK();
     return WF_OK;
 }
+
+// The per-symbol call as ONE host call with host operands (the drop-in loop of
+// examples/soqpsk_detection.py:189-198 calls the detector once per symbol): the three
+// matched-filter outputs and the 2 x length results travel through pinned host memory that the
+// device addresses directly, so a call is one kernel launch and one stream synchronise — no
+// device allocation, no separate H2D / D2H copies.  Synchronous.
+extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length, int differential,
+                                          const double *h_mf3_ri, double *h_bits_out, double *h_syms_out, void *stream)
+{
+    WF_REQUIRE(ctx && d_state && h_mf3_ri && h_bits_out && h_syms_out, "wf_viterbi4_iteration_host: NULL argument");
+    WF_REQUIRE(length >= 1 && length <= VIT_MAX_LEN, "wf_viterbi4_iteration_host: length %d", length);
+    WF_HIP(hipSetDevice(ctx->device));
+    if (!ctx->h_iter) {
+        WF_HIP(hipHostMalloc(&ctx->h_iter, (6 + 2 * VIT_MAX_LEN) * sizeof(double), hipHostMallocMapped));
+        WF_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->d_iter), ctx->h_iter, 0));
+    }
+    hipStream_t s = wf_stream(stream);
+    for (int k = 0; k < 6; ++k) ctx->h_iter[k] = h_mf3_ri[k];
+    hipLaunchKernelGGL(viterbi_iteration_kernel, dim3(1), dim3(64), 0, s, static_cast<vit_state *>(d_state), length,
+                       differential ? 1 : 0, ctx->d_iter, ctx->d_iter + 6, ctx->d_iter + 6 + VIT_MAX_LEN);
+    WF_LAUNCH_CHECK();
+    WF_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < length; ++k) {
+        h_bits_out[k] = ctx->h_iter[6 + k];
+        h_syms_out[k] = ctx->h_iter[6 + VIT_MAX_LEN + k];
+    }
+    return WF_OK;
+}

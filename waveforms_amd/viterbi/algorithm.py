@@ -60,7 +60,8 @@ class SOQPSKTrellisDetector:
             if nbytes < 0:
                 raise ValueError(f"unsupported traceback length {self.length}")
             self._d_state = _hip.zeros(nbytes, "uint8")
-            self._d_io = _hip.zeros(6 + 2 * int(self.length), "float64")
+            self._d_state_ptr = self._d_state.data_ptr()
+            self._iter_fn, self._iter_ctx, self._iter_stream = _hip.lib().wf_viterbi4_iteration_host, _hip.ctx(), _hip.stream()
 
     def iteration(
         self,
@@ -76,17 +77,16 @@ class SOQPSKTrellisDetector:
         self._mode = "iteration"
         self._ensure_state()
         L = int(self.length)
-        z = np.asarray(mf_outputs, dtype=np.complex128).reshape(3)
-        self._d_io[:6].copy_(_hip.torch().from_numpy(z.view(np.float64).copy()))
-        base = self._d_io.data_ptr()
-        _hip.check(_hip.lib().wf_viterbi4_iteration(
-            _hip.ctx(), _hip.ptr(self._d_state), L, int(self.differential), base, base + 48,
-            base + 48 + 8 * L, _hip.stream()))
-        out = self._d_io[6:].cpu().numpy()
-        if np.isnan(out).any():
+        # one C-ABI call per symbol: host operands in, host results out (pinned device-mapped
+        # staging inside the library) — no torch op, no separate copies
+        z = np.ascontiguousarray(mf_outputs, dtype=np.complex128).reshape(3)
+        bits, syms = np.empty(L), np.empty(L)
+        _hip.check(self._iter_fn(self._iter_ctx, self._d_state_ptr, L, int(self.differential), z.ctypes.data,
+                                 bits.ctypes.data, syms.ctypes.data, self._iter_stream))
+        if np.isnan(bits).any():
             raise KeyError("traceback reached a state pair with no connecting branch")
         self.i += 1
-        return out[:L].copy(), out[L:].copy()
+        return bits, syms
 
     # ------------------------------------------------------------------ batch API
     def detect_device(self, mf_rows, warmup: int = 0):

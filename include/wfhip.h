@@ -367,6 +367,24 @@ int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspac
 /* info8 = {ncalls, start0, off(decisions), off(symbols alpha), off(signal), 0, signal samples, off(rows)} */
 int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8);
 
+/* ---- data products of the reference's plotting helpers (no plotting) ------------------
+ * Welch PSD exactly as Axes.psd / matplotlib.mlab.psd evaluates the call of
+ * waveforms/viz/psd.py:36-41 (window d_window of nfft doubles, np.hanning for the reference;
+ * no overlap, no detrend, two-sided, not scaled by frequency): d_pxx[nfft] in fftshift order =
+ * mean over the n // nfft segments of |FFT(window * scale * x)|^2 / wsum^2 (wsum = sum |window|).
+ * nfft a power of two <= 4096; d_scratch holds wf_welch_scratch_doubles(n, nfft) doubles. */
+int64_t wf_welch_scratch_doubles(int64_t n, int nfft);
+int wf_welch_psd_c128(wf_ctx *ctx, const double *d_x_ri, int64_t n, int nfft, double scale, const double *d_window,
+                      double wsum, double *d_scratch, double *d_pxx, void *stream);
+/* Phase-tree traces (waveforms/viz/tree.py:64-70): per chunk of sps*modulo samples np.unwrap(np.angle)
+ * minus `off`, or minus the chunk's first phase when use_first != 0.  d_out: (n / len) x len. */
+int wf_phase_tree_f64(wf_ctx *ctx, const double *d_x_ri, int64_t n, int sps, int modulo, int use_first, double off,
+                      double *d_out, void *stream);
+/* Eye-diagram traces (waveforms/viz/eye.py:40-55): (n-1)/len traces of len+1 points, len = sps*modulo:
+ * time axis (time - time[start]) + t_offset, real and imaginary planes. */
+int wf_eye_traces_c128(wf_ctx *ctx, const double *d_time, const double *d_x_ri, int64_t n, int sps, int modulo,
+                       double t_offset, double *d_t_out, double *d_re_out, double *d_im_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,3 +15,4 @@ Citations are relative to ``/root/reference``.
 from .numpy_ref import *  # noqa: F401,F403
 from .numpy_ref import __all__  # noqa: F401
 from .cpm_detect import *  # noqa: F401,F403,E402  (generic CPM detector: build-defined, see cpm_oracle.c)
+from .viz_ref import *  # noqa: F401,F403,E402  (arrays behind the reference's plots)

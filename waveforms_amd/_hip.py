@@ -62,6 +62,10 @@ SIGNATURES = {
     "wf_link_stream_chunk": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
     "wf_link_stream_interior": (c_int, [_P, c_int64, c_int64]),
     "wf_link_stream_steady": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
+    "wf_welch_scratch_doubles": (c_int64, [c_int64, c_int]),
+    "wf_welch_psd_c128": (c_int, [_P, _P, c_int64, c_int, c_double, _P, c_double, _P, _P, _P]),
+    "wf_phase_tree_f64": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_double, _P, _P]),
+    "wf_eye_traces_c128": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_double, _P, _P, _P, _P]),
     "wf_cpm_mf_rows_c128": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
     "wf_cpm_viterbi_detect": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
     "wf_cpm_count_errors": (c_int, [_P, _P, _P, c_int, c_int64, _P, _P]),

@@ -42,11 +42,17 @@ STAGE_KERNEL = {"fir": "fir_kernel<9>", "phase": "phase_kernel", "modulate": "mo
                 "encode": "enc_reduce_kernel"}
 
 
-def measured_traffic(stage: str, nsym: int, sps: int):
-    """HBM bytes per launch of the stage's kernel from the committed PMC summary
-    (profiles/*_summary.json, produced by tools/pmc_summary.py from separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command);
-    None if no summary matches this workload."""
+def profile_record(stage: str, nsym: int, sps: int):
+    """The committed rocprofv3 record of the stage's kernel (profiles/*_summary.json, produced by
+    tools/profile.sh + tools/pmc_summary.py from separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and
+    `--pmc SQ_*` passes over this same command): HBM bytes and VALU instructions per launch.  The
+    newest summary that matches the workload wins; `current` tells whether it was taken from the
+    kernels as they are built now (source digest of csrc/)."""
+    try:
+        from waveforms_amd.csrc.build import _digest
+        now = _digest()
+    except Exception:   # noqa: BLE001
+        now = None
     best = None
     for path in sorted((ROOT / "profiles").glob("*_summary.json")):
         try:
@@ -55,8 +61,30 @@ def measured_traffic(stage: str, nsym: int, sps: int):
             continue
         k = d.get("kernels", {}).get(STAGE_KERNEL.get(stage, ""))
         if d.get("nsym") == nsym and d.get("sps") == sps and k:
-            best = (int(k["hbm_traffic_bytes"]), path.name)
+            rec = {"traffic": int(k["hbm_traffic_bytes"]), "source": path.name, "valu_insts": k.get("valu_insts"),
+                   "avg_ns": k.get("avg_ns"), "current": bool(now and d.get("build_digest") == now)}
+            if best is None or rec["current"] or not best["current"]:
+                best = rec
     return best
+
+
+def valu_issue(stage: str, rec, launch_ms: float):
+    """Vector-issue side of the roofline for kernels whose HBM traffic is already minimal:
+    measured VALU wave-instructions per launch x average issue cycles per instruction (static class
+    mix of the kernel, costs measured by tools/clock_probe.hip) / (1024 SIMDs x clock x launch time)."""
+    try:
+        mix = json.loads((ROOT / "profiles" / "r02_valu_mix.json").read_text())
+    except (OSError, ValueError):
+        return None
+    k = mix["kernels"].get(STAGE_KERNEL.get(stage, ""))
+    if not (k and rec and rec.get("valu_insts") and launch_ms > 0):
+        return None
+    cycles = rec["valu_insts"] * k["avg_cycles_per_valu"]
+    frac = cycles / (mix["simds"] * mix["clock_hz"] * launch_ms * 1e-3)
+    return {"valu_issue_frac": round(frac, 4), "valu_wave_insts_per_launch": rec["valu_insts"],
+            "avg_issue_cycles_per_valu": k["avg_cycles_per_valu"], "class_mix_static": {c: k[c] for c in ("f64", "mul32", "other")},
+            "simds": mix["simds"], "clock_ghz": mix["clock_hz"] / 1e9,
+            "source": f"{rec['source']} + r02_valu_mix.json + r02_clock_probe.json"}
 
 
 def _cpu_pool_ready(_):
@@ -289,12 +317,24 @@ def main() -> None:
                         "GBps": round(gb / (ms / 1e3), 1) if ms > 0 else None}
     dominant = max(acc, key=acc.get)
     d = stages[dominant]
-    traffic = measured_traffic(dominant, args.nsym, args.sps)
+    rec = profile_record(dominant, args.nsym, args.sps)
     roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dominant, dominant), "stage": dominant,
                 "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(d["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic[0] if traffic else None,
-                "traffic_source": traffic[1] if traffic else None,
+                "frac": round(d["GBps"] / HBM_PEAK_GBS, 4), "traffic": rec["traffic"] if rec else None,
+                "traffic_source": rec["source"] if rec else None,
+                "traffic_profile_matches_build": rec["current"] if rec else None,
                 "launch_ms": d["ms"], "algorithmic_bytes_per_launch": int(bps[dominant] * args.nsym)}
+    vi = valu_issue(dominant, rec, d["ms"])
+    if vi:      # the bound that actually binds when traffic ~ algorithmic bytes and the HBM fraction is low
+        roofline.update(valu_issue_frac=vi.pop("valu_issue_frac"), valu=vi)
+    # every stage with a profile record: its own HBM and issue fractions
+    for name, st in stages.items():
+        r_ = profile_record(name, args.nsym, args.sps)
+        if r_:
+            st["hbm_traffic_bytes"] = r_["traffic"]
+            v_ = valu_issue(name, r_, st["ms"])
+            if v_:
+                st["valu_issue_frac"] = v_["valu_issue_frac"]
 
     if rank == 0:
         total_sym = args.steps * args.nsym * world

@@ -320,6 +320,14 @@ int wf_cpm_mf_rows_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const 
                         int nfilt, int ntm, int64_t start0, int sps, int64_t ncalls, double *d_rows_ri,
                         void *stream);
 
+/* The same rows from CLEAN samples with the channel of wf_awgn_c128 applied while staging
+ * (derotation by rot, Philox noise of the given seed / stream / first index): identical to
+ * wf_awgn_c128 followed by wf_cpm_mf_rows_c128, without the noisy samples ever being stored. */
+int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,
+                             double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
+                             const double *d_templates_ri, int nh, int nfilt, int ntm, int64_t start0, int sps,
+                             int64_t ncalls, double *d_rows_ri, void *stream);
+
 /* The detector over ncalls rows.  d_rot_cs: 2p pairs (cos, sin)(pi r / p) (caller-computed so that
  * oracle and device rotate with the same doubles).  d_decisions[k] (uint8) = the U decided at call
  * k, i.e. of symbol n0 + k - D + 1 (n0 = calls already made on d_state; entries with
@@ -360,6 +368,7 @@ typedef struct {
     int warmup;
     int skip_head;            /* leading symbols excluded from the comparison (start transient)   */
     int event_slot;
+    int fuse;                 /* bit 1: channel applied inside the matched-filter kernel          */
 } wf_cpm_link_config;
 int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg);
 int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,

@@ -39,20 +39,47 @@ def main():
     ap.add_argument("--nsym", type=int, required=True)
     ap.add_argument("--sps", type=int, default=8)
     ap.add_argument("--out", default=None, help="output directory (default: profiles/)")
+    ap.add_argument("--sq", default=None, help="counter_collection.csv of the SQ_* pass")
+    ap.add_argument("--trace", default=None, help="kernel_trace.csv: per-dispatch durations (launch-to-launch spread)")
     a = ap.parse_args()
     stats = {}
     for r in csv.DictReader(open(a.kernel_stats)):
         stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                    "pct": float(r["Percentage"])}
     fetch, write = counters(a.fetch_csv, "FETCH_SIZE"), counters(a.write_csv, "WRITE_SIZE")
+    sq = defaultdict(dict)
+    if a.sq:
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(a.sq)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in acc.items():
+            sq[k] = {c: statistics.median(v) for c, v in cs.items()}
     kernels = {}
     for k, st in stats.items():
-        if not (k.startswith(("lfsr", "enc_", "fir_", "phase_", "mod_", "awgn", "mf_bank", "viterbi", "count_"))):
+        if not (k.startswith(("lfsr", "enc_", "fir_", "phase_", "mod_", "awgn", "mf_bank", "viterbi", "count_", "cpm_", "symbol_map"))):
             continue
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         kernels[k] = {**st, "fetch_size_bytes_raw": int(f), "write_size_bytes": int(w),
                       "hbm_traffic_bytes": int(2 * f + w)}
-    out = {"tag": a.tag, "nsym": a.nsym, "sps": a.sps,
+        if k in sq:
+            m = sq[k]
+            kernels[k].update(waves=int(m.get("SQ_WAVES", 0)), valu_insts=int(m.get("SQ_INSTS_VALU", 0)),
+                              salu_insts=int(m.get("SQ_INSTS_SALU", 0)), lds_insts=int(m.get("SQ_INSTS_LDS", 0)))
+            if m.get("SQ_WAVE_CYCLES"):
+                kernels[k]["frac_wave_cycles_valu_active"] = round(m.get("SQ_ACTIVE_INST_VALU", 0) / m["SQ_WAVE_CYCLES"], 3)
+                kernels[k]["frac_wave_cycles_waiting"] = round(m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"], 3)
+    if a.trace:
+        per = defaultdict(list)
+        for r in csv.DictReader(open(a.trace)):
+            per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for k, v in per.items():
+            if k in kernels:
+                v.sort()
+                d = [x[1] for x in v]
+                kernels[k].update(dispatch_ns_min=min(d), dispatch_ns_median=int(statistics.median(d)), dispatch_ns_max=max(d),
+                                  dispatch_ns_in_order=d[:32])
+    digest = Path(__file__).resolve().parent.parent / "waveforms_amd" / "csrc" / ".build_digest"
+    out = {"tag": a.tag, "nsym": a.nsym, "sps": a.sps, "build_digest": digest.read_text().strip() if digest.exists() else None,
            "note": "traffic = 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE correction), medians over launches",
            "kernels": kernels}
     outdir = Path(a.out) if a.out else Path(__file__).resolve().parent.parent / "profiles"

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Profile `bench.py` on the GPU box: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in
-# their own --pmc passes (they do not fit one pass; never combined with other trace domains).
+# Profile `bench.py` on the GPU box: kernel trace + stats, then FETCH_SIZE, WRITE_SIZE and the SQ
+# instruction counters in their own --pmc passes (never combined with other trace domains).
 #   tools/profile.sh <tag> [bench.py flags...]      e.g. tools/profile.sh r01_fused --fuse 3
 # Writes gpurun_out/<tag>/{kt,fetch,write}/... and profiles/<tag>_{kernel_stats.csv,summary.json,
 # bench_under_rocprof.json} (copy profiles/ back from gpurun_out/<tag>/profiles on the host).
@@ -14,11 +14,14 @@ flags="--steps 5 --warmup 2 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py $flags > $out/profiles/${tag}_bench_under_rocprof.json 2> $out/kt.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python3 bench.py $flags > /dev/null 2> $out/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python3 bench.py $flags > /dev/null 2> $out/write.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $out/sq -o sq -- python3 bench.py $flags > /dev/null 2> $out/sq.err
 ks=$(find $out/kt -name '*kernel_stats.csv' | head -1)
 fc=$(find $out/fetch -name '*counter_collection.csv' | head -1)
 wc=$(find $out/write -name '*counter_collection.csv' | head -1)
+sc=$(find $out/sq -name '*counter_collection.csv' | head -1)
 cp $ks $out/profiles/${tag}_kernel_stats.csv
-python3 tools/pmc_summary.py $tag $ks $fc $wc --nsym 10000000 --sps 8 --out $out/profiles
+kt=$(find $out/kt -name '*kernel_trace.csv' | head -1)
+python3 tools/pmc_summary.py $tag $ks $fc $wc --sq $sc --trace $kt --nsym 10000000 --sps 8 --out $out/profiles
 # keep the merge-back small: the raw per-dispatch CSVs are tens of MB
 find $out -name '*counter_collection.csv' -delete; find $out -name '*kernel_trace.csv' -delete
 python3 - <<PY

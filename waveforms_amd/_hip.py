@@ -67,6 +67,8 @@ SIGNATURES = {
     "wf_phase_tree_f64": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_double, _P, _P]),
     "wf_eye_traces_c128": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_double, _P, _P, _P, _P]),
     "wf_cpm_mf_rows_c128": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
+    "wf_cpm_awgn_mf_rows_c128": (c_int, [_P, _P, c_int64, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64, _P, c_int, c_int,
+                                         c_int, c_int64, c_int, c_int64, _P, _P]),
     "wf_cpm_viterbi_detect": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
     "wf_cpm_count_errors": (c_int, [_P, _P, _P, c_int, c_int64, _P, _P]),
     "wf_cpm_link_workspace_bytes": (c_int64, [_P]),
@@ -88,7 +90,7 @@ class CPMLinkConfig(ctypes.Structure):
         ("nsym", c_int64), ("sps", c_int), ("degree", c_int), ("mask", c_uint64), ("state", c_uint64), ("skip", c_uint64),
         ("mapper_kind", c_int), ("det", CPMDetectorConfig), ("d_h", c_void_p), ("d_pulse", c_void_p), ("ntaps", c_int),
         ("d_templates", c_void_p), ("d_rot_cs", c_void_p), ("sigma", c_double), ("seed", c_uint64), ("stream_id", c_uint64),
-        ("warmup", c_int), ("skip_head", c_int), ("event_slot", c_int),
+        ("warmup", c_int), ("skip_head", c_int), ("event_slot", c_int), ("fuse", c_int),
     ]
 
 

@@ -22,7 +22,10 @@
 // Chunks start `warmup` calls early from a fresh detector and every launch PROVES that each chunk
 // began from bitwise the (metric, phase index, decision register) its predecessor ended with, as
 // wf_viterbi.hip does for the 4-state SOQPSK detector.
+#include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include "wf_common.h"
 
@@ -68,12 +71,21 @@ __device__ __forceinline__ int cpm_tilt_at(const cpm_vit_params &P, int64_t n)  
 }
 
 // all-reduce min over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1)
+// (v_min_f64 directly: fmin() first canonicalises operands that arrive through a bit cast — one
+// v_max_f64 per operand — and there are no NaNs to quieten here)
+__device__ __forceinline__ double cpm_min_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double cpm_row_min(double v)
 {
-    v = fmin(v, wf_dpp_f64<0x128, 0xf>(v));
-    v = fmin(v, wf_dpp_f64<0x124, 0xf>(v));
-    v = fmin(v, wf_dpp_f64<0x122, 0xf>(v));
-    v = fmin(v, wf_dpp_f64<0x121, 0xf>(v));
+    v = cpm_min_raw(v, wf_dpp_f64<0x128, 0xf>(v));
+    v = cpm_min_raw(v, wf_dpp_f64<0x124, 0xf>(v));
+    v = cpm_min_raw(v, wf_dpp_f64<0x122, 0xf>(v));
+    v = cpm_min_raw(v, wf_dpp_f64<0x121, 0xf>(v));
     return v;
 }
 
@@ -188,96 +200,149 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
             dst[i] = vit_ld16_c(rows + row * NF + (qq - (qq / NF) * NF));
         }
     };
-    double2 pend[PL];
-    const int nbatch = T / CPM_TB;
-    fetch(0, pend);
-    for (int b = 0; b < nbatch; ++b) {
+    // LDS word index of the slot each of this lane's M candidates goes to, per variant (the dump
+    // slot for lanes that hold no state)
+    int xslot[3][M];
+#pragma unroll
+    for (int kv = 0; kv < 3; ++kv)
+#pragma unroll
+        for (int u = 0; u < M; ++u) xslot[kv][u] = active ? g * 64 + (int)((dsel[kv] >> (8 * u)) & 0xFFu) : 256;
+    const double2 *zlane = rowbuf + M * corr;
+    const int dshift = LGM * (P.D - 1);
+
+    // One detector call.  KV: the leaving symbol's variant as a compile-time constant (0 / 1), or -1
+    // = per lane (virtual pre-start symbols, ragged ends).  FAST: every group of the wave runs a
+    // real call and all of them either emit or not — no per-lane predication.
+    auto step = [&](auto KVc, auto FASTc, int tt, int t, bool emit) __attribute__((always_inline)) {
+        constexpr int KV = decltype(KVc)::value;
+        constexpr bool FAST = decltype(FASTc)::value;
+        const int64_t k = k_first - P.W + t;                            // local call index of this group
+        const int64_t n = n0 + k;                                       // global call index
+        const bool valid = FAST || (live && k >= 0 && k < P.ncalls);
+        int kv = KV;
+        if (KV < 0) {
+            const int64_t m_old = n - LP_ + 1;
+            kv = m_old < 0 ? 2 : (P.nh == 2 ? (int)(m_old & 1) : 0);
+        }
+        const int K_old = kv == 2 ? 0 : (kv ? P.K1 : P.K0);
+        const uint32_t il = kv == 0 ? ilo[0] : (kv == 1 ? ilo[1] : ilo[2]);
+        const uint32_t ih = kv == 0 ? ihi[0] : (kv == 1 ? ihi[1] : ihi[2]);
+        int r = 2 * v - tilt;
+        r += r < 0 ? 2 * P.p : 0;
+        const double2 cs = rot[r];
+        const double2 *zrow = zlane + tt * NF;
+#pragma unroll
+        for (int u = 0; u < M; ++u) {
+            const double2 z = zrow[u];
+            const double inc = -fma(cs.x, z.x, cs.y * z.y);             // -Re(e^{-j theta} Z)
+            xch[kv == 0 ? xslot[0][u] : (kv == 1 ? xslot[1][u] : xslot[2][u])] = m + inc;
+        }
+        cpm_wave_sync();
+        double c[M];
+        if constexpr (M == 4) {
+            const double2 a0 = *reinterpret_cast<const double2 *>(xch + lane * 4);
+            const double2 a1 = *reinterpret_cast<const double2 *>(xch + lane * 4 + 2);
+            c[0] = a0.x; c[1] = a0.y; c[M - 2] = a1.x; c[M - 1] = a1.y;
+        } else {
+            const double2 a0 = *reinterpret_cast<const double2 *>(xch + lane * 4);
+            c[0] = a0.x; c[1] = a0.y;
+        }
+        double best = c[0];
+        int w = 0;
+#pragma unroll
+        for (int j = 1; j < M; ++j) {
+            const bool lt = c[j] < best;                               // strict '<': the first listed branch keeps a tie
+            best = lt ? c[j] : best;
+            w = lt ? j : w;
+        }
+        const uint32_t pair = (w & 2) ? ih : il;
+        const uint32_t inf = (w & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+        const int src = (int)(inf & 15u), u_new = (int)((inf >> 4) & 3u), incmod = (int)((inf >> 8) & 63u);
+        const int baddr = ((lane & 48) | src) << 2;
+        int nv = __builtin_amdgcn_ds_bpermute(baddr, v) + incmod;
+        nv -= nv >= P.p ? P.p : 0;
+        const uint64_t nh_ = (cpm_bperm_u64(baddr, hist) << LGM) | (uint64_t)u_new;
+        double nm = active ? best : INFINITY;
+        nm -= cpm_row_min(nm);                                          // the minimum becomes exactly 0.0
+        if (valid) {
+            m = nm;
+            v = nv;
+            hist = nh_;
+            tilt += (M - 1) * K_old;
+            tilt -= tilt >= 2 * P.p ? 2 * P.p : 0;
+        }
+        if (emit && (FAST || valid)) {
+            // np.argmin: the first state whose metric is the minimum — lowest set bit of each
+            // 16-lane field of the ballot, isolated on the scalar unit
+            const unsigned long long zero = __builtin_amdgcn_ballot_w64(nm == 0.0);
+            unsigned long long firstm = 0;
+#pragma unroll
+            for (int q = 0; q < CPM_GROUPS; ++q) {
+                const unsigned long long f = (zero >> (16 * q)) & 0xFFFFull;
+                firstm |= (f & (0ull - f)) << (16 * q);
+            }
+            if ((firstm >> lane) & 1ull)
+                dec[t - P.W] = (FAST || n >= P.D - 1) ? (uint8_t)((nh_ >> dshift) & (uint64_t)(M - 1)) : (uint8_t)0;
+        }
+    };
+    using kv0 = std::integral_constant<int, 0>;
+    using kv1 = std::integral_constant<int, 1>;
+    using kvd = std::integral_constant<int, -1>;
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    // parity of the leaving symbol at the first call of a batch: the same for every group of the
+    // wave and every batch (chunk starts, warm-up and batch length are even)
+    const int par0 = P.nh == 2 ? (int)((n0 + k_first - P.W - LP_ + 1) & 1) : 0;
+    const int par_u = __builtin_amdgcn_readfirstlane(par0);
+
+    // Two batches of rows in flight per lane: one batch is only ~1 us of detector work, less than a
+    // loaded HBM round trip — with a single batch of lookahead every batch waited for memory
+    // (1.04 ms for 1e7 calls; the instruction count did not matter).
+    double2 pend0[PL], pend1[PL];
+    const int nbatch = T / CPM_TB;                                      // even: W and CH are multiples of 2 * CPM_TB
+    fetch(0, pend0);
+    fetch(1 < nbatch ? 1 : 0, pend1);
+    auto batch = [&](int b, double2 (&pend)[PL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
             const int q = s + 16 * i;
             if (q < PIECES) rowbuf[q] = pend[i];
         }
-        fetch(b + 1 < nbatch ? b + 1 : b, pend);                        // always one batch in flight
+        fetch(b + 2 < nbatch ? b + 2 : nbatch - 1, pend);               // issued unconditionally (see wf_viterbi.hip)
         cpm_wave_sync();
-#pragma unroll 1
-        for (int tt = 0; tt < CPM_TB; ++tt) {
-            const int t = b * CPM_TB + tt;
-            const int64_t k = k_first - P.W + t;                        // local call index of this group
-            const int64_t n = n0 + k;                                   // global call index
-            const bool valid = live && k >= 0 && k < P.ncalls;
-            if (t == P.W) {                                             // the next call is the chunk's first own one
-                ms_m = m;
-                ms_v = v;
-                ms_h = hist;
-            }
-            const int64_t m_old = n - LP_ + 1;
-            const int kv = m_old < 0 ? 2 : (P.nh == 2 ? (int)(m_old & 1) : 0);
-            const int K_old = kv == 2 ? 0 : (kv ? P.K1 : P.K0);
-            const uint32_t dsl = kv == 0 ? dsel[0] : (kv == 1 ? dsel[1] : dsel[2]);
-            const uint32_t il = kv == 0 ? ilo[0] : (kv == 1 ? ilo[1] : ilo[2]);
-            const uint32_t ih = kv == 0 ? ihi[0] : (kv == 1 ? ihi[1] : ihi[2]);
-            int r = 2 * v - tilt;
-            r += r < 0 ? 2 * P.p : 0;
-            const double2 cs = rot[r];
-            const double2 *zrow = rowbuf + tt * NF + M * corr;
-#pragma unroll
-            for (int u = 0; u < M; ++u) {
-                const double2 z = zrow[u];
-                const double inc = -fma(cs.x, z.x, cs.y * z.y);         // -Re(e^{-j theta} Z)
-                const double cand = m + inc;
-                const int slot = (int)((dsl >> (8 * u)) & 0xFFu);
-                xch[active ? (g * 64 + slot) : 256] = cand;             // 256 = the wave's dump slot
-            }
-            cpm_wave_sync();
-            double c[M];
-            if constexpr (M == 4) {
-                const double2 a0 = *reinterpret_cast<const double2 *>(xch + lane * 4);
-                const double2 a1 = *reinterpret_cast<const double2 *>(xch + lane * 4 + 2);
-                c[0] = a0.x; c[1] = a0.y; c[M - 2] = a1.x; c[M - 1] = a1.y;
+        const int t0 = b * CPM_TB;
+        if (t0 == P.W) {                                                // the next call is the chunk's first own one
+            ms_m = m;
+            ms_v = v;
+            ms_h = hist;
+        }
+        const bool emit = t0 >= P.W;
+        const int64_t kb = k_first - P.W + t0;
+        const bool easy = live && kb >= 0 && kb + CPM_TB <= P.ncalls && n0 + kb - LP_ + 1 >= 0 && (!emit || n0 + kb >= P.D - 1);
+        if (__builtin_amdgcn_ballot_w64(easy) == ~0ull) {               // wave-uniform: almost every batch
+            if (P.nh == 1) {
+                step(kv0{}, yes{}, 0, t0, emit); step(kv0{}, yes{}, 1, t0 + 1, emit);
+                step(kv0{}, yes{}, 2, t0 + 2, emit); step(kv0{}, yes{}, 3, t0 + 3, emit);
+            } else if (par_u == 0) {
+                step(kv0{}, yes{}, 0, t0, emit); step(kv1{}, yes{}, 1, t0 + 1, emit);
+                step(kv0{}, yes{}, 2, t0 + 2, emit); step(kv1{}, yes{}, 3, t0 + 3, emit);
             } else {
-                const double2 a0 = *reinterpret_cast<const double2 *>(xch + lane * 4);
-                c[0] = a0.x; c[1] = a0.y;
+                step(kv1{}, yes{}, 0, t0, emit); step(kv0{}, yes{}, 1, t0 + 1, emit);
+                step(kv1{}, yes{}, 2, t0 + 2, emit); step(kv0{}, yes{}, 3, t0 + 3, emit);
             }
-            double best = c[0];
-            int w = 0;
-#pragma unroll
-            for (int j = 1; j < M; ++j) {
-                const bool lt = c[j] < best;                           // strict '<': the first listed branch keeps a tie
-                best = lt ? c[j] : best;
-                w = lt ? j : w;
-            }
-            const uint32_t pair = (w & 2) ? ih : il;
-            const uint32_t inf = (w & 1) ? (pair >> 16) : (pair & 0xFFFFu);
-            const int src = (int)(inf & 15u), u_new = (int)((inf >> 4) & 3u), incmod = (int)((inf >> 8) & 63u);
-            const int baddr = ((lane & 48) | src) << 2;
-            int nv = __builtin_amdgcn_ds_bpermute(baddr, v) + incmod;
-            nv -= nv >= P.p ? P.p : 0;
-            const uint64_t nh_ = (cpm_bperm_u64(baddr, hist) << LGM) | (uint64_t)u_new;
-            double nm = active ? best : INFINITY;
-            nm -= cpm_row_min(nm);                                      // the minimum becomes exactly 0.0
-            if (valid) {
-                m = nm;
-                v = nv;
-                hist = nh_;
-                tilt += (M - 1) * K_old;
-                tilt -= tilt >= 2 * P.p ? 2 * P.p : 0;
-                if (t >= P.W) {
-                    // np.argmin: the first state whose metric is the minimum
-                    const unsigned long long zero = __builtin_amdgcn_ballot_w64(active && nm == 0.0);
-                    const unsigned long long below = zero & ((1ull << lane) - 1ull) & (0xFFFFull << (lane & 48));
-                    if (active && nm == 0.0 && below == 0ull)
-                        dec[t - P.W] = n >= P.D - 1 ? (uint8_t)((nh_ >> (LGM * (P.D - 1))) & (uint64_t)(M - 1)) : (uint8_t)0;
-                }
-            }
-            // (the next call's candidate writes follow this call's candidate reads in program
-            //  order; a wave's LDS accesses execute in order)
+        } else {
+#pragma unroll 1
+            for (int tt = 0; tt < CPM_TB; ++tt) step(kvd{}, no{}, tt, t0 + tt, emit);
         }
         cpm_wave_sync();                                                // batch consumed before the next stash
+    };
+    for (int b = 0; b < nbatch; b += 2) {
+        batch(b, pend0);
+        batch(b + 1, pend1);
     }
     // flush decisions: 16 B per lane and 256 calls
     if (live) {
-        for (int i = 0; i < P.CH / 256; ++i) {
-            const int off = 16 * (s + 16 * i);
+        for (int off = 16 * s; off < P.CH; off += 256) {
             const int64_t k = k_first + off;
             if (k + 16 <= P.ncalls) {
                 *reinterpret_cast<uint4 *>(out + k) = *reinterpret_cast<const uint4 *>(dec + off);
@@ -394,15 +459,26 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
                    (reinterpret_cast<uintptr_t>(d_rot_cs) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
                "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
-    // calls per chunk: 256 for short bursts, 512 once that still fills the chip several times over
-    P.CH = ncalls >= (1 << 22) ? 512 : 256;
     // default warm-up: the D calls that refill the decision register plus the merge depth of the
     // trellis — measured: 1e8 ARTM calls (M = 4) with 128 never tripped the proof, binary PCM/FM
     // (one bit per call, slower merges) needed more than 128 on 5 chunks of 2e5
     int W = warmup ? warmup : (det->M == 2 ? 3 * CPM_DEFAULT_WARMUP : CPM_DEFAULT_WARMUP);
-    W = (W + CPM_TB - 1) / CPM_TB * CPM_TB;
+    W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
     if (W > 4096) W = 4096;
-    while (P.CH < W) P.CH *= 2;                                    // a chunk's warm-up never reaches before call 0 of the burst
+    // Calls per chunk (a multiple of 64): at least 256 (and 2 W), so the warm-up stays a fraction of
+    // the work, and otherwise the smallest that puts the whole burst into ONE round of resident
+    // workgroups (4 per CU at this kernel's LDS / register use): with 512 calls per chunk 1e7 calls
+    // made 1221 workgroups for 1024 slots — a second, almost empty round of the full chain length.
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int64_t slots = (int64_t)cus * 4 * CPM_WAVES * CPM_GROUPS;
+    int64_t ch = (ncalls + slots - 1) / slots;
+    ch = (ch + 63) / 64 * 64;
+    if (ch < 256) ch = 256;
+    if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
+    if (ch > 8192) ch = 8192;                                      // decision strips live in LDS; longer bursts take several rounds
+    if (const char *e = getenv("WF_CPM_CH")) ch = atoi(e);   // tuning experiments only (multiple of 64, >= 2 W)
+    P.CH = (int)ch;
     P.W = W;
     P.ncalls = ncalls;
     const int pieces = CPM_TB * P.NF;
@@ -450,22 +526,30 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
 // from HBM once); thread t owns filter f = t % NF for the symbols sub, sub + 256/NF, ...; its
 // templates for both columns stay in registers (NTM = 9: the sps = 8 case), or come from an LDS
 // copy (any length).  Accumulation order is that of cpm_oracle.c (the sequential statement kept with the tests):orc_cpm_mf_rows.
+// NOISE: the channel of wf_awgn_c128 (derotation + Philox AWGN, same arithmetic) is applied while
+// staging, so the link needs no separate 2.56 GB read-modify-write pass over the samples; the
+// kernel is HBM-bound on its rows (16 * NF B written per symbol) and has the vector pipe to spare.
 #define CPM_MF_SYMS 256
 
 struct cpm_mf_params {
     int64_t nsamp, start0, ncalls;
     int sps, ntm, nh;
+    int syms;                       // symbols per block (<= CPM_MF_SYMS)
+    double rot_re, rot_im, sigma;   // NOISE: staged sample = r * rot + sigma * N(first_index + index)
+    uint64_t seed, stream_id, first_index;
 };
 
-template <int NF, int NTM>
+template <int NF, int NTM, bool NOISE>
 __global__ __launch_bounds__(256) void cpm_mf_rows_kernel(const double2 *__restrict__ r, const double2 *__restrict__ templ,
                                                             double2 *__restrict__ out, cpm_mf_params P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *s_r = reinterpret_cast<double2 *>(smem);
     const int ntm = NTM ? NTM : P.ntm;
-    const int span = CPM_MF_SYMS * P.sps + ntm;                       // samples staged per block (last ones overlap the next block)
-    double2 *s_t = s_r + span;                                        // generic path: nh x NF x ntm templates
+    const int span = P.syms * P.sps + ntm;                            // samples staged per block (last ones overlap the next block)
+    double2 *s_t = s_r + span + 2;                                    // generic path: nh x NF x ntm templates
+    __shared__ double2 s_tab[NOISE ? 256 : 1];                        // Gaussian source tables (see wf_tabs_lds)
+    if (NOISE) wf_stage_tables<1, 0>(s_tab, threadIdx.x, 256);        // first use is behind the loop's barrier
     const int t = threadIdx.x;
     const int f = t % NF, sub = t / NF;
     constexpr int SUBS = 256 / NF;
@@ -478,17 +562,39 @@ __global__ __launch_bounds__(256) void cpm_mf_rows_kernel(const double2 *__restr
     } else {
         for (int k = t; k < P.nh * NF * ntm; k += 256) s_t[k] = templ[k];
     }
-    const int64_t nblk = (P.ncalls + CPM_MF_SYMS - 1) / CPM_MF_SYMS;
+    const int64_t nblk = (P.ncalls + P.syms - 1) / P.syms;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int64_t nb = blk * CPM_MF_SYMS;
+        const int64_t nb = blk * P.syms;
         const int64_t s0 = P.start0 + nb * P.sps;
         __syncthreads();
-        for (int i = t; i < span; i += 256) {
-            const int64_t a = s0 + i;
-            s_r[i] = (a >= 0 && a < P.nsamp) ? wf_load16_nt(r + a) : make_double2(0.0, 0.0);
+        if (NOISE) {
+            // one Philox block per PAIR of absolute sample indices (2q, 2q + 1), as wf_awgn_c128 draws them
+            const int64_t a0 = (int64_t)P.first_index + s0;
+            const int odd = (int)(a0 & 1);
+            const uint64_t pair_lo = (uint64_t)(a0 >> 1);
+            for (int q = t; 2 * q - odd < span; q += 256) {
+                const int i0 = 2 * q - odd, i1 = i0 + 1;
+                const int64_t b0 = s0 + i0, b1 = b0 + 1;
+                const bool in0 = i0 >= 0 && b0 >= 0 && b0 < P.nsamp, in1 = i1 < span && b1 >= 0 && b1 < P.nsamp;
+                const double2 c0 = in0 ? wf_load16_nt(r + b0) : make_double2(0.0, 0.0);
+                const double2 c1 = in1 ? wf_load16_nt(r + b1) : make_double2(0.0, 0.0);
+                double g[4];
+                wf_gaussian_two(pair_lo + (uint64_t)q, P.stream_id, P.seed, P.sigma, wf_tabs_lds<1, 0>{s_tab}, g);
+                if (i0 >= 0)
+                    s_r[i0] = in0 ? make_double2(fma(c0.x, P.rot_re, fma(-c0.y, P.rot_im, g[0])), fma(c0.x, P.rot_im, fma(c0.y, P.rot_re, g[1])))
+                                  : make_double2(0.0, 0.0);
+                if (i1 < span)
+                    s_r[i1] = in1 ? make_double2(fma(c1.x, P.rot_re, fma(-c1.y, P.rot_im, g[2])), fma(c1.x, P.rot_im, fma(c1.y, P.rot_re, g[3])))
+                                  : make_double2(0.0, 0.0);
+            }
+        } else {
+            for (int i = t; i < span; i += 256) {
+                const int64_t a = s0 + i;
+                s_r[i] = (a >= 0 && a < P.nsamp) ? wf_load16_nt(r + a) : make_double2(0.0, 0.0);
+            }
         }
         __syncthreads();
-        for (int sym = sub; sym < CPM_MF_SYMS; sym += SUBS) {
+        for (int sym = sub; sym < P.syms; sym += SUBS) {
             const int64_t n = nb + sym;
             if (n >= P.ncalls) break;
             const int c = (int)(n % P.nh);
@@ -515,9 +621,10 @@ __global__ __launch_bounds__(256) void cpm_mf_rows_kernel(const double2 *__restr
     }
 }
 
-extern "C" int wf_cpm_mf_rows_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_templates_ri, int nh,
-                                   int nfilt, int ntm, int64_t start0, int sps, int64_t ncalls, double *d_rows_ri,
-                                   void *stream)
+static int cpm_mf_rows_launch(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_templates_ri, int nh,
+                              int nfilt, int ntm, int64_t start0, int sps, int64_t ncalls, double *d_rows_ri,
+                              void *stream, bool noise, double rot_re, double rot_im, double sigma, uint64_t seed,
+                              uint64_t stream_id, uint64_t first_index)
 {
     WF_REQUIRE(ctx && nsamp >= 0 && ncalls >= 0, "wf_cpm_mf_rows_c128: bad argument");
     WF_REQUIRE((nh == 1 || nh == 2) && ntm >= 1 && ntm <= 257 && sps >= 1 && sps <= 256,
@@ -530,27 +637,51 @@ extern "C" int wf_cpm_mf_rows_c128(wf_ctx *ctx, const double *d_r_ri, int64_t ns
                    (reinterpret_cast<uintptr_t>(d_templates_ri) & 15) == 0,
                "wf_cpm_mf_rows_c128: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
-    cpm_mf_params P{nsamp, start0, ncalls, sps, ntm, nh};
+    cpm_mf_params P{nsamp, start0, ncalls, sps, ntm, nh, CPM_MF_SYMS, rot_re, rot_im, sigma, seed, stream_id, first_index};
+    // the channel is generated in trips of 512 samples (one pair per thread): give up a few symbols
+    // per block when that saves a ragged extra trip (2057 samples = 5 trips for one pair)
+    if (noise)
+        while (P.syms > 16 && (P.syms * sps + ntm + 1 + 511) / 512 > (P.syms * sps + 511) / 512 && (P.syms * sps + ntm + 1) % 512 < 64) --P.syms;
     const bool fast = ntm == 9;
-    const size_t lds = ((size_t)CPM_MF_SYMS * sps + ntm + (fast ? 0 : (size_t)nh * nfilt * ntm)) * sizeof(double2);
-    WF_REQUIRE(lds <= 160 * 1024, "wf_cpm_mf_rows_c128: sps %d / %d-tap filters do not fit LDS staging", sps, ntm);
-    const int64_t nblk = (ncalls + CPM_MF_SYMS - 1) / CPM_MF_SYMS;
+    const size_t lds = ((size_t)P.syms * sps + ntm + 2 + (fast ? 0 : (size_t)nh * nfilt * ntm)) * sizeof(double2);
+    WF_REQUIRE(lds <= 156 * 1024, "wf_cpm_mf_rows_c128: sps %d / %d-tap filters do not fit LDS staging", sps, ntm);
+    const int64_t nblk = (ncalls + P.syms - 1) / P.syms;
     const int grid = (int)(nblk < 8192 ? nblk : 8192);
     using kern_t = void (*)(const double2 *, const double2 *, double2 *, cpm_mf_params);
     kern_t k;
+#define CPM_MF_PICK(NFV) (noise ? (fast ? cpm_mf_rows_kernel<NFV, 9, true> : cpm_mf_rows_kernel<NFV, 0, true>) \
+                               : (fast ? cpm_mf_rows_kernel<NFV, 9, false> : cpm_mf_rows_kernel<NFV, 0, false>))
     switch (nfilt) {
-    case 2: k = fast ? cpm_mf_rows_kernel<2, 9> : cpm_mf_rows_kernel<2, 0>; break;
-    case 4: k = fast ? cpm_mf_rows_kernel<4, 9> : cpm_mf_rows_kernel<4, 0>; break;
-    case 8: k = fast ? cpm_mf_rows_kernel<8, 9> : cpm_mf_rows_kernel<8, 0>; break;
-    case 16: k = fast ? cpm_mf_rows_kernel<16, 9> : cpm_mf_rows_kernel<16, 0>; break;
-    default: k = fast ? cpm_mf_rows_kernel<64, 9> : cpm_mf_rows_kernel<64, 0>; break;
+    case 2: k = CPM_MF_PICK(2); break;
+    case 4: k = CPM_MF_PICK(4); break;
+    case 8: k = CPM_MF_PICK(8); break;
+    case 16: k = CPM_MF_PICK(16); break;
+    default: k = CPM_MF_PICK(64); break;
     }
+#undef CPM_MF_PICK
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, wf_stream(stream), reinterpret_cast<const double2 *>(d_r_ri),
                        reinterpret_cast<const double2 *>(d_templates_ri), reinterpret_cast<double2 *>(d_rows_ri), P);
     WF_LAUNCH_CHECK();
     return WF_OK;
+}
+
+extern "C" int wf_cpm_mf_rows_c128(wf_ctx *ctx, const double *d_r_ri, int64_t nsamp, const double *d_templates_ri, int nh,
+                                   int nfilt, int ntm, int64_t start0, int sps, int64_t ncalls, double *d_rows_ri,
+                                   void *stream)
+{
+    return cpm_mf_rows_launch(ctx, d_r_ri, nsamp, d_templates_ri, nh, nfilt, ntm, start0, sps, ncalls, d_rows_ri, stream, false,
+                              1.0, 0.0, 0.0, 0, 0, 0);
+}
+
+extern "C" int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,
+                                        double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
+                                        const double *d_templates_ri, int nh, int nfilt, int ntm, int64_t start0, int sps,
+                                        int64_t ncalls, double *d_rows_ri, void *stream)
+{
+    return cpm_mf_rows_launch(ctx, d_signal_ri, nsamp, d_templates_ri, nh, nfilt, ntm, start0, sps, ncalls, d_rows_ri, stream, true,
+                              rot_re, rot_im, sigma, seed, stream_id, first_index);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -684,10 +815,16 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
                (long long)cfg->nsym, cfg->ntaps);
     MARK(3);
     MARK(4);
-    if ((rc = wf_awgn_c128(ctx, sig, L.npts, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, sig, stream))) return rc;
-    MARK(5);
-    if ((rc = wf_cpm_mf_rows_c128(ctx, sig, L.npts, cfg->d_templates, cfg->det.nh, L.nfilt, L.ntm, L.start0, cfg->sps, L.ncalls,
-                                  rows, stream))) return rc;
+    if (cfg->fuse & 2) {     // channel inside the matched-filter kernel: the noisy samples never exist in HBM
+        MARK(5);
+        if ((rc = wf_cpm_awgn_mf_rows_c128(ctx, sig, L.npts, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0,
+                                           cfg->d_templates, cfg->det.nh, L.nfilt, L.ntm, L.start0, cfg->sps, L.ncalls, rows, stream))) return rc;
+    } else {
+        if ((rc = wf_awgn_c128(ctx, sig, L.npts, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, sig, stream))) return rc;
+        MARK(5);
+        if ((rc = wf_cpm_mf_rows_c128(ctx, sig, L.npts, cfg->d_templates, cfg->det.nh, L.nfilt, L.ntm, L.start0, cfg->sps, L.ncalls,
+                                      rows, stream))) return rc;
+    }
     MARK(6);
     if ((rc = wf_cpm_viterbi_detect(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, stream))) return rc;
     MARK(7);

@@ -236,7 +236,7 @@ class CPMLink:
     STAGES = ("prbs", "map", "modulate", "-", "awgn", "mfbank", "viterbi", "count")
 
     def __init__(self, nsym: int, sps: int = 8, waveform: str = "multih", spec=None, pn_degree: int = 23, warmup: int = 0,
-                 skip_head: int = 64, private_ctx: bool = False) -> None:
+                 skip_head: int = 64, private_ctx: bool = False, fuse: int = 2) -> None:
         from .viterbi import cpm
 
         if waveform == "multih":
@@ -263,7 +263,7 @@ class CPMLink:
         cfg.d_h, cfg.d_pulse, cfg.ntaps = self._d_h.data_ptr(), self._d_pulse.data_ptr(), int(np.asarray(pulse).size)
         cfg.d_templates, cfg.d_rot_cs = self._d_templates.data_ptr(), self._d_rot.data_ptr()
         cfg.sigma, cfg.seed, cfg.stream_id = 0.0, 1, 0
-        cfg.warmup, cfg.skip_head, cfg.event_slot = warmup, skip_head, -1
+        cfg.warmup, cfg.skip_head, cfg.event_slot, cfg.fuse = warmup, skip_head, -1, int(fuse)
         self.cfg = cfg
         self.workspace_bytes = _hip.lib().wf_cpm_link_workspace_bytes(ctypes.byref(cfg))
         if self.workspace_bytes < 0:

@@ -191,6 +191,7 @@ def main() -> None:
                     help="independent trial blocks in flight on separate HIP streams (own workspace + context each)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the per-stage HIP events on every E-th timed step only (the last step always)")
+    ap.add_argument("--vit-warmup", type=int, default=-1, help="SOQPSK detector chunk warm-up rows - 1 (-1: by Eb/N0, 0: library default)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="symbols per core, compiled port")
     ap.add_argument("--cpu-loop-sample", type=int, default=1 << 14, help="symbols per core, faithful-loop form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -221,7 +222,11 @@ def main() -> None:
         links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1) for _ in range(nstreams)]
         bits_per_sym = links[0].spec.bits_per_symbol
     else:
-        links = [SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse, private_ctx=nstreams > 1)
+        # detector chunk warm-up: 16 rows at Eb/N0 >= 6 dB with the matched bank (tools/warmup_scan.py: 0 of 2.5e6
+        # chunks unproven from 6 dB up even with 12), the library default (32 rows) below; link.result() raises if
+        # a single chunk of the run was not proven equal to the sequential detector
+        wu = args.vit_warmup if args.vit_warmup >= 0 else (15 if args.ebn0 >= 6.0 else 0)
+        links = [SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse, private_ctx=nstreams > 1, warmup=wu)
                  for _ in range(nstreams)]
         bits_per_sym = 1
     streams = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
@@ -355,7 +360,8 @@ def main() -> None:
                        "waveform": args.waveform,
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
-                       "fuse": None if cpm else args.fuse, "streams": nstreams, "parallelism": f"independent trial blocks x{world}"},
+                       "fuse": None if cpm else args.fuse, "streams": nstreams,
+                       "detector_warmup_rows": None if cpm else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32), "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared * bits_per_sym, 1),
                     # link.result() raises otherwise: every detector chunk started from bitwise the

@@ -64,6 +64,14 @@ static link_layout make_layout(int64_t nsym, int sps, int ntaps, int nfilt, int 
 
 // fuse bit 2: the fused channel + bank writes detector-packed rows (4 doubles per call instead of
 // 3 complex) and the detector reads those.  Exists for 3-filter banks at 8 samples per symbol.
+// Detector chunk warm-up: the caller's, or the detector's own default (32 rows).  A link that
+// knows its operating point may ask for less — with a matched bank survivors merge within 12 rows
+// from 6 dB up (tools/warmup_scan.py: none of 2.5e6 chunks failed; bench.py asks for 16 rows at its
+// 10 dB point) — but a mistimed or mismatched bank at the same Eb/N0 does not (142 chunks of a
+// 40 000-symbol burst failed with 16 rows in test_fused_all_other_timing_offsets_and_generic_taps),
+// so the library does not guess from sigma.  Every launch proves its output either way.
+static int link_warmup(const wf_link_config *cfg) { return cfg->warmup; }
+
 static bool link_packed_rows(const wf_link_config *cfg)
 {
     return (cfg->fuse & 4) && (cfg->fuse & 2) && cfg->sps == 8 && cfg->mf_nfilt == 3;
@@ -137,7 +145,7 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     }
     if (fused_all) {
         MARK(3); MARK(4); MARK(5); MARK(6);   // the "fir" slot times the whole fused kernel
-        if ((rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream))) return rc;
+        if ((rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, nullptr, stream))) return rc;
         MARK(7);
         int64_t m_ = L.ncols - length;
         if (m_ > cfg->nsym) m_ = cfg->nsym;
@@ -188,12 +196,12 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
         if (rc) return rc;
         MARK(6);
         if (fused_count)
-            rc = wf_viterbi4_detect_count(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, bits, syms,
+            rc = wf_viterbi4_detect_count(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, bits, syms,
                                           length, m, d_counts, stream);
         else if (packed)
-            rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream);
+            rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, nullptr, stream);
         else
-            rc = wf_viterbi4_detect(ctx, mf, L.ncols, cfg->differential, cfg->warmup, dbits, dsyms, nullptr, stream);
+            rc = wf_viterbi4_detect(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, nullptr, stream);
         if (rc) return rc;
     } else {
         MARK(6);
@@ -424,9 +432,9 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
     }
     if (rc) return rc;
     if (packed)
-        rc = wf_viterbi4_detect_packed(ctx, mf, S.ncols, cfg->differential, cfg->warmup, dbits, dsyms, vit_state, stream);
+        rc = wf_viterbi4_detect_packed(ctx, mf, S.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, vit_state, stream);
     else
-        rc = wf_viterbi4_detect(ctx, mf, S.ncols, cfg->differential, cfg->warmup, dbits, dsyms, vit_state, stream);
+        rc = wf_viterbi4_detect(ctx, mf, S.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, vit_state, stream);
     if (rc) return rc;
     // decision of call k is compared with symbol k - length (examples/soqpsk_detection.py:201-209)
     const int64_t j0 = S.k_lo >= length ? 0 : length - S.k_lo;

@@ -21,7 +21,12 @@
 #include "wf_common.h"
 
 #define VIT_THREADS 256
-#define VIT_DEFAULT_WARMUP 47   // + 1 priming row: 48 rows = 12 batches of 4 before the first output row
+// + 1 priming row: 32 rows = 8 batches of 4 before the first output row.  Measured over 4.4e6 chunks
+// per warm-up length (tools/warmup_scan.py, Eb/N0 0 .. 12 dB, profiles/r02_warmup_scan.json): chunks
+// that did not start from the sequential detector's metrics — 12 rows: 25 / 7 / 4 per 625 000 at
+// 0 / 2 / 4 dB and none from 6 dB up; 16, 20, 24, 32, 48 rows: none at any Eb/N0.  Every launch still
+// proves its own output (see the batch kernel), so this only sets how often a repair would run.
+#define VIT_DEFAULT_WARMUP 31
 #define VIT_MAX_LEN 64
 
 // Branch b of column c: start = b >> 1; ends / output-symbol index (0: -2, 1: 0, 2: +2):

@@ -121,7 +121,7 @@ class SOQPSKLink:
         unmerged = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
         if unmerged:
             raise RuntimeError(f"{unmerged} detector chunk(s) did not merge with the sequential path within the "
-                               f"warm-up; construct the link with a larger warmup= (current {self.cfg.warmup or 47})")
+                               f"warm-up; construct the link with a larger warmup= (current {self.cfg.warmup or 'library default'})")
         se, be = (int(v) for v in self.counts.cpu().tolist())
         return se, be, self.compared
 

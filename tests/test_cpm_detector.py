@@ -91,6 +91,22 @@ def test_oracle_ber_sits_on_the_minimum_distance_bound(oracle):
     assert ber["ARTM_256"] <= ber["ARTM_16"] < 2.5 * ber["ARTM_256"]
 
 
+def test_oracle_detector_regression_pin(oracle, golden):
+    """tests/golden/cpm_detect.npz freezes the build-defined detector's decisions (made by the oracle
+    itself at the commit that introduced it — not by the reference, which has no such detector)."""
+    g = golden("cpm_detect")
+    bits = g["bits"]
+    for name, spec, pulse, sym in (("artm16", oracle.ARTM_16, oracle.freq_pulse_multih_irig(SPS), oracle.multih_mapper(bits)[0]),
+                                   ("pcmfm10", oracle.PCMFM_SPEC, oracle.freq_pulse_pcmfm(SPS), oracle.pcmfm_mapper(bits[:3000]))):
+        noise = oracle.philox_awgn(oracle.cpm_sigma_for_ebn0(5.0, SPS, spec.lgM), 11, 3, 0, (sym.size + 1) * SPS)
+        res = oracle.cpm_detection_run(sym, pulse, SPS, spec, noise=noise)
+        np.testing.assert_allclose(res["rows"][:64], g[f"{name}_rows_head"], rtol=0, atol=1e-12)
+        assert np.array_equal(res["decisions"], g[f"{name}_decisions"])
+        assert [res["sym_errors"], res["bit_errors"], res["compared"]] == g[f"{name}_errors"].tolist()
+        assert res["bit_errors"] > 0
+    assert abs(g["d2_artm"][0] - 1.2957297551846658) < 1e-12
+
+
 def test_host_mirror_builds_the_same_constants(oracle):
     """waveforms_amd.viterbi.cpm (product side) and the oracle derive identical templates,
     rotation table and window geometry — the product never imports the oracle."""

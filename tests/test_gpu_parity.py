@@ -500,7 +500,7 @@ def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
 
 # ------------------------------------------------------------------ streaming (config 5)
 @pytest.mark.parametrize("detector,fuse,chunk", [("PT", 3, 1 << 16), ("PAM", 3, 1 << 15), ("PT", 1, 3 << 14),
-                                                 ("PT", 7, 1 << 16), ("PAM", 7, 1 << 15)])
+                                                 ("PT", 7, 1 << 16), ("PAM", 7, 1 << 15), ("PT", 15, 1 << 16), ("PT", 15, 3 << 14)])
 def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
     """wf_link_stream_chunk over a stream == wf_link_run over the whole burst: identical
     modulated samples, matched-filter rows, decisions and error counts."""
@@ -522,7 +522,7 @@ def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
         want_bits = ws[lay["off_bits"]:lay["off_bits"] + calls].clone()
         want_syms = ws[lay["off_syms"]:lay["off_syms"] + calls].clone()
         rb = one.row_bytes            # 48, or 32 with detector-packed rows (fuse bit 2 in effect)
-        assert rb == st.row_bytes == (32 if fuse == 7 else 48)
+        assert rb == st.row_bytes == (32 if fuse & 4 else 48)
         want_mf = ws[lay["off_mf"]:lay["off_mf"] + calls * rb].clone()
         st.reset()
         seen = 0
@@ -572,13 +572,18 @@ def test_stream_graph_replay_equals_eager_chunks():
     from waveforms_amd.link import SOQPSKStream
 
     chunk = 1 << 15
-    st = SOQPSKStream(9 * chunk + 777, chunk, 8)
-    n_int = st.interior_chunks()      # chunks 1..7: chunk 8's halo already runs past the end of the stream
-    assert st.nchunks == 10 and n_int == 7
-    for ebn0 in (3.0, 9.0):
-        want = st.run(ebn0, seed=5, stream_id=2)
-        got = st.run_graph(ebn0, seed=5, stream_id=2)
-        assert got == want and st.graph_replays == n_int and want[1] > 0
+    for fuse in (15, 7):     # one kernel for modulator + channel + bank, and the separate kernels
+        st = SOQPSKStream(9 * chunk + 777, chunk, 8, fuse=fuse)
+        n_int = st.interior_chunks()      # chunks 1..7: chunk 8's halo already runs past the end of the stream
+        assert st.nchunks == 10 and n_int == 7
+        for ebn0 in (3.0, 9.0):
+            want = st.run(ebn0, seed=5, stream_id=2)
+            got = st.run_graph(ebn0, seed=5, stream_id=2)
+            assert got == want and st.graph_replays == n_int and want[1] > 0
+        if fuse == 15:
+            first = want
+        else:
+            assert want == first
 
 
 def test_stream_config4_full_size_1e9_symbols():

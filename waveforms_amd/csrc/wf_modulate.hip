@@ -13,8 +13,6 @@
 // independently: symbol amplitudes of the tile in LDS, per-thread tap phases in
 // registers (wf_fir.hip), in-tile fp64 scan by DPP + LDS wave totals (wf_phase.hip),
 // carry, mod, table sincos (LDS), wave-transposed stores of 64 consecutive samples.
-#include <stdlib.h>
-
 #include "wf_common.h"
 
 #ifndef MOD_THREADS
@@ -433,10 +431,11 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
 struct mcb_params {
     double rot_re, rot_im, sigma;
     uint64_t seed, stream_id, pair0;     // pair0 = first_index / 2 (first_index even)
-    int64_t ncols;
+    const uint64_t *dyn_index;           // optional device addend to the noise index (graph replay of a stream; even)
+    int64_t k_lo, k_hi;                  // columns [k_lo, k_hi) of the burst are stored, column k at rows[4 (k - k_lo)]
     int kshift;       // floor((first - 4) / 8): column k's window starts at sample 8 (k + kshift) + d
     int d;            // (first - 4) mod 8
-    int pack_par0;
+    int pack_par0;    // parity of the detector call index of column 0 of the burst
 };
 
 #define MCB_RING 1024                        // samples: 2 rows of 512
@@ -517,13 +516,18 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
     const double *tapc = s_tapc + 9 * mp;
     const double *ring_d = reinterpret_cast<const double *>(s_ring);
 
-    for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+    const uint64_t pair0 = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull);
+    for (int64_t ltile = blockIdx.x; ltile < P.ntiles; ltile += gridDim.x) {
+        // a window of a longer stream: local tile `ltile` is tile `tile` of the burst (P.tile_lo = 0,
+        // P.ntiles = all of them for a one-shot burst); carries Wq are indexed locally, everything
+        // else (symbols via mod_amp, samples, noise, columns) in burst coordinates
+        const int64_t tile = P.tile_lo + ltile;
         const int64_t tile_base = tile * tile_len;
         const int64_t sym_base = tile_base / sps;
         const int64_t mp1_lo = sym_base + cq - JMAX + 1;
         const bool full_tile = tile_base + tile_len <= P.out_len;
         // columns this tile may store, relative to its first symbol (32-bit tests per row)
-        const int64_t klo64 = -sym_base, khi64 = Q.ncols - sym_base;
+        const int64_t klo64 = Q.k_lo - sym_base, khi64 = Q.k_hi - sym_base;
         const int klo = klo64 < -(1 << 20) ? -(1 << 20) : (int)klo64, khi = khi64 > (1 << 20) ? (1 << 20) : (int)khi64;
         wf_lds_barrier();                                     // previous tile's columns are done with the ring
         for (int k = t; k < win; k += MOD_THREADS) s_amp[k] = mod_amp(symbols, hvec, P, mp1_lo + k - 1);
@@ -533,16 +537,16 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
         double run = 0.0;
         const int lpart = (int)((sym_base - P.dsh + 1) - mp1_lo);
         if (tile > 0) {
-            run = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
+            run = (double)Wq[ltile] * 0x1.0p-62 * P.sps_d;
             double part = 0.0;
             for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + l], Gpart[l], part);
             run += part;
         }
         // the first 8 samples of the NEXT tile (lanes 0..3 of wave 0), by that tile's own row-0 expressions
         if (wave == 0 && lane < 4) s_halo[2 * lane] = s_halo[2 * lane + 1] = make_double2(0.0, 0.0);
-        if (wave == 0 && tile + 1 < P.ntiles) {
+        if (wave == 0 && ltile + 1 < P.ntiles) {   // (the last tile of a window is itself halo: its last columns belong to the next chunk)
             double2 h0 = make_double2(0.0, 0.0), h1 = h0;
-            double runn = (double)Wq[tile + 1] * 0x1.0p-62 * P.sps_d;
+            double runn = (double)Wq[ltile + 1] * 0x1.0p-62 * P.sps_d;
             double part = 0.0;
             for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + MOD_ROWS * sym_per_row + l], Gpart[l], part);
             runn += part;
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
             wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
             const int64_t n0 = tile_base + tile_len + 2 * lane;
             double g[4];
-            wf_gaussian_two(Q.pair0 + (uint64_t)(n0 >> 1), Q.stream_id, Q.seed, Q.sigma, tb, g);
+            wf_gaussian_two(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, Q.seed, Q.sigma, tb, g);
             if (n0 < P.out_len) h0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
             if (n0 + 1 < P.out_len) h1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
             if (lane < 4) {                                   // parked until row 15 has been consumed (same wave reads it back)
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
                 const double va = odd ? C + D : A - B;                    // Im z0 | Re z0
                 const double vb = odd ? A + B : D - C;                    // Re z2 | Im z2
                 const double val = mp < 2 ? U : (mp == 2 ? va : vb);
-                if (k_ok) rows[4 * k + mp] = val;
+                if (k_ok) rows[4 * (k - Q.k_lo) + mp] = val;
             } else {
                 // any 3 x 9 bank: lane p keeps the one chain of the packed row it stores
                 const int f = mp < 2 ? 1 : (mp == 2 ? 0 : 2);
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
                     const double2 tp = s_taps[f * 9 + (8 - j)];
                     acc = imag ? fma(x.x, tp.y, fma(x.y, tp.x, acc)) : fma(x.x, tp.x, fma(-x.y, tp.y, acc));
                 }
-                if (k_ok) rows[4 * k + mp] = acc;
+                if (k_ok) rows[4 * (k - Q.k_lo) + mp] = acc;
             }
         };
 #pragma unroll 2
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
             // channel (wf_awgn_c128): derotate + Philox AWGN, one block per thread and row
             const int64_t n0 = tile_base + (int64_t)u * 512 + 2 * t;
             double g[4];
-            wf_gaussian_two(Q.pair0 + (uint64_t)(n0 >> 1), Q.stream_id, Q.seed, Q.sigma, tb, g);
+            wf_gaussian_two(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, Q.seed, Q.sigma, tb, g);
             double2 x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
             double2 x1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
             if (!full_tile) {                                   // (tile-uniform) samples past the end of the burst are zeros to the bank
@@ -790,34 +794,50 @@ extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_
 // Returns 1 — not an error — when the configuration is outside the fused kernel (the caller then
 // runs the separate kernels): needs sps 8, a pulse of at most 9 symbols inside the fused
 // modulator's envelope, an even first noise index.
-int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
-                            const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
-                            double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
-                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream)
+// Window form (streaming link): tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total symbols,
+// d_symbols[0] = symbol sym_origin (nloc resident), phase carry of the first tile from *d_q_in
+// (ignored for tile_lo == 0), carry of local tile q_out_tile to *d_q_out, columns [k_lo, k_lo + ncols)
+// stored at d_rows4[4 (k - k_lo)].  One-shot: tile_lo = 0, ntiles = -1 (all), k_lo = 0.
+int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total,
+                            const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
+                            int64_t tile_lo, int64_t ntiles, const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile,
+                            const double *d_mf_taps, double rot_re, double rot_im, double sigma, uint64_t seed,
+                            uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index, int64_t first,
+                            int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream)
 {
-    WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_mf_taps && d_rows4, "wf_mod_chan_bank_packed: NULL argument");
+    WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_mf_taps && d_rows4, "wf_mod_chan_bank: NULL argument");
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_rows4) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_mf_taps) & 15) == 0,
-               "wf_mod_chan_bank_packed: device pointers must be 16-byte aligned");
+               "wf_mod_chan_bank: device pointers must be 16-byte aligned");
     mod_params P;
-    if (sps != 8 || (first_index & 1) || first < 0 || first >= 8 || ncols < 1) return 1;
-    if (!mod_setup(P, nsym, nh, ntaps, sps, phi0) || P.rs != 2 * MOD_THREADS) return 1;
+    if (sps != 8 || (first_index & 1) || first < 0 || first >= 8 || ncols < 1 || k_lo < 0) return 1;
+    if (!mod_setup(P, nsym_total, nh, ntaps, sps, phi0) || P.rs != 2 * MOD_THREADS) return 1;
     const int J = (ntaps + sps - 1) / sps;
     if (J > 9) return 1;
-    WF_REQUIRE(first + (ncols - 1) * 8 < P.out_len, "wf_mod_chan_bank_packed: columns run past the burst");
+    WF_REQUIRE(first + (k_lo + ncols - 1) * 8 < P.out_len, "wf_mod_chan_bank: columns run past the burst");
+    if (ntiles < 0) ntiles = P.ntiles;
+    WF_REQUIRE(tile_lo >= 0 && ntiles >= 1 && tile_lo + ntiles <= P.ntiles, "wf_mod_chan_bank: bad tile window");
+    P.sym_origin = sym_origin;
+    P.nloc = nloc;
+    P.tile_lo = tile_lo;
+    P.ntiles = ntiles;
+    P.q_out_tile = q_out_tile;
     WF_HIP(hipSetDevice(ctx->device));
-    int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, nullptr, nullptr, stream);
+    int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, d_q_in, d_q_out, stream);
     if (rc) return rc;
     mcb_params Q;
     Q.rot_re = rot_re; Q.rot_im = rot_im; Q.sigma = sigma;
     Q.seed = seed; Q.stream_id = stream_id; Q.pair0 = first_index >> 1;
-    Q.ncols = ncols;
+    Q.dyn_index = d_dyn_index;
+    Q.k_lo = k_lo;
+    Q.k_hi = k_lo + ncols;
     Q.kshift = first >= 4 ? 0 : -1;
     Q.d = (int)((first - 4 + 8) & 7);
     Q.pack_par0 = pack_par0 & 1;
     const int JM = J <= 4 ? 4 : 9;
     const int win = MOD_ROWS * 64 + JM + 2;
-    size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)MCB_SLOTS * sizeof(double2);
-    if (const char *pad = getenv("WF_MCB_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
+    // (occupancy experiment, LDS padded to force fewer workgroups per CU with the 4-row ring of the
+    //  first version: 1 per CU 0.97 ms, 2: 0.63, 3: 0.56 — the 2-row ring's 4 per CU: 0.53)
+    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)MCB_SLOTS * sizeof(double2);
     const int64_t max_grid = 2048;
     const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
@@ -828,6 +848,16 @@ int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, 
                        d_rows4, P, Q);
     WF_LAUNCH_CHECK();
     return WF_OK;
+}
+
+int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
+                            const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
+                            double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
+                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream)
+{
+    return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
+                                   d_mf_taps, rot_re, rot_im, sigma, seed, stream_id, first_index, nullptr, first, 0, ncols,
+                                   pack_par0, d_rows4, stream);
 }
 
 // Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total

@@ -413,13 +413,26 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
     const int64_t at = S.ws_next - S.ws;
     if ((rc = wf_fsm_encode_core(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, S.nloc, S.ws, 0, enc_state, syms, nullptr,
                                  at <= S.nloc ? enc_state : nullptr, at, stream))) return rc;
-    if ((rc = wf_cpm_modulate_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4,
-                                     S.tile_lo, S.ntiles, sig, S.out_origin, q_phase, q_phase, S.q_out_tile, stream))) return rc;
     const double rot_re = cos(-M_PI / 4), rot_im = sin(-M_PI / 4);
-    const int64_t first_local = S.first + S.k_lo * cfg->sps - S.out_origin;
     WF_REQUIRE(!steady || (cfg->fuse & 2), "wf_link_stream_steady needs the fused channel (fuse bit 1)");
     const bool packed = link_packed_rows(cfg);
-    if (cfg->fuse & 2) {
+    // fuse bit 3: modulator + channel + bank of the chunk's tiles in one kernel (no samples in HBM);
+    // the tile before the chunk is processed too — its last column is the chunk's first
+    bool fused_all = false;
+    if ((cfg->fuse & 8) && packed && cfg->mf_ntaps == 9) {
+        rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
+                                     S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_mf_taps, rot_re, rot_im, cfg->sigma, cfg->seed,
+                                     cfg->stream_id, 0, steady ? dyn + 1 : nullptr, S.first, S.k_lo, S.ncols, 0, mf, stream);
+        if (rc < 0) return rc;
+        fused_all = rc == 0;
+    }
+    if (!fused_all)
+        if ((rc = wf_cpm_modulate_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4,
+                                         S.tile_lo, S.ntiles, sig, S.out_origin, q_phase, q_phase, S.q_out_tile, stream))) return rc;
+    const int64_t first_local = S.first + S.k_lo * cfg->sps - S.out_origin;
+    if (fused_all) {
+        rc = WF_OK;
+    } else if (cfg->fuse & 2) {
         rc = wf_awgn_mf_bank_dyn(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
                                  (uint64_t)S.out_origin, steady ? dyn + 1 : nullptr, cfg->d_mf_taps, cfg->mf_nfilt,
                                  cfg->mf_ntaps, first_local, cfg->sps, S.ncols, mf, stream,

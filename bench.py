@@ -193,7 +193,7 @@ def main() -> None:
                     help="record the per-stage HIP events on every E-th timed step only (the last step always)")
     ap.add_argument("--vit-warmup", type=int, default=-1, help="SOQPSK detector chunk warm-up rows - 1 (-1: by Eb/N0, 0: library default)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="symbols per core, compiled port")
-    ap.add_argument("--cpu-loop-sample", type=int, default=1 << 14, help="symbols per core, faithful-loop form")
+    ap.add_argument("--cpu-loop-sample", type=int, default=1 << 16, help="symbols per core, faithful-loop form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -195,6 +195,9 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
             const int q = s + 16 * i;
             int64_t row = kb + q / NF;
             row = row < 0 ? 0 : (row >= P.ncalls ? P.ncalls - 1 : row);   // never decoded when clamped
+#ifdef WF_ABL_CPM_SAMEROWS   // ablation only: every chunk reads the same 1 MB of rows (cache-resident)
+            row &= 4095;
+#endif
             const int qq = q < PIECES ? q : 0;
             dst[i] = vit_ld16_c(rows + row * NF + (qq - (qq / NF) * NF));
         }
@@ -228,7 +231,11 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
         const uint32_t ih = kv == 0 ? ihi[0] : (kv == 1 ? ihi[1] : ihi[2]);
         int r = 2 * v - tilt;
         r += r < 0 ? 2 * P.p : 0;
+#ifdef WF_ABL_CPM_NOROT     // ablation only: no dependent table read
+        const double2 cs = make_double2(1.0 - 1e-3 * r, 1e-3 * r);
+#else
         const double2 cs = rot[r];
+#endif
         const double2 *zrow = zlane + tt * NF;
 #pragma unroll
         for (int u = 0; u < M; ++u) {
@@ -258,11 +265,21 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
         const uint32_t inf = (w & 1) ? (pair >> 16) : (pair & 0xFFFFu);
         const int src = (int)(inf & 15u), u_new = (int)((inf >> 4) & 3u), incmod = (int)((inf >> 8) & 63u);
         const int baddr = ((lane & 48) | src) << 2;
+#ifdef WF_ABL_CPM_NOBPERM   // ablation only: no cross-lane fetch of the winner's registers
+        int nv = v + incmod + (baddr & 4);
+        nv -= nv >= P.p ? P.p : 0;
+        const uint64_t nh_ = (hist << LGM) | (uint64_t)u_new;
+#else
         int nv = __builtin_amdgcn_ds_bpermute(baddr, v) + incmod;
         nv -= nv >= P.p ? P.p : 0;
         const uint64_t nh_ = (cpm_bperm_u64(baddr, hist) << LGM) | (uint64_t)u_new;
+#endif
         double nm = active ? best : INFINITY;
+#ifdef WF_ABL_CPM_NOMIN     // ablation only: no 16-lane all-reduce
+        nm -= 0.5 * best;
+#else
         nm -= cpm_row_min(nm);                                          // the minimum becomes exactly 0.0
+#endif
         if (valid) {
             m = nm;
             v = nv;

@@ -289,7 +289,14 @@ def main() -> None:
         # bits -> symbols -> c128 samples -> noisy samples in place -> nf complex rows -> one decision byte
         bps = {"prbs": bits_per_sym, "map": bits_per_sym + 1, "modulate": 1 + 16 * args.sps, "awgn": 32 * args.sps,
                "mfbank": 16 * args.sps + 16 * nf, "viterbi": 16 * nf + 1, "count": 2}
-        STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}>",
+        if links[0].cfg.fuse & 8 and acc.get("mfbank", 1.0) < 0.05 * max(acc.get("modulate", 0.0), 1e-9):
+            # fuse bit 3 in effect: the "modulate" slot timed modulator + channel + filters (one kernel)
+            acc["mod+awgn+mfbank"] = acc.pop("modulate")
+            acc.pop("awgn", None)
+            acc.pop("mfbank", None)
+            bps["mod+awgn+mfbank"] = 1 + 16 * nf
+            STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<4, {nf}>"
+        STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}, {'true' if links[0].cfg.fuse & 2 else 'false'}>",
                              "viterbi": f"cpm_viterbi_kernel<{links[0].spec.M}, {links[0].spec.Lp}>", "map": "symbol_map_kernel",
                              "modulate": "mod_main_kernel<4, true>"})
     one_kernel = not cpm and (args.fuse & 15) == 15 and links[0].row_bytes == 32 and links[0].cfg.mf_ntaps == 9 and args.sps == 8

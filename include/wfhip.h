@@ -368,7 +368,9 @@ typedef struct {
     int warmup;
     int skip_head;            /* leading symbols excluded from the comparison (start transient)   */
     int event_slot;
-    int fuse;                 /* bit 1: channel applied inside the matched-filter kernel          */
+    int fuse;                 /* bit 1: channel applied inside the matched-filter kernel;         */
+                              /* bit 3 (with bit 1, sps 8, 4 or 16 filters): modulator + channel  */
+                              /* + matched-filter rows in one kernel, no samples in HBM           */
 } wf_cpm_link_config;
 int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg);
 int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,

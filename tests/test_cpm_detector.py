@@ -230,14 +230,14 @@ def test_gpu_detector_reports_and_repairs_unmerged_chunks(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fuse", [2, 0])
+@pytest.mark.parametrize("fuse", [10, 2, 0])
 @pytest.mark.parametrize("waveform,nsym", [("multih", 100_000), ("pcmfm", 60_000), ("multih", 777)])
 def test_gpu_cpm_link_equals_oracle_chain(oracle, waveform, nsym, fuse):
     """wf_cpm_link_run (PRBS -> mapper -> modulate -> Philox AWGN -> rows -> detector -> count)
     against the oracle chain fed the same noise: identical symbol and bit error counts."""
     from waveforms_amd.link import CPMLink
 
-    link = CPMLink(nsym, SPS, waveform=waveform, fuse=fuse)      # fuse 2: channel inside the matched-filter kernel
+    link = CPMLink(nsym, SPS, waveform=waveform, fuse=fuse)      # fuse 10: modulator + channel + filters in one kernel; 2: channel inside the filter kernel
     spec = oracle.ARTM_16 if waveform == "multih" else oracle.PCMFM_SPEC
     pulse = oracle.freq_pulse_multih_irig(SPS) if waveform == "multih" else oracle.freq_pulse_pcmfm(SPS)
     bps = spec.lgM

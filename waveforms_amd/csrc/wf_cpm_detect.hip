@@ -827,13 +827,27 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     // MultiHSymbolMapper on an even number of bits leaves its parity at 0 (precoder.py:22)
     if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, L.nbits, 0, 0, 0, syms, stream))) return rc;
     MARK(2);
-    rc = wf_cpm_modulate_c128(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, sig, stream);
-    if (rc < 0) return rc;
-    WF_REQUIRE(rc == 0, "wf_cpm_link_run: burst / pulse outside the fused modulator (%lld symbols, %d taps)",
-               (long long)cfg->nsym, cfg->ntaps);
+    // fuse bit 3 (with bit 1): modulator + channel + matched-filter rows in one kernel
+    // (mod_chan_bank_kernel, wf_modulate.hip) — the baseband samples never reach HBM
+    bool fused_all = false;
+    if ((cfg->fuse & 8) && (cfg->fuse & 2) && L.ncalls > 0) {
+        rc = wf_mod_chan_cpm_rows(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_templates,
+                                  L.nfilt, L.ntm, L.start0, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, L.ncalls,
+                                  rows, stream);
+        if (rc < 0) return rc;
+        fused_all = rc == 0;
+    }
+    if (!fused_all) {
+        rc = wf_cpm_modulate_c128(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, sig, stream);
+        if (rc < 0) return rc;
+        WF_REQUIRE(rc == 0, "wf_cpm_link_run: burst / pulse outside the fused modulator (%lld symbols, %d taps)",
+                   (long long)cfg->nsym, cfg->ntaps);
+    }
     MARK(3);
     MARK(4);
-    if (cfg->fuse & 2) {     // channel inside the matched-filter kernel: the noisy samples never exist in HBM
+    if (fused_all) {
+        MARK(5);
+    } else if (cfg->fuse & 2) {     // channel inside the matched-filter kernel: the noisy samples never exist in HBM
         MARK(5);
         if ((rc = wf_cpm_awgn_mf_rows_c128(ctx, sig, L.npts, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0,
                                            cfg->d_templates, cfg->det.nh, L.nfilt, L.ntm, L.start0, cfg->sps, L.ncalls, rows, stream))) return rc;

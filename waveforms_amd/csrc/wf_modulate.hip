@@ -436,6 +436,7 @@ struct mcb_params {
     int kshift;       // floor((first - 4) / 8): column k's window starts at sample 8 (k + kshift) + d
     int d;            // (first - 4) mod 8
     int pack_par0;    // parity of the detector call index of column 0 of the burst
+    int cpm_nh;       // CPMNF instantiations: number of modulation-index columns of the templates (1 or 2)
 };
 
 #define MCB_RING 1024                        // samples: 2 rows of 512
@@ -450,7 +451,12 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm broadc
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-template <int JMAX>
+// CPMNF = 0: the SOQPSK pulse-truncation bank with detector-packed rows (above).  CPMNF = 4 | 16: the
+// matched-filter rows of the generic CPM detector (wf_cpm_detect.hip: CPMNF templates of 9 taps per
+// modulation-index column, Z = sum_k r[8 n + start + k] conj(T[n % nh][f][k]), full complex rows of
+// CPMNF filters) — thread = (symbol, quarter of the filters), templates in LDS, same accumulation
+// order as cpm_mf_rows_kernel.
+template <int JMAX, int CPMNF>
 __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols,
                                                                      const double *__restrict__ hvec,
                                                                      const double *__restrict__ pulse,
@@ -464,19 +470,23 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
     double2 *s_ring = reinterpret_cast<double2 *>(s_dyn + ((win + 1) & ~1));     // noisy samples, 4 rows
     __shared__ double s_tot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
-    __shared__ double2 s_taps[27];
+    __shared__ double2 s_taps[CPMNF ? 2 * CPMNF * 9 : 27];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     static_assert(MOD_WAVES == 4, "the row-total prefix below is written out for 4 waves");
     wf_stage_tables<1, 0>(s_tab, t, MOD_THREADS);
-    if (t < 27) s_taps[t] = reinterpret_cast<const double2 *>(mf_taps)[t];
+    if (CPMNF) {
+        for (int k = t; k < Q.cpm_nh * CPMNF * 9; k += MOD_THREADS) s_taps[k] = reinterpret_cast<const double2 *>(mf_taps)[k];
+    } else if (t < 27) {
+        s_taps[t] = reinterpret_cast<const double2 *>(mf_taps)[t];
+    }
     const double2 *s_cis = s_tab + 128;
     const wf_tabs_lds<1, 0> tb{s_tab};
     // pulse-truncation structure of the bank (block-uniform, read straight from global memory):
     // filter 1 all ones, filter 2 = conj(filter 0)
-    bool sym_taps = true;
-    {
+    bool sym_taps = CPMNF == 0;
+    if (CPMNF == 0) {
         const double2 *tg = reinterpret_cast<const double2 *>(mf_taps);
         for (int j = 0; j < 9; ++j) {
             const double2 t0 = tg[j], t1 = tg[9 + j], t2 = tg[18 + j];
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
     //   A: Re x * Re tap | B: Im x * Im tap | C: Re x * Im tap | D: Im x * Re tap
     __shared__ double s_tapc[4 * 9];
     __shared__ double2 s_halo[8];
-    if (t < 36) {
+    if (CPMNF == 0 && t < 36) {
         const double2 tp = reinterpret_cast<const double2 *>(mf_taps)[8 - t % 9];
         s_tapc[t] = (t / 9 == 0 || t / 9 == 3) ? tp.x : tp.y;
     }
@@ -589,7 +599,31 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t
             const bool k_ok = kr >= klo && kr < khi;
             const int grp = (64 * rho + mq) & (MCB_RING / 8 - 1);       // pad group of the window start
             const bool odd = ((Q.pack_par0 + kr + (int)(sym_base & 1)) & 1) != 0;
-            if (sym_taps) {
+            if constexpr (CPMNF != 0) {
+                // rows of the generic CPM detector: this lane's CPMNF / 4 filters of symbol k
+                constexpr int FPT = CPMNF / 4;
+                const double2 *xb = s_ring + 9 * grp;
+                const int col = Q.cpm_nh == 2 ? (int)((sym_base + kr) & 1) : 0;      // modulation-index column of symbol k
+                const double2 *tb_ = s_taps + (col * CPMNF + FPT * mp) * 9;
+                double zr[FPT], zi[FPT];
+#pragma unroll
+                for (int f = 0; f < FPT; ++f) zr[f] = zi[f] = 0.0;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const double2 xv = xb[j < 8 ? j : 9];
+#pragma unroll
+                    for (int f = 0; f < FPT; ++f) {
+                        const double2 tp = tb_[f * 9 + j];
+                        zr[f] = fma(xv.x, tp.x, fma(xv.y, tp.y, zr[f]));
+                        zi[f] = fma(xv.y, tp.x, fma(-xv.x, tp.y, zi[f]));
+                    }
+                }
+                if (k_ok) {
+                    double2 *o = reinterpret_cast<double2 *>(rows) + (k - Q.k_lo) * CPMNF + FPT * mp;
+#pragma unroll
+                    for (int f = 0; f < FPT; ++f) o[f] = make_double2(zr[f], zi[f]);
+                }
+            } else if (sym_taps) {
                 const double *xb = ring_d + 2 * (9 * grp) + (mp & 1);
                 double S = 0.0, U = 0.0;
 #pragma unroll
@@ -803,9 +837,11 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             int64_t tile_lo, int64_t ntiles, const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile,
                             const double *d_mf_taps, double rot_re, double rot_im, double sigma, uint64_t seed,
                             uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index, int64_t first,
-                            int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream)
+                            int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf, int cpm_nh)
 {
     WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_mf_taps && d_rows4, "wf_mod_chan_bank: NULL argument");
+    if (cpm_nf != 0 && cpm_nf != 4 && cpm_nf != 16) return 1;
+    if (cpm_nf && cpm_nh != 1 && cpm_nh != 2) return 1;
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_rows4) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_mf_taps) & 15) == 0,
                "wf_mod_chan_bank: device pointers must be 16-byte aligned");
     mod_params P;
@@ -833,6 +869,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     Q.kshift = first >= 4 ? 0 : -1;
     Q.d = (int)((first - 4 + 8) & 7);
     Q.pack_par0 = pack_par0 & 1;
+    Q.cpm_nh = cpm_nh;
     const int JM = J <= 4 ? 4 : 9;
     const int win = MOD_ROWS * 64 + JM + 2;
     // (occupancy experiment, LDS padded to force fewer workgroups per CU with the 4-row ring of the
@@ -841,7 +878,9 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     const int64_t max_grid = 2048;
     const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
-    kern_t k = JM == 4 ? mod_chan_bank_kernel<4> : mod_chan_bank_kernel<9>;
+    kern_t k = cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
+             : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)
+                            : (JM == 4 ? mod_chan_bank_kernel<4, 0> : mod_chan_bank_kernel<9, 0>);
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(MOD_THREADS), lds, wf_stream(stream), d_symbols, d_h, d_pulse, ctx->d_mod_scratch, d_mf_taps,
@@ -857,7 +896,21 @@ int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, 
 {
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_mf_taps, rot_re, rot_im, sigma, seed, stream_id, first_index, nullptr, first, 0, ncols,
-                                   pack_par0, d_rows4, stream);
+                                   pack_par0, d_rows4, stream, 0, 1);
+}
+
+// The same kernel producing the generic CPM detector's matched-filter rows (nfilt = 4 or 16 templates
+// of 9 taps per modulation-index column; row n from samples [start0 + 8 n, + 8]).  Returns 1 when
+// outside the kernel (caller runs modulator, channel and wf_cpm_mf_rows_c128 separately).
+int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse,
+                         int ntaps, int sps, double phi0, const double *d_templates, int nfilt, int ntm, int64_t start0,
+                         double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id, int64_t ncalls,
+                         double *d_rows, void *stream)
+{
+    if (ntm != 9 || start0 < -4 || start0 > 3 || (nfilt != 4 && nfilt != 16)) return 1;
+    return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
+                                   d_templates, rot_re, rot_im, sigma, seed, stream_id, 0, nullptr, start0 + 4, 0, ncalls, 0,
+                                   d_rows, stream, nfilt, nh);
 }
 
 // Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total

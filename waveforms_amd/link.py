@@ -236,7 +236,7 @@ class CPMLink:
     STAGES = ("prbs", "map", "modulate", "-", "awgn", "mfbank", "viterbi", "count")
 
     def __init__(self, nsym: int, sps: int = 8, waveform: str = "multih", spec=None, pn_degree: int = 23, warmup: int = 0,
-                 skip_head: int = 64, private_ctx: bool = False, fuse: int = 2) -> None:
+                 skip_head: int = 64, private_ctx: bool = False, fuse: int = 10) -> None:
         from .viterbi import cpm
 
         if waveform == "multih":

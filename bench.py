@@ -219,7 +219,7 @@ def main() -> None:
     if cpm:
         from waveforms_amd.link import CPMLink
 
-        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1) for _ in range(nstreams)]
+        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1, fuse=args.fuse) for _ in range(nstreams)]
         bits_per_sym = links[0].spec.bits_per_symbol
     else:
         # detector chunk warm-up: 16 rows at Eb/N0 >= 6 dB with the matched bank (tools/warmup_scan.py: 0 of 2.5e6
@@ -367,7 +367,7 @@ def main() -> None:
                        "waveform": args.waveform,
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
-                       "fuse": None if cpm else args.fuse, "streams": nstreams,
+                       "fuse": args.fuse, "streams": nstreams,
                        "detector_warmup_rows": None if cpm else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32), "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared * bits_per_sym, 1),

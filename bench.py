@@ -306,7 +306,7 @@ def main() -> None:
             acc.pop(k, None)
         bps["mod+awgn+mfbank"] = 1 + 32
         bps["viterbi"] = 32 + 2
-        STAGE_KERNEL["mod+awgn+mfbank"] = "mod_chan_bank_kernel<9>"
+        STAGE_KERNEL["mod+awgn+mfbank"] = "mod_chan_bank_kernel<9, 0>"
         STAGE_KERNEL["viterbi"] = "viterbi_batch_kernel<true>"
     elif not cpm and args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
         acc["modulate"] = acc.pop("fir")

@@ -339,6 +339,9 @@ def main() -> None:
     vi = valu_issue(dominant, rec, d["ms"])
     if vi:      # the bound that actually binds when traffic ~ algorithmic bytes and the HBM fraction is low
         roofline.update(valu_issue_frac=vi.pop("valu_issue_frac"), valu=vi)
+        # which of the two sides of this kernel's roofline is the higher (= the binding) one
+        binding = "valu_issue" if roofline["valu_issue_frac"] > roofline["frac"] else "hbm"
+        roofline.update(binding=binding, binding_frac=max(roofline["valu_issue_frac"], roofline["frac"]))
     # every stage with a profile record: its own HBM and issue fractions
     for name, st in stages.items():
         r_ = profile_record(name, args.nsym, args.sps)

@@ -219,7 +219,11 @@ def main() -> None:
     if cpm:
         from waveforms_amd.link import CPMLink
 
-        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1, fuse=args.fuse) for _ in range(nstreams)]
+        # detector chunk warm-up: the library default is safe at any Eb/N0 (256 / 384 calls); from 8 dB up 128 (multih) /
+        # 192 (pcmfm) left no chunk unproven in tools/cpm_warmup_scan.py — link.result() raises if one ever is
+        cwu = args.vit_warmup if args.vit_warmup >= 0 else ((128 if args.waveform == "multih" else 192) if args.ebn0 >= 8.0 else 0)
+        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1, fuse=args.fuse, warmup=cwu)
+                 for _ in range(nstreams)]
         bits_per_sym = links[0].spec.bits_per_symbol
     else:
         # detector chunk warm-up: 16 rows at Eb/N0 >= 6 dB with the matched bank (tools/warmup_scan.py: 0 of 2.5e6
@@ -371,7 +375,7 @@ def main() -> None:
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
                        "fuse": args.fuse, "streams": nstreams,
-                       "detector_warmup_rows": None if cpm else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32), "parallelism": f"independent trial blocks x{world}"},
+                       "detector_warmup_rows": (links[0].cfg.warmup or "library default") if cpm else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32), "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared * bits_per_sym, 1),
                     # link.result() raises otherwise: every detector chunk started from bitwise the

@@ -273,3 +273,24 @@ def test_gpu_multih_full_size_noiseless_and_ber(oracle):
     ber = be / (2 * m)
     q = 0.5 * math.erfc(math.sqrt(1.2957 * 10.0) / math.sqrt(2))
     assert q < ber < 5e-4, (ber, q)
+
+
+@pytest.mark.gpu
+def test_gpu_cpm_ber_sweep_through_the_bert_harness():
+    """waveforms.bert serves the generic CPM detector's waveforms too (SweepPlan.waveform): three blocks
+    in flight on separate streams, library-default warm-up (safe at any Eb/N0), curve monotone and
+    above the minimum-distance term Q(sqrt(1.2957 Eb/N0)) by a small factor."""
+    from waveforms.bert import SweepPlan, ber_sweep
+
+    ebn0 = [6.0, 8.0, 10.0]
+    plan = SweepPlan(ebn0_db=ebn0, blocks_per_point=6, nsym=1 << 21, waveform="multih")
+    assert plan.bits_per_symbol == 2 and plan.skip_bits(3) == 3 * (1 << 22)
+    counts = ber_sweep(plan, rank=0, world=1)
+    ber = counts[:, 1] / (2.0 * counts[:, 2])
+    assert (counts[:, 2] == 6 * ((1 << 21) - 31 - 64)).all()
+    assert ber[0] > ber[1] > ber[2] > 0
+    q = [0.5 * math.erfc(math.sqrt(1.2957 * 10 ** (e / 10) / 2)) for e in ebn0]
+    for b, lo in zip(ber, q):
+        assert lo < b < 6 * lo, (ber, q)
+    pc = ber_sweep(SweepPlan(ebn0_db=[4.0, 7.0], blocks_per_point=3, nsym=1 << 20, waveform="pcmfm"), rank=0, world=1)
+    assert pc[0, 1] > pc[1, 1] > 0 and (pc[:, 0] == pc[:, 1]).all()          # binary: symbol errors = bit errors

@@ -1,0 +1,37 @@
+"""Chunk warm-up of the generic CPM detector: chunks whose start state was not bitwise the sequential
+detector's (the launch's own proof), per warm-up length and Eb/N0.
+    python tools/cpm_warmup_scan.py [--waveform multih] [--symbols-per-point 4e7]"""
+import argparse, json, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--waveform", default="multih")
+    ap.add_argument("--symbols-per-point", type=float, default=4e7)
+    a = ap.parse_args()
+    import torch
+    from waveforms_amd import device as dev
+    from waveforms_amd.link import CPMLink
+    nsym = 10_000_000
+    blocks = max(1, int(a.symbols_per_point / nsym))
+    out = []
+    for w in (64, 128, 192, 256, 384, 512):
+        link = CPMLink(nsym, 8, waveform=a.waveform, warmup=w)
+        row = {"waveform": a.waveform, "warmup": w, "unmerged_by_ebn0": {}}
+        for e in (0, 2, 4, 6, 8, 10, 12):
+            dev.viterbi_unmerged(reset=True, ctx=link._ctx)
+            for b in range(blocks):
+                link.run_block(float(e), seed=5, stream_id=(e << 20) | b, skip_bits=b * nsym * link.spec.bits_per_symbol)
+            torch.cuda.synchronize()
+            row["unmerged_by_ebn0"][e] = dev.viterbi_unmerged(reset=True, ctx=link._ctx)
+        link.run_block(10.0, event_slot=0)
+        row["viterbi_ms"] = round(link.stage_ms(0)["viterbi"], 4)
+        out.append(row)
+        print(json.dumps(row), flush=True)
+        del link
+    Path("gpurun_out").mkdir(exist_ok=True)
+    Path(f"gpurun_out/r02_cpm_warmup_scan_{a.waveform}.json").write_text(json.dumps(out, indent=1))
+
+if __name__ == "__main__":
+    main()

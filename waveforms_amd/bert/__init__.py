@@ -26,6 +26,7 @@ class SweepPlan:
     detector: str = "PT"
     sps: int = 8
     pn_degree: int = 23
+    waveform: str = "soqpsk"       # "soqpsk" (detector PT / PAM), or "multih" / "pcmfm" through the generic CPM detector
     jobs: list[tuple[int, int]] = field(default_factory=list)   # (point index, block index)
 
     def __post_init__(self):
@@ -38,8 +39,12 @@ class SweepPlan:
     def stream_id(self, point: int, block: int) -> int:
         return (point << 32) | block
 
+    @property
+    def bits_per_symbol(self) -> int:
+        return 2 if self.waveform == "multih" else 1
+
     def skip_bits(self, block: int) -> int:
-        return block * self.nsym
+        return block * self.nsym * self.bits_per_symbol
 
 
 def dist_env() -> tuple[int, int, int]:
@@ -99,12 +104,19 @@ def gpu_block_runner(plan: SweepPlan, streams: int = 3):
     import ctypes
 
     from waveforms_amd import _hip, device as dev
-    from waveforms_amd.link import SOQPSKLink, sigma_for_ebn0
+    from waveforms_amd.link import CPMLink, SOQPSKLink, sigma_for_ebn0
+    from waveforms_amd.viterbi.cpm import sigma_for_ebn0 as cpm_sigma
 
     torch = _hip.torch()
     n = max(1, int(streams))
-    links = [SOQPSKLink(plan.nsym, plan.sps, detector=plan.detector, pn_degree=plan.pn_degree, private_ctx=n > 1)
-             for _ in range(n)]
+    cpm = plan.waveform != "soqpsk"
+    if cpm:
+        links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, pn_degree=plan.pn_degree, private_ctx=n > 1) for _ in range(n)]
+        run_fn = _hip.lib().wf_cpm_link_run
+    else:
+        links = [SOQPSKLink(plan.nsym, plan.sps, detector=plan.detector, pn_degree=plan.pn_degree, private_ctx=n > 1)
+                 for _ in range(n)]
+        run_fn = _hip.lib().wf_link_run
     lanes = [torch.cuda.Stream() for _ in range(n)] if n > 1 else [torch.cuda.current_stream()]
     npts = len(plan.ebn0_db)
     tables = [_hip.zeros((npts, 2), "int64") for _ in range(n)]
@@ -117,13 +129,14 @@ def gpu_block_runner(plan: SweepPlan, streams: int = 3):
         k = issued[0] % n
         issued[0] += 1
         link, c = links[k], links[k].cfg
-        c.sigma, c.seed = sigma_for_ebn0(plan.ebn0_db[point], plan.sps), plan.seed
+        c.sigma = (cpm_sigma(plan.ebn0_db[point], plan.sps, plan.bits_per_symbol) if cpm
+                   else sigma_for_ebn0(plan.ebn0_db[point], plan.sps))
+        c.seed = plan.seed
         c.stream_id, c.skip, c.event_slot = plan.stream_id(point, block), plan.skip_bits(block), -1
         m = ctypes.c_int64(0)
         with torch.cuda.stream(lanes[k]):
-            _hip.check(_hip.lib().wf_link_run(link._ctx, ctypes.byref(c), link.workspace.data_ptr(),
-                                              link.workspace_bytes, tables[k].data_ptr() + 16 * point,
-                                              ctypes.byref(m), _hip.stream()))
+            _hip.check(run_fn(link._ctx, ctypes.byref(c), link.workspace.data_ptr(), link.workspace_bytes,
+                              tables[k].data_ptr() + 16 * point, ctypes.byref(m), _hip.stream()))
         compared[point] += m.value
 
     def finish() -> np.ndarray:

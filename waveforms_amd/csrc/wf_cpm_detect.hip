@@ -32,7 +32,7 @@
 #define CPM_WAVES (CPM_THREADS / WF_WAVE)
 #define CPM_GROUPS 4            // 16-lane detectors per wave
 #define CPM_TB 4                // calls per staged batch of rows
-#define CPM_DEFAULT_WARMUP 128
+#define CPM_DEFAULT_WARMUP 256
 
 struct cpm_tables {
     // variant kv: 0 / 1 = the symbol leaving the window uses K[0] / K[1]; 2 = it is a virtual
@@ -475,10 +475,13 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
                    (reinterpret_cast<uintptr_t>(d_rot_cs) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
                "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
-    // default warm-up: the D calls that refill the decision register plus the merge depth of the
-    // trellis — measured: 1e8 ARTM calls (M = 4) with 128 never tripped the proof, binary PCM/FM
-    // (one bit per call, slower merges) needed more than 128 on 5 chunks of 2e5
-    int W = warmup ? warmup : (det->M == 2 ? 3 * CPM_DEFAULT_WARMUP : CPM_DEFAULT_WARMUP);
+    // Default warm-up: the D calls that refill the decision register plus the merge depth of the
+    // trellis at ANY Eb/N0 (tools/cpm_warmup_scan.py, profiles/r02_cpm_warmup_scan_*.json, 62 500 chunks
+    // per point): ARTM 16-state — 128 calls leave 128 / 71 / 34 chunks unproven at 0 / 2 / 4 dB and none
+    // from 6 dB up, 192 leave 4 / 2 at 0 / 2 dB, 256 none anywhere; binary PCM/FM (one bit per call,
+    // slower merges) — 256 still leave 1 at 0 dB, 384 none.  A caller that knows its operating point
+    // may pass less (bench.py: 128 / 192 at 10 dB); every launch proves its output either way.
+    int W = warmup ? warmup : (det->M == 2 ? CPM_DEFAULT_WARMUP * 3 / 2 : CPM_DEFAULT_WARMUP);
     W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
     if (W > 4096) W = 4096;
     // Calls per chunk (a multiple of 64): at least 256 (and 2 W), so the warm-up stays a fraction of

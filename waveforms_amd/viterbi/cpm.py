@@ -13,12 +13,14 @@ Lp - 1 previous symbols), matched filters over Lp symbols of the phase pulse (pu
 as examples/soqpsk_detection.py:134-156 does for SOQPSK), branch increment
 Re(rotation * mf) minimised with the reference detector's tie-breaks.
 
-Designs (bit-error rates measured with the sequential statement of the detector (cpm_oracle.c), 4e5 bits per point):
+Designs (bit-error rates of the sequential statement of the detector (cpm_oracle.c), 4e6 bits per point
+for the first three rows, 4e5 for the last two; the 16-state row is reproduced by the GPU link at
+2e8 bits per point: 7.6e-3, 1.9e-3, 3.7e-4, 5.4e-5):
 
     ARTM multi-h, Eb/N0 (dB)        8        9        10       11
-    256 states (Lp 3, NC 16)     3.6e-3   6.6e-4   6.5e-5   2.8e-5     full trellis p M^(L-1)
-     64 states (Lp 2, NC 16)     4.2e-3   7.8e-4   1.2e-4   1.0e-5
-     16 states (Lp 2, NC  4)     5.7e-3   1.1e-3   1.7e-4   2.3e-5     <- ARTM_16 (BASELINE configs[2]), ~0.2 dB
+    256 states (Lp 3, NC 16)     5.3e-3   1.3e-3   2.6e-4   4.0e-5     full trellis p M^(L-1)
+     64 states (Lp 2, NC 16)     5.8e-3   1.4e-3   2.6e-4   3.7e-5
+     16 states (Lp 2, NC  4)     7.5e-3   1.9e-3   3.3e-4   5.6e-5     <- ARTM_16 (BASELINE configs[2]), 0.2 dB
      16 states (Lp 1, NC 16)     4.1e-2   2.0e-2   9.4e-3   3.7e-3     one-symbol filters: unusable
      16 states (Lp 3, NC  1)     6.6e-2   3.5e-2   1.3e-2   3.9e-3     no phase state at all: unusable
 """

@@ -294,3 +294,27 @@ def test_gpu_cpm_ber_sweep_through_the_bert_harness():
         assert lo < b < 6 * lo, (ber, q)
     pc = ber_sweep(SweepPlan(ebn0_db=[4.0, 7.0], blocks_per_point=3, nsym=1 << 20, waveform="pcmfm"), rank=0, world=1)
     assert pc[0, 1] > pc[1, 1] > 0 and (pc[:, 0] == pc[:, 1]).all()          # binary: symbol errors = bit errors
+
+
+@pytest.mark.gpu
+def test_gpu_cpm_detection_example(oracle):
+    """examples/cpm_detection.py (the soqpsk_detection example's counterpart for the waveforms the
+    reference only modulates) reproduces the oracle chain's counts through the public API."""
+    import importlib.util
+    from pathlib import Path
+
+    path = Path(__file__).resolve().parent.parent / "examples" / "cpm_detection.py"
+    spec_ = importlib.util.spec_from_file_location("cpm_detection_example", path)
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    got = mod.run(ebn0_db=7.0, nsym=20000, pn_degree=17, seed=1)
+    rng = np.random.Generator(np.random.PCG64(seed=1))
+    pn = oracle.pn_sequence(17)
+    for label, spec, pulse, bps in (("ARTM multi-h", oracle.ARTM_16, oracle.freq_pulse_multih_irig(SPS), 2),
+                                    ("PCM/FM", oracle.PCMFM_SPEC, oracle.freq_pulse_pcmfm(SPS), 1)):
+        bits = np.resize(pn, 20000 * bps)
+        sym = oracle.multih_mapper(bits)[0] if bps == 2 else oracle.pcmfm_mapper(bits)
+        noise = oracle.numpy_awgn(oracle.cpm_sigma_for_ebn0(7.0, SPS, bps), (sym.size + 1) * SPS, rng)
+        res = oracle.cpm_detection_run(sym, pulse, SPS, spec, noise=noise)
+        assert got[label] == (res["sym_errors"], res["bit_errors"], res["compared"]), label
+    assert got["ARTM multi-h"][1] > 0

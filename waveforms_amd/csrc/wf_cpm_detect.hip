@@ -50,15 +50,6 @@ struct cpm_vit_params {
     cpm_tables T;
 };
 
-static int cpm_ksum_mod(int nh, int K0, int K1, int p, int64_t m)   // sum of K over symbols 0 .. m-1, mod 2p
-{
-    if (m <= 0) return 0;
-    const int per = nh == 2 ? K0 + K1 : K0;
-    int64_t acc = (m / nh) % (2 * p) * per;
-    if (nh == 2 && (m & 1)) acc += K0;
-    return (int)(acc % (2 * p));
-}
-
 __device__ __forceinline__ int cpm_tilt_at(const cpm_vit_params &P, int64_t n)   // (M-1) * sum K over symbols 0 .. n-Lp, mod 2p
 {
     const int64_t m = n - P.Lp + 1;

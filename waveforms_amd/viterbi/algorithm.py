@@ -61,7 +61,7 @@ class SOQPSKTrellisDetector:
                 raise ValueError(f"unsupported traceback length {self.length}")
             self._d_state = _hip.zeros(nbytes, "uint8")
             self._d_state_ptr = self._d_state.data_ptr()
-            self._iter_fn, self._iter_ctx, self._iter_stream = _hip.lib().wf_viterbi4_iteration_host, _hip.ctx(), _hip.stream()
+            self._iter_fn, self._iter_ctx = _hip.lib().wf_viterbi4_iteration_host, _hip.ctx()
 
     def iteration(
         self,
@@ -82,7 +82,7 @@ class SOQPSKTrellisDetector:
         z = np.ascontiguousarray(mf_outputs, dtype=np.complex128).reshape(3)
         bits, syms = np.empty(L), np.empty(L)
         _hip.check(self._iter_fn(self._iter_ctx, self._d_state_ptr, L, int(self.differential), z.ctypes.data,
-                                 bits.ctypes.data, syms.ctypes.data, self._iter_stream))
+                                 bits.ctypes.data, syms.ctypes.data, _hip.stream()))
         if np.isnan(bits).any():
             raise KeyError("traceback reached a state pair with no connecting branch")
         self.i += 1

@@ -278,6 +278,16 @@ int wf_link_stream_layout(const wf_link_config *cfg, int64_t chunk_symbols, int6
 int wf_link_stream_chunk(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
                          void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
                          int64_t *h_compared, void *stream);
+/* Parts of a chunk, for callers that pipeline chunks on two streams with a workspace AND a wf_ctx
+ * each (the parts of one chunk use the same pair).  `phases` is a bit set; each part needs the same
+ * part of the previous chunk (its carry in d_state) and the earlier parts of its own chunk:
+ *   bit 0 (1): PRBS, encoder, modulator carries          (carries: encoder state, modulator phase)
+ *   bit 2 (4): modulator + channel + bank                 (with fuse bit 3: no carry of its own)
+ *   bit 1 (2): detector + error count                     (carry: detector state)
+ * phases = 7: the whole chunk = wf_link_stream_chunk. */
+int wf_link_stream_chunk_phase(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
+                               void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
+                               int64_t *h_compared, int phases, void *stream);
 /* Steady state for hipGraph replay: the launch sequence of an INTERIOR chunk with the only
  * two per-chunk quantities (PRBS position, noise counter) kept in d_state and advanced on the
  * device, so every call issues identical launches.  Use: chunk 0 with wf_link_stream_chunk,

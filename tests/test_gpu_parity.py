@@ -586,6 +586,25 @@ def test_stream_graph_replay_equals_eager_chunks():
             assert want == first
 
 
+@pytest.mark.parametrize("fuse,chunk", [(15, 1 << 16), (7, 3 << 14), (3, 1 << 15)])
+def test_stream_two_stream_pipeline_equals_sequential_chunks(fuse, chunk):
+    """SOQPSKStream.run_pipelined: chunk c's detector + count overlap chunk c + 1's front end on a second
+    stream (ordering by events on the carries) — identical counts and final decisions."""
+    import torch
+
+    from waveforms_amd.link import SOQPSKStream
+
+    st = SOQPSKStream(7 * chunk + 999, chunk, 8, fuse=fuse)
+    for ebn0 in (2.0, 9.0):
+        want = st.run(ebn0, seed=4, stream_id=9)
+        info = st.chunk_info(st.nchunks - 1)
+        last = st.workspace[info["off_bits"]:info["off_bits"] + info["calls"]].clone()
+        got = st.run_pipelined(ebn0, seed=4, stream_id=9)
+        assert got == want and want[1] > 0
+        ws = (st.workspace, st._ws2)[(st.nchunks - 1) & 1]
+        assert torch.equal(ws[info["off_bits"]:info["off_bits"] + info["calls"]], last)
+
+
 def test_stream_config4_full_size_1e9_symbols():
     """BASELINE configs[4] at its real size: a 1e9-symbol continuous stream (PN31) in chunks of
     2^22 symbols.  Size-independent properties: the error counts do not depend on the chunking
@@ -599,6 +618,7 @@ def test_stream_config4_full_size_1e9_symbols():
     assert a.nchunks == 239 and want[2] == total - 3        # ncols - length compared, like the one-shot link
     got_graph = a.run_graph(10.0, seed=1, stream_id=4)
     assert got_graph == want and a.graph_replays == a.interior_chunks() >= 236
+    assert a.run_pipelined(10.0, seed=1, stream_id=4) == want
     del a
     b = SOQPSKStream(total, 3 << 21, 8, pn_degree=31)
     assert b.nchunks == 159 and b.run(10.0, seed=1, stream_id=4) == want

@@ -60,6 +60,7 @@ SIGNATURES = {
     "wf_link_stream_workspace_bytes": (c_int64, [_P, c_int64]),
     "wf_link_stream_layout": (c_int, [_P, c_int64, c_int64, POINTER(c_int64)]),
     "wf_link_stream_chunk": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
+    "wf_link_stream_chunk_phase": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), c_int, _P]),
     "wf_link_stream_interior": (c_int, [_P, c_int64, c_int64]),
     "wf_link_stream_steady": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
     "wf_welch_scratch_doubles": (c_int64, [c_int64, c_int]),

@@ -837,8 +837,13 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             int64_t tile_lo, int64_t ntiles, const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile,
                             const double *d_mf_taps, double rot_re, double rot_im, double sigma, uint64_t seed,
                             uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index, int64_t first,
-                            int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf, int cpm_nh)
+                            int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf, int cpm_nh,
+                            int stage)
 {
+    // stage 1: the two carry kernels only (they also export the phase carry of a stream window);
+    // stage 2: the main kernel only, on carries an earlier stage-1 call left in this context's
+    // scratch; 3: both.  Callers that pipeline chunks split them so that the next chunk's carries do
+    // not wait for this chunk's main kernel.
     WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_mf_taps && d_rows4, "wf_mod_chan_bank: NULL argument");
     if (cpm_nf != 0 && cpm_nf != 4 && cpm_nf != 16) return 1;
     if (cpm_nf && cpm_nh != 1 && cpm_nh != 2) return 1;
@@ -858,8 +863,12 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     P.ntiles = ntiles;
     P.q_out_tile = q_out_tile;
     WF_HIP(hipSetDevice(ctx->device));
-    int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, d_q_in, d_q_out, stream);
-    if (rc) return rc;
+    if (stage & 1) {
+        int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, d_q_in, d_q_out, stream);
+        if (rc) return rc;
+    }
+    if (!(stage & 2)) return WF_OK;
+    WF_REQUIRE(ctx->d_mod_scratch != nullptr, "wf_mod_chan_bank: stage 2 without the carries of stage 1");
     mcb_params Q;
     Q.rot_re = rot_re; Q.rot_im = rot_im; Q.sigma = sigma;
     Q.seed = seed; Q.stream_id = stream_id; Q.pair0 = first_index >> 1;
@@ -896,7 +905,7 @@ int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, 
 {
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_mf_taps, rot_re, rot_im, sigma, seed, stream_id, first_index, nullptr, first, 0, ncols,
-                                   pack_par0, d_rows4, stream, 0, 1);
+                                   pack_par0, d_rows4, stream, 0, 1, 3);
 }
 
 // The same kernel producing the generic CPM detector's matched-filter rows (nfilt = 4 or 16 templates
@@ -910,7 +919,7 @@ int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, con
     if (ntm != 9 || start0 < -4 || start0 > 3 || (nfilt != 4 && nfilt != 16)) return 1;
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_templates, rot_re, rot_im, sigma, seed, stream_id, 0, nullptr, start0 + 4, 0, ncalls, 0,
-                                   d_rows, stream, nfilt, nh);
+                                   d_rows, stream, nfilt, nh, 3);
 }
 
 // Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total

@@ -326,7 +326,7 @@ __global__ void stream_advance_kernel(uint64_t *dyn, uint64_t dskip, uint64_t di
 
 static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
                              void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
-                             int64_t *h_compared, void *stream, bool steady);
+                             int64_t *h_compared, void *stream, bool steady, int phases = 7);
 extern "C" int wf_link_stream_interior(const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index);
 
 extern "C" int wf_link_stream_chunk(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
@@ -361,9 +361,24 @@ extern "C" int wf_link_stream_steady(wf_ctx *ctx, const wf_link_config *cfg, int
                              stream, true);
 }
 
+// Parts of a chunk for callers that pipeline chunks on two streams (own workspace AND own wf_ctx per
+// stream): bit 0 = PRBS, encoder, modulator carries (needs the encoder / phase carries the previous
+// chunk's bit-0 part left in d_state); bit 2 = modulator + channel + bank (needs only this chunk's
+// bit-0 part; with the separate kernels — fuse without bit 3 — also the previous chunk's bit-2 part);
+// bit 1 = detector + error count (needs the detector carry of the previous chunk's bit-1 part).
+// phases = 7: the whole chunk (wf_link_stream_chunk).
+extern "C" int wf_link_stream_chunk_phase(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
+                                          void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
+                                          int64_t *h_compared, int phases, void *stream)
+{
+    WF_REQUIRE(phases >= 1 && phases <= 7, "wf_link_stream_chunk_phase: phases %d", phases);
+    return stream_chunk_impl(ctx, cfg, chunk_symbols, chunk_index, d_state, d_workspace, workspace_bytes, d_counts, h_compared,
+                             stream, false, phases);
+}
+
 static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
                              void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
-                             int64_t *h_compared, void *stream, bool steady)
+                             int64_t *h_compared, void *stream, bool steady, int phases)
 {
     WF_REQUIRE(ctx && cfg && d_state && d_workspace && d_counts, "wf_link_stream_chunk: NULL argument");
     WF_REQUIRE(cfg->nsym >= 1 && cfg->sps >= 2 && cfg->mf_nfilt == 3 && chunk_index >= 0, "wf_link_stream_chunk: bad configuration");
@@ -407,43 +422,49 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
             next[c][s][(b & 1) ^ flip] = (uint8_t)e;
             outp[c][s][(b & 1) ^ flip] = kOut[c][b];
         }
-    int rc;
-    if ((rc = wf_lfsr_generate_dyn(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip + (uint64_t)S.ws, steady ? dyn : nullptr,
-                                   bits, S.nloc, nullptr, stream))) return rc;
-    const int64_t at = S.ws_next - S.ws;
-    if ((rc = wf_fsm_encode_core(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, S.nloc, S.ws, 0, enc_state, syms, nullptr,
-                                 at <= S.nloc ? enc_state : nullptr, at, stream))) return rc;
+    int rc = WF_OK;
+    const bool packed = link_packed_rows(cfg);
     const double rot_re = cos(-M_PI / 4), rot_im = sin(-M_PI / 4);
     WF_REQUIRE(!steady || (cfg->fuse & 2), "wf_link_stream_steady needs the fused channel (fuse bit 1)");
-    const bool packed = link_packed_rows(cfg);
+    if (phases & 1) {
+        if ((rc = wf_lfsr_generate_dyn(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip + (uint64_t)S.ws, steady ? dyn : nullptr,
+                                       bits, S.nloc, nullptr, stream))) return rc;
+        const int64_t at = S.ws_next - S.ws;
+        if ((rc = wf_fsm_encode_core(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, S.nloc, S.ws, 0, enc_state, syms, nullptr,
+                                     at <= S.nloc ? enc_state : nullptr, at, stream))) return rc;
+    }
     // fuse bit 3: modulator + channel + bank of the chunk's tiles in one kernel (no samples in HBM);
-    // the tile before the chunk is processed too — its last column is the chunk's first
+    // the tile before the chunk is processed too — its last column is the chunk's first.  Its two
+    // carry kernels (stage 1) belong to part bit 0, the main kernel (stage 2) to part bit 2.
     bool fused_all = false;
-    if ((cfg->fuse & 8) && packed && cfg->mf_ntaps == 9) {
+    if ((cfg->fuse & 8) && packed && cfg->mf_ntaps == 9 && (phases & 5)) {
+        const int stage = ((phases & 1) ? 1 : 0) | ((phases & 4) ? 2 : 0);
         rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
                                      S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_mf_taps, rot_re, rot_im, cfg->sigma, cfg->seed,
-                                     cfg->stream_id, 0, steady ? dyn + 1 : nullptr, S.first, S.k_lo, S.ncols, 0, mf, stream);
+                                     cfg->stream_id, 0, steady ? dyn + 1 : nullptr, S.first, S.k_lo, S.ncols, 0, mf, stream, 0, 1, stage);
         if (rc < 0) return rc;
         fused_all = rc == 0;
     }
-    if (!fused_all)
+    if ((phases & 4) && !fused_all) {
+        // separate kernels: the modulator call computes its own carries (so this part then depends
+        // on the previous chunk's bit-2 part through the phase carry)
         if ((rc = wf_cpm_modulate_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4,
                                          S.tile_lo, S.ntiles, sig, S.out_origin, q_phase, q_phase, S.q_out_tile, stream))) return rc;
-    const int64_t first_local = S.first + S.k_lo * cfg->sps - S.out_origin;
-    if (fused_all) {
-        rc = WF_OK;
-    } else if (cfg->fuse & 2) {
-        rc = wf_awgn_mf_bank_dyn(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
-                                 (uint64_t)S.out_origin, steady ? dyn + 1 : nullptr, cfg->d_mf_taps, cfg->mf_nfilt,
-                                 cfg->mf_ntaps, first_local, cfg->sps, S.ncols, mf, stream,
-                                 packed ? (int)(S.k_lo & 1) : -1);
-    } else {
-        if ((rc = wf_awgn_c128(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
-                               (uint64_t)S.out_origin, sig, stream))) return rc;
-        rc = wf_mf_bank_c128(ctx, sig, S.local_len, cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, first_local, cfg->sps, S.ncols,
-                             mf, stream);
+        const int64_t first_local = S.first + S.k_lo * cfg->sps - S.out_origin;
+        if (cfg->fuse & 2) {
+            rc = wf_awgn_mf_bank_dyn(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
+                                     (uint64_t)S.out_origin, steady ? dyn + 1 : nullptr, cfg->d_mf_taps, cfg->mf_nfilt,
+                                     cfg->mf_ntaps, first_local, cfg->sps, S.ncols, mf, stream,
+                                     packed ? (int)(S.k_lo & 1) : -1);
+        } else {
+            if ((rc = wf_awgn_c128(ctx, sig, S.local_len, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id,
+                                   (uint64_t)S.out_origin, sig, stream))) return rc;
+            rc = wf_mf_bank_c128(ctx, sig, S.local_len, cfg->d_mf_taps, cfg->mf_nfilt, cfg->mf_ntaps, first_local, cfg->sps, S.ncols,
+                                 mf, stream);
+        }
+        if (rc) return rc;
     }
-    if (rc) return rc;
+    if (!(phases & 2)) return WF_OK;
     if (packed)
         rc = wf_viterbi4_detect_packed(ctx, mf, S.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, vit_state, stream);
     else

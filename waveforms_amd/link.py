@@ -186,6 +186,55 @@ class SOQPSKStream:
             self.run_chunk(c, ebn0_db, seed, stream_id)
         return self.result()
 
+    def run_pipelined(self, ebn0_db: float, seed: int = 1, stream_id: int = 0) -> tuple[int, int, int]:
+        """Like :meth:`run` with consecutive chunks alternating between two HIP streams, each with its own
+        workspace and library context.  A chunk is issued as three parts (``wf_link_stream_chunk_phase``)
+        and each part waits only for the same part of the previous chunk, which is where its carry comes
+        from: PRBS / encoder / modulator carries (encoder state, modulator phase), the modulator + channel
+        + bank kernel, detector + error count (detector state).  So the small serial kernels of chunk c + 1
+        and the detector of chunk c run beside a main kernel instead of between two.  Same decisions and
+        counts as :meth:`run`."""
+        torch = _hip.torch()
+        self.reset()
+        cfg = self.cfg
+        cfg.sigma, cfg.seed, cfg.stream_id, cfg.event_slot = sigma_for_ebn0(ebn0_db, self.sps), seed, stream_id, -1
+        if getattr(self, "_ws2", None) is None:
+            self._ws2 = _hip.empty(self.workspace_bytes, "uint8")
+            self._ctx2 = _hip.new_ctx()
+            self._lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
+        main = torch.cuda.current_stream()
+        for lane in self._lanes:
+            lane.wait_stream(main)                       # the carry block / counters were zeroed on the caller's stream
+        lib, m = _hip.lib(), ctypes.c_int64(0)
+        done = {1: None, 4: None, 2: None}
+        for c in range(self.nchunks):
+            lane, ws, ctx = self._lanes[c & 1], (self.workspace, self._ws2)[c & 1], (self._ctx, self._ctx2)[c & 1]
+            with torch.cuda.stream(lane):
+                for part in (1, 4, 2):
+                    if done[part] is not None:
+                        lane.wait_event(done[part])
+                    _hip.check(lib.wf_link_stream_chunk_phase(ctx, ctypes.byref(cfg), self.chunk_symbols, c, self.state.data_ptr(),
+                                                              ws.data_ptr(), self.workspace_bytes, self.counts.data_ptr(),
+                                                              ctypes.byref(m), part, lane.cuda_stream))
+                    done[part] = torch.cuda.Event()
+                    done[part].record(lane)
+                self.compared += m.value
+        for lane in self._lanes:
+            main.wait_stream(lane)
+        from waveforms_amd import device as dev
+
+        _hip.check(lib.wf_ctx_check(self._ctx2, _hip.stream()))
+        late = dev.viterbi_unmerged(reset=True, ctx=self._ctx2)     # the first context's count is read by result()
+        if late:
+            dev.viterbi_unmerged(reset=True, ctx=self._ctx)
+            raise RuntimeError(f"{late} detector chunk(s) did not merge with the sequential path within the warm-up")
+        return self.result()
+
+    def __del__(self):
+        if getattr(self, "_ctx2", None):
+            _hip.free_ctx(self._ctx2)
+            self._ctx2 = None
+
     def interior_chunks(self) -> int:
         """Number of consecutive chunks 1, 2, ... that issue exactly the launches of chunk 1."""
         n = 0

@@ -456,8 +456,14 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm broadc
 // modulation-index column, Z = sum_k r[8 n + start + k] conj(T[n % nh][f][k]), full complex rows of
 // CPMNF filters) — thread = (symbol, quarter of the filters), templates in LDS, same accumulation
 // order as cpm_mf_rows_kernel.
+// Waves per SIMD the register allocator is held to (the unified file has 512 registers per lane):
+// the SOQPSK form fits 4 (<= 128 registers; left alone it takes 131 = 3 waves and runs 7 % slower),
+// the CPM forms with a short pulse 3 (<= 168; 170 = 2 waves otherwise); nothing spills at these.
+#ifndef WF_MCB_WAVES
+#define WF_MCB_WAVES 4
+#endif
 template <int JMAX, int CPMNF>
-__global__ __launch_bounds__(MOD_THREADS) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols,
+__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? 3 : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols,
                                                                      const double *__restrict__ hvec,
                                                                      const double *__restrict__ pulse,
                                                                      const double *__restrict__ scratch,

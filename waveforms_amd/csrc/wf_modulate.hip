@@ -443,7 +443,7 @@ struct mcb_params {
 #define MCB_SLOTS (MCB_RING + MCB_RING / 8 + 16)  // one pad slot per 8 samples (conflict-free column reads) + the wrap copy
 
 template <int CTRL>
-__device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm broadcast of lane CTRL & 3 of each quad
+__device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm CTRL (2 bits per lane: its source lane in the quad)
 {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
@@ -461,6 +461,9 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm broadc
 // the CPM forms with a short pulse 3 (<= 168; 170 = 2 waves otherwise); nothing spills at these.
 #ifndef WF_MCB_WAVES
 #define WF_MCB_WAVES 4
+#endif
+#ifndef WF_MCB_UNROLL
+#define WF_MCB_UNROLL 2
 #endif
 template <int JMAX, int CPMNF>
 __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? 3 : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols,
@@ -521,15 +524,26 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     const double *Gpart = scratch + MOD_OFF_GPART;
     // bank: quad per column, one sum chain per lane
     const int mq = t >> 2, mp = t & 3;
-    // per-part tap component, in LDS (as registers they cost a fifth wave per SIMD):
-    //   A: Re x * Re tap | B: Im x * Im tap | C: Re x * Im tap | D: Im x * Re tap
-    __shared__ double s_tapc[4 * 9];
+    // The four shared sums of the pulse-truncation bank,
+    //   A: Re x * Re tap | B: Im x * Im tap | C: Re x * Im tap | D: Im x * Re tap,
+    // leave as  va = odd ? C + D : A - B  (packed slot 2) and  vb = odd ? A + B : D - C  (slot 3).
+    // Lanes 0, 1 of the quad run the two chains of vb and lanes 2, 3 those of va, with the sign
+    // folded into the tap component (a chain over negated taps is exactly the negated chain, and
+    // a - b == a + (-b)): ONE quad swap + add then gives vb in lanes 0, 1 and va in lanes 2, 3.
+    //   even column:  -C | D | A | -B        odd column:  A | B | C | D      (lane 0 | 1 | 2 | 3)
+    // Even lanes read Re x, odd lanes Im x, so the plain sums U (z1) sit in lanes 0 / 3 as Re / Im.
+    // The column parity of a lane does not change with the row (64 columns per row, tiles start on
+    // even symbols).  Tap components in LDS (as registers they cost a fifth wave per SIMD).
+    __shared__ double s_tapc[2 * 4 * 9];
     __shared__ double2 s_halo[8];
-    if (CPMNF == 0 && t < 36) {
+    if (CPMNF == 0 && t < 72) {
         const double2 tp = reinterpret_cast<const double2 *>(mf_taps)[8 - t % 9];
-        s_tapc[t] = (t / 9 == 0 || t / 9 == 3) ? tp.x : tp.y;
+        const int part = (t % 36) / 9;
+        s_tapc[t] = t < 36 ? ((part == 0 || part == 3) ? -tp.y : tp.x) : ((part == 0 || part == 3) ? tp.x : tp.y);
     }
-    const double *tapc = s_tapc + 9 * mp;
+    const int odd_l = (Q.pack_par0 + mq - Q.kshift) & 1;
+    const double *tapc = s_tapc + 9 * (4 * odd_l + mp);
+    const int slot_l = (mp & 1) ? 4 - mp : mp;                     // packed slot this lane stores: 0, 3, 2, 1
     const double *ring_d = reinterpret_cast<const double *>(s_ring);
 
     const uint64_t pair0 = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull);
@@ -638,12 +652,9 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                     S = fma(x, tapc[j], S);
                     U += x;
                 }
-                const double A = mcb_quad_bcast<0x00>(S), B = mcb_quad_bcast<0x55>(S);
-                const double C = mcb_quad_bcast<0xAA>(S), D = mcb_quad_bcast<0xFF>(S);
-                const double va = odd ? C + D : A - B;                    // Im z0 | Re z0
-                const double vb = odd ? A + B : D - C;                    // Re z2 | Im z2
-                const double val = mp < 2 ? U : (mp == 2 ? va : vb);
-                if (k_ok) rows[4 * (k - Q.k_lo) + mp] = val;
+                const double T = S + mcb_quad_bcast<0xB1>(S);            // quad_perm [1, 0, 3, 2]: vb | vb | va | va
+                const double val = (mp == 0 || mp == 3) ? U : T;
+                if (k_ok) rows[4 * (k - Q.k_lo) + slot_l] = val;
             } else {
                 // any 3 x 9 bank: lane p keeps the one chain of the packed row it stores
                 const int f = mp < 2 ? 1 : (mp == 2 ? 0 : 2);
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                 if (k_ok) rows[4 * (k - Q.k_lo) + mp] = acc;
             }
         };
-#pragma unroll 2
+#pragma unroll WF_MCB_UNROLL
         for (int u = 0; u < MOD_ROWS; ++u) {
             double acc0 = 0.0, acc1 = 0.0;
             {
@@ -675,7 +686,9 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
             const double ex = wf_wave_shr1(inc);
             double *tot = s_tot + (u & 1) * MOD_WAVES;
             if (lane == 63) tot[wave] = inc;
+#ifndef WF_ABL_MCB_NOBAR1   // ablation only (timing; results are wrong)
             wf_lds_barrier();
+#endif
             // same sums in the same order as mod_main_kernel's loop (0.0 + t0 == t0)
             const double t0_ = tot[0], p1_ = t0_ + tot[1], p2_ = p1_ + tot[2], rowtot = p2_ + tot[3];
             const double offw = wave_u == 0 ? 0.0 : (wave_u == 1 ? t0_ : (wave_u == 2 ? p1_ : p2_));
@@ -688,7 +701,20 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
             // channel (wf_awgn_c128): derotate + Philox AWGN, one block per thread and row
             const int64_t n0 = tile_base + (int64_t)u * 512 + 2 * t;
             double g[4];
-            wf_gaussian_two(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, Q.seed, Q.sigma, tb, g);
+#ifdef WF_ABL_MCB_NONOISE   // ablation only
+            g[0] = g[1] = g[2] = g[3] = (double)(n0 & 7);
+#else
+            {
+                // The Philox key schedule (20 words: seed + r * Weyl) is uniform and loop-invariant; left to
+                // the compiler it is hoisted into 20 SGPRs and pushes as many other uniforms into spill
+                // lanes (v_readlane reloads in this loop).  Opaque per row => re-derived by scalar adds.
+                uint32_t k0 = (uint32_t)Q.seed, k1 = (uint32_t)(Q.seed >> 32);
+#ifndef WF_ABL_MCB_HOISTKEYS
+                asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
+                wf_gaussian_two(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
+            }
+#endif
             double2 x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
             double2 x1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
             if (!full_tile) {                                   // (tile-uniform) samples past the end of the burst are zeros to the bank
@@ -704,8 +730,12 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
             // (row u + 1, behind the NEXT row's first barrier) comes after every wave has left
             // bank_row(u - 1) — one more barrier per row than a four-row ring, 18 KB less LDS
             // (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
+#ifndef WF_ABL_MCB_NOBAR2   // ablation only
             wf_lds_barrier();
+#endif
+#ifndef WF_ABL_MCB_NOBANK   // ablation only
             if (u >= 1 || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);
+#endif
             run += rowtot;
         }
         wf_lds_barrier();                                     // every wave is done with row 14

@@ -56,6 +56,9 @@ __device__ __forceinline__ double mod_amp(const int8_t *__restrict__ symbols, co
 // then ntiles u64 carries Wq.
 #define MOD_OFF_GPART 2
 #define MOD_OFF_P (2 + MOD_MAX_PART)
+// ... 8 spare words, then Gcum = running sum of the taps (ntaps doubles): the main kernels take their
+// per-lane tap-phase tables from it, so tile carries and in-tile sums use the very same doubles
+#define MOD_OFF_GCUM(ntiles) ((size_t)MOD_OFF_P + 2 * (size_t)(ntiles) + 8)
 
 __device__ __forceinline__ double mod_pos_d(double v, double sps, double inv_sps)
 {
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
             s_T = T;
             s_K0 = k0;
         }
+        for (int k = t; k < P.ntaps; k += 1024) scratch[MOD_OFF_GCUM(P.ntiles) + k] = s_pulse[k];
     } else if (t == 0) {
         // very long pulses: one sequential pass over the taps in global memory
         int R = (P.c - P.ntaps) % P.sps;
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
         int hn = P.c - 1, hn_q = hn >= 0 ? hn / P.sps : 0, hn_r = hn >= 0 ? hn - hn_q * P.sps : 0;
         for (int k = 0; k < P.ntaps; ++k) {
             run += pulse[k];
+            scratch[MOD_OFF_GCUM(P.ntiles) + k] = run;
             if (num > 0 && num_r == 0) {
                 const int l = num_q - 1;
                 if (l >= 0 && l < P.npart) scratch[MOD_OFF_GPART + l] = run;
@@ -262,6 +267,122 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
     if (have && q_out) *q_out = exported;
 }
 
+
+// ---- In-tile phase from the pulse's own prefix sums ("phase tree") -----------------------------
+// The running sum of the frequency-pulse train at sample n is (file header)
+//     cum[n] = T * S(m_new - J)  +  sum_{j < J} amp[m_new - j] * Gcum[min(r + j sps, ntaps - 1)]  -  K0,
+// m_new = the newest symbol under the pulse at n, r = its tap index there, J * sps >= ntaps.  The tile
+// carry Wq IS  T * S(last symbol fully elapsed at the tile edge) - K0  (62-bit fixed point), and what
+// is left of the prefix, S(m_new - J) - S(edge), is h times an INTEGER: a sum of raw symbols.  So the
+// window of symbol amplitudes a tile stages in LDS gets a companion: 32-bit prefix counts of the raw
+// symbols (one set per modulation index), built once per tile by a block scan of ~4 symbols per
+// thread.  A sample then costs J multiply-adds + one count read — no scan across the row's 512
+// samples, no wave totals through LDS, no workgroup barrier, and no rounding that grows along the row
+// (the first version ran FIR -> 64-lane DPP scan -> wave totals -> carry per row: 20 DPP moves, a
+// barrier and ~25 % of the modulator's instructions).
+//   s_amp[k] = amplitude of window symbol k  (global 0-based index m0 + k; 0 outside the burst)
+//   s_pi[c * (win + 1) + k] = sum of the raw symbols of index class c (m % nh) over window symbols < k
+__device__ __forceinline__ int mod_sym_raw(const int8_t *__restrict__ symbols, const mod_params &P, int64_t m)
+{
+    const int64_t l = m - P.sym_origin;
+    return (m < 0 || m >= P.nsym || l < 0 || l >= P.nloc) ? 0 : (int)symbols[l];
+}
+
+__device__ __forceinline__ int mod_wave_incl_scan_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// Called by all MOD_THREADS threads; leaves with a barrier (window and counts visible).  s_wtot: 2 * MOD_WAVES ints.
+__device__ __forceinline__ void mod_stage_window(const int8_t *__restrict__ symbols, const double *__restrict__ hvec,
+                                                 const mod_params &P, int64_t m0, int win, double *s_amp, int *s_pi, int *s_wtot)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (win + MOD_THREADS) / MOD_THREADS;          // ceil((win + 1) / MOD_THREADS): entry `win` is the total
+    const int k0 = t * per;
+    // a window inside the burst and resident (all but the first and last tiles): no per-symbol tests
+    const int64_t l0 = m0 - P.sym_origin;
+    const bool inner = m0 >= 0 && m0 + win <= P.nsym && l0 >= 0 && l0 + win <= P.nloc;
+    const int8_t *sp = symbols + l0;
+    const int par0 = P.nh > 1 ? (int)(m0 & 1) : 0;              // (nh <= 2) class of window symbol k = (par0 + k) & (nh - 1)
+    const double h0 = hvec[0], h1 = P.nh > 1 ? hvec[1] : 0.0;
+    auto sym_at = [&](int k) __attribute__((always_inline)) { return inner ? (int)sp[k] : mod_sym_raw(symbols, P, m0 + k); };
+    int sa = 0, sb = 0;
+    for (int e = 0; e < per; ++e) {
+        const int k = k0 + e;
+        if (k < win) {
+            const int a = sym_at(k);
+            const bool second = P.nh > 1 && ((par0 + k) & 1) != 0;
+            s_amp[k] = (double)a * (second ? h1 : h0);
+            sa += second ? 0 : a;
+            sb += second ? a : 0;
+        }
+    }
+    const int ia = mod_wave_incl_scan_i32(sa), ib = mod_wave_incl_scan_i32(sb);
+    if (lane == 63) {
+        s_wtot[wave] = ia;
+        s_wtot[MOD_WAVES + wave] = ib;
+    }
+    wf_lds_barrier();
+    int ra = ia - sa, rb = ib - sb;                      // exclusive prefix of this thread's first symbol
+    for (int w = 0; w < wave; ++w) {
+        ra += s_wtot[w];
+        rb += s_wtot[MOD_WAVES + w];
+    }
+    for (int e = 0; e < per; ++e) {
+        const int k = k0 + e;
+        if (k <= win) {                                 // k == win: the total
+            s_pi[k] = ra;
+            if (P.nh > 1) s_pi[win + 1 + k] = rb;
+            if (k < win) {
+                const int a = sym_at(k);
+                const bool second = P.nh > 1 && ((par0 + k) & 1) != 0;
+                ra += second ? 0 : a;
+                rb += second ? a : 0;
+            }
+        }
+    }
+    wf_lds_barrier();
+}
+
+// The two phases (mod sps, in pulse units) of the sample pair of one thread in one row.
+//   a  = &s_amp[index of the newest symbol under the first sample, + 1]      (the old FIR's window top)
+//   pi = &s_pi[index of the first symbol NOT yet elapsed for the first sample]  (= q0 - cq + row offset)
+// wrap: the second sample already sees the next symbol (per lane; any_wrap: some lane of the kernel does).
+template <int JMAX>
+__device__ __forceinline__ void mod_pair_phase(const double (&Q0)[JMAX], const double (&Q1)[JMAX], const double *a, const int *pi,
+                                               int wrap, bool any_wrap, int nh, int pstride, int ref_a, int ref_b, double W,
+                                               double Th_a, double Th_b, double sps_d, double inv_sps, double &ra, double &rb)
+{
+    const double *a1 = any_wrap ? a + wrap : a;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        acc0 = fma(Q0[j], a[-1 - j], acc0);
+        acc1 = fma(Q1[j], a1[-1 - j], acc1);
+    }
+    double b0 = fma((double)(pi[0] - ref_a), Th_a, W);
+    if (nh > 1) b0 = fma((double)(pi[pstride] - ref_b), Th_b, b0);
+    double b1 = b0;
+    if (any_wrap) {
+        b1 = fma((double)(pi[wrap] - ref_a), Th_a, W);
+        if (nh > 1) b1 = fma((double)(pi[pstride + wrap] - ref_b), Th_b, b1);
+    }
+    const double v0 = b0 + acc0, v1 = b1 + acc1;
+    // one reduction mod sps per pair (the second sample is a single frequency-pulse value further); a
+    // remainder that rounds to -eps or sps+eps needs no fix-up because the sector split of
+    // wf_sincos_sectors is exact for any argument
+    const double kq = floor(v0 * inv_sps);
+    ra = fma(-kq, sps_d, v0);
+    rb = fma(-kq, sps_d, v1);
+}
+
 #ifndef MOD_MIN_WAVES
 #define MOD_MIN_WAVES 1
 #endif
@@ -274,8 +395,8 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                                                                 const double *__restrict__ scratch,
                                                                 double *__restrict__ out, mod_params P)
 {
-    extern __shared__ double s_amp[];       // window of symbol amplitudes
-    __shared__ double s_tot[2 * MOD_WAVES];
+    extern __shared__ double s_amp[];       // window of symbol amplitudes, then its prefix counts (ints)
+    __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_xp[2 * MOD_THREADS];   // wave-private transpose: pairs per lane -> rows of 64 samples
     __shared__ double2 s_cis[128];              // sincos sector table (LDS copy: see wf_sincos_sectors)
     wf_stage_cis_table(s_cis, threadIdx.x, MOD_THREADS);   // the tile loop starts with a barrier
@@ -290,19 +411,24 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
     const int r0 = (2 * t + P.c) - q0 * sps;
     const int wrap = (r0 + 1 == sps) ? 1 : 0;
     const int r1 = wrap ? 0 : r0 + 1;
-    double tap0[JMAX + 1], tap1[JMAX + 1];
+    const bool any_wrap = (sps & 1) != 0 || (P.c & 1) != 0;      // r0 = (2 t + c) mod sps is even otherwise
+    // per-lane tap phases of the two samples: Gcum at r + j sps, clamped to the last tap (= T)
+    const double *Gcum = scratch + MOD_OFF_GCUM(P.ntiles);
+    double Q0[JMAX], Q1[JMAX];
 #pragma unroll
-    for (int i = 0; i <= JMAX; ++i) {
-        const int j0 = i - 1, k0 = r0 + j0 * sps;
-        tap0[i] = (j0 >= 0 && k0 < P.ntaps) ? pulse[k0] : 0.0;
-        const int j1 = i - 1 + wrap, k1 = r1 + j1 * sps;
-        tap1[i] = (j1 >= 0 && j1 < JMAX && k1 < P.ntaps) ? pulse[k1] : 0.0;
+    for (int j = 0; j < JMAX; ++j) {
+        const int k0 = r0 + j * sps, k1 = r1 + j * sps;
+        Q0[j] = Gcum[k0 < P.ntaps ? k0 : P.ntaps - 1];
+        Q1[j] = Gcum[k1 < P.ntaps ? k1 : P.ntaps - 1];
     }
     const double sec_per_unit = 128.0 * P.inv_sps, sec_phi0 = 128.0 * P.phi0_turns;   // phase units -> 1/128 turns
     const int l_top0p1 = (q0 - cq) + JMAX;
     const int win = MOD_ROWS * sym_per_row + JMAX + 2;
+    int *s_pi = reinterpret_cast<int *>(s_amp + ((win + 1) & ~1));
     const uint64_t *Wq = reinterpret_cast<const uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
-    const double *Gpart = scratch + MOD_OFF_GPART;
+    const double T = scratch[0];
+    const double Th_a = T * hvec[0], Th_b = P.nh > 1 ? T * hvec[1] : 0.0;
+    const int lpart = JMAX - cq - P.dsh;        // window index of the first symbol not fully elapsed at the tile edge
 
     for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
         const int64_t tile_g = P.tile_lo + tile;          // global tile index
@@ -310,62 +436,21 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
         const int64_t sym_base = tile_base / sps;
         const int64_t mp1_lo = sym_base + cq - JMAX + 1;
         const bool full_tile = tile_base >= P.out_origin && tile_base + tile_len <= P.out_hi;
-        wf_lds_barrier();
-        for (int k = t; k < win; k += MOD_THREADS) s_amp[k] = mod_amp(symbols, hvec, P, mp1_lo + k - 1);
-        wf_lds_barrier();
-        // carry into the tile: T*S(m_full) - K0 (fixed point, from the scan kernel) + the
-        // symbols still under the pulse at the tile edge
-        double run = 0.0;   // running sum at the start of the current row (identical in every thread)
-        if (tile_g > 0) {
-            run = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
-            // first partial symbol: mp1 = sym_base - D + 1  -> local index in s_amp
-            const int lpart = (int)((sym_base - P.dsh + 1) - mp1_lo);
-            double part = 0.0;
-            for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + l], Gpart[l], part);
-            run += part;
-        }
-        // Row by row: FIR (taps in registers, amplitudes from LDS) -> wave scan -> wave totals
-        // through LDS (double-buffered: ONE barrier per row) -> carry, mod, sincos, store.
-        // The stores of row u drain while row u+1 is being computed.
+        wf_lds_barrier();                                 // the previous tile's rows are done with the window
+        mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot);
+        // carry into the tile: T * S(symbols fully elapsed at the tile edge) - K0, fixed point, from the
+        // scan kernel (tile 0: -K0, the head truncation; a stream window: the previous window's export)
+        const double W = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
+        const int ref_a = s_pi[lpart], ref_b = P.nh > 1 ? s_pi[win + 1 + lpart] : 0;
+        // Row by row: J multiply-adds per sample against the staged amplitudes + the prefix count ->
+        // mod, sincos, store.  Rows are independent: no barrier inside the tile.
 #pragma unroll 2
         for (int u = 0; u < MOD_ROWS; ++u) {
-            double acc0 = 0.0, acc1 = 0.0;
-#ifdef WF_ABL_NO_FIR
-            if (false) {
-#else
-            if (active) {
-#endif
-                const double *a = &s_amp[l_top0p1 + u * sym_per_row];
-#pragma unroll
-                for (int i = 0; i <= JMAX; ++i) {
-                    const double v = a[-i];
-                    acc0 = fma(tap0[i], v, acc0);
-                    acc1 = fma(tap1[i], v, acc1);
-                }
-            }
-#ifdef WF_ABL_NO_SCAN
-            const double inc = acc0 + acc1;
-#else
-            const double inc = wf_wave_incl_scan(acc0 + acc1);
-#endif
-            const double ex = wf_wave_shr1(inc);   // exclusive prefix (0 in lane 0)
-            double *tot = s_tot + (u & 1) * MOD_WAVES;
-            if (lane == 63) tot[wave] = inc;
-            wf_lds_barrier();
-            double offw = 0.0, rowtot = 0.0;
-#pragma unroll
-            for (int w = 0; w < MOD_WAVES; ++w) {
-                if (w == wave) offw = rowtot;
-                rowtot += tot[w];
-            }
             double2 e0 = make_double2(0.0, 0.0), e1 = e0;   // samples 2t and 2t + 1 of the row
             if (active) {
-                const double v0 = run + (offw + ex + acc0);
-                // one reduction mod sps per pair (the second sample is a single frequency-pulse value
-                // further); a remainder that rounds to -eps or sps+eps needs no fix-up because the
-                // sector split of wf_sincos_sectors is exact for any argument
-                const double ra = fma(-floor(v0 * P.inv_sps), P.sps_d, v0);
-                const double rb = ra + acc1;
+                double ra, rb;
+                mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap,
+                                     P.nh, win + 1, ref_a, ref_b, W, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb);
 #ifdef WF_ABL_NO_SINCOS
                 e0 = make_double2(ra + 1, ra); e1 = make_double2(rb + 1, rb);
 #else
@@ -384,7 +469,6 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                 if (active && n >= P.out_origin && n < P.out_hi) o[n - P.out_origin] = e0;
                 if (active && n + 1 >= P.out_origin && n + 1 < P.out_hi) o[n + 1 - P.out_origin] = e1;
             }
-            run += rowtot;
             continue;
 #endif
             double2 *xw = s_xp + wave * (2 * WF_WAVE);
@@ -407,7 +491,6 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                 if ((FULLROW || col < P.rs) && na >= P.out_origin && na < P.out_hi) wf_store16_nt(o + (na - P.out_origin), xa);
                 if ((FULLROW || col + WF_WAVE < P.rs) && nb >= P.out_origin && nb < P.out_hi) wf_store16_nt(o + (nb - P.out_origin), xb);
             }
-            run += rowtot;
         }
     }
 }
@@ -476,14 +559,13 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     const int win = MOD_ROWS * 64 + JMAX + 2;
     double *s_amp = s_dyn;                                                       // window of symbol amplitudes
-    double2 *s_ring = reinterpret_cast<double2 *>(s_dyn + ((win + 1) & ~1));     // noisy samples, 4 rows
-    __shared__ double s_tot[2 * MOD_WAVES];
+    double2 *s_ring = reinterpret_cast<double2 *>(s_dyn + ((win + 1) & ~1));     // noisy samples, 2 rows
+    int *s_pi = reinterpret_cast<int *>(s_ring + MCB_SLOTS);                     // prefix counts of the window's raw symbols
+    __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
     __shared__ double2 s_taps[CPMNF ? 2 * CPMNF * 9 : 27];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    static_assert(MOD_WAVES == 4, "the row-total prefix below is written out for 4 waves");
     wf_stage_tables<1, 0>(s_tab, t, MOD_THREADS);
     if (CPMNF) {
         for (int k = t; k < Q.cpm_nh * CPMNF * 9; k += MOD_THREADS) s_taps[k] = reinterpret_cast<const double2 *>(mf_taps)[k];
@@ -510,18 +592,22 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     const int r0 = (2 * t + P.c) - q0 * sps;
     const int wrap = (r0 + 1 == sps) ? 1 : 0;
     const int r1 = wrap ? 0 : r0 + 1;
-    double tap0[JMAX + 1], tap1[JMAX + 1];
+    const bool any_wrap = (P.c & 1) != 0;                     // sps = 8: r0 = (2 t + c) mod 8 is even unless c is odd
+    // per-lane tap phases of the two samples (mod_pair_phase): Gcum at r + 8 j, clamped to the last tap
+    const double *Gcum = scratch + MOD_OFF_GCUM(P.ntiles);
+    double Q0[JMAX], Q1[JMAX];
 #pragma unroll
-    for (int i = 0; i <= JMAX; ++i) {
-        const int j0 = i - 1, k0 = r0 + j0 * sps;
-        tap0[i] = (j0 >= 0 && k0 < P.ntaps) ? pulse[k0] : 0.0;
-        const int j1 = i - 1 + wrap, k1 = r1 + j1 * sps;
-        tap1[i] = (j1 >= 0 && j1 < JMAX && k1 < P.ntaps) ? pulse[k1] : 0.0;
+    for (int j = 0; j < JMAX; ++j) {
+        const int k0 = r0 + j * sps, k1 = r1 + j * sps;
+        Q0[j] = Gcum[k0 < P.ntaps ? k0 : P.ntaps - 1];
+        Q1[j] = Gcum[k1 < P.ntaps ? k1 : P.ntaps - 1];
     }
     const double sec_per_unit = 128.0 * P.inv_sps, sec_phi0 = 128.0 * P.phi0_turns;
     const int l_top0p1 = (q0 - cq) + JMAX;
     const uint64_t *Wq = reinterpret_cast<const uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
-    const double *Gpart = scratch + MOD_OFF_GPART;
+    const double T = scratch[0];
+    const double Th_a = T * hvec[0], Th_b = P.nh > 1 ? T * hvec[1] : 0.0;
+    const int lpart = JMAX - cq - P.dsh;        // window index of the first symbol not fully elapsed at the tile edge
     // bank: quad per column, one sum chain per lane
     const int mq = t >> 2, mp = t & 3;
     // The four shared sums of the pulse-truncation bank,
@@ -547,7 +633,14 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     const double *ring_d = reinterpret_cast<const double *>(s_ring);
 
     const uint64_t pair0 = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull);
-    for (int64_t ltile = blockIdx.x; ltile < P.ntiles; ltile += gridDim.x) {
+    // A workgroup takes a RUN of consecutive tiles: rows then follow each other across the tile edge in the
+    // ring exactly as inside a tile (row 15's last column completes when the next tile's row 0 is in), and
+    // only the run's last tile has to compute the 8 samples after it itself (a whole extra row step for
+    // wave 0: 6 % of a tile when every tile did it).
+    const int64_t per_blk = (P.ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t lt0 = (int64_t)blockIdx.x * per_blk, lt1 = lt0 + per_blk < P.ntiles ? lt0 + per_blk : P.ntiles;
+    for (int64_t ltile = lt0; ltile < lt1; ++ltile) {
+        const bool run_first = ltile == lt0, run_last = ltile + 1 == lt1;
         // a window of a longer stream: local tile `ltile` is tile `tile` of the burst (P.tile_lo = 0,
         // P.ntiles = all of them for a one-shot burst); carries Wq are indexed locally, everything
         // else (symbols via mod_amp, samples, noise, columns) in burst coordinates
@@ -559,41 +652,23 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
         // columns this tile may store, relative to its first symbol (32-bit tests per row)
         const int64_t klo64 = Q.k_lo - sym_base, khi64 = Q.k_hi - sym_base;
         const int klo = klo64 < -(1 << 20) ? -(1 << 20) : (int)klo64, khi = khi64 > (1 << 20) ? (1 << 20) : (int)khi64;
-        wf_lds_barrier();                                     // previous tile's columns are done with the ring
-        for (int k = t; k < win; k += MOD_THREADS) s_amp[k] = mod_amp(symbols, hvec, P, mp1_lo + k - 1);
+        wf_lds_barrier();                                     // previous tile's columns are done with the ring and the window
         if (tile == 0)                                        // samples before the burst (row -1): ring row 3 and the group before it
             for (int k = t; k < 512 + 64 + 9; k += MOD_THREADS) s_ring[(MCB_RING / 512 - 1) * 576 - 9 + k] = make_double2(0.0, 0.0);
-        wf_lds_barrier();
-        double run = 0.0;
-        const int lpart = (int)((sym_base - P.dsh + 1) - mp1_lo);
-        if (tile > 0) {
-            run = (double)Wq[ltile] * 0x1.0p-62 * P.sps_d;
-            double part = 0.0;
-            for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + l], Gpart[l], part);
-            run += part;
-        }
-        // the first 8 samples of the NEXT tile (lanes 0..3 of wave 0), by that tile's own row-0 expressions
-        if (wave == 0 && lane < 4) s_halo[2 * lane] = s_halo[2 * lane + 1] = make_double2(0.0, 0.0);
-        if (wave == 0 && ltile + 1 < P.ntiles) {   // (the last tile of a window is itself halo: its last columns belong to the next chunk)
+        mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot);
+        const double W = (double)Wq[ltile] * 0x1.0p-62 * P.sps_d;             // tile carry (tile 0: the head truncation -K0)
+        const int ref_a = s_pi[lpart], ref_b = P.nh > 1 ? s_pi[win + 1 + lpart] : 0;
+        // the first 8 samples of the NEXT tile (lanes 0..3 of wave 0), by that tile's own row-0 expressions:
+        // its carry, its window = this one shifted by a tile's symbols (counts are differences: same integers)
+        if (run_last && wave == 0 && lane < 4) s_halo[2 * lane] = s_halo[2 * lane + 1] = make_double2(0.0, 0.0);
+        if (run_last && wave == 0 && ltile + 1 < P.ntiles) {   // (the last tile of a window is itself halo: its last columns belong to the next chunk)
             double2 h0 = make_double2(0.0, 0.0), h1 = h0;
-            double runn = (double)Wq[ltile + 1] * 0x1.0p-62 * P.sps_d;
-            double part = 0.0;
-            for (int l = 0; l < P.npart; ++l) part = fma(s_amp[lpart + MOD_ROWS * sym_per_row + l], Gpart[l], part);
-            runn += part;
-            double acc0 = 0.0, acc1 = 0.0;
-            const double *a = &s_amp[l_top0p1 + MOD_ROWS * sym_per_row];
-#pragma unroll
-            for (int i = 0; i <= JMAX; ++i) {
-                const double v = lane < 4 ? a[-i] : 0.0;
-                acc0 = fma(tap0[i], v, acc0);
-                acc1 = fma(tap1[i], v, acc1);
-            }
-            const double inc = wf_wave_incl_scan(acc0 + acc1);
-            const double ex = wf_wave_shr1(inc);
-            const double offw = 0.0;
-            const double v0 = runn + (offw + ex + acc0);
-            const double ra = fma(-floor(v0 * P.inv_sps), P.sps_d, v0);
-            const double rb = ra + acc1;
+            const double Wn = (double)Wq[ltile + 1] * 0x1.0p-62 * P.sps_d;
+            const int shift = MOD_ROWS * sym_per_row;
+            const int refn_a = s_pi[lpart + shift], refn_b = P.nh > 1 ? s_pi[win + 1 + lpart + shift] : 0;
+            double ra, rb;
+            mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + shift], &s_pi[(q0 - cq) + shift], wrap, any_wrap, P.nh, win + 1, refn_a, refn_b,
+                                 Wn, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb);
             double2 e0, e1;
             wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
             wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
@@ -672,29 +747,9 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
         };
 #pragma unroll WF_MCB_UNROLL
         for (int u = 0; u < MOD_ROWS; ++u) {
-            double acc0 = 0.0, acc1 = 0.0;
-            {
-                const double *a = &s_amp[l_top0p1 + u * sym_per_row];
-#pragma unroll
-                for (int i = 0; i <= JMAX; ++i) {
-                    const double v = a[-i];
-                    acc0 = fma(tap0[i], v, acc0);
-                    acc1 = fma(tap1[i], v, acc1);
-                }
-            }
-            const double inc = wf_wave_incl_scan(acc0 + acc1);
-            const double ex = wf_wave_shr1(inc);
-            double *tot = s_tot + (u & 1) * MOD_WAVES;
-            if (lane == 63) tot[wave] = inc;
-#ifndef WF_ABL_MCB_NOBAR1   // ablation only (timing; results are wrong)
-            wf_lds_barrier();
-#endif
-            // same sums in the same order as mod_main_kernel's loop (0.0 + t0 == t0)
-            const double t0_ = tot[0], p1_ = t0_ + tot[1], p2_ = p1_ + tot[2], rowtot = p2_ + tot[3];
-            const double offw = wave_u == 0 ? 0.0 : (wave_u == 1 ? t0_ : (wave_u == 2 ? p1_ : p2_));
-            const double v0 = run + (offw + ex + acc0);
-            const double ra = fma(-floor(v0 * P.inv_sps), P.sps_d, v0);
-            const double rb = ra + acc1;
+            double ra, rb;
+            mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap, P.nh,
+                                 win + 1, ref_a, ref_b, W, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb);
             double2 e0, e1;
             wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
             wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
@@ -721,23 +776,26 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                 if (n0 >= P.out_len) x0 = make_double2(0.0, 0.0);
                 if (n0 + 1 >= P.out_len) x1 = make_double2(0.0, 0.0);
             }
+            // Two-row ring: row u takes the slots of row u - 2, whose last readers are the waves still in
+            // bank_row(u - 2) ...
+#ifndef WF_ABL_MCB_NOBAR1   // ablation only (timing; results are wrong)
+            wf_lds_barrier();
+#endif
             const int ia = ((u << 9) + 2 * t - Q.d) & (MCB_RING - 1), ib = (ia + 1) & (MCB_RING - 1);
             s_ring[ia + (ia >> 3)] = x0;
             s_ring[ib + (ib >> 3)] = x1;
             if (ia == 0) s_ring[MCB_RING + MCB_RING / 8] = x0;  // index 2048: read by the window that ends the ring
             if (ib == 0) s_ring[MCB_RING + MCB_RING / 8] = x1;
-            // Two-row ring: row u is complete after this barrier, and the next write into the ring
-            // (row u + 1, behind the NEXT row's first barrier) comes after every wave has left
-            // bank_row(u - 1) — one more barrier per row than a four-row ring, 18 KB less LDS
-            // (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
+            // ... and row u is complete after this barrier — one more barrier per row than a four-row
+            // ring, 18 KB less LDS (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
 #ifndef WF_ABL_MCB_NOBAR2   // ablation only
             wf_lds_barrier();
 #endif
 #ifndef WF_ABL_MCB_NOBANK   // ablation only
-            if (u >= 1 || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);
+            if (u >= 1 || !run_first || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);   // u = 0: the previous tile's row 15
 #endif
-            run += rowtot;
         }
+        if (!run_last) continue;
         wf_lds_barrier();                                     // every wave is done with row 14
         if (wave == 0 && lane < 4) {                          // row 16's first 8 samples
             const int ia = (2 * lane - Q.d) & (MCB_RING - 1), ib = (ia + 1) & (MCB_RING - 1);
@@ -759,7 +817,7 @@ static bool mod_setup(mod_params &P, int64_t nsym, int nh, int ntaps, int sps, d
 {
     // outside 2 <= sps <= 256 the row length below is 0 (or the lcm divides by 0): not a
     // configuration of the fused kernel.  P is left in a defined state for callers that read it.
-    if (sps < 2 || sps > 256 || ntaps < 1 || nsym < 1 || nh < 1) {
+    if (sps < 2 || sps > 256 || ntaps < 1 || nsym < 1 || nh < 1 || nh > 2) {      // (prefix counts: one or two modulation indices)
         P = mod_params{};
         P.sps = sps;
         P.ntaps = ntaps;
@@ -802,7 +860,7 @@ static int mod_launch_carries(wf_ctx *ctx, const mod_params &P, const int8_t *d_
                               const double *d_pulse, const uint64_t *d_q_in, uint64_t *d_q_out, void *stream)
 {
     hipStream_t s = wf_stream(stream);
-    const size_t words = (size_t)MOD_OFF_P + 2 * (size_t)P.ntiles + 8;
+    const size_t words = MOD_OFF_GCUM(P.ntiles) + (size_t)P.ntaps;
     int rc = wf_ctx_reserve_mod(ctx, words);
     if (rc) return rc;
     double *scratch = ctx->d_mod_scratch;
@@ -827,13 +885,13 @@ static int mod_launch(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols,
     const int sps = P.sps;
 #define MOD_LAUNCH(JM)                                                                                   \
     do {                                                                                                 \
-        const size_t lds = (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2) * sizeof(double);                  \
-        if (P.rs == 2 * MOD_THREADS)                                                                     \
-            hipLaunchKernelGGL((mod_main_kernel<JM, true>), dim3(grid), dim3(MOD_THREADS), lds, s, d_symbols, d_h, \
-                               d_pulse, scratch, d_out_ri, P);                                           \
-        else                                                                                             \
-            hipLaunchKernelGGL((mod_main_kernel<JM, false>), dim3(grid), dim3(MOD_THREADS), lds, s, d_symbols, d_h, \
-                               d_pulse, scratch, d_out_ri, P);                                           \
+        const size_t win = (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2);                                   \
+        const size_t lds = ((win + 1) & ~(size_t)1) * sizeof(double) + (size_t)P.nh * (win + 1) * sizeof(int); \
+        using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, double *, mod_params); \
+        const kern_t k = P.rs == 2 * MOD_THREADS ? mod_main_kernel<JM, true> : mod_main_kernel<JM, false>; \
+        if (lds > 48 * 1024)                                                                             \
+            WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MOD_THREADS), lds, s, d_symbols, d_h, d_pulse, scratch, d_out_ri, P); \
     } while (0)
     if (J <= 4) MOD_LAUNCH(4);
     else if (J <= 9) MOD_LAUNCH(9);
@@ -919,9 +977,16 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     const int win = MOD_ROWS * 64 + JM + 2;
     // (occupancy experiment, LDS padded to force fewer workgroups per CU with the 4-row ring of the
     //  first version: 1 per CU 0.97 ms, 2: 0.63, 3: 0.56 — the 2-row ring's 4 per CU: 0.53)
-    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)MCB_SLOTS * sizeof(double2);
-    const int64_t max_grid = 2048;
-    const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
+    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)MCB_SLOTS * sizeof(double2) + (size_t)nh * (win + 1) * sizeof(int);
+    // one run of consecutive tiles per resident workgroup (4 per CU for the SOQPSK form, 3 for the CPM forms)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+#ifndef WF_MCB_RUNS_PER_SLOT
+#define WF_MCB_RUNS_PER_SLOT 4   // same-box A/B at 1e7 symbols: 1 run per slot 0.517 ms, 2: 0.500, 4: 0.478, 5 / 10: 0.486 (finer runs balance better; longer ones save more halo rows)
+#endif
+    const int64_t max_grid = (int64_t)cus * (cpm_nf ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
+    const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
+    const int grid = (int)((P.ntiles + per_run - 1) / per_run);
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
     kern_t k = cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)

@@ -62,16 +62,19 @@ def profile_record(stage: str, nsym: int, sps: int):
         k = d.get("kernels", {}).get(STAGE_KERNEL.get(stage, ""))
         if d.get("nsym") == nsym and d.get("sps") == sps and k:
             rec = {"traffic": int(k["hbm_traffic_bytes"]), "source": path.name, "valu_insts": k.get("valu_insts"),
-                   "avg_ns": k.get("avg_ns"), "current": bool(now and d.get("build_digest") == now)}
+                   "shader_cycles": k.get("shader_cycles"), "avg_ns": k.get("avg_ns"),
+                   "current": bool(now and d.get("build_digest") == now)}
             if best is None or rec["current"] or not best["current"]:
                 best = rec
     return best
 
 
 def valu_issue(stage: str, rec, launch_ms: float):
-    """Vector-issue side of the roofline for kernels whose HBM traffic is already minimal:
-    measured VALU wave-instructions per launch x average issue cycles per instruction (static class
-    mix of the kernel, costs measured by tools/clock_probe.hip) / (1024 SIMDs x clock x launch time)."""
+    """Vector-issue side of the roofline for kernels whose HBM traffic is already minimal: measured VALU
+    wave-instructions per launch (SQ_INSTS_VALU) x average issue cycles per instruction (static class mix of
+    the kernel, per-class costs measured by tools/valu_probe.hip) / (1024 SIMDs x shader cycles of the launch).
+    The shader cycles are those of the SAME counter pass (GRBM_GUI_ACTIVE / 8 XCDs), so no clock is assumed;
+    profiles without that counter fall back to 2.2 GHz x the live launch time."""
     try:
         mix = json.loads((ROOT / "profiles" / "r02_valu_mix.json").read_text())
     except (OSError, ValueError):
@@ -80,11 +83,17 @@ def valu_issue(stage: str, rec, launch_ms: float):
     if not (k and rec and rec.get("valu_insts") and launch_ms > 0):
         return None
     cycles = rec["valu_insts"] * k["avg_cycles_per_valu"]
-    frac = cycles / (mix["simds"] * mix["clock_hz"] * launch_ms * 1e-3)
-    return {"valu_issue_frac": round(frac, 4), "valu_wave_insts_per_launch": rec["valu_insts"],
-            "avg_issue_cycles_per_valu": k["avg_cycles_per_valu"], "class_mix_static": {c: k[c] for c in ("f64", "mul32", "other")},
-            "simds": mix["simds"], "clock_ghz": mix["clock_hz"] / 1e9,
-            "source": f"{rec['source']} + r02_valu_mix.json + r02_clock_probe.json"}
+    shader_cycles = rec.get("shader_cycles") or 2.2e9 * launch_ms * 1e-3
+    frac = cycles / (mix["simds"] * shader_cycles)
+    out = {"valu_issue_frac": round(frac, 4), "valu_wave_insts_per_launch": rec["valu_insts"],
+           "avg_issue_cycles_per_valu": k["avg_cycles_per_valu"],
+           "class_mix_static": {c: k[c] for c in ("full", "fast", "trans64", "trans32") if c in k},
+           "simds": mix["simds"], "shader_cycles_per_launch": int(shader_cycles),
+           "shader_cycles_source": "GRBM_GUI_ACTIVE / 8 in the profile's counter pass" if rec.get("shader_cycles") else "2.2 GHz x live launch time",
+           "source": f"{rec['source']} + r02_valu_mix.json + r02_valu_probe.json"}
+    if rec.get("shader_cycles") and rec.get("avg_ns"):
+        out["shader_clock_ghz_in_profile"] = round(rec["shader_cycles"] / rec["avg_ns"], 3)
+    return out
 
 
 def _cpu_pool_ready(_):

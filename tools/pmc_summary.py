@@ -65,6 +65,14 @@ def main():
             m = sq[k]
             kernels[k].update(waves=int(m.get("SQ_WAVES", 0)), valu_insts=int(m.get("SQ_INSTS_VALU", 0)),
                               salu_insts=int(m.get("SQ_INSTS_SALU", 0)), lds_insts=int(m.get("SQ_INSTS_LDS", 0)))
+            # shader cycles of the launch: GRBM_GUI_ACTIVE is summed over the 8 XCDs (SQ_BUSY_CYCLES over the
+            # 32 shader engines; the two agree within 2-4 % on the probe kernels of tools/valu_probe.hip)
+            if m.get("GRBM_GUI_ACTIVE"):
+                kernels[k]["shader_cycles"] = int(m["GRBM_GUI_ACTIVE"] / 8)
+            elif m.get("SQ_BUSY_CYCLES"):
+                kernels[k]["shader_cycles"] = int(m["SQ_BUSY_CYCLES"] / 32)
+            if m.get("SQ_ACTIVE_INST_VALU"):
+                kernels[k]["valu_active_quad_cycles"] = int(m["SQ_ACTIVE_INST_VALU"])   # 1 per instruction (4 per fp64 transcendental)
             if m.get("SQ_WAVE_CYCLES"):
                 kernels[k]["frac_wave_cycles_valu_active"] = round(m.get("SQ_ACTIVE_INST_VALU", 0) / m["SQ_WAVE_CYCLES"], 3)
                 kernels[k]["frac_wave_cycles_waiting"] = round(m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"], 3)

@@ -2,12 +2,23 @@
 
     python tools/valu_mix.py [--out profiles/r02_valu_mix.json]
 
-For the kernels whose HBM traffic equals their algorithmic bytes but whose HBM fraction is low,
-the bound is vector-instruction ISSUE.  bench.py prices a launch as
-    issue cycles = SQ_INSTS_VALU (measured, tools/sq_profile.sh) x average cycles per VALU instruction
+For the kernels whose HBM traffic equals their algorithmic bytes but whose HBM fraction is low, the
+bound is vector-instruction ISSUE.  bench.py prices a launch as
+    issue cycles = SQ_INSTS_VALU (measured, tools/profile.sh) x average cycles per VALU instruction
 with the average taken over this static mix and the per-class costs measured on the chip by
-tools/clock_probe.hip (profiles/r02_clock_probe.json): fp64 arithmetic 8 cycles per wave64
-instruction, v_mad_u64_u32 / 32-bit multiplies 8, every other VALU instruction 4, at 2.35 GHz.
+tools/valu_probe.hip (profiles/r02_valu_probe.json; exact instruction counts, inline asm), in
+shader cycles per wave64 instruction per SIMD at 4-8 waves per SIMD:
+    full  4.2   everything not listed below: fp64 add / mul / fma / min / cmp / cvt / floor / ldexp,
+                32 x 32 multiplies and v_mad_u64_u32, every 64-bit integer op and v_mov_b64, every
+                three-operand 32-bit integer op (v_add3, v_xad, v_lshl_add, v_bfe, v_perm, v_and_or,
+                v_alignbit, v_mad_u32_u24), compares, v_cndmask with an SGPR mask, DPP moves, v_readlane
+    fast  2.3   two-operand 32-bit integer / logic / shift ops and v_mov_b32 in the e32 encoding,
+                v_cndmask_b32 on vcc, fp32 add / mul / fma
+    trans64 16.2  v_rcp_f64, v_rsq_f64, v_sqrt_f64
+    trans32 8.2   fp32 transcendentals
+(An earlier probe, tools/clock_probe.hip, let the compiler add three v_mov_b64 per iteration to its
+fp64 loop and so read 7.7 cycles for v_fma_f64; the figures priced with that — fp64 8, mul32 8,
+other 4 — overstated every issue fraction by about a third.)
 """
 import argparse
 import json
@@ -19,15 +30,19 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 CSRC = ROOT / "waveforms_amd" / "csrc"
-COST = {"f64": 8, "mul32": 8, "other": 4}
+COST = {"full": 4.2, "fast": 2.3, "trans64": 16.2, "trans32": 8.2}
 
 
 def classify(op: str) -> str:
-    if re.search(r"_f64|_u64_u32|_i64_i32", op) and not op.startswith("v_mov") and "cndmask" not in op:
-        return "mul32" if "u64_u32" in op or "i64_i32" in op else "f64"
-    if re.match(r"v_mul_(lo|hi)_[ui]32", op):
-        return "mul32"
-    return "other"
+    if re.match(r"v_(rsq|rcp|sqrt)_f64", op):
+        return "trans64"
+    if re.match(r"v_(log|exp|rcp|rsq|sqrt|sin|cos)_f32", op):
+        return "trans32"
+    if op.endswith("_e32") and not re.search(r"f64|b64|u64|i64|mul_lo|mul_hi|mul_u32|mul_i32|cmp", op):
+        return "fast"
+    if re.match(r"v_(fma|fmac|add|mul|sub)_f32", op):
+        return "fast"
+    return "full"
 
 
 def main():
@@ -45,7 +60,7 @@ def main():
             m = re.match(r"^(_Z\w+):\s*(;.*)?$", line)
             if m:
                 cur = m.group(1)
-                kernels[cur] = {"f64": 0, "mul32": 0, "other": 0}
+                kernels[cur] = {c: 0 for c in COST}
                 continue
             if cur and re.match(r"^\s+s_endpgm", line):
                 cur = None
@@ -64,9 +79,9 @@ def main():
             continue
         out[short] = {**c, "valu_static": n,
                       "avg_cycles_per_valu": round(sum(COST[k] * v for k, v in c.items()) / n, 3)}
-    doc = {"note": "static VALU class mix per kernel (hipcc -S of the in-tree sources); costs per wave64 instruction: "
-                   f"{COST} cycles (tools/clock_probe.hip on MI355X: fp64 fma 7.7, v_mad_u64_u32 6.8, fp32 / integer 4.5-4.9)",
-           "build_digest": _digest(), "clock_hz": 2.35e9, "simds": 1024, "kernels": out}
+    doc = {"note": "static VALU class mix per kernel (hipcc -S of the in-tree sources); issue cost per wave64 instruction per SIMD "
+                   f"by class: {COST} shader cycles (tools/valu_probe.hip on MI355X, profiles/r02_valu_probe.json)",
+           "build_digest": _digest(), "simds": 1024, "kernels": out}
     Path(a.out).write_text(json.dumps(doc, indent=1) + "\n")
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["valu_static"])[:12]:
         print(f"{k[:60]:60s} {v}")

@@ -132,8 +132,9 @@ DEF_KERNEL(k_s_barrier, U8, ALL8(BARR, ""), SUMU)
 typedef void (*kern_t)(double *, uint64_t *, int);
 struct entry { const char *name; kern_t k; };
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool quick = argc > 1;      // `valu_probe quick`: 3 launches per kernel, 8 waves per SIMD only (for runs under rocprofv3 --pmc)
     const entry tab[] = {
         {"v_fma_f64 (8 chains)", k_fma_f64}, {"v_fma_f64 (4 chains)", k_fma_f64_c4}, {"v_fma_f64 (2 chains)", k_fma_f64_c2},
         {"v_fma_f64 (1 chain)", k_fma_f64_c1}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_min_f64", k_min_f64},
@@ -156,11 +157,12 @@ int main()
     std::vector<uint64_t> h(2 * 256 * 8);
     printf("[\n");
     bool first = true;
-    for (int waves : {8, 4, 1}) {                    // waves per SIMD: 256 CUs x (waves) blocks of 256 threads
+    for (int waves : {8, 4, 1}) {
+        if (quick && waves != 8) continue;                    // waves per SIMD: 256 CUs x (waves) blocks of 256 threads
         const int blocks = 256 * waves;
         for (const entry &e : tab) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            for (int rep = 0; rep < 60; ++rep) {        // back-to-back launches, time the last one
+            for (int rep = 0; rep < (quick ? 3 : 60); ++rep) {        // back-to-back launches, time the last one
                 hipEventRecord(e0);
                 hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, sink, stamps, iters);
                 hipEventRecord(e1);

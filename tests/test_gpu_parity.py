@@ -188,7 +188,11 @@ def test_frequency_and_phase_modulate(oracle, golden):
     (8, "tg", (0.25,), (-2, 0, 2), 300_000), (10, "tg", (0.25,), (-2, 0, 2), 123_457),
     (8, "mil", (0.25,), (-2, 0, 2), 50_000), (8, "multih", (4 / 16, 5 / 16), (-3, -1, 1, 3), 200_001),
     (8, "pcmfm", (0.7,), (-1, 1), 100_000), (5, "pcmfm", (0.7,), (-1, 1), 33_333), (20, "pcmfm", (0.7,), (-1, 1), 20_000),
-    (8, "b", (0.25,), (-2, 0, 2), 70_000), (8, "tg", (0.25,), (-2, 0, 2), 600), (4, "tg", (0.3,), (-2, 0, 2), 5_000)])
+    (8, "b", (0.25,), (-2, 0, 2), 70_000), (8, "tg", (0.25,), (-2, 0, 2), 600), (4, "tg", (0.3,), (-2, 0, 2), 5_000),
+    # three modulation indices: outside the one-pass kernel's prefix counts (<= 2) -> it declines, the stage kernels run
+    (8, "tg", (0.25, 0.3, 0.35), (-2, 0, 2), 20_000),
+    # odd sps and an even-length pulse: sample pairs that straddle a symbol edge (the `wrap` lanes of mod_pair_phase)
+    (5, "tg", (0.25,), (-2, 0, 2), 40_001), (7, "multih", (4 / 16, 5 / 16), (-3, -1, 1, 3), 30_000)])
 def test_fused_modulator_equals_stage_kernels_and_oracle(oracle, sps, pulse_name, hs, alphabet, nsym):
     """wf_cpm_modulate_c128 (analytic tile carries) vs FIR + chained scan vs the oracle."""
     from waveforms_amd import _hip

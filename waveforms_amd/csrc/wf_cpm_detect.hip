@@ -697,12 +697,37 @@ extern "C" int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, 
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void cpm_count_kernel(const uint8_t *__restrict__ dec, const int8_t *__restrict__ alpha, int M, int64_t m,
-                                 unsigned long long *__restrict__ counts)
+// 16 symbols per thread and trip (the arrays may start at any byte offset: gfx950 global loads need no
+// alignment), one pair of atomics per workgroup — the first form loaded a byte per thread and issued
+// 4096 same-address atomics: 54 us for 1e7 symbols against 14 us for the SOQPSK counter.
+__global__ __launch_bounds__(256) void cpm_count_kernel(const uint8_t *__restrict__ dec, const int8_t *__restrict__ alpha, int M,
+                                                        int64_t m, unsigned long long *__restrict__ counts)
 {
+    __shared__ long long s_part[2][4];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     long long se = 0, be = 0;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    const unsigned long long addm = 0x0101010101010101ull * (unsigned)(M - 1);
+    const int64_t nvec = m / 16;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        ulonglong2 d, a;
+        __builtin_memcpy(&d, dec + 16 * v, 16);
+        __builtin_memcpy(&a, alpha + 16 * v, 16);
+        // u = (alpha + M - 1) >> 1 per byte.  alpha is a signed byte, so the add is done on the low 7 bits with
+        // the sign bit folded back in (no carry leaves a byte: 0x7F + 3 < 0x100); the mask after the shift drops
+        // the bit that came in from the byte above
+        auto x_of = [&](unsigned long long dd, unsigned long long aa) {
+            const unsigned long long sum = ((aa & 0x7F7F7F7F7F7F7F7Full) + addm) ^ (aa & 0x8080808080808080ull);
+            return dd ^ ((sum >> 1) & 0x0303030303030303ull);
+        };
+        const unsigned long long x0 = x_of(d.x, a.x), x1 = x_of(d.y, a.y);
+        be += __popcll(x0) + __popcll(x1);
+        auto nz = [](unsigned long long x) {       // symbols are 2 bits wide
+            x |= x >> 1;
+            return __popcll(x & 0x0101010101010101ull);
+        };
+        se += nz(x0) + nz(x1);
+    }
+    for (int64_t k = 16 * nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
         const int u = ((int)alpha[k] + (M - 1)) >> 1;
         const int x = (int)dec[k] ^ u;
         se += x != 0;
@@ -710,9 +735,20 @@ __global__ void cpm_count_kernel(const uint8_t *__restrict__ dec, const int8_t *
     }
     se = wf_wave_sum_i64(se);
     be = wf_wave_sum_i64(be);
-    if ((threadIdx.x & 63) == 0 && (se | be)) {
-        atomicAdd(counts, (unsigned long long)se);
-        atomicAdd(counts + 1, (unsigned long long)be);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_part[0][wave] = se;
+        s_part[1][wave] = be;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long a = 0, b = 0;
+        for (int w = 0; w < 4; ++w) {
+            a += s_part[0][w];
+            b += s_part[1][w];
+        }
+        if (a) atomicAdd(&counts[0], (unsigned long long)a);
+        if (b) atomicAdd(&counts[1], (unsigned long long)b);
     }
 }
 
@@ -723,7 +759,7 @@ extern "C" int wf_cpm_count_errors(wf_ctx *ctx, const uint8_t *d_decided_u, cons
     if (m == 0) return WF_OK;
     WF_REQUIRE(d_decided_u && d_ref_alpha, "wf_cpm_count_errors: NULL device pointer");
     WF_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(cpm_count_kernel, dim3(wf_grid_for(m, 256 * 16, 512)), dim3(256), 0, wf_stream(stream), d_decided_u,
+    hipLaunchKernelGGL(cpm_count_kernel, dim3(wf_grid_for(m, 256 * 16 * 8, 256)) /* <= 512 same-address atomics */, dim3(256), 0, wf_stream(stream), d_decided_u,
                        d_ref_alpha, M, m, reinterpret_cast<unsigned long long *>(d_counts));
     WF_LAUNCH_CHECK();
     return WF_OK;

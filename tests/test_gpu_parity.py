@@ -760,7 +760,9 @@ def torch_f64():
 
 
 @pytest.mark.parametrize("nsym,pulse_name,differential", [((1 << 18) + 77, "tg", True), (1024 * 5, "tg", False), (1024 * 3 + 1, "mil", True),
-                                                          (70_001, "tg", True), (1500, "tg", True), (1023, "mil", False)])
+                                                          (70_001, "tg", True), (1500, "tg", True), (1023, "mil", False),
+                                                          # 63 taps: centre 31 is odd, so every fourth sample pair straddles a symbol edge
+                                                          (40_003, "tg63", True), (9_000, "tg63", False)])
 def test_fused_modulator_channel_bank_rows_bit_identical(oracle, nsym, pulse_name, differential):
     """fuse bit 3: modulator + channel + pulse-truncation bank in ONE kernel (the clean baseband
     samples never reach HBM).  Its detector-packed rows are bit for bit those of fuse = 7
@@ -769,7 +771,8 @@ def test_fused_modulator_channel_bank_rows_bit_identical(oracle, nsym, pulse_nam
     and for the one-symbol MIL pulse."""
     from waveforms_amd.link import SOQPSKLink
 
-    pulse = oracle.freq_pulse_soqpsk_tg(8) if pulse_name == "tg" else oracle.freq_pulse_soqpsk_mil(8)
+    pulse = {"tg": lambda: oracle.freq_pulse_soqpsk_tg(8), "mil": lambda: oracle.freq_pulse_soqpsk_mil(8),
+             "tg63": lambda: np.ascontiguousarray(oracle.freq_pulse_soqpsk_tg(8)[1:-1])}[pulse_name]()
     ref = SOQPSKLink(nsym, 8, fuse=7, differential=differential, pulse=pulse)
     fus = SOQPSKLink(nsym, 8, fuse=15, differential=differential, pulse=pulse)
     assert ref.row_bytes == fus.row_bytes == 32

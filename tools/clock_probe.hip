@@ -1,3 +1,6 @@
+// SUPERSEDED for instruction costs by tools/valu_probe.hip: the compiler adds three v_mov_b64 per iteration to
+// the fp64 loop below (7 instructions, not 4), so the 7.7 "cycles per fp64 FMA" this printed were wrong — the
+// real figure is 4.2.  Kept for the clock reading only.
 // Diagnostic only (not part of libwfhip.so): the shader clock the chip sustains under a dense fp64
 // VALU load, measured in-kernel as delta s_memtime / delta s_memrealtime x 100 MHz
 // (MI355X_MICROARCH.md, "DVFS give-back" item 6).  Build and run on the GPU box:

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__res
 // barrier and ~25 % of the modulator's instructions).
 //   s_amp[k] = amplitude of window symbol k  (global 0-based index m0 + k; 0 outside the burst)
 //   s_pi[c * (win + 1) + k] = sum of the raw symbols of index class c (m % nh) over window symbols < k
-__device__ __forceinline__ int mod_sym_raw(const int8_t *__restrict__ symbols, const mod_params &P, int64_t m)
+template <class PT>
+__device__ __forceinline__ int mod_sym_raw(const int8_t *__restrict__ symbols, const PT &P, int64_t m)
 {
     const int64_t l = m - P.sym_origin;
     return (m < 0 || m >= P.nsym || l < 0 || l >= P.nloc) ? 0 : (int)symbols[l];
@@ -300,10 +301,12 @@ __device__ __forceinline__ int mod_wave_incl_scan_i32(int v)
 }
 
 // Called by all MOD_THREADS threads; leaves with a barrier (window and counts visible).  s_wtot: 2 * MOD_WAVES ints.
+template <class PT>   // PT: mod_params, or the same struct read through the kernarg segment (constant address space)
 __device__ __forceinline__ void mod_stage_window(const int8_t *__restrict__ symbols, const double *__restrict__ hvec,
-                                                 const mod_params &P, int64_t m0, int win, double *s_amp, int *s_pi, int *s_wtot)
+                                                 const PT &P, int64_t m0, int win, double *s_amp, int *s_pi, int *s_wtot,
+                                                 int t = threadIdx.x)
 {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = t >> 6;
     const int per = (win + MOD_THREADS) / MOD_THREADS;          // ceil((win + 1) / MOD_THREADS): entry `win` is the total
     const int k0 = t * per;
     // a window inside the burst and resident (all but the first and last tiles): no per-symbol tests
@@ -548,14 +551,43 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm CTRL (
 #ifndef WF_MCB_UNROLL
 #define WF_MCB_UNROLL 2
 #endif
+// The kernel's arguments as they lie in the kernarg segment (each at its natural alignment, in order).
+// The kernel reads them THROUGH this view, from a pointer it makes opaque once per tile: left as plain
+// by-value arguments, the ~70 uniform words of the two structs are loaded once at the top and stay live
+// across the whole kernel — with the row loop's own uniforms that was 88 SGPR spills (v_writelane /
+// v_readlane into two reserved VGPRs, ~200 reloads per tile) and 16 VGPR spills in <9,0>.  Re-reading a
+// field where it is used is a scalar load that hits the constant cache.
+struct mcb_kargs {
+    const int8_t *symbols;
+    const double *hvec, *pulse, *scratch, *mf_taps;
+    double *rows;
+    mod_params P;
+    mcb_params Q;
+};
+typedef const __attribute__((address_space(4))) mcb_kargs *mcb_kptr;
+
 template <int JMAX, int CPMNF>
-__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? 3 : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols,
-                                                                     const double *__restrict__ hvec,
-                                                                     const double *__restrict__ pulse,
-                                                                     const double *__restrict__ scratch,
-                                                                     const double *__restrict__ mf_taps,
-                                                                     double *__restrict__ rows, mod_params P, mcb_params Q)
+__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? 3 : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
+                                                                     const double *__restrict__ hvec_,
+                                                                     const double *__restrict__ pulse_,
+                                                                     const double *__restrict__ scratch_,
+                                                                     const double *__restrict__ mf_taps_,
+                                                                     double *__restrict__ rows_, mod_params P_, mcb_params Q_)
 {
+#ifdef WF_MCB_BYVALUE   // A/B only: the round-2 form (arguments by value)
+    const mcb_kargs KAv{symbols_, hvec_, pulse_, scratch_, mf_taps_, rows_, P_, Q_};
+    const mcb_kargs *const KA0 = &KAv;
+#define MCB_FRESH(ka) ((void)0)
+#else
+    mcb_kptr const KA0 = (mcb_kptr)__builtin_amdgcn_kernarg_segment_ptr();
+#define MCB_FRESH(ka) asm volatile("" : "+s"(ka))
+#endif
+    auto ka = KA0;
+    const auto &P = ka->P;
+    const auto &Q = ka->Q;
+    const double *__restrict__ const hvec = ka->hvec;
+    const double *__restrict__ const scratch = ka->scratch;
+    const double *__restrict__ const mf_taps = ka->mf_taps;
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     const int win = MOD_ROWS * 64 + JMAX + 2;
     double *s_amp = s_dyn;                                                       // window of symbol amplitudes
@@ -565,7 +597,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
     __shared__ double2 s_taps[CPMNF ? 2 * CPMNF * 9 : 27];
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(t) >> 6;      // the same number as a scalar
     wf_stage_tables<1, 0>(s_tab, t, MOD_THREADS);
     if (CPMNF) {
         for (int k = t; k < Q.cpm_nh * CPMNF * 9; k += MOD_THREADS) s_taps[k] = reinterpret_cast<const double2 *>(mf_taps)[k];
@@ -574,16 +606,21 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     }
     const double2 *s_cis = s_tab + 128;
     const wf_tabs_lds<1, 0> tb{s_tab};
-    // pulse-truncation structure of the bank (block-uniform, read straight from global memory):
-    // filter 1 all ones, filter 2 = conj(filter 0)
+    // pulse-truncation structure of the bank (block-uniform): filter 1 all ones, filter 2 = conj(filter 0).
+    // Read per lane through a non-uniform index: as scalar loads the 27 complex taps were 108 SGPRs in flight
+    // at once — the kernel's register-pressure peak, before the first tile.
     bool sym_taps = CPMNF == 0;
     if (CPMNF == 0) {
-        const double2 *tg = reinterpret_cast<const double2 *>(mf_taps);
+        int lane_zero = 0;
+        asm volatile("" : "+v"(lane_zero));
+        const double2 *tg = reinterpret_cast<const double2 *>(mf_taps) + lane_zero;
+#pragma unroll 1
         for (int j = 0; j < 9; ++j) {
             const double2 t0 = tg[j], t1 = tg[9 + j], t2 = tg[18 + j];
             sym_taps = sym_taps && t1.x == 1.0 && t1.y == 0.0 && t2.x == t0.x && t2.y == -t0.y;
         }
     }
+    const int sym_taps_i = __builtin_amdgcn_readfirstlane(sym_taps ? 1 : 0);   // one scalar word, not a 64-bit lane mask carried through the loops
     const int sps = 8;
     const int sym_per_row = 64;
     const int tile_len = MOD_ROWS * 512;
@@ -604,10 +641,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     }
     const double sec_per_unit = 128.0 * P.inv_sps, sec_phi0 = 128.0 * P.phi0_turns;
     const int l_top0p1 = (q0 - cq) + JMAX;
-    const uint64_t *Wq = reinterpret_cast<const uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
     const double T = scratch[0];
     const double Th_a = T * hvec[0], Th_b = P.nh > 1 ? T * hvec[1] : 0.0;
-    const int lpart = JMAX - cq - P.dsh;        // window index of the first symbol not fully elapsed at the tile edge
     // bank: quad per column, one sum chain per lane
     const int mq = t >> 2, mp = t & 3;
     // The four shared sums of the pulse-truncation bank,
@@ -621,7 +656,6 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     // The column parity of a lane does not change with the row (64 columns per row, tiles start on
     // even symbols).  Tap components in LDS (as registers they cost a fifth wave per SIMD).
     __shared__ double s_tapc[2 * 4 * 9];
-    __shared__ double2 s_halo[8];
     if (CPMNF == 0 && t < 72) {
         const double2 tp = reinterpret_cast<const double2 *>(mf_taps)[8 - t % 9];
         const int part = (t % 36) / 9;
@@ -638,50 +672,49 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     // only the run's last tile has to compute the 8 samples after it itself (a whole extra row step for
     // wave 0: 6 % of a tile when every tile did it).
     const int64_t per_blk = (P.ntiles + gridDim.x - 1) / gridDim.x;
-    const int64_t lt0 = (int64_t)blockIdx.x * per_blk, lt1 = lt0 + per_blk < P.ntiles ? lt0 + per_blk : P.ntiles;
-    for (int64_t ltile = lt0; ltile < lt1; ++ltile) {
-        const bool run_first = ltile == lt0, run_last = ltile + 1 == lt1;
+    const int64_t lt0_ = (int64_t)blockIdx.x * per_blk, lt1_ = lt0_ + per_blk < P.ntiles ? lt0_ + per_blk : P.ntiles;
+    const int lt0 = (int)lt0_, lt1 = (int)lt1_;       // (the host checks ntiles < 2^31: one scalar register each across the loops)
+    if (lt0 == 0 && P.tile_lo == 0)                           // samples before the burst (row -1 of tile 0): ring row 1 and the group before it
+        for (int k = t; k < 512 + 64 + 9; k += MOD_THREADS) s_ring[(MCB_RING / 512 - 1) * 576 - 9 + k] = make_double2(0.0, 0.0);
+    bool run_first = true;
+    for (int ltile = lt0; ltile < lt1; ++ltile, run_first = false) {
+        const bool run_last = ltile + 1 == lt1;
+        // this tile's view of the arguments (see mcb_kargs): what only the tile prologue needs dies there
+        auto kt = KA0;
+        MCB_FRESH(kt);
+        const auto &P = kt->P;
+        const auto &Q = kt->Q;
+        const int8_t *__restrict__ const symbols = kt->symbols;
+        const double *__restrict__ const hvec = kt->hvec;
+        double *__restrict__ const rows = kt->rows;
         // a window of a longer stream: local tile `ltile` is tile `tile` of the burst (P.tile_lo = 0,
         // P.ntiles = all of them for a one-shot burst); carries Wq are indexed locally, everything
         // else (symbols via mod_amp, samples, noise, columns) in burst coordinates
         const int64_t tile = P.tile_lo + ltile;
         const int64_t tile_base = tile * tile_len;
         const int64_t sym_base = tile_base / sps;
-        const int64_t mp1_lo = sym_base + cq - JMAX + 1;
+        const int cq_t = P.c / sps;                 // (= cq; per tile, so that it and what hangs on it are not carried across the row loop)
+        const int64_t mp1_lo = sym_base + cq_t - JMAX + 1;
+        const int lpart = JMAX - cq_t - P.dsh;      // window index of the first symbol not fully elapsed at the tile edge
         const bool full_tile = tile_base + tile_len <= P.out_len;
         // columns this tile may store, relative to its first symbol (32-bit tests per row)
         const int64_t klo64 = Q.k_lo - sym_base, khi64 = Q.k_hi - sym_base;
         const int klo = klo64 < -(1 << 20) ? -(1 << 20) : (int)klo64, khi = khi64 > (1 << 20) ? (1 << 20) : (int)khi64;
         wf_lds_barrier();                                     // previous tile's columns are done with the ring and the window
-        if (tile == 0)                                        // samples before the burst (row -1): ring row 3 and the group before it
-            for (int k = t; k < 512 + 64 + 9; k += MOD_THREADS) s_ring[(MCB_RING / 512 - 1) * 576 - 9 + k] = make_double2(0.0, 0.0);
-        mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot);
+        // The prologue's thread index is opaque per tile: otherwise every lane predicate and index of the
+        // staging code below (t * 5 + e, lane == 63, t < 4, ...) is hoisted out of the tile loop as a
+        // loop invariant and then SPILLED around the row loop (SGPR pairs for the masks, scratch for the indices).
+        int tp = t;
+        asm volatile("" : "+v"(tp));
+        mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot, tp);
+        const uint64_t *Wq = reinterpret_cast<const uint64_t *>(kt->scratch + MOD_OFF_P + P.ntiles);
         const double W = (double)Wq[ltile] * 0x1.0p-62 * P.sps_d;             // tile carry (tile 0: the head truncation -K0)
         const int ref_a = s_pi[lpart], ref_b = P.nh > 1 ? s_pi[win + 1 + lpart] : 0;
-        // the first 8 samples of the NEXT tile (lanes 0..3 of wave 0), by that tile's own row-0 expressions:
-        // its carry, its window = this one shifted by a tile's symbols (counts are differences: same integers)
-        if (run_last && wave == 0 && lane < 4) s_halo[2 * lane] = s_halo[2 * lane + 1] = make_double2(0.0, 0.0);
-        if (run_last && wave == 0 && ltile + 1 < P.ntiles) {   // (the last tile of a window is itself halo: its last columns belong to the next chunk)
-            double2 h0 = make_double2(0.0, 0.0), h1 = h0;
-            const double Wn = (double)Wq[ltile + 1] * 0x1.0p-62 * P.sps_d;
-            const int shift = MOD_ROWS * sym_per_row;
-            const int refn_a = s_pi[lpart + shift], refn_b = P.nh > 1 ? s_pi[win + 1 + lpart + shift] : 0;
-            double ra, rb;
-            mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + shift], &s_pi[(q0 - cq) + shift], wrap, any_wrap, P.nh, win + 1, refn_a, refn_b,
-                                 Wn, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb);
-            double2 e0, e1;
-            wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
-            wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
-            const int64_t n0 = tile_base + tile_len + 2 * lane;
-            double g[4];
-            wf_gaussian_two(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, Q.seed, Q.sigma, tb, g);
-            if (n0 < P.out_len) h0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
-            if (n0 + 1 < P.out_len) h1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
-            if (lane < 4) {                                   // parked until row 15 has been consumed (same wave reads it back)
-                s_halo[2 * lane] = h0;
-                s_halo[2 * lane + 1] = h1;
-            }
-        }
+        // The first 8 samples of the NEXT tile — the last columns of row 15 look at them — are computed by the
+        // run's last tile itself as "row 16" (row_step below: wave 0, the next tile's own carry; its window is
+        // this one shifted by a tile's symbols, counts are differences: same integers, same expressions, so the
+        // samples are bit-identical to the next tile's own row 0).  The last tile of a stream window is itself
+        // halo (its last columns belong to the next chunk): zeros.
         // The ring is indexed by i' = (sample - d) mod 2048, d = offset of the window starts inside
         // the symbol grid: every window then starts on a pad-group boundary (8 samples + 1 pad slot),
         // so its 9 samples sit at CONSTANT slot offsets 0..7 and 9 from the group's first slot —
@@ -718,7 +751,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
 #pragma unroll
                     for (int f = 0; f < FPT; ++f) o[f] = make_double2(zr[f], zi[f]);
                 }
-            } else if (sym_taps) {
+            } else if (sym_taps_i != 0) {
                 const double *xb = ring_d + 2 * (9 * grp) + (mp & 1);
                 double S = 0.0, U = 0.0;
 #pragma unroll
@@ -745,11 +778,23 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                 if (k_ok) rows[4 * (k - Q.k_lo) + mp] = acc;
             }
         };
-#pragma unroll WF_MCB_UNROLL
-        for (int u = 0; u < MOD_ROWS; ++u) {
+        // One row: 512 samples by the 256 threads (EXTRA: "row 16", only what row 15's columns still need).
+        auto row_step = [&](const int u) __attribute__((always_inline)) {
+            const bool EXTRA = u >= MOD_ROWS;                   // (uniform; false for every row but the run's last one)
+            double2 x0 = make_double2(0.0, 0.0), x1 = x0;
+            bool have_next = true;
+            if (!EXTRA || wave_u == 0) {
+            double Wu = W;
+            int refu_a = ref_a, refu_b = ref_b;
+            if (EXTRA) {                                        // the next tile's carry and reference counts (fetched here: nothing of row 16 is live across the other rows)
+                have_next = ltile + 1 < P.ntiles;
+                Wu = have_next ? (double)Wq[ltile + 1] * 0x1.0p-62 * P.sps_d : 0.0;
+                refu_a = s_pi[lpart + MOD_ROWS * sym_per_row];
+                refu_b = P.nh > 1 ? s_pi[win + 1 + lpart + MOD_ROWS * sym_per_row] : 0;
+            }
             double ra, rb;
             mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap, P.nh,
-                                 win + 1, ref_a, ref_b, W, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb);
+                                 win + 1, refu_a, refu_b, Wu, Th_a, Th_b, 8.0, 0.125, ra, rb);   // (sps = 8 here: P.sps_d, P.inv_sps as literals)
             double2 e0, e1;
             wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
             wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
@@ -770,11 +815,12 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                 wf_gaussian_two(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
             }
 #endif
-            double2 x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
-            double2 x1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
-            if (!full_tile) {                                   // (tile-uniform) samples past the end of the burst are zeros to the bank
-                if (n0 >= P.out_len) x0 = make_double2(0.0, 0.0);
-                if (n0 + 1 >= P.out_len) x1 = make_double2(0.0, 0.0);
+            x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
+            x1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
+            if (EXTRA || !full_tile) {                          // (tile-uniform) samples past the end of the burst are zeros to the bank
+                if (n0 >= P.out_len || (EXTRA && !have_next)) x0 = make_double2(0.0, 0.0);
+                if (n0 + 1 >= P.out_len || (EXTRA && !have_next)) x1 = make_double2(0.0, 0.0);
+            }
             }
             // Two-row ring: row u takes the slots of row u - 2, whose last readers are the waves still in
             // bank_row(u - 2) ...
@@ -782,10 +828,12 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
             wf_lds_barrier();
 #endif
             const int ia = ((u << 9) + 2 * t - Q.d) & (MCB_RING - 1), ib = (ia + 1) & (MCB_RING - 1);
-            s_ring[ia + (ia >> 3)] = x0;
-            s_ring[ib + (ib >> 3)] = x1;
-            if (ia == 0) s_ring[MCB_RING + MCB_RING / 8] = x0;  // index 2048: read by the window that ends the ring
-            if (ib == 0) s_ring[MCB_RING + MCB_RING / 8] = x1;
+            if (!EXTRA || t < 4) {                              // (row 16: its first 8 samples; the lanes above computed on window slots that do not exist)
+                s_ring[ia + (ia >> 3)] = x0;
+                s_ring[ib + (ib >> 3)] = x1;
+                if (ia == 0) s_ring[MCB_RING + MCB_RING / 8] = x0;  // index 2048: read by the window that ends the ring
+                if (ib == 0) s_ring[MCB_RING + MCB_RING / 8] = x1;
+            }
             // ... and row u is complete after this barrier — one more barrier per row than a four-row
             // ring, 18 KB less LDS (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
 #ifndef WF_ABL_MCB_NOBAR2   // ablation only
@@ -794,20 +842,18 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
 #ifndef WF_ABL_MCB_NOBANK   // ablation only
             if (u >= 1 || !run_first || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);   // u = 0: the previous tile's row 15
 #endif
+        };
+        // two rows per trip, ONE copy of the row code: row 16 goes through the same loop body (a separate
+        // inlined copy — or the compiler's remainder loop — is a second 1200-instruction body whose
+        // temporaries, added to everything live across the row loop, were what spilled)
+        const int nrow = run_last ? MOD_ROWS + 1 : MOD_ROWS;
+#pragma unroll 1
+        for (int u = 0; u < nrow; u += 2) {
+            row_step(u);
+            if (u + 1 < nrow) row_step(u + 1);
         }
-        if (!run_last) continue;
-        wf_lds_barrier();                                     // every wave is done with row 14
-        if (wave == 0 && lane < 4) {                          // row 16's first 8 samples
-            const int ia = (2 * lane - Q.d) & (MCB_RING - 1), ib = (ia + 1) & (MCB_RING - 1);
-            const double2 h0 = s_halo[2 * lane], h1 = s_halo[2 * lane + 1];
-            s_ring[ia + (ia >> 3)] = h0;
-            s_ring[ib + (ib >> 3)] = h1;
-            if (ia == 0) s_ring[MCB_RING + MCB_RING / 8] = h0;
-            if (ib == 0) s_ring[MCB_RING + MCB_RING / 8] = h1;
-        }
-        wf_lds_barrier();
-        bank_row(MOD_ROWS - 1);
     }
+#undef MCB_FRESH
 }
 
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
@@ -950,7 +996,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     if (J > 9) return 1;
     WF_REQUIRE(first + (k_lo + ncols - 1) * 8 < P.out_len, "wf_mod_chan_bank: columns run past the burst");
     if (ntiles < 0) ntiles = P.ntiles;
-    WF_REQUIRE(tile_lo >= 0 && ntiles >= 1 && tile_lo + ntiles <= P.ntiles, "wf_mod_chan_bank: bad tile window");
+    WF_REQUIRE(tile_lo >= 0 && ntiles >= 1 && tile_lo + ntiles <= P.ntiles && ntiles < (int64_t)1 << 31, "wf_mod_chan_bank: bad tile window");
     P.sym_origin = sym_origin;
     P.nloc = nloc;
     P.tile_lo = tile_lo;

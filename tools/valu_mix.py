@@ -1,6 +1,6 @@
 """Static VALU class mix of every kernel of libwfhip.so (CPU box: hipcc -S of the in-tree sources).
 
-    python tools/valu_mix.py [--out profiles/r02_valu_mix.json]
+    python tools/valu_mix.py [--out profiles/r03_valu_mix.json]
 
 For the kernels whose HBM traffic equals their algorithmic bytes but whose HBM fraction is low, the
 bound is vector-instruction ISSUE.  bench.py prices a launch as
@@ -31,6 +31,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 CSRC = ROOT / "waveforms_amd" / "csrc"
 COST = {"full": 4.2, "fast": 2.3, "trans64": 16.2, "trans32": 8.2}
+LOOP_WEIGHT = 16     # assumed trips per loop level when weighting the static mix by loop depth
 
 
 def classify(op: str) -> str:
@@ -47,28 +48,45 @@ def classify(op: str) -> str:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=str(ROOT / "profiles" / "r02_valu_mix.json"))
+    ap.add_argument("--out", default=str(ROOT / "profiles" / "r03_valu_mix.json"))
     a = ap.parse_args()
     from waveforms_amd.csrc.build import FLAGS, SOURCES, _digest
 
-    kernels = {}
+    kernels, loopw = {}, {}
     for src in SOURCES:
         asm = subprocess.run(["/opt/rocm/bin/hipcc", *[f for f in FLAGS if f != "-fPIC"], "-S", "--cuda-device-only", str(CSRC / src), "-o", "-"],
                              capture_output=True, text=True, check=True).stdout
         cur = None
+        depth, in_label = 0, False
         for line in asm.splitlines():
             m = re.match(r"^(_Z\w+):\s*(;.*)?$", line)
             if m:
                 cur = m.group(1)
                 kernels[cur] = {c: 0 for c in COST}
+                loopw[cur] = {c: 0.0 for c in COST}
+                depth, in_label = 0, False
                 continue
             if cur and re.match(r"^\s+s_endpgm", line):
                 cur = None
                 continue
             if cur:
+                # basic-block labels carry the loop depth LLVM computed: "; in Loop: Header=BBx_y Depth=N" or
+                # "; =>This [Inner] Loop Header: Depth=N" (possibly on the comment lines that follow the label);
+                # "Parent Loop" / "Child Loop" lines describe OTHER loops
+                if re.match(r"^(\.LBB\w+:|; %bb\.\d+:)", line):
+                    depth, in_label = 0, True
+                if in_label and (line.startswith(".LBB") or line.lstrip().startswith(";")):
+                    if "Child Loop" not in line and "Parent Loop" not in line:
+                        dm = re.search(r"(?:in Loop: Header=\w+|Loop Header:) Depth=(\d+)", line)
+                        if dm:
+                            depth = max(depth, int(dm.group(1)))
+                else:
+                    in_label = False
                 mm = re.match(r"^\s+(v_\w+)", line)
                 if mm:
-                    kernels[cur][classify(mm.group(1))] += 1
+                    cls = classify(mm.group(1))
+                    kernels[cur][cls] += 1
+                    loopw[cur][cls] += float(LOOP_WEIGHT ** depth)
     names = subprocess.run(["c++filt"], input="\n".join(kernels), capture_output=True, text=True).stdout.splitlines()
     out = {}
     for mangled, dem in zip(kernels, names):
@@ -77,9 +95,13 @@ def main():
         n = sum(c.values())
         if n < 20:
             continue
+        lw = loopw[mangled]
         out[short] = {**c, "valu_static": n,
-                      "avg_cycles_per_valu": round(sum(COST[k] * v for k, v in c.items()) / n, 3)}
-    doc = {"note": "static VALU class mix per kernel (hipcc -S of the in-tree sources); issue cost per wave64 instruction per SIMD "
+                      "avg_cycles_per_valu": round(sum(COST[k] * v for k, v in c.items()) / n, 3),
+                      # each instruction weighted LOOP_WEIGHT ** (loop depth of its basic block): what the loops execute
+                      "avg_cycles_per_valu_loop": round(sum(COST[k] * v for k, v in lw.items()) / max(sum(lw.values()), 1e-9), 3)}
+    doc = {"note": "static VALU class mix per kernel (hipcc -S of the in-tree sources; avg_cycles_per_valu_loop weights every instruction "
+                   f"by {LOOP_WEIGHT} ** loop depth of its basic block, i.e. it is the mix of what the inner loops execute); issue cost per wave64 instruction per SIMD "
                    f"by class: {COST} shader cycles (tools/valu_probe.hip on MI355X, profiles/r02_valu_probe.json)",
            "build_digest": _digest(), "simds": 1024, "kernels": out}
     Path(a.out).write_text(json.dumps(doc, indent=1) + "\n")

@@ -22,6 +22,8 @@
 // Chunks start `warmup` calls early from a fresh detector and every launch PROVES that each chunk
 // began from bitwise the (metric, phase index, decision register) its predecessor ended with, as
 // wf_viterbi.hip does for the 4-state SOQPSK detector.
+#include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -33,11 +35,22 @@
 #define CPM_GROUPS 4            // 16-lane detectors per wave
 #define CPM_TB 4                // calls per staged batch of rows
 #define CPM_DEFAULT_WARMUP 256
+// Candidate exchange of one wave: SLOT-major, candidate j of end lane L at word j * CPM_XS + L.  A lane's M
+// incoming candidates are then M conflict-free 8 B column reads (two ds_read2_b64), and the scattered
+// writes of one input symbol u — in every group the 4 (or NC) end states with that newest symbol, slots
+// 0..M-1 — fall into distinct banks: 8 B words, stride 68 = 64 + 4, so slot j starts 8 banks further.
+// (The first layout, [lane][4 slots], put the 16-lane passes of the 16 B reads on 8 bank groups — two-way
+// conflicts — and all four groups' writes of one symbol on the same 32 banks: 16 % of the LDS cycles of the
+// ARTM detector and 42 % of the PCM/FM one were bank conflicts, profiles/r03_pmc_cpmvit_*.json.)
+#define CPM_XS 68
+#define CPM_ROT_SIN 128     // rotation table: cos at [r], sin at [CPM_ROT_SIN + r], r < 2p <= 128 (a compile-time distance: one ds_read2_b64)
 
 struct cpm_tables {
     // variant kv: 0 / 1 = the symbol leaving the window uses K[0] / K[1]; 2 = it is a virtual
     // pre-start symbol (no phase).  dest[kv][s][u] = 4 * end_state + slot of branch (s, u);
-    // info[kv][e][j] = src | u << 4 | ((K * u_old) mod p) << 8 for slot j of end state e.
+    // info[kv][e][j] = src | u << 4 | delta << 8 for slot j of end state e, delta = (2 (K u_old mod p) - (M - 1) K) mod 2p:
+    // what the branch adds to the survivor's TILTED phase index r = (2 v - tilt) mod 2p (v: phase index mod p,
+    // tilt: (M - 1) * sum of K over the symbols that left the window) — the rotation table's own index.
     uint8_t dest[3][16][4];
     uint16_t info[3][16][4];
 };
@@ -45,7 +58,7 @@ struct cpm_tables {
 struct cpm_vit_params {
     int M, lgM, p, nh, K0, K1, Lp, NC, D, S, NF;
     int CH, W;
-    int64_t ncalls;
+    int64_t ncalls, nchunks;
     int rows_off, xch_off, dec_off, wave_bytes, rot_off;   // dynamic LDS layout (bytes)
     cpm_tables T;
 };
@@ -111,7 +124,7 @@ __device__ __forceinline__ void cpm_wave_sync()
 }
 
 // Device-resident detector state (WF_CPM_STATE_BYTES): words 0..63 current, 64..127 staging.
-//   [0] calls made (as int64), [1..16] metrics (double), [17..32] phase indices (int64),
+//   [0] calls made (as int64), [1..16] metrics (double), [17..32] tilted phase indices r (int64),
 //   [33..48] decision registers (uint64)
 #define CPM_ST_N 0
 #define CPM_ST_M 1
@@ -119,11 +132,19 @@ __device__ __forceinline__ void cpm_wave_sync()
 #define CPM_ST_H 33
 #define CPM_ST_STAGE 64
 
-// edge buffer per wave: [0] group 0's start state, [1] group 3's end state; 16 lanes x 3 words each
+// proof record per CHUNK: [0] the state its own calls started from, [1] the state it ended with; 16 lanes x 3
+// words each (metric, phase index, decision register).  cpm_verify_kernel compares chunk c's start with chunk
+// c - 1's end.  (Until round 3 the start state stayed in five registers per lane for an in-kernel compare.)
 #define CPM_EDGE_WORDS (2 * 16 * 3)
 
+// Waves per SIMD the register allocator is held to: 5 (<= 96 registers) for the binary trellises with
+// up to 4 filters (left alone they took 97 / 98: one register over), 4 (<= 128) for ARTM's 16 filters per
+// call (quaternary, one-symbol filters: 101 — at 96 it spills).
+#ifndef CPM_MIN_WAVES
+#define CPM_MIN_WAVES(M, LP) ((M) == 2 && (LP) <= 2 ? 5 : ((M) == 4 && (LP) == 3 ? 2 : 4))
+#endif
 template <int M_, int LP_>
-__global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 *__restrict__ rows,
+__global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viterbi_kernel(const double2 *__restrict__ rows,
                                                                   const double2 *__restrict__ rot_cs,
                                                                   uint8_t *__restrict__ out, uint64_t *__restrict__ state,
                                                                   uint64_t *__restrict__ edge,
@@ -142,10 +163,16 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
     const int corr = s / P.NC;
     char *wbase = smem + wave * P.wave_bytes;
     double2 *rowbuf = reinterpret_cast<double2 *>(wbase + P.rows_off) + g * PIECES;
-    double *xch = reinterpret_cast<double *>(wbase + P.xch_off);      // [64 lanes][4 slots] + 1 dump slot
+    double *xch = reinterpret_cast<double *>(wbase + P.xch_off);      // [4 slots][CPM_XS] (see CPM_XS)
     uint8_t *dec = reinterpret_cast<uint8_t *>(wbase + P.dec_off) + g * P.CH;
-    double2 *rot = reinterpret_cast<double2 *>(smem + P.rot_off);
-    for (int k = threadIdx.x; k < 2 * P.p; k += CPM_THREADS) rot[k] = rot_cs[k];
+    // rotation table as two 8 B columns (cos | sin): 2p <= 128 distinct entries land in distinct banks (equal
+    // entries are broadcast); as 16 B pairs entries 16 apart shared their banks
+    double *rot = reinterpret_cast<double *>(smem + P.rot_off);
+    for (int k = threadIdx.x; k < 2 * P.p; k += CPM_THREADS) {
+        const double2 e = rot_cs[k];
+        rot[k] = e.x;
+        rot[CPM_ROT_SIN + k] = e.y;
+    }
     __syncthreads();
 
     const int64_t n0 = state ? (int64_t)state[CPM_ST_N] : 0;          // calls made before this launch
@@ -165,18 +192,19 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
 
     // detector registers of this state
     double m = active ? 0.0 : INFINITY;
-    int v = s % P.NC;
+    // The survivor's phase is carried as the TILTED index r = (2 v - tilt) mod 2p, the index of its rotation:
+    // a branch adds one table constant to it (cpm_tables), where v and the tilt kept apart cost two modular
+    // updates and the index arithmetic on every call.
+    const int64_t k_start = chunk == 0 ? 0 : k_first - P.W;            // first call this group really runs
+    int r = 2 * (s % P.NC) - cpm_tilt_at(P, n0 + k_start);
+    r += r < 0 ? 2 * P.p : 0;
     uint64_t hist = 0;
     if (state && chunk == 0 && n0 > 0) {                               // continue the carried detector
         m = active ? __longlong_as_double((long long)state[CPM_ST_M + s]) : INFINITY;
-        v = (int)state[CPM_ST_V + s];
+        r = (int)state[CPM_ST_V + s];
         hist = state[CPM_ST_H + s];
     }
-    const int64_t k_start = chunk == 0 ? 0 : k_first - P.W;            // first call this group really runs
-    int tilt = cpm_tilt_at(P, n0 + k_start);
-    double ms_m = m;
-    int ms_v = v;
-    uint64_t ms_h = hist;
+    uint64_t *const erec = edge + chunk * CPM_EDGE_WORDS;               // (written only when the chunk is live)
 
     // cooperative row fetch: piece q = s + 16 i of the batch's CPM_TB * NF pieces
     auto fetch = [&](int b, double2 (&dst)[PL]) __attribute__((always_inline)) {
@@ -193,13 +221,19 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
             dst[i] = vit_ld16_c(rows + row * NF + (qq - (qq / NF) * NF));
         }
     };
-    // LDS word index of the slot each of this lane's M candidates goes to, per variant (the dump
-    // slot for lanes that hold no state)
-    int xslot[3][M];
+    // LDS word index of the slot each of this lane's M candidates goes to (dest = 4 * end state + slot), for
+    // the two real variants; the third (virtual pre-start symbols: the first Lp - 1 calls of a burst) is
+    // worked out where it is used.  Lanes that hold no state park theirs in their own column, which only
+    // they read (and ignore).
+    auto slot_of = [&](uint32_t dsel_kv, int u) __attribute__((always_inline)) {
+        const int dst = (int)((dsel_kv >> (8 * u)) & 0xFFu);
+        return active ? (dst & 3) * CPM_XS + g * 16 + (dst >> 2) : u * CPM_XS + lane;
+    };
+    int xslot[2][M];
 #pragma unroll
-    for (int kv = 0; kv < 3; ++kv)
+    for (int kv = 0; kv < 2; ++kv)
 #pragma unroll
-        for (int u = 0; u < M; ++u) xslot[kv][u] = active ? g * 64 + (int)((dsel[kv] >> (8 * u)) & 0xFFu) : 256;
+        for (int u = 0; u < M; ++u) xslot[kv][u] = slot_of(dsel[kv], u);
     const double2 *zlane = rowbuf + M * corr;
     const int dshift = LGM * (P.D - 1);
 
@@ -217,55 +251,54 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
             const int64_t m_old = n - LP_ + 1;
             kv = m_old < 0 ? 2 : (P.nh == 2 ? (int)(m_old & 1) : 0);
         }
-        const int K_old = kv == 2 ? 0 : (kv ? P.K1 : P.K0);
         const uint32_t il = kv == 0 ? ilo[0] : (kv == 1 ? ilo[1] : ilo[2]);
         const uint32_t ih = kv == 0 ? ihi[0] : (kv == 1 ? ihi[1] : ihi[2]);
-        int r = 2 * v - tilt;
-        r += r < 0 ? 2 * P.p : 0;
-#ifdef WF_ABL_CPM_NOROT     // ablation only: no dependent table read
-        const double2 cs = make_double2(1.0 - 1e-3 * r, 1e-3 * r);
-#else
-        const double2 cs = rot[r];
-#endif
+        const double2 cs = make_double2(rot[r], rot[CPM_ROT_SIN + r]);        // (one ds_read2_b64)
         const double2 *zrow = zlane + tt * NF;
+        // all M filter outputs first, then the candidates: rows and exchange slots live in the same LDS array,
+        // so a read placed after a slot write is kept behind it — read, wait, write, read, wait, ... put M
+        // dependent LDS round trips on every call's critical path
+        double2 zz[M];
+#ifndef CPM_HOIST_Z
+#define CPM_HOIST_Z(M) ((M) == 2)   // (M = 4: the 16 extra live registers spill; measured 3 % slower)
+#endif
+        if (CPM_HOIST_Z(M)) {
+#pragma unroll
+            for (int u = 0; u < M; ++u) zz[u] = zrow[u];
+        }
 #pragma unroll
         for (int u = 0; u < M; ++u) {
-            const double2 z = zrow[u];
+            const double2 z = CPM_HOIST_Z(M) ? zz[u] : zrow[u];
             const double inc = -fma(cs.x, z.x, cs.y * z.y);             // -Re(e^{-j theta} Z)
-            xch[kv == 0 ? xslot[0][u] : (kv == 1 ? xslot[1][u] : xslot[2][u])] = m + inc;
+            xch[kv == 0 ? xslot[0][u] : (kv == 1 ? xslot[1][u] : slot_of(dsel[2], u))] = m + inc;
         }
         cpm_wave_sync();
         double c[M];
-        if constexpr (M == 4) {
-            const double2 a0 = *reinterpret_cast<const double2 *>(xch + lane * 4);
-            const double2 a1 = *reinterpret_cast<const double2 *>(xch + lane * 4 + 2);
-            c[0] = a0.x; c[1] = a0.y; c[M - 2] = a1.x; c[M - 1] = a1.y;
-        } else {
-            const double2 a0 = *reinterpret_cast<const double2 *>(xch + lane * 4);
-            c[0] = a0.x; c[1] = a0.y;
-        }
-        double best = c[0];
-        int w = 0;
 #pragma unroll
-        for (int j = 1; j < M; ++j) {
-            const bool lt = c[j] < best;                               // strict '<': the first listed branch keeps a tie
-            best = lt ? c[j] : best;
-            w = lt ? j : w;
+        for (int j = 0; j < M; ++j) c[j] = xch[j * CPM_XS + lane];
+        // First arg-min over the M slots in list order (strict '<': the first listed branch keeps a tie), as a
+        // tree of v_min_f64 + compare — the winner's index only exists as lane masks (the compares' SGPR
+        // pairs), combined on the scalar unit; a select chain cost two v_cndmask per comparison more.
+        double best;
+        uint32_t inf;                                                   // the winner's table entry in the low 16 bits (junk above)
+        if constexpr (M == 4) {
+            const unsigned long long f01 = __builtin_amdgcn_ballot_w64(c[1] < c[0]), f23 = __builtin_amdgcn_ballot_w64(c[3] < c[2]);
+            const double b01 = cpm_min_raw(c[0], c[1]), b23 = cpm_min_raw(c[2], c[3]);
+            const unsigned long long f = __builtin_amdgcn_ballot_w64(b23 < b01);
+            best = cpm_min_raw(b01, b23);
+            const uint32_t pair = __builtin_amdgcn_inverse_ballot_w64(f) ? ih : il;
+            inf = pair >> (__builtin_amdgcn_inverse_ballot_w64((f & f23) | (~f & f01)) ? 16 : 0);
+        } else {
+            const bool f01 = c[1] < c[0];
+            best = cpm_min_raw(c[0], c[1]);
+            inf = il >> (f01 ? 16 : 0);
         }
-        const uint32_t pair = (w & 2) ? ih : il;
-        const uint32_t inf = (w & 1) ? (pair >> 16) : (pair & 0xFFFFu);
-        const int src = (int)(inf & 15u), u_new = (int)((inf >> 4) & 3u), incmod = (int)((inf >> 8) & 63u);
+        const int src = (int)(inf & 15u), u_new = (int)((inf >> 4) & 3u), delta = (int)((inf >> 8) & 0x7Fu);
         const int baddr = ((lane & 48) | src) << 2;
-#ifdef WF_ABL_CPM_NOBPERM   // ablation only: no cross-lane fetch of the winner's registers
-        int nv = v + incmod + (baddr & 4);
-        nv -= nv >= P.p ? P.p : 0;
-        const uint64_t nh_ = (hist << LGM) | (uint64_t)u_new;
-#else
-        int nv = __builtin_amdgcn_ds_bpermute(baddr, v) + incmod;
-        nv -= nv >= P.p ? P.p : 0;
+        int nr = __builtin_amdgcn_ds_bpermute(baddr, r) + delta;
+        nr -= nr >= 2 * P.p ? 2 * P.p : 0;
         const uint64_t nh_ = (cpm_bperm_u64(baddr, hist) << LGM) | (uint64_t)u_new;
-#endif
-        double nm = active ? best : INFINITY;
+        double nm = best;      // (lanes that hold no state: metric +inf, candidates parked in their own column, so best = +inf by itself)
 #ifdef WF_ABL_CPM_NOMIN     // ablation only: no 16-lane all-reduce
         nm -= 0.5 * best;
 #else
@@ -273,10 +306,8 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
 #endif
         if (valid) {
             m = nm;
-            v = nv;
+            r = nr;
             hist = nh_;
-            tilt += (M - 1) * K_old;
-            tilt -= tilt >= 2 * P.p ? 2 * P.p : 0;
         }
         if (emit && (FAST || valid)) {
             // np.argmin: the first state whose metric is the minimum — lowest set bit of each
@@ -288,7 +319,7 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
                 const unsigned long long f = (zero >> (16 * q)) & 0xFFFFull;
                 firstm |= (f & (0ull - f)) << (16 * q);
             }
-            if ((firstm >> lane) & 1ull)
+            if (__builtin_amdgcn_inverse_ballot_w64(firstm))           // (the mask goes straight into exec)
                 dec[t - P.W] = (FAST || n >= P.D - 1) ? (uint8_t)((nh_ >> dshift) & (uint64_t)(M - 1)) : (uint8_t)0;
         }
     };
@@ -318,10 +349,10 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
         fetch(b + 2 < nbatch ? b + 2 : nbatch - 1, pend);               // issued unconditionally (see wf_viterbi.hip)
         cpm_wave_sync();
         const int t0 = b * CPM_TB;
-        if (t0 == P.W) {                                                // the next call is the chunk's first own one
-            ms_m = m;
-            ms_v = v;
-            ms_h = hist;
+        if (t0 == P.W && live) {                                        // the next call is the chunk's first own one
+            erec[3 * s] = (uint64_t)__double_as_longlong(m);
+            erec[3 * s + 1] = (uint64_t)(int64_t)r;
+            erec[3 * s + 2] = hist;
         }
         const bool emit = t0 >= P.W;
         const int64_t kb = k_first - P.W + t0;
@@ -358,50 +389,36 @@ __global__ __launch_bounds__(CPM_THREADS) void cpm_viterbi_kernel(const double2 
             }
         }
     }
-    // proof: this chunk started from bitwise what its predecessor ended with
-    {
-        const int pa = ((lane - 16) & 63) << 2;
-        const double pm = cpm_bperm_f64(pa, m);
-        const int pv = __builtin_amdgcn_ds_bpermute(pa, v);
-        const uint64_t ph = cpm_bperm_u64(pa, hist);
-        // only the D decisions still inside the register can reach an output
-        const uint64_t hmask = LGM * P.D >= 64 ? ~0ull : ((1ull << (LGM * P.D)) - 1ull);
-        bool bad = __double_as_longlong(pm) != __double_as_longlong(ms_m) || pv != ms_v || ((ph ^ ms_h) & hmask) != 0ull;
-        bad = bad && live && active && g > 0;
-        const unsigned long long nb = __builtin_amdgcn_ballot_w64(bad);
-        if (nb && lane == 0) atomicAdd(unmerged, 1ull);
-        uint64_t *e = edge + ((int64_t)blockIdx.x * CPM_WAVES + wave) * CPM_EDGE_WORDS;
-        if (g == 0 && live && s < 16) {
-            e[3 * s] = (uint64_t)__double_as_longlong(ms_m);
-            e[3 * s + 1] = (uint64_t)(int64_t)ms_v;
-            e[3 * s + 2] = ms_h;
-        }
-        if (g == CPM_GROUPS - 1) {
-            // a chunk that is not live leaves an all-ones marker: viterbi verify skips it
-            e[48 + 3 * s] = live ? (uint64_t)__double_as_longlong(m) : ~0ull;
-            e[48 + 3 * s + 1] = (uint64_t)(int64_t)v;
-            e[48 + 3 * s + 2] = hist;
-        }
+    // proof record: what this chunk ended with
+    if (live) {
+        erec[48 + 3 * s] = (uint64_t)__double_as_longlong(m);
+        erec[48 + 3 * s + 1] = (uint64_t)(int64_t)r;
+        erec[48 + 3 * s + 2] = hist;
     }
     if (state && live && k_first + P.CH >= P.ncalls) {                 // the group that owns the last call
         state[CPM_ST_STAGE + CPM_ST_N] = (uint64_t)(n0 + P.ncalls);
         state[CPM_ST_STAGE + CPM_ST_M + s] = (uint64_t)__double_as_longlong(m);
-        state[CPM_ST_STAGE + CPM_ST_V + s] = (uint64_t)(int64_t)v;
+        state[CPM_ST_STAGE + CPM_ST_V + s] = (uint64_t)(int64_t)r;
         state[CPM_ST_STAGE + CPM_ST_H + s] = hist;
     }
 }
 
-// Wave w's first chunk against wave w-1's last one (see the end of cpm_viterbi_kernel).
-__global__ void cpm_verify_kernel(const uint64_t *__restrict__ edge, int64_t nwaves, int S, uint64_t hmask,
+// Every chunk against its predecessor: thread = (chunk c >= 1, state s); one count per chunk that did NOT start
+// from bitwise the (metric, phase index, last D decisions) chunk c - 1 ended with.
+__global__ void cpm_verify_kernel(const uint64_t *__restrict__ edge, int64_t nchunks, int S, uint64_t hmask,
                                   unsigned long long *__restrict__ unmerged)
 {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (w >= nwaves) return;
-    const uint64_t *a = edge + w * CPM_EDGE_WORDS, *b = edge + (w - 1) * CPM_EDGE_WORDS + 48;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = idx / 16 + 1;
+    const int s = (int)(idx & 15);
     bool bad = false;
-    for (int s = 0; s < S; ++s)
-        bad |= a[3 * s] != b[3 * s] || a[3 * s + 1] != b[3 * s + 1] || ((a[3 * s + 2] ^ b[3 * s + 2]) & hmask) != 0ull;
-    if (bad) atomicAdd(unmerged, 1ull);
+    if (c < nchunks && s < S) {
+        const uint64_t *a = edge + c * CPM_EDGE_WORDS, *b = edge + (c - 1) * CPM_EDGE_WORDS + 48;
+        bad = a[3 * s] != b[3 * s] || a[3 * s + 1] != b[3 * s + 1] || ((a[3 * s + 2] ^ b[3 * s + 2]) & hmask) != 0ull;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
+    const int lane = threadIdx.x & 63;
+    if (s == 0 && ((m >> (lane & 48)) & 0xFFFFull)) atomicAdd(unmerged, 1ull);
 }
 
 __global__ void cpm_carry_commit_kernel(uint64_t *state)
@@ -444,7 +461,8 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
                 const int j = fill[s2]++;
                 WF_REQUIRE(j < M, "wf_cpm: internal: more than M branches into a state");
                 P.T.dest[kv][s][u] = (uint8_t)(4 * s2 + j);
-                P.T.info[kv][s2][j] = (uint16_t)(s | (u << 4) | (inc << 8));
+                const int delta = ((2 * inc - (M - 1) * K_old) % (2 * p) + 2 * p) % (2 * p);
+                P.T.info[kv][s2][j] = (uint16_t)(s | (u << 4) | (delta << 8));
             }
         }
         for (int s = 0; s < S; ++s) WF_REQUIRE(fill[s] == M, "wf_cpm: internal: state %d has %d incoming branches", s, fill[s]);
@@ -481,11 +499,13 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     // made 1221 workgroups for 1024 slots — a second, almost empty round of the full chain length.
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const int64_t slots = (int64_t)cus * 4 * CPM_WAVES * CPM_GROUPS;
+    const int wg_per_cu = CPM_MIN_WAVES(P.M, P.Lp);                 // resident workgroups per CU = waves per SIMD (4 waves per workgroup)
+    const int64_t slots = (int64_t)cus * wg_per_cu * CPM_WAVES * CPM_GROUPS;
     int64_t ch = (ncalls + slots - 1) / slots;
     ch = (ch + 63) / 64 * 64;
     if (ch < 256) ch = 256;
     if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
+    if (const char *e = getenv("WF_CPM_CH")) ch = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : ch;   // tuning aid (tools/cpm_vit_time.py)
     if (ch > 8192) ch = 8192;                                      // decision strips live in LDS; longer bursts take several rounds
     // (measured at 1e7 ARTM calls, W = 128: 384 calls per chunk 1.07 ms, 512: 1.03, 640: 1.00, 768: 1.19,
     //  1024: 1.28, 1536: 1.68 — longer chunks do less warm-up work but leave fewer waves to hide the
@@ -496,16 +516,17 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     const int pieces = CPM_TB * P.NF;
     P.rows_off = 0;
     P.xch_off = CPM_GROUPS * pieces * 16;
-    P.dec_off = P.xch_off + (64 * 4 + 2) * 8;
+    P.dec_off = P.xch_off + 4 * CPM_XS * 8;
     P.wave_bytes = (P.dec_off + CPM_GROUPS * P.CH + 15) / 16 * 16;
     P.rot_off = CPM_WAVES * P.wave_bytes;
-    const size_t lds = (size_t)P.rot_off + (size_t)2 * P.p * 16;
+    const size_t lds = (size_t)P.rot_off + (size_t)2 * CPM_ROT_SIN * 8;
     WF_REQUIRE(lds <= 160 * 1024, "wf_cpm_viterbi_detect: chunk of %d calls does not fit LDS", P.CH);
     const int64_t nchunks = (ncalls + P.CH - 1) / P.CH;
     const int64_t nwaves = (nchunks + CPM_GROUPS - 1) / CPM_GROUPS;
     const int64_t nblocks = (nwaves + CPM_WAVES - 1) / CPM_WAVES;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_viterbi_detect: burst too long for one launch");
-    rc = wf_ctx_reserve_vit(ctx, (size_t)nblocks * CPM_WAVES * CPM_EDGE_WORDS);
+    P.nchunks = nchunks;
+    rc = wf_ctx_reserve_vit(ctx, (size_t)nchunks * CPM_EDGE_WORDS);
     if (rc) return rc;
     uint64_t *edge = reinterpret_cast<uint64_t *>(ctx->d_vit_edge);
     hipStream_t s = wf_stream(stream);
@@ -519,9 +540,9 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
                        reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
                        ctx->d_vit_unmerged, P);
     WF_LAUNCH_CHECK();
-    if (nwaves > 1) {
-        const uint64_t hmask = P.lgM * P.D >= 64 ? ~0ull : ((1ull << (P.lgM * P.D)) - 1ull);
-        hipLaunchKernelGGL(cpm_verify_kernel, dim3((unsigned)((nwaves - 1 + 255) / 256)), dim3(256), 0, s, edge, nwaves, P.S,
+    if (nchunks > 1) {
+        const uint64_t hmask = P.lgM * P.D >= 64 ? ~0ull : ((1ull << (P.lgM * P.D)) - 1ull);   // only the D decisions still inside the register can reach an output
+        hipLaunchKernelGGL(cpm_verify_kernel, dim3((unsigned)(((nchunks - 1) * 16 + 255) / 256)), dim3(256), 0, s, edge, nchunks, P.S,
                            hmask, ctx->d_vit_unmerged);
         WF_LAUNCH_CHECK();
     }

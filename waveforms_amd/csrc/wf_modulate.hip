@@ -391,13 +391,28 @@ __device__ __forceinline__ void mod_pair_phase(const double (&Q0)[JMAX], const d
 #endif
 // FULLROW: the row is exactly 2 * MOD_THREADS samples (sps divides 512: every thread is active and
 // every column is in the row), so the per-lane activity tests and their zero fills drop out.
+// The arguments as they lie in the kernarg segment; the kernel reads them through this view from a pointer
+// made opaque once per tile (see mcb_kargs below: held by value, the struct's ~35 uniform words stay live
+// across the kernel and were spilled around the row loop — 21–32 SGPR spills, reloads inside the rows).
+struct mod_kargs {
+    const int8_t *symbols;
+    const double *hvec, *pulse, *scratch;
+    double *out;
+    mod_params P;
+};
+typedef const __attribute__((address_space(4))) mod_kargs *mod_kptr;
+
 template <int JMAX, bool FULLROW>
-__global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(const int8_t *__restrict__ symbols,
-                                                                const double *__restrict__ hvec,
-                                                                const double *__restrict__ pulse,
-                                                                const double *__restrict__ scratch,
-                                                                double *__restrict__ out, mod_params P)
+__global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(const int8_t *__restrict__ symbols_,
+                                                                const double *__restrict__ hvec_,
+                                                                const double *__restrict__ pulse_,
+                                                                const double *__restrict__ scratch_,
+                                                                double *__restrict__ out_, mod_params P_)
 {
+    mod_kptr const KA0 = (mod_kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto &P = KA0->P;
+    const double *__restrict__ const hvec = KA0->hvec;
+    const double *__restrict__ const scratch = KA0->scratch;
     extern __shared__ double s_amp[];       // window of symbol amplitudes, then its prefix counts (ints)
     __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_xp[2 * MOD_THREADS];   // wave-private transpose: pairs per lane -> rows of 64 samples
@@ -428,19 +443,27 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
     const int l_top0p1 = (q0 - cq) + JMAX;
     const int win = MOD_ROWS * sym_per_row + JMAX + 2;
     int *s_pi = reinterpret_cast<int *>(s_amp + ((win + 1) & ~1));
-    const uint64_t *Wq = reinterpret_cast<const uint64_t *>(scratch + MOD_OFF_P + P.ntiles);
     const double T = scratch[0];
     const double Th_a = T * hvec[0], Th_b = P.nh > 1 ? T * hvec[1] : 0.0;
     const int lpart = JMAX - cq - P.dsh;        // window index of the first symbol not fully elapsed at the tile edge
 
     for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        auto kt = KA0;
+        asm volatile("" : "+s"(kt));
+        const auto &P = kt->P;
+        const int8_t *__restrict__ const symbols = kt->symbols;
+        const double *__restrict__ const hvec = kt->hvec;
+        double *__restrict__ const out = kt->out;
+        const uint64_t *Wq = reinterpret_cast<const uint64_t *>(kt->scratch + MOD_OFF_P + P.ntiles);
+        int tp = t;                                       // (opaque per tile: the staging code's lane predicates and indices are not loop invariants to be spilled)
+        asm volatile("" : "+v"(tp));
         const int64_t tile_g = P.tile_lo + tile;          // global tile index
         const int64_t tile_base = tile_g * tile_len;      // global sample index
         const int64_t sym_base = tile_base / sps;
         const int64_t mp1_lo = sym_base + cq - JMAX + 1;
         const bool full_tile = tile_base >= P.out_origin && tile_base + tile_len <= P.out_hi;
         wf_lds_barrier();                                 // the previous tile's rows are done with the window
-        mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot);
+        mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot, tp);
         // carry into the tile: T * S(symbols fully elapsed at the tile edge) - K0, fixed point, from the
         // scan kernel (tile 0: -K0, the head truncation; a stream window: the previous window's export)
         const double W = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;

@@ -69,28 +69,44 @@ def profile_record(stage: str, nsym: int, sps: int):
     return best
 
 
+def _current_digest():
+    try:
+        from waveforms_amd.csrc.build import _digest
+        return _digest()
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def valu_issue(stage: str, rec, launch_ms: float):
     """Vector-issue side of the roofline for kernels whose HBM traffic is already minimal: measured VALU
     wave-instructions per launch (SQ_INSTS_VALU) x average issue cycles per instruction (static class mix of
     the kernel, per-class costs measured by tools/valu_probe.hip) / (1024 SIMDs x shader cycles of the launch).
     The shader cycles are those of the SAME counter pass (GRBM_GUI_ACTIVE / 8 XCDs), so no clock is assumed;
     profiles without that counter fall back to 2.2 GHz x the live launch time."""
-    try:
-        mix = json.loads((ROOT / "profiles" / "r02_valu_mix.json").read_text())
-    except (OSError, ValueError):
+    mix, mix_name = None, None
+    for path in sorted((ROOT / "profiles").glob("r*_valu_mix.json")):       # newest round last
+        try:
+            mix, mix_name = json.loads(path.read_text()), path.name
+        except (OSError, ValueError):
+            continue
+    if mix is None:
         return None
     k = mix["kernels"].get(STAGE_KERNEL.get(stage, ""))
     if not (k and rec and rec.get("valu_insts") and launch_ms > 0):
         return None
-    cycles = rec["valu_insts"] * k["avg_cycles_per_valu"]
+    # mean issue cost of what the loops execute (static mix weighted by loop depth), not of the whole kernel text
+    avg = k.get("avg_cycles_per_valu_loop", k["avg_cycles_per_valu"])
+    cycles = rec["valu_insts"] * avg
     shader_cycles = rec.get("shader_cycles") or 2.2e9 * launch_ms * 1e-3
     frac = cycles / (mix["simds"] * shader_cycles)
     out = {"valu_issue_frac": round(frac, 4), "valu_wave_insts_per_launch": rec["valu_insts"],
-           "avg_issue_cycles_per_valu": k["avg_cycles_per_valu"],
+           "avg_issue_cycles_per_valu": avg, "avg_issue_cycles_whole_kernel_text": k["avg_cycles_per_valu"],
+           "mix": "static class mix weighted by loop depth (tools/valu_mix.py)" if "avg_cycles_per_valu_loop" in k else "static, whole kernel",
            "class_mix_static": {c: k[c] for c in ("full", "fast", "trans64", "trans32") if c in k},
-           "simds": mix["simds"], "shader_cycles_per_launch": int(shader_cycles),
+           "simds": mix["simds"], "issue_cycles_per_launch": int(cycles), "shader_cycles_per_launch": int(shader_cycles),
            "shader_cycles_source": "GRBM_GUI_ACTIVE / 8 in the profile's counter pass" if rec.get("shader_cycles") else "2.2 GHz x live launch time",
-           "source": f"{rec['source']} + r02_valu_mix.json + r02_valu_probe.json"}
+           "mix_matches_build": bool(mix.get("build_digest") and mix.get("build_digest") == _current_digest()),
+           "source": f"{rec['source']} + {mix_name} + r02_valu_probe.json"}
     if rec.get("shader_cycles") and rec.get("avg_ns"):
         out["shader_clock_ghz_in_profile"] = round(rec["shader_cycles"] / rec["avg_ns"], 3)
     return out
@@ -144,7 +160,7 @@ def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int, waveform
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = host_cores
-    cores = max(1, min(usable, 16))          # the CPU share of a one-GPU box is 16 cores
+    cores = max(1, min(usable, 16))          # a 16-core SHARE of the host (what a one-GPU box grants), not all of its cores
     ctx = mp.get_context("spawn")            # never fork a process that has initialised HIP
     out = {}
     with ctx.Pool(cores) as pool:
@@ -164,6 +180,7 @@ def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int, waveform
                 "sample": f"same {waveform} @{sps}sps chain, Eb/N0 {ebn0:.1f} dB, sequential C detector + numpy (the reference has no "
                           f"detector for this waveform: build-defined oracle), PCG64 noise: {o['sample']}"}
     return {"value": out["port"]["value"], "unit": "Msym/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+            "cores_note": f"a {cores}-core share of the host's {host_cores} cores (one process per core), not the whole host",
             "single_core": out["port"]["single_core"],
             "sample": "same SOQPSK-TG @%dsps chain, Eb/N0 %.1f dB, oracle C loops + numpy, PCG64 noise: %s"
                       % (sps, ebn0, out["port"]["sample"]),
@@ -203,10 +220,15 @@ def main() -> None:
                          "blocks in flight on separate HIP streams, reported as `overlapped` (0 = skip)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the per-stage HIP events on every E-th timed step only (the last step always)")
-    ap.add_argument("--vit-warmup", type=int, default=-1, help="SOQPSK detector chunk warm-up rows - 1 (-1: by Eb/N0, 0: library default)")
+    ap.add_argument("--vit-warmup", type=int, default=-1,
+                    help="detector chunk warm-up in rows (= detector calls before a chunk's own first call), any waveform; "
+                         "-1: by Eb/N0 (waveforms_amd.link.operating_point_warmup), 0: library default")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="symbols per core, compiled port")
     ap.add_argument("--cpu-loop-sample", type=int, default=1 << 16, help="symbols per core, faithful-loop form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steady-steps", type=int, default=2000,
+                    help="after the timed region (single GPU): this many more steps in one go, reported as `steady_state` — long "
+                         "enough (>= 1 s) that clock ramp and the 13 ms timed window can be told apart (0 = skip)")
     args = ap.parse_args()
 
     from waveforms_amd.bert import init_ranks, spawn_ranks
@@ -224,24 +246,23 @@ def main() -> None:
     rank, world, dist, coll_dev = init_ranks(rehearsal=os.environ.get("WF_BENCH_REHEARSAL") == "1")
 
     from waveforms_amd import _hip
-    from waveforms_amd.link import SOQPSKLink
+    from waveforms_amd.link import SOQPSKLink, operating_point_warmup, soqpsk_warmup_param
 
     nstreams = max(1, args.streams)
     cpm = args.waveform != "soqpsk"
     if cpm:
         from waveforms_amd.link import CPMLink
 
-        # detector chunk warm-up: the library default is safe at any Eb/N0 (256 / 384 calls); from 8 dB up 128 (multih) /
-        # 192 (pcmfm) left no chunk unproven in tools/cpm_warmup_scan.py — link.result() raises if one ever is
-        cwu = args.vit_warmup if args.vit_warmup >= 0 else ((128 if args.waveform == "multih" else 192) if args.ebn0 >= 8.0 else 0)
+        # detector chunk warm-up rows: by operating point (waveforms_amd.link.operating_point_warmup), or --vit-warmup
+        cwu = args.vit_warmup if args.vit_warmup >= 0 else operating_point_warmup(args.waveform, args.ebn0)
         links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1, fuse=args.fuse, warmup=cwu)
                  for _ in range(nstreams)]
         bits_per_sym = links[0].spec.bits_per_symbol
     else:
-        # detector chunk warm-up: 16 rows at Eb/N0 >= 6 dB with the matched bank (tools/warmup_scan.py: 0 of 2.5e6
-        # chunks unproven from 6 dB up even with 12), the library default (32 rows) below; link.result() raises if
-        # a single chunk of the run was not proven equal to the sequential detector
-        wu = args.vit_warmup if args.vit_warmup >= 0 else (15 if args.ebn0 >= 6.0 else 0)
+        # detector chunk warm-up rows: by operating point (16 at Eb/N0 >= 6 dB, else the library default of 32), or
+        # --vit-warmup; link.result() raises if a single chunk of the run was not proven equal to the sequential detector
+        wu_rows = args.vit_warmup if args.vit_warmup >= 0 else operating_point_warmup("soqpsk", args.ebn0)
+        wu = soqpsk_warmup_param(wu_rows)
         links = [SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse, private_ctx=nstreams > 1, warmup=wu)
                  for _ in range(nstreams)]
         bits_per_sym = 1
@@ -279,8 +300,14 @@ def main() -> None:
         step(k, True)
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        # every rank's own time (all_gather of one double), so that the first real N-GPU run shows imbalance
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -305,7 +332,7 @@ def main() -> None:
         # bits -> symbols -> c128 samples -> noisy samples in place -> nf complex rows -> one decision byte
         bps = {"prbs": bits_per_sym, "map": bits_per_sym + 1, "modulate": 1 + 16 * args.sps, "awgn": 32 * args.sps,
                "mfbank": 16 * args.sps + 16 * nf, "viterbi": 16 * nf + 1, "count": 2}
-        if links[0].cfg.fuse & 8 and acc.get("mfbank", 1.0) < 0.05 * max(acc.get("modulate", 0.0), 1e-9):
+        if links[0].layout()["one_kernel_front_end"]:
             # fuse bit 3 in effect: the "modulate" slot timed modulator + channel + filters (one kernel)
             acc["mod+awgn+mfbank"] = acc.pop("modulate")
             acc.pop("awgn", None)
@@ -346,18 +373,24 @@ def main() -> None:
     dominant = max(acc, key=acc.get)
     d = stages[dominant]
     rec = profile_record(dominant, args.nsym, args.sps)
-    roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dominant, dominant), "stage": dominant,
-                "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(d["GBps"] / HBM_PEAK_GBS, 4), "traffic": rec["traffic"] if rec else None,
+    hbm = {"achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["GBps"] / HBM_PEAK_GBS, 4)}
+    roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dominant, dominant), "stage": dominant, **hbm,
+                "traffic": rec["traffic"] if rec else None,
                 "traffic_source": rec["source"] if rec else None,
                 "traffic_profile_matches_build": rec["current"] if rec else None,
-                "launch_ms": d["ms"], "algorithmic_bytes_per_launch": int(bps[dominant] * args.nsym)}
+                "launch_ms": d["ms"], "algorithmic_bytes_per_launch": int(bps[dominant] * args.nsym),
+                "hbm_frac": hbm["frac"], "hbm": hbm}
     vi = valu_issue(dominant, rec, d["ms"])
-    if vi:      # the bound that actually binds when traffic ~ algorithmic bytes and the HBM fraction is low
-        roofline.update(valu_issue_frac=vi.pop("valu_issue_frac"), valu=vi)
-        # which of the two sides of this kernel's roofline is the higher (= the binding) one
-        binding = "valu_issue" if roofline["valu_issue_frac"] > roofline["frac"] else "hbm"
-        roofline.update(binding=binding, binding_frac=max(roofline["valu_issue_frac"], roofline["frac"]))
+    if vi:
+        # The roofline that BINDS is the one reported as bound / achieved / peak / frac: for the fused kernels HBM
+        # traffic is already minimal and the vector pipe's issue slots are the scarce resource ("the
+        # fully fused pipeline is compute-bound"); the HBM side stays beside it as hbm_frac / hbm.
+        vfrac = vi.pop("valu_issue_frac")
+        roofline.update(valu_issue_frac=vfrac, valu=vi)
+        if vfrac > hbm["frac"]:
+            roofline.update(bound="valu_issue", achieved=vi["issue_cycles_per_launch"],
+                            peak=vi["simds"] * vi["shader_cycles_per_launch"], unit="SIMD issue cycles per launch", frac=vfrac)
+        roofline.update(binding=roofline["bound"], binding_frac=roofline["frac"])
     # every stage with a profile record: its own HBM and issue fractions
     for name, st in stages.items():
         r_ = profile_record(name, args.nsym, args.sps)
@@ -399,6 +432,21 @@ def main() -> None:
                       "same_blocks_same_counts": tot[1] == be and tot[0] == se}
         del extra
 
+    steady = None
+    if world == 1 and nstreams == 1 and args.steady_steps > 0:
+        for l in links:
+            l.reset_counts()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for k in range(args.steady_steps):
+            links[0].run_block(args.ebn0, seed=1, stream_id=k & 0xFFFFFFFF, skip_bits=(k % 4096) * args.nsym * bits_per_sym)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        s2 = links[0].result()                 # raises if a chunk went unproven
+        steady = {"steps": args.steady_steps, "seconds": round(dt2, 3), "ms_per_step": round(dt2 / args.steady_steps * 1e3, 4),
+                  "value": round(args.steady_steps * args.nsym / dt2 / 1e6, 2), "unit": "Msym/s", "bit_errors": int(s2[1]),
+                  "note": "same step, same single stream, outside the driver-timed K steps"}
+
     if rank == 0:
         total_sym = args.steps * args.nsym * world
         out = {
@@ -419,7 +467,8 @@ def main() -> None:
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
                        "fuse": args.fuse, "streams": nstreams,
-                       "detector_warmup_rows": (links[0].cfg.warmup or "library default") if cpm else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32), "parallelism": f"independent trial blocks x{world}"},
+                       "detector_warmup_rows": (links[0].cfg.warmup or ("320 (library default)" if args.waveform == "multih" else "384 (library default)")) if cpm
+                                               else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32), "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared * bits_per_sym, 1),
                     # link.result() raises otherwise: every detector chunk started from bitwise the
@@ -430,7 +479,12 @@ def main() -> None:
         }
         if overlapped:
             out["overlapped"] = overlapped
-        if not args.no_cpu_baseline and world == 1:
+        if steady:
+            out["steady_state"] = steady
+        if world > 1:
+            out["per_rank_ms_per_step"] = [round(v, 4) for v in rank_ms]
+            out["rank_time_max_over_min"] = round(max(rank_ms) / max(min(rank_ms), 1e-12), 4)
+        if not args.no_cpu_baseline:    # rank 0 only, after the timed region, at any N (the other ranks wait at the final barrier)
             out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample, args.waveform)
         print(json.dumps(out), flush=True)
     if dist is not None:

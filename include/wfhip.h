@@ -385,7 +385,8 @@ typedef struct {
 int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg);
 int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
                     int64_t *d_counts, int64_t *h_compared, void *stream);
-/* info8 = {ncalls, start0, off(decisions), off(symbols alpha), off(signal), 0, signal samples, off(rows)} */
+/* info8 = {ncalls, start0, off(decisions), off(symbols alpha), off(signal), one_kernel (1: fuse bits 1 + 3 run modulator +
+ * channel + filters as one kernel for this configuration), signal samples, off(rows)} */
 int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8);
 
 /* ---- data products of the reference's plotting helpers (no plotting) ------------------
@@ -402,7 +403,7 @@ int wf_welch_psd_c128(wf_ctx *ctx, const double *d_x_ri, int64_t n, int nfft, do
 int wf_phase_tree_f64(wf_ctx *ctx, const double *d_x_ri, int64_t n, int sps, int modulo, int use_first, double off,
                       double *d_out, void *stream);
 /* Eye-diagram traces (waveforms/viz/eye.py:40-55): (n-1)/len traces of len+1 points, len = sps*modulo:
- * time axis (time - time[start]) + t_offset, real and imaginary planes. */
+ * time axis (time - time[start]) + t_offset, real and imaginary planes.  BOTH d_time and d_x_ri must hold n elements. */
 int wf_eye_traces_c128(wf_ctx *ctx, const double *d_time, const double *d_x_ri, int64_t n, int sps, int modulo,
                        double t_offset, double *d_t_out, double *d_re_out, double *d_im_out, void *stream);
 

@@ -57,7 +57,7 @@ def test_gpu_ber_curve_within_0p05_db_of_reference(detector):
 
     from waveforms.bert import SweepPlan, ber_sweep, ebn0_at_ber
 
-    ebn0 = list(range(6, 13))
+    ebn0 = list(range(0, 13))           # all 13 points of BASELINE configs[3] (0 .. 12 dB)
     plan = SweepPlan(ebn0_db=ebn0, blocks_per_point=1024, nsym=BLOCK, detector=detector)
     counts = ber_sweep(plan, rank=0, world=1)
     ber = counts[:, 1] / counts[:, 2]
@@ -80,3 +80,25 @@ def test_gpu_ber_curve_within_0p05_db_of_reference(detector):
         # crossing (0.007 - 0.015 dB with the 4.4e7 reference symbols per point committed for
         # 10 - 12 dB) is printed above for the reader, not added to the tolerance
         assert abs(mine - ref) <= 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waveform,warmup,ebn0", [("soqpsk", 1, 0.0), ("multih", 16, 2.0)])
+def test_gpu_sweep_repairs_unproven_chunks(waveform, warmup, ebn0):
+    """A sweep whose detector warm-up is far too short (chunks do not merge: the launch's own proof fails)
+    ends with exactly the counts of a sweep with the default warm-up — the runner repeats the affected
+    blocks with a doubled warm-up instead of losing the sweep (round-2 advisor finding)."""
+    from waveforms.bert import SweepPlan, gpu_block_runner
+
+    def sweep(wu):
+        plan = SweepPlan(ebn0_db=[ebn0, 6.0], blocks_per_point=3, nsym=1 << 19, waveform=waveform, warmup=wu)
+        run, finish = gpu_block_runner(plan, streams=2)
+        for point, block in plan.shard(0, 1):
+            run(point, block)
+        return finish(), run.stats
+
+    good, st_good = sweep(0)
+    short, st_short = sweep(warmup)
+    assert st_good["repaired_jobs"] == 0
+    assert st_short["repaired_jobs"] > 0, "the short warm-up was expected to leave chunks unproven"
+    assert np.array_equal(good, short), (good, short)

@@ -58,8 +58,10 @@ def test_rccl_all_reduce_of_the_counter_table_world1():
     """The `nccl` (= RCCL) branches — init_process_group("nccl", device_id=...) of init_ranks and the
     .cuda() all-reduce of all_reduce_counts — executed once, in a world-size-1 group on cuda:0."""
     code = """
-import os, json, numpy as np
-os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29653")
+import os, json, socket, numpy as np
+with socket.socket() as s:                    # a free rendezvous port, picked like spawn_ranks does
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 from waveforms_amd.bert import init_ranks, all_reduce_counts
 import torch, torch.distributed as dist
 rank, world, d, dev = init_ranks()
@@ -74,3 +76,40 @@ print(json.dumps({"same": bool((out == t).all()), "dtype": str(out.dtype), "max"
 """
     out = _run([sys.executable, "-c", code])
     assert out == {"same": True, "dtype": "int64", "max": 1.0}
+
+
+def _gpu_count():
+    try:
+        import torch
+
+        return torch.cuda.device_count()        # (does not initialise HIP on this image)
+    except Exception:   # noqa: BLE001
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: real RCCL between two ranks")
+def test_bench_gpus_2_real_nccl_equals_rehearsal():
+    """Two ranks on two GPUs with backend nccl (= RCCL over xGMI): the all-reduced counters equal the one-GPU
+    rehearsal's (both ranks on cuda:0, gloo), per-rank times are reported, the CPU baseline stays in the line."""
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--nsym", "1000000",
+           "--cpu-sample", "65536", "--cpu-loop-sample", "4096"]
+    real = _run(cmd)
+    reh = _run(cmd + ["--no-cpu-baseline"], {"WF_BENCH_REHEARSAL": "1"})
+    assert real["n_gpus"] == 2 and real["ber"] == reh["ber"]
+    assert len(real["per_rank_ms_per_step"]) == 2 and real["rank_time_max_over_min"] >= 1.0
+    assert real["cpu_baseline"]["value"] > 0
+
+
+def test_bench_line_reports_binding_roofline_and_steady_state():
+    """One-GPU line: the roofline that binds is the one in bound / frac (HBM kept as hbm_frac), the CPM path is
+    asked from the library, and the long steady-state figure sits beside the driver-timed value."""
+    out = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--steady-steps", "200",
+                "--overlap-streams", "0"])
+    r = out["roofline"]
+    assert r["bound"] in ("hbm", "valu_issue") and r["frac"] == r["binding_frac"] and 0 < r["hbm_frac"] <= 1
+    if "valu_issue_frac" in r:
+        assert r["frac"] == max(r["valu_issue_frac"], r["hbm_frac"])
+    assert out["steady_state"]["steps"] == 200 and out["steady_state"]["value"] > 0
+    out = _run([sys.executable, "bench.py", "--waveform", "multih", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                "--steady-steps", "0", "--overlap-streams", "0", "--nsym", "1000000"])
+    assert out["roofline"]["kernel"].startswith(("mod_chan_bank_kernel<4, 16>", "cpm_viterbi_kernel<4, 2>"))

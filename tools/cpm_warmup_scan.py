@@ -8,7 +8,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--waveform", default="multih")
-    ap.add_argument("--symbols-per-point", type=float, default=4e7)
+    ap.add_argument("--symbols-per-point", type=float, default=6.4e8, help="1e6 chunks of 640 calls per point by default")
+    ap.add_argument("--warmups", default="32,48,64,96,128,192,256,320,384,512")
+    ap.add_argument("--ebn0", default="0,2,4,6,8,10,12")
     a = ap.parse_args()
     import torch
     from waveforms_amd import device as dev
@@ -16,10 +18,10 @@ def main():
     nsym = 10_000_000
     blocks = max(1, int(a.symbols_per_point / nsym))
     out = []
-    for w in (64, 128, 192, 256, 384, 512):
+    for w in [int(x) for x in a.warmups.split(",")]:
         link = CPMLink(nsym, 8, waveform=a.waveform, warmup=w)
-        row = {"waveform": a.waveform, "warmup": w, "unmerged_by_ebn0": {}}
-        for e in (0, 2, 4, 6, 8, 10, 12):
+        row = {"waveform": a.waveform, "warmup": w, "blocks_per_point": blocks, "symbols_per_block": nsym, "unmerged_by_ebn0": {}}
+        for e in [int(x) for x in a.ebn0.split(",")]:
             dev.viterbi_unmerged(reset=True, ctx=link._ctx)
             for b in range(blocks):
                 link.run_block(float(e), seed=5, stream_id=(e << 20) | b, skip_bits=b * nsym * link.spec.bits_per_symbol)
@@ -31,7 +33,7 @@ def main():
         print(json.dumps(row), flush=True)
         del link
     Path("gpurun_out").mkdir(exist_ok=True)
-    Path(f"gpurun_out/r02_cpm_warmup_scan_{a.waveform}.json").write_text(json.dumps(out, indent=1))
+    Path(f"gpurun_out/r03_cpm_warmup_scan_{a.waveform}.json").write_text(json.dumps(out, indent=1))
 
 if __name__ == "__main__":
     main()

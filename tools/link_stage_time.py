@@ -19,12 +19,12 @@ def main():
     a = ap.parse_args()
     import torch
 
-    from waveforms_amd.link import CPMLink, SOQPSKLink
+    from waveforms_amd.link import CPMLink, SOQPSKLink, operating_point_warmup, soqpsk_warmup_param
 
     if a.waveform == "soqpsk":
-        link = SOQPSKLink(a.nsym, 8, pn_degree=23, warmup=15, fuse=15 if a.fuse < 0 else a.fuse)
+        link = SOQPSKLink(a.nsym, 8, pn_degree=23, warmup=soqpsk_warmup_param(operating_point_warmup("soqpsk", 10.0)), fuse=15 if a.fuse < 0 else a.fuse)
     else:
-        link = CPMLink(a.nsym, 8, waveform=a.waveform, warmup=128 if a.waveform == "multih" else 192, fuse=10 if a.fuse < 0 else a.fuse)
+        link = CPMLink(a.nsym, 8, waveform=a.waveform, warmup=operating_point_warmup(a.waveform, 10.0), fuse=10 if a.fuse < 0 else a.fuse)
     acc = {}
     for k in range(a.steps + 3):
         link.run_block(10.0, seed=1, stream_id=k, event_slot=0)

@@ -22,13 +22,14 @@ def main():
     ap.add_argument("--pn-degree", type=int, default=31)
     ap.add_argument("--graph", action="store_true", help="replay the steady-state chunk as a hipGraph")
     ap.add_argument("--pipelined", action="store_true", help="consecutive chunks on two streams (detector of chunk c under the front end of c + 1)")
-    ap.add_argument("--vit-warmup", type=int, default=-1, help="detector chunk warm-up rows - 1 (-1: 15 from 6 dB up, else library default)")
+    ap.add_argument("--vit-warmup", type=int, default=-1, help="detector chunk warm-up rows (-1: by Eb/N0, waveforms_amd.link.operating_point_warmup; 0: library default)")
     a = ap.parse_args()
     import torch
 
     from waveforms_amd.link import SOQPSKStream
 
-    wu = a.vit_warmup if a.vit_warmup >= 0 else (15 if a.ebn0 >= 6.0 else 0)    # tools/warmup_scan.py; result() raises if a chunk is unproven
+    from waveforms_amd.link import operating_point_warmup, soqpsk_warmup_param
+    wu = soqpsk_warmup_param(a.vit_warmup if a.vit_warmup >= 0 else operating_point_warmup("soqpsk", a.ebn0))    # result() raises if a chunk is unproven
     st = SOQPSKStream(int(a.total), a.chunk, 8, detector=a.detector, pn_degree=a.pn_degree, warmup=wu)
     st.run_chunk(0, a.ebn0)           # warm-up (allocations, code objects)
     torch.cuda.synchronize()

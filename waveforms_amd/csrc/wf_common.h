@@ -50,6 +50,9 @@ struct wf_ctx {
     uint8_t *d_tables = nullptr;  // small table upload area (fsm encode)
     uint8_t h_tables_cache[2048] = {0};  // what d_tables currently holds (uploads are skipped when unchanged)
     int tables_cached = 0;
+    hipEvent_t tables_event = nullptr;   // recorded behind the last table upload (on tables_stream); cleared once seen complete
+    hipStream_t tables_stream = nullptr;
+    bool tables_pending = false;
     uint64_t *d_fsm_scratch = nullptr;
     size_t fsm_scratch_words = 0;
     int *h_small = nullptr;  // pinned, small D2H results
@@ -97,6 +100,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index, int64_t first,
                             int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf = 0, int cpm_nh = 1,
                             int stage = 3);
+int wf_mod_chan_cpm_rows_applies(int64_t nsym, int nh, int ntaps, int sps, int nfilt, int ntm, int64_t start0);
 int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse,
                          int ntaps, int sps, double phi0, const double *d_templates, int nfilt, int ntm, int64_t start0,
                          double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id, int64_t ncalls,

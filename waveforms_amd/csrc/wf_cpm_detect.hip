@@ -295,8 +295,8 @@ __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viter
         }
         const int src = (int)(inf & 15u), u_new = (int)((inf >> 4) & 3u), delta = (int)((inf >> 8) & 0x7Fu);
         const int baddr = ((lane & 48) | src) << 2;
-        int nr = __builtin_amdgcn_ds_bpermute(baddr, r) + delta;
-        nr -= nr >= 2 * P.p ? 2 * P.p : 0;
+        const uint32_t nr_raw = (uint32_t)(__builtin_amdgcn_ds_bpermute(baddr, r) + delta);   // < 4p
+        const int nr = (int)min(nr_raw, nr_raw - (uint32_t)(2 * P.p));   // mod 2p: the difference wraps to a huge value when nr_raw < 2p
         const uint64_t nh_ = (cpm_bperm_u64(baddr, hist) << LGM) | (uint64_t)u_new;
         double nm = best;      // (lanes that hold no state: metric +inf, candidates parked in their own column, so best = +inf by itself)
 #ifdef WF_ABL_CPM_NOMIN     // ablation only: no 16-lane all-reduce
@@ -484,13 +484,15 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
                    (reinterpret_cast<uintptr_t>(d_rot_cs) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
                "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
-    // Default warm-up: the D calls that refill the decision register plus the merge depth of the
-    // trellis at ANY Eb/N0 (tools/cpm_warmup_scan.py, profiles/r02_cpm_warmup_scan_*.json, 62 500 chunks
-    // per point): ARTM 16-state — 128 calls leave 128 / 71 / 34 chunks unproven at 0 / 2 / 4 dB and none
-    // from 6 dB up, 192 leave 4 / 2 at 0 / 2 dB, 256 none anywhere; binary PCM/FM (one bit per call,
-    // slower merges) — 256 still leave 1 at 0 dB, 384 none.  A caller that knows its operating point
-    // may pass less (bench.py: 128 / 192 at 10 dB); every launch proves its output either way.
-    int W = warmup ? warmup : (det->M == 2 ? CPM_DEFAULT_WARMUP * 3 / 2 : CPM_DEFAULT_WARMUP);
+    // Default warm-up: the D calls that refill the decision register plus the merge depth of the trellis at
+    // ANY Eb/N0, backed by a RATE (tools/cpm_warmup_scan.py, profiles/r03_cpm_warmup_scan_*.json: 1e6 chunks
+    // per point, 0 .. 12 dB).  ARTM 16-state, chunks left unproven per 1e6: 128 calls 2290 / 409 / 14 / 0 at
+    // 0 / 4 / 6 / 8 dB; 192: 51 / 1 / 0; 256: 1 / 0; 320: 0 anywhere — about 30x fewer per 64 calls, so 320
+    // sits near 1e-7 per chunk at 0 dB.  Binary PCM/FM merges slowly at EVERY Eb/N0 (one bit per call):
+    // 192 calls still leave 2 .. 5 per 1e6 from 2 dB up (422 at 0 dB), 256: 25 at 0 dB and 1 at 6 dB, 320 and
+    // 384 none.  A caller that knows its operating point may pass less (bench.py: ARTM 128 from 8 dB up);
+    // every launch proves its output either way and waveforms.bert repeats a block whose proof failed.
+    int W = warmup ? warmup : (det->M == 2 ? 384 : 320);
     W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
     if (W > 4096) W = 4096;
     // Calls per chunk (a multiple of 64): at least 256 (and 2 W), so the warm-up stays a fraction of
@@ -841,7 +843,10 @@ extern "C" int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8)
     cpm_link_layout L;
     if (!info8 || !cpm_make_layout(cfg, L)) return WF_ERR_VALUE;
     info8[0] = L.ncalls; info8[1] = L.start0; info8[2] = (int64_t)L.off_dec; info8[3] = (int64_t)L.off_syms;
-    info8[4] = (int64_t)L.off_sig; info8[5] = 0; info8[6] = L.npts; info8[7] = (int64_t)L.off_rows;
+    info8[4] = (int64_t)L.off_sig; info8[6] = L.npts; info8[7] = (int64_t)L.off_rows;
+    // [5]: 1 when fuse bits 1 + 3 will run modulator + channel + filters as ONE kernel for this configuration
+    info8[5] = ((cfg->fuse & 8) && (cfg->fuse & 2) && L.ncalls > 0 &&
+                wf_mod_chan_cpm_rows_applies(cfg->nsym, cfg->det.nh, cfg->ntaps, cfg->sps, L.nfilt, L.ntm, L.start0)) ? 1 : 0;
     return WF_OK;
 }
 

@@ -61,6 +61,7 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
     if (c->d_fault) (void)hipFree(c->d_fault);
     if (c->h_fault) (void)hipHostFree(c->h_fault);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->tables_event) (void)hipEventDestroy(c->tables_event);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_iter) (void)hipHostFree(c->h_iter);

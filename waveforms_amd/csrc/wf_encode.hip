@@ -311,10 +311,19 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
         memcpy(ctx->h_tables_cache, h_next, tabn);
         memcpy(ctx->h_tables_cache + 1024, h_out, tabn);
         ctx->tables_cached = tabn;
-        // The cache is per context, the upload is ordered on this call's stream only: a later call
-        // with the same tables on ANOTHER stream skips the upload, so it must already have landed.
+        // The cache is per context and the upload is ordered on THIS call's stream only, so an event is
+        // recorded behind it; a later call on another stream waits for that event (below) instead of the
+        // host blocking here on everything queued on the stream.  (The upload itself is a copy from
+        // pageable memory: the FIRST call of a context with a given table set must not be made inside a
+        // hipGraph capture; later calls — cache hits — may.)
         WF_HIP(hipMemcpyAsync(ctx->d_tables, ctx->h_tables_cache, 2048, hipMemcpyHostToDevice, s));
-        WF_HIP(hipStreamSynchronize(s));
+        if (!ctx->tables_event) WF_HIP(hipEventCreateWithFlags(&ctx->tables_event, hipEventDisableTiming));
+        WF_HIP(hipEventRecord(ctx->tables_event, s));
+        ctx->tables_stream = s;
+        ctx->tables_pending = true;
+    } else if (ctx->tables_pending) {
+        if (hipEventQuery(ctx->tables_event) == hipSuccess) ctx->tables_pending = false;      // landed: nothing to order any more
+        else if (s != ctx->tables_stream) WF_HIP(hipStreamWaitEvent(s, ctx->tables_event, 0));
     }
     enc_params P{columns, states, card, ninp, (int)(i0 % columns), state0, nsym, 0u, 0ull, 0ull};
     const bool small = states <= 4 && tabn <= 16 && columns * ninp <= 4;

@@ -1078,6 +1078,17 @@ int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, 
                                    pack_par0, d_rows4, stream, 0, 1, 3);
 }
 
+// Would the one-kernel front end take this CPM configuration?  (The answer wf_mod_chan_cpm_rows gives by
+// returning 0 / 1, without launching anything: wf_cpm_link_layout reports it, so that callers need not infer
+// the path from stage times.)
+int wf_mod_chan_cpm_rows_applies(int64_t nsym, int nh, int ntaps, int sps, int nfilt, int ntm, int64_t start0)
+{
+    if (ntm != 9 || start0 < -4 || start0 > 3 || (nfilt != 4 && nfilt != 16) || sps != 8 || (nh != 1 && nh != 2)) return 0;
+    mod_params P;
+    if (!mod_setup(P, nsym, nh, ntaps, sps, 0.0) || P.rs != 2 * MOD_THREADS) return 0;
+    return (ntaps + sps - 1) / sps <= 9;
+}
+
 // The same kernel producing the generic CPM detector's matched-filter rows (nfilt = 4 or 16 templates
 // of 9 taps per modulation-index column; row n from samples [start0 + 8 n, + 8]).  Returns 1 when
 // outside the kernel (caller runs modulator, channel and wf_cpm_mf_rows_c128 separately).

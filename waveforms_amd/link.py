@@ -23,6 +23,28 @@ def sigma_for_ebn0(ebn0_db: float, sps: int) -> float:
     return math.sqrt(sps / (2.0 * 10.0 ** (ebn0_db / 10.0)))
 
 
+def operating_point_warmup(waveform: str, ebn0_db: float | None) -> int:
+    """Detector chunk warm-up in ROWS (= detector calls run before a chunk's own first call) for a link at a
+    known operating point; 0 = the library default, safe at any Eb/N0.  One table for bench.py and the
+    timing tools (tools/link_stage_time.py, tools/stream_bench.py).  Backed by the proof-failure scans
+    (tools/warmup_scan.py, tools/cpm_warmup_scan.py; profiles/r02_warmup_scan.json, r03_cpm_warmup_scan_*.json):
+    SOQPSK 4-state: 16 rows from 6 dB up (0 of 2.5e6 chunks unproven even with 12); ARTM 16-state: 128 from
+    8 dB up (0 of 1e6 chunks); binary PCM/FM merges slowly at every Eb/N0: 320.  Every launch still proves its
+    own output, and ``result()`` raises if a chunk was not proven."""
+    if ebn0_db is None:
+        return 0
+    if waveform == "soqpsk":
+        return 16 if ebn0_db >= 6.0 else 0
+    if waveform == "multih":
+        return 128 if ebn0_db >= 8.0 else 0
+    return 320 if ebn0_db >= 8.0 else 0
+
+
+def soqpsk_warmup_param(rows: int) -> int:
+    """``wf_link_config.warmup`` of the SOQPSK link counts the rows AFTER the priming row (rows - 1; 0 = default)."""
+    return max(int(rows) - 1, 0)
+
+
 class SOQPSKLink:
     def __init__(self, nsym: int, sps: int = 8, **kw) -> None:
         self._configure(nsym, sps, **kw)
@@ -329,7 +351,7 @@ class CPMLink:
     def layout(self) -> dict:
         info = (ctypes.c_int64 * 8)()
         _hip.check(_hip.lib().wf_cpm_link_layout(ctypes.byref(self.cfg), info))
-        keys = ("calls", "start0", "off_decisions", "off_syms", "off_signal", "_", "signal_len", "off_rows")
+        keys = ("calls", "start0", "off_decisions", "off_syms", "off_signal", "one_kernel_front_end", "signal_len", "off_rows")
         return dict(zip(keys, (int(v) for v in info)))
 
     def reset_counts(self) -> None:

@@ -44,7 +44,9 @@ def eye_diagram_data(time, signal, sps: int = 8, modulo: int = 4, t_offset: floa
     """(t, re, im), each [traces][sps * modulo + 1]: the curves waveforms/viz/eye.py:40-55 draws."""
     time = np.ascontiguousarray(time, dtype=np.float64)
     x = _dev_c128(signal)
-    n = int(time.size)
+    # both arrays are read up to n: the shorter one bounds it, as numpy slicing does in the reference
+    # (waveforms/viz/eye.py:40-55); a signal shorter than `time` must never be read past its end on the device
+    n = min(int(time.size), int(x.shape[0]))
     length = sps * modulo
     ntr = (n - 1) // length if n >= 1 else 0
     outs = [_hip.empty((max(ntr, 0), length + 1), "float64") for _ in range(3)]

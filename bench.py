@@ -304,9 +304,9 @@ def main() -> None:
     if dist is not None:
         # every rank's own time (all_gather of one double), so that the first real N-GPU run shows imbalance
         mine = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in gathered]
         t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

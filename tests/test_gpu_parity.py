@@ -414,6 +414,57 @@ def test_detector_batch_is_stateful(golden, diff):
         det.iteration(trip[0])
 
 
+@pytest.mark.parametrize("length", [4, 6])
+@pytest.mark.parametrize("diff", [True, False])
+def test_window_detector_batch_on_reference_triplets(golden, length, diff):
+    """detect() with a longer traceback window (algorithm.py:19-42) against what the reference's own
+    .iteration() returned for those lengths (element [0] of each call), in one call and in pieces of odd sizes."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detect")
+    trip = g["triplets"]
+    want_b, want_s = g[f"trip_L{length}_diff{int(diff)}_bits"][:, 0], g[f"trip_L{length}_diff{int(diff)}_syms"][:, 0]
+    bits, syms = SOQPSKTrellisDetector(length, differantial_encoding=diff).detect(trip)
+    assert np.array_equal(bits, want_b) and np.array_equal(syms, want_s)
+    det = SOQPSKTrellisDetector(length, differantial_encoding=diff)
+    cuts = [0, 1, 2, 5, 131, 1000, 1777, 3999, 4000]
+    parts = [det.detect(trip[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert det.i == 4000
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), want_b)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), want_s)
+
+
+@pytest.mark.parametrize("length,ebn0", [(4, 0.0), (4, 10.0), (6, 4.0), (8, 0.0), (8, 10.0), (16, 4.0)])
+def test_window_detector_chunk_parallel_equals_sequential(oracle, length, ebn0):
+    """1.2e6 noisy rows: the chunk-parallel window kernel's decisions are bit-identical to the sequential
+    oracle's for the same traceback length, and the launch's own proof found no unmerged chunk."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+    from waveforms_amd import _hip, device as dev
+
+    n = 1_200_000
+    bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, n)
+    noise = oracle.philox_awgn(oracle.sigma_for_ebn0(ebn0, 8), 5, length, 0, (n + 1) * 8)
+    res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise, length=length)
+    det = SOQPSKTrellisDetector(length)
+    got_b, got_s = det.detect(res["mf_rows"])
+    assert np.array_equal(got_b, res["det_bits"]) and np.array_equal(got_s, res["det_syms"])
+    # a 2-row warm-up cannot merge: the proof must notice, and detect() must repair it
+    rows = _hip.to_device(np.ascontiguousarray(res["mf_rows"][:300_000]))
+    dev.viterbi_unmerged(reset=True)
+    dev.viterbi_detect_window(rows, length, warmup=2)
+    assert dev.viterbi_unmerged(reset=True) > 0
+    b2, s2 = SOQPSKTrellisDetector(length).detect(res["mf_rows"][:300_000], warmup=2)
+    assert np.array_equal(b2, res["det_bits"][:300_000]) and np.array_equal(s2, res["det_syms"][:300_000])
+
+
+def test_window_detector_rejects_odd_and_long_lengths():
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    for length in (3, 18):
+        with pytest.raises(ValueError):
+            SOQPSKTrellisDetector(length).detect(np.zeros((8, 3), dtype=np.complex128))
+
+
 def test_count_errors():
     from waveforms_amd import _hip, device as dev
 

@@ -48,6 +48,8 @@ SIGNATURES = {
     "wf_viterbi4_unmerged": (c_int, [_P, POINTER(c_int64), c_int, _P]),
     "wf_viterbi4_detect_count": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P, _P]),
     "wf_viterbi4_detect": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "wf_viterbi4_detect_window": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "wf_viterbi4_window_state_bytes": (c_int64, []),
     "wf_viterbi4_state_bytes": (c_int64, [c_int]),
     "wf_viterbi4_iteration": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
     "wf_viterbi4_iteration_host": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),

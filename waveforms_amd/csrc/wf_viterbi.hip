@@ -577,6 +577,266 @@ extern "C" int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int6
 }
 
 // ------------------------------------------------------------------------------------
+// Batch detector for any EVEN window length 2 <= L <= VWIN_MAX_LEN (algorithm.py:19-42: `length` is a
+// free parameter of the reference; its window loop :69-87 and depth-`length` traceback :90-98 are
+// only self-consistent for even lengths — odd ones use different trellis sections for a row's
+// increments and for its ACS stage).  What one .iteration() call k does, restated:
+//   - the window holds the rows of calls k-L+1 .. k (a row's 8 branch increments are 4 signed
+//     components of it, vit_comp; rows before the burst are zeros = the zero-initialised history),
+//   - entering metrics e = C - min(C), C = the stage-0 metrics the PREVIOUS call produced (:65-67),
+//   - stage 0 on row k-L+1 gives the new C; stages 1 .. L-1 look ahead over the newer rows (:69-87),
+//   - the decision is the stage-0 branch on the path that ends in the first arg-min state of
+//     stage L-1 (:90-98, element [0] of what the call returns).
+// The traceback is a register exchange here: every state carries the code (input bit, output
+// symbol) of the stage-0 branch its survivor went through; an ACS stage selects the code along with
+// the metric, the best end state's code is the decision — L x 4 selects instead of L dependent
+// table walks.
+// Parallelism as in viterbi_batch_kernel: a lane owns CH consecutive calls and re-derives C over W
+// earlier calls from zero metrics (the trellis is the same 4-state one: survivors merge within a few
+// tens of rows); every launch records, per chunk, the C its own calls started from and the C it
+// ended with, and vwin_verify_kernel counts the chunks whose start is not BITWISE the predecessor's
+// end (wf_viterbi4_unmerged) — the condition under which every decision is the sequential detector's.
+// The window lives in a lane-private LDS ring of L rows (33 16-byte slots per lane at most: an odd
+// stride, so the lanes' ds_read_b128 hit different banks); stage loops are rolled, so one kernel
+// serves every even L.  Carry block (d_state, VWIN_STATE_DOUBLES doubles, zeros = a fresh detector):
+// [0] calls made, [1..4] C, [8 + 4 q ..] components of the row of call i-L+1+q, q < L-1; staging at +128.
+#define VWIN_THREADS 128
+#define VWIN_MAX_LEN 16
+#define VWIN_STATE_DOUBLES 256
+#define VWIN_STAGE 128
+
+template <int COL>
+__device__ __forceinline__ void vwin_acs(const double m[4], const vit_comp &q, double out[4], bool lt[4])
+{
+    double fa[4], fb[4];
+    if (COL == 0) {
+        fa[0] = m[0] - q.i1; fb[0] = m[2] + q.a;
+        fa[1] = m[1] - q.r1; fb[1] = m[3] + q.b;
+        fa[2] = m[0] - q.b;  fb[2] = m[2] + q.r1;
+        fa[3] = m[1] - q.a;  fb[3] = m[3] + q.i1;
+    } else {
+        fa[0] = m[0] - q.i1; fb[0] = m[1] - q.b;
+        fa[1] = m[0] - q.a;  fb[1] = m[1] - q.r1;
+        fa[2] = m[2] + q.r1; fb[2] = m[3] + q.a;
+        fa[3] = m[2] + q.b;  fb[3] = m[3] + q.i1;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        lt[s] = fb[s] < fa[s];                    // strict '<': the first listed branch keeps a tie (algorithm.py:79-83)
+        out[s] = lt[s] ? fb[s] : fa[s];
+    }
+}
+
+// code of branch (start -> end e) of section col: input bit | output-symbol index << 1
+__device__ __forceinline__ uint32_t vwin_code(int col, int e, int second, int diff)
+{
+    const int start = col == 0 ? (e & 1) + 2 * second : (e & 2) + second;
+    const int b = 2 * start + (col == 0 ? e >> 1 : e & 1);
+    return (uint32_t)br_inp(col, b, diff) | ((uint32_t)kOutIdx[col][b] << 1);
+}
+
+template <int COL>
+__device__ __forceinline__ void vwin_stage(double m[4], uint32_t d[4], const vit_comp &q, bool first, int diff)
+{
+    double o[4];
+    bool lt[4];
+    vwin_acs<COL>(m, q, o, lt);
+    uint32_t n[4];
+    if (first) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) n[e] = lt[e] ? vwin_code(COL, e, 1, diff) : vwin_code(COL, e, 0, diff);
+    } else if (COL == 0) {      // predecessors of end state e in list order: (e & 1), (e & 1) + 2
+        n[0] = lt[0] ? d[2] : d[0]; n[1] = lt[1] ? d[3] : d[1]; n[2] = lt[2] ? d[2] : d[0]; n[3] = lt[3] ? d[3] : d[1];
+    } else {                    // (e & 2), (e & 2) + 1
+        n[0] = lt[0] ? d[1] : d[0]; n[1] = lt[1] ? d[1] : d[0]; n[2] = lt[2] ? d[3] : d[2]; n[3] = lt[3] ? d[3] : d[2];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        m[e] = o[e];
+        d[e] = n[e];
+    }
+}
+
+__global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const double2 *__restrict__ rows, int64_t ncalls, int L, int CH, int W,
+                                                                       int diff, uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
+                                                                       double *__restrict__ state, double *__restrict__ erec)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s_ring[];
+    const int stride = 2 * L + 1;                                     // 16-byte slots per lane (odd)
+    double2 *ring = s_ring + (size_t)threadIdx.x * stride;
+    const int64_t chunk = (int64_t)blockIdx.x * VWIN_THREADS + threadIdx.x;
+    const int64_t a = chunk * CH;
+    const bool live = a < ncalls;
+    const int64_t i0 = state ? (int64_t)state[0] : 0;                 // calls made before this launch
+    const int64_t kend = live ? (a + CH < ncalls ? a + CH : ncalls) : 0;
+    const bool exact = a <= W;                                        // starts at call 0 from the carried detector itself
+    const int64_t ks = exact ? 0 : a - W;                             // even: CH and W are even
+    double C[4] = {0.0, 0.0, 0.0, 0.0};
+    if (exact && state && i0 > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[q] = state[1 + q];
+    }
+    // components of the row of local call kp (its trellis section = parity of its global call index)
+    auto comps = [&](int64_t kp) __attribute__((always_inline)) {
+        vit_comp c;
+        if (kp >= 0) {
+            const int64_t kk = kp < ncalls ? kp : ncalls - 1;         // (clamped rows are never decoded)
+            const double2 z0 = vit_ld16(rows + 3 * kk), z1 = vit_ld16(rows + 3 * kk + 1), z2 = vit_ld16(rows + 3 * kk + 2);
+            const bool odd = ((i0 + kp) & 1) != 0;
+            c.r1 = z1.x; c.i1 = z1.y;
+            c.a = odd ? z0.y : z0.x;
+            c.b = odd ? z2.x : z2.y;
+        } else if (state && i0 > 0) {                                 // before this launch: the carried window
+            const double *p = state + 8 + 4 * (L - 1 + kp);
+            c.r1 = p[0]; c.i1 = p[1]; c.a = p[2]; c.b = p[3];
+        } else {
+            c.r1 = c.i1 = c.a = c.b = 0.0;                            // the reference's zero-initialised history
+        }
+        return c;
+    };
+    auto slot = [&](int64_t kp) __attribute__((always_inline)) { return (int)(((kp % L) + L) % L); };
+    auto put = [&](int64_t kp, const vit_comp &c) __attribute__((always_inline)) {
+        const int q = slot(kp);
+        ring[2 * q] = make_double2(c.r1, c.i1);
+        ring[2 * q + 1] = make_double2(c.a, c.b);
+    };
+    auto get = [&](int q) __attribute__((always_inline)) {
+        const double2 u = ring[2 * q], v = ring[2 * q + 1];
+        vit_comp c;
+        c.r1 = u.x; c.i1 = u.y; c.a = v.x; c.b = v.y;
+        return c;
+    };
+    if (live)
+        for (int q = 1; q < L; ++q) put(ks - L + q, comps(ks - L + q));
+    vit_comp nxt = comps(ks);
+    const int nsteps = W + CH;                                        // common trip count; a lane is active while k < kend
+    const int par = (int)((i0 + 1) & 1);                              // section of stage 0 at step t: (i0 + ks + t - L + 1) & 1, ks and L even
+    for (int t = 0; t < nsteps; ++t) {
+        const int64_t k = ks + t;
+        const bool act = live && k < kend;                            // (no barrier below: inactive lanes just idle)
+        if (!act) continue;
+        put(k, nxt);
+        nxt = comps(k + 1);                                           // next call's row: in flight during this call's stages
+        if (k == a && erec) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) erec[8 * chunk + q] = C[q];
+        }
+        const double mn = fmin(fmin(C[0], C[1]), fmin(C[2], C[3]));
+        double m[4] = {C[0] - mn, C[1] - mn, C[2] - mn, C[3] - mn};
+        uint32_t d[4] = {0u, 0u, 0u, 0u};
+        int q = slot(k - L + 1);
+        const bool odd0 = ((par + t) & 1) != 0;                       // wave-uniform
+        // stages in (stage 0's section, the other one) pairs: L is even
+        for (int j = 0; j < L; j += 2) {
+            const vit_comp r0 = get(q);
+            q = q + 1 == L ? 0 : q + 1;
+            const vit_comp r1 = get(q);
+            q = q + 1 == L ? 0 : q + 1;
+            if (!odd0) {
+                vwin_stage<0>(m, d, r0, j == 0, diff);
+                if (j == 0) { C[0] = m[0]; C[1] = m[1]; C[2] = m[2]; C[3] = m[3]; }
+                vwin_stage<1>(m, d, r1, false, diff);
+            } else {
+                vwin_stage<1>(m, d, r0, j == 0, diff);
+                if (j == 0) { C[0] = m[0]; C[1] = m[1]; C[2] = m[2]; C[3] = m[3]; }
+                vwin_stage<0>(m, d, r1, false, diff);
+            }
+        }
+        if (k >= a) {
+            // np.argmin: the first minimum
+            double best = m[0];
+            uint32_t dec = d[0];
+#pragma unroll
+            for (int e = 1; e < 4; ++e) {
+                const bool lt = m[e] < best;
+                best = lt ? m[e] : best;
+                dec = lt ? d[e] : dec;
+            }
+            bits[k] = (uint8_t)(dec & 1u);
+            syms[k] = (int8_t)(2 * (int)((dec >> 1) & 3u) - 2);
+        }
+    }
+    if (live && erec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) erec[8 * chunk + 4 + q] = C[q];
+    }
+    if (live && state && kend == ncalls) {                            // the lane that owns the last call: carry out (staging)
+        state[VWIN_STAGE] = (double)(i0 + ncalls);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) state[VWIN_STAGE + 1 + q] = C[q];
+        for (int q = 0; q < L - 1; ++q) {
+            const int64_t kp = ncalls - (L - 1) + q;
+            // rows of this launch are in the ring when this lane walked them; older ones come from the inputs again
+            const vit_comp c = (kp >= ks - L + 1) ? get(slot(kp)) : comps(kp);
+            double *p = state + VWIN_STAGE + 8 + 4 * q;
+            p[0] = c.r1; p[1] = c.i1; p[2] = c.a; p[3] = c.b;
+        }
+    }
+}
+
+__global__ void vwin_verify_kernel(const double *__restrict__ erec, int64_t nchunks, unsigned long long *__restrict__ unmerged)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (c >= nchunks) return;
+    const unsigned long long *s = reinterpret_cast<const unsigned long long *>(erec + 8 * c);
+    const unsigned long long *e = reinterpret_cast<const unsigned long long *>(erec + 8 * (c - 1) + 4);
+    if (s[0] != e[0] || s[1] != e[1] || s[2] != e[2] || s[3] != e[3]) atomicAdd(unmerged, 1ull);
+}
+
+__global__ void vwin_carry_commit_kernel(double *state, int n)
+{
+    const int t = threadIdx.x;
+    if (t < n) state[t] = state[VWIN_STAGE + t];
+}
+
+extern "C" int wf_viterbi4_detect_window(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int length, int differential,
+                                         int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream)
+{
+    WF_REQUIRE(ctx && ncalls >= 0 && warmup >= 0, "wf_viterbi4_detect_window: bad argument");
+    WF_REQUIRE(length >= 2 && length <= VWIN_MAX_LEN && length % 2 == 0,
+               "wf_viterbi4_detect_window: window length %d (even lengths 2 .. %d: the reference's stage / history sections only agree for even lengths)",
+               length, VWIN_MAX_LEN);
+    if (ncalls == 0) return WF_OK;
+    WF_REQUIRE(d_mf_ri && d_bits && d_syms, "wf_viterbi4_detect_window: NULL device pointer");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_mf_ri) & 15) == 0, "wf_viterbi4_detect_window: rows must be 16-byte aligned");
+    WF_HIP(hipSetDevice(ctx->device));
+    // warm-up: the merge depth of the 4-state trellis (the L = 2 kernel's scan: 16 .. 48 rows never left a chunk
+    // unproven) — the look-ahead does not change which C a chunk converges to, only how late its decisions come
+    int W = warmup ? warmup : VIT_DEFAULT_WARMUP + 1;
+    W = (W + 1) / 2 * 2;
+    if (W > 4096) W = 4096;
+    // calls per lane: even, enough lanes for ~2 waves per SIMD on a long burst, the warm-up a fraction of the work
+    int64_t ch = (ncalls + 131071) / 131072;
+    ch = (ch + 1) / 2 * 2;
+    if (ch < 4 * W) ch = 4 * W;
+    if (ch > (1 << 20)) ch = 1 << 20;
+    const int64_t nchunks = (ncalls + ch - 1) / ch;
+    const int64_t nblocks = (nchunks + VWIN_THREADS - 1) / VWIN_THREADS;
+    WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect_window: burst too long for one launch");
+    int rc = wf_ctx_reserve_vit(ctx, (size_t)nchunks * 8);
+    if (rc) return rc;
+    hipStream_t s = wf_stream(stream);
+    const size_t lds = (size_t)VWIN_THREADS * (2 * length + 1) * sizeof(double2);
+    if (lds > 48 * 1024)
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(viterbi_window_kernel, dim3((unsigned)nblocks), dim3(VWIN_THREADS), lds, s, reinterpret_cast<const double2 *>(d_mf_ri),
+                       ncalls, length, (int)ch, W, differential ? 1 : 0, d_bits, d_syms, d_state, ctx->d_vit_edge);
+    WF_LAUNCH_CHECK();
+    if (nchunks > 1) {
+        hipLaunchKernelGGL(vwin_verify_kernel, dim3((unsigned)((nchunks - 1 + 255) / 256)), dim3(256), 0, s, ctx->d_vit_edge, nchunks,
+                           ctx->d_vit_unmerged);
+        WF_LAUNCH_CHECK();
+    }
+    if (d_state) {
+        hipLaunchKernelGGL(vwin_carry_commit_kernel, dim3(1), dim3(128), 0, s, d_state, 8 + 4 * (length - 1));
+        WF_LAUNCH_CHECK();
+    }
+    return WF_OK;
+}
+
+extern "C" int64_t wf_viterbi4_window_state_bytes(void) { return (int64_t)(VWIN_STATE_DOUBLES * sizeof(double)); }
+
+// ------------------------------------------------------------------------------------
 // Literal single-call form for any window length (the per-symbol drop-in API).
 struct vit_state {
     long long i;

@@ -169,6 +169,18 @@ def viterbi_detect(mf_rows, differential: bool = True, warmup: int = 0, state=No
     return bits[:ncalls], syms[:ncalls]
 
 
+def viterbi_detect_window(mf_rows, length: int, differential: bool = True, warmup: int = 0, state=None, ctx=None):
+    """K8-K10 for any even window ``length`` (2 .. 16) -> (bits u8[ncalls], symbols i8[ncalls]) on device;
+    ``state``: float64[wf_viterbi4_window_state_bytes() / 8] carry (zeros = a fresh detector) or None."""
+    ncalls = int(mf_rows.shape[0])
+    bits = _hip.empty(ncalls + 16, "uint8")
+    syms = _hip.empty(ncalls + 16, "int8")
+    _hip.check(_hip.lib().wf_viterbi4_detect_window(ctx if ctx is not None else _hip.ctx(), _hip.ptr(mf_rows), ncalls, int(length),
+                                                    int(bool(differential)), warmup, _hip.ptr(bits), _hip.ptr(syms),
+                                                    _hip.ptr(state), _hip.stream()))
+    return bits[:ncalls], syms[:ncalls]
+
+
 def viterbi_unmerged(reset: bool = True, ctx=None) -> int:
     """Chunks of the batch detector whose warm-up did not arrive at the true path metrics since the
     last reset (``wf_viterbi4_unmerged``; synchronises).  0 = every batch call reproduced the

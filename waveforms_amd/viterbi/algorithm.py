@@ -4,9 +4,11 @@
 the GPU with the detector state resident in HBM (csrc/wf_viterbi.hip,
 viterbi_iteration_kernel), any window ``length``.  ``detect`` is the batch form the
 MI355X path is built for: a whole burst of matched-filter rows in one launch
-(chunk-parallel ACS + depth-2 traceback), ``length == 2`` only, returning for every row
-exactly what ``iteration(row)[...][0]`` would; it is stateful like ``iteration`` (successive
-calls continue the same burst through a device-resident carry).
+(chunk-parallel ACS + traceback), any EVEN ``length`` from 2 to 16 (length 2: the kernel the link
+runs; 4 .. 16: a window kernel with ``length`` - 1 stages of look-ahead per row), returning for
+every row exactly what ``iteration(row)[...][0]`` would; it is stateful like ``iteration``
+(successive calls continue the same burst through a device-resident carry).  Odd lengths stay on
+``iteration``: the reference's stage and history sections only agree for even ones.
 """
 from __future__ import annotations
 
@@ -95,13 +97,14 @@ class SOQPSKTrellisDetector:
 
         from waveforms_amd import _hip
 
-        if self.length != 2:
-            raise ValueError("batch detection implements the reference default length=2")
+        L = int(self.length)
+        if L < 2 or L > 16 or L % 2:
+            raise ValueError("batch detection implements even window lengths 2 .. 16 (use iteration() for the others)")
         if self._mode == "iteration":
             raise ValueError("this detector has been driven through iteration(); use one API per burst")
         self._mode = "batch"
         if self._d_carry is None:
-            self._d_carry = _hip.zeros(32, "float64")
+            self._d_carry = _hip.zeros(32 if L == 2 else _hip.lib().wf_viterbi4_window_state_bytes() // 8, "float64")
         # The kernel is chunk-parallel; it reports chunks whose warm-up did not reach the true path
         # metrics (none in practice).  Such a call is repeated from the same carried state with a
         # longer warm-up until it is provably the sequential detector's output.
@@ -115,7 +118,8 @@ class SOQPSKTrellisDetector:
         dev.viterbi_unmerged(reset=True, ctx=self._ctx)
         w = warmup
         while True:
-            out = dev.viterbi_detect(mf_rows, self.differential, w, self._d_carry, ctx=self._ctx)
+            out = (dev.viterbi_detect(mf_rows, self.differential, w, self._d_carry, ctx=self._ctx) if L == 2 else
+                   dev.viterbi_detect_window(mf_rows, L, self.differential, w, self._d_carry, ctx=self._ctx))
             unmerged = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
             if unmerged == 0:
                 break

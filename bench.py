@@ -338,18 +338,19 @@ def main() -> None:
             acc.pop("awgn", None)
             acc.pop("mfbank", None)
             bps["mod+awgn+mfbank"] = 1 + 16 * nf
-            STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<4, {nf}>"
+            STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<4, {nf}, 8>"
         STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}, {'true' if links[0].cfg.fuse & 2 else 'false'}>",
                              "viterbi": f"cpm_viterbi_kernel<{links[0].spec.M}, {links[0].spec.Lp}>", "map": "symbol_map_kernel",
                              "modulate": "mod_main_kernel<4, true>"})
-    one_kernel = not cpm and (args.fuse & 15) == 15 and links[0].row_bytes == 32 and links[0].cfg.mf_ntaps == 9 and args.sps == 8
+    one_kernel = not cpm and bool(links[0].layout()["one_kernel_front_end"])     # asked from the library (wf_link_layout)
     if one_kernel:      # fuse bit 3: the "fir" slot times modulator + channel + bank; symbols in, packed rows out
         acc["mod+awgn+mfbank"] = acc.pop("fir")
         for k in ("phase", "awgn", "mfbank"):
             acc.pop(k, None)
         bps["mod+awgn+mfbank"] = 1 + 32
         bps["viterbi"] = 32 + 2
-        STAGE_KERNEL["mod+awgn+mfbank"] = "mod_chan_bank_kernel<9, 0>"
+        jm = 4 if -(-links[0].cfg.ntaps // args.sps) <= 4 else 9
+        STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<{jm}, 0, {args.sps}>"
         STAGE_KERNEL["viterbi"] = "viterbi_batch_kernel<true>"
     elif not cpm and args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out
         acc["modulate"] = acc.pop("fir")

@@ -264,9 +264,11 @@ int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_workspace, int64
 int wf_link_stage_ms(wf_ctx *ctx, int event_slot, float *h_ms);
 
 /* Workspace offsets of a wf_link_run block, for callers that want the intermediates:
- * info8 = {ncols, 0, off(detected bits), off(detected symbols), off(signal), 0,
- *          signal samples, off(MF rows)} (offsets in bytes into the workspace; with fuse bit 2
- *          in effect the MF rows area holds 4 doubles per call). */
+ * info8 = {ncols, one_kernel, off(detected bits), off(detected symbols), off(signal), row_bytes,
+ *          signal samples, off(MF rows)} (offsets in bytes into the workspace).  one_kernel = 1: fuse = 15 runs
+ *          modulator + channel + bank as ONE kernel for this configuration (3 x (sps + 1) bank at 8, 10 or 20
+ *          samples per symbol, pulse of at most 9 symbols); row_bytes = 32 when the MF rows area holds the 4
+ *          doubles per call the detector reads (fuse bit 2 in effect), else 16 * mf_nfilt. */
 int wf_link_layout(const wf_link_config *cfg, int64_t *info8);
 
 /* ---- streaming link (continuous stream in chunks) -------------------------------

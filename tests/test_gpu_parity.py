@@ -843,6 +843,35 @@ def test_fused_modulator_channel_bank_rows_bit_identical(oracle, nsym, pulse_nam
     assert ref.result()[1] >= 0
 
 
+@pytest.mark.parametrize("sps,nsym,pulse_name", [(10, 70_001, "tg"), (10, 1200, "tg"), (10, 30_000, "mil"), (20, 50_003, "tg"),
+                                                 (20, 700, "mil")])
+def test_one_kernel_front_end_other_sample_rates_rows(oracle, sps, nsym, pulse_name):
+    """The one-kernel front end at 10 and 20 samples per symbol (rows of 510 / 500 samples, 51 / 25 columns
+    per row: the column parity alternates row by row; tile edges at 8160 / 8000 samples; every decimation phase):
+    its packed rows are the 4 detector components of the rows the separate kernels (fuse 7: modulator ->
+    channel + generic bank, 48 B rows) produce — to rounding, the two banks sum in different orders — and the
+    decisions and counts are identical."""
+    from waveforms_amd.link import SOQPSKLink
+
+    pulse = oracle.freq_pulse_soqpsk_tg(sps) if pulse_name == "tg" else oracle.freq_pulse_soqpsk_mil(sps)
+    for off in ((-1, 0, 3, -sps // 2) if nsym > 20_000 and pulse_name == "tg" else (-1,)):
+        ref = SOQPSKLink(nsym, sps, fuse=7, pulse=pulse, timing_offset=off)
+        fus = SOQPSKLink(nsym, sps, fuse=15, pulse=pulse, timing_offset=off)
+        assert (ref.row_bytes, fus.row_bytes) == (48, 32) and fus.layout()["one_kernel_front_end"] == 1
+        for link in (ref, fus):
+            link.run_block(4.0, seed=7, stream_id=9, skip_bits=55)
+        assert ref.result() == fus.result(), off
+        lr, lf = ref.layout(), fus.layout()
+        calls = lr["calls"]
+        a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 48].view(torch_f64()).reshape(calls, 3, 2).cpu().numpy()
+        b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+        odd = (np.arange(calls) & 1) == 1
+        want = np.stack([a[:, 1, 0], a[:, 1, 1], np.where(odd, a[:, 0, 1], a[:, 0, 0]), np.where(odd, a[:, 2, 0], a[:, 2, 1])], axis=1)
+        np.testing.assert_allclose(b, want, rtol=0, atol=1e-12)
+        for key in ("off_bits", "off_syms"):
+            assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
+
+
 def test_fused_all_other_timing_offsets_and_generic_taps(oracle):
     """The one-kernel link for every decimation phase (window start anywhere in the symbol) and for
     a 3 x 9 bank WITHOUT the pulse-truncation symmetry (generic MAC path): rows == fuse 7."""
@@ -930,16 +959,19 @@ def test_detector_reports_and_repairs_unmerged_chunks(oracle):
     assert dev.viterbi_unmerged(reset=True) == 0
 
 
-@pytest.mark.parametrize("sps,detector", [(4, "PT"), (10, "PT"), (6, "PAM"), (16, "PT")])
+@pytest.mark.parametrize("sps,detector", [(4, "PT"), (10, "PT"), (20, "PT"), (6, "PAM"), (10, "PAM"), (16, "PT")])
 def test_link_other_sample_rates_equal_oracle(oracle, sps, detector):
-    """The link away from the tuned 8-samples-per-symbol path (generic bank and staging kernels,
-    unpacked rows) still equals the oracle chain count for count."""
+    """The link away from the tuned 8-samples-per-symbol path still equals the oracle chain count for count:
+    generic bank and staging kernels with unpacked rows (fuse 0 / 7), and with fuse 15 the one-kernel front end at
+    10 samples per symbol (the reference's own examples/soqpsk_detection.py:38) and 20 (examples/pcmfm_test.py:25)."""
     from waveforms_amd.link import SOQPSKLink
 
     nsym = 30_000
-    for fuse in (0, 7):
+    for fuse in (0, 7, 15):
         link = SOQPSKLink(nsym, sps, detector=detector, fuse=fuse)
-        assert link.row_bytes == (32 if sps == 8 and fuse == 7 else 48)
+        one_kernel = fuse == 15 and detector == "PT" and sps in (8, 10, 20)
+        assert link.layout()["one_kernel_front_end"] == int(one_kernel)
+        assert link.row_bytes == (32 if one_kernel or (sps == 8 and fuse & 4) else 48)
         link.run_block(5.0, seed=21, stream_id=3, skip_bits=777)
         got = link.result()
         bits = oracle.glfsr_bits(0x420000, 0x7FFFFF, 777 + nsym)[0][777:]

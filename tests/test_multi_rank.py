@@ -112,4 +112,4 @@ def test_bench_line_reports_binding_roofline_and_steady_state():
     assert out["steady_state"]["steps"] == 200 and out["steady_state"]["value"] > 0
     out = _run([sys.executable, "bench.py", "--waveform", "multih", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                 "--steady-steps", "0", "--overlap-streams", "0", "--nsym", "1000000"])
-    assert out["roofline"]["kernel"].startswith(("mod_chan_bank_kernel<4, 16>", "cpm_viterbi_kernel<4, 2>"))
+    assert out["roofline"]["kernel"].startswith(("mod_chan_bank_kernel<4, 16, 8>", "cpm_viterbi_kernel<4, 2>"))

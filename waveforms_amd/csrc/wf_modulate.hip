@@ -548,8 +548,25 @@ struct mcb_params {
     int cpm_nh;       // CPMNF instantiations: number of modulation-index columns of the templates (1 or 2)
 };
 
-#define MCB_RING 1024                        // samples: 2 rows of 512
+// Geometry of the 2-row ring per samples-per-symbol SPS (8: the BASELINE configuration; 10: the reference's own
+// examples/soqpsk_detection.py:38; 20: examples/pcmfm_test.py:25).  A row is the largest multiple of lcm(2, SPS)
+// samples 256 threads x 2 samples cover (512 / 510 / 500); the ring is indexed by (sample - d) mod RING with one
+// pad slot per SPS samples, so the SPS + 1 samples of a pulse-truncation window sit at slot offsets 0 .. SPS-1 and
+// SPS + 1 of the pad group they start in.
+template <int SPS>
+struct mcb_geom {
+    static constexpr int L2 = (SPS % 2 == 0) ? SPS : 2 * SPS;      // lcm(2, SPS)
+    static constexpr int RS = (2 * MOD_THREADS / L2) * L2;           // samples per row
+    static constexpr int CPR = RS / SPS;                             // symbols (= detector columns) per row
+    static constexpr int NT = SPS + 1;                               // taps of the pulse-truncation bank
+    static constexpr int RING = 2 * RS;                              // samples
+    static constexpr int GROUPS = RING / SPS;                        // pad groups
+    static constexpr int GS = SPS + 1;                               // slots per pad group
+    static constexpr int SLOTS = GROUPS * GS + 16;                   // + the wrap copy of index RING (= 0 one turn later)
+};
+#define MCB_RING 1024                        // samples: 2 rows of 512 (SPS = 8)
 #define MCB_SLOTS (MCB_RING + MCB_RING / 8 + 16)  // one pad slot per 8 samples (conflict-free column reads) + the wrap copy
+static_assert(mcb_geom<8>::RING == MCB_RING && mcb_geom<8>::SLOTS == MCB_SLOTS, "SPS = 8 geometry");
 
 template <int CTRL>
 __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm CTRL (2 bits per lane: its source lane in the quad)
@@ -589,7 +606,7 @@ struct mcb_kargs {
 };
 typedef const __attribute__((address_space(4))) mcb_kargs *mcb_kptr;
 
-template <int JMAX, int CPMNF>
+template <int JMAX, int CPMNF, int SPS = 8>     // SPS != 8: CPMNF = 0 only (the CPM detector's 9-tap templates are an sps-8 design)
 __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? 3 : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
                                                                      const double *__restrict__ hvec_,
                                                                      const double *__restrict__ pulse_,
@@ -611,20 +628,24 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     const double *__restrict__ const hvec = ka->hvec;
     const double *__restrict__ const scratch = ka->scratch;
     const double *__restrict__ const mf_taps = ka->mf_taps;
+    static_assert(SPS == 8 || CPMNF == 0, "the CPM detector rows are an sps-8 design");
+    using G = mcb_geom<SPS>;
+    constexpr int NT = G::NT, RS = G::RS, CPR = G::CPR;
+    constexpr bool FULLROW = RS == 2 * MOD_THREADS;                              // every thread owns two samples of a row
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    const int win = MOD_ROWS * 64 + JMAX + 2;
+    const int win = MOD_ROWS * CPR + JMAX + 2;
     double *s_amp = s_dyn;                                                       // window of symbol amplitudes
     double2 *s_ring = reinterpret_cast<double2 *>(s_dyn + ((win + 1) & ~1));     // noisy samples, 2 rows
-    int *s_pi = reinterpret_cast<int *>(s_ring + MCB_SLOTS);                     // prefix counts of the window's raw symbols
+    int *s_pi = reinterpret_cast<int *>(s_ring + G::SLOTS);                      // prefix counts of the window's raw symbols
     __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
-    __shared__ double2 s_taps[CPMNF ? 2 * CPMNF * 9 : 27];
+    __shared__ double2 s_taps[CPMNF ? 2 * CPMNF * 9 : 3 * NT];
     const int t = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(t) >> 6;      // the same number as a scalar
     wf_stage_tables<1, 0>(s_tab, t, MOD_THREADS);
     if (CPMNF) {
         for (int k = t; k < Q.cpm_nh * CPMNF * 9; k += MOD_THREADS) s_taps[k] = reinterpret_cast<const double2 *>(mf_taps)[k];
-    } else if (t < 27) {
+    } else if (t < 3 * NT) {
         s_taps[t] = reinterpret_cast<const double2 *>(mf_taps)[t];
     }
     const double2 *s_cis = s_tab + 128;
@@ -638,21 +659,22 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
         asm volatile("" : "+v"(lane_zero));
         const double2 *tg = reinterpret_cast<const double2 *>(mf_taps) + lane_zero;
 #pragma unroll 1
-        for (int j = 0; j < 9; ++j) {
-            const double2 t0 = tg[j], t1 = tg[9 + j], t2 = tg[18 + j];
+        for (int j = 0; j < NT; ++j) {
+            const double2 t0 = tg[j], t1 = tg[NT + j], t2 = tg[2 * NT + j];
             sym_taps = sym_taps && t1.x == 1.0 && t1.y == 0.0 && t2.x == t0.x && t2.y == -t0.y;
         }
     }
     const int sym_taps_i = __builtin_amdgcn_readfirstlane(sym_taps ? 1 : 0);   // one scalar word, not a 64-bit lane mask carried through the loops
-    const int sps = 8;
-    const int sym_per_row = 64;
-    const int tile_len = MOD_ROWS * 512;
+    constexpr int sps = SPS;
+    constexpr int sym_per_row = CPR;
+    constexpr int tile_len = MOD_ROWS * RS;
+    const bool active = FULLROW || 2 * t < RS;                // (SPS 10 / 20: rows of 510 / 500 samples)
     const int cq = P.c / sps;
     const int q0 = (2 * t + P.c) / sps;
     const int r0 = (2 * t + P.c) - q0 * sps;
     const int wrap = (r0 + 1 == sps) ? 1 : 0;
     const int r1 = wrap ? 0 : r0 + 1;
-    const bool any_wrap = (P.c & 1) != 0;                     // sps = 8: r0 = (2 t + c) mod 8 is even unless c is odd
+    const bool any_wrap = (sps & 1) != 0 || (P.c & 1) != 0;   // even sps: r0 = (2 t + c) mod sps is even unless c is odd
     // per-lane tap phases of the two samples (mod_pair_phase): Gcum at r + 8 j, clamped to the last tap
     const double *Gcum = scratch + MOD_OFF_GCUM(P.ntiles);
     double Q0[JMAX], Q1[JMAX];
@@ -676,16 +698,16 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     // a - b == a + (-b)): ONE quad swap + add then gives vb in lanes 0, 1 and va in lanes 2, 3.
     //   even column:  -C | D | A | -B        odd column:  A | B | C | D      (lane 0 | 1 | 2 | 3)
     // Even lanes read Re x, odd lanes Im x, so the plain sums U (z1) sit in lanes 0 / 3 as Re / Im.
-    // The column parity of a lane does not change with the row (64 columns per row, tiles start on
-    // even symbols).  Tap components in LDS (as registers they cost a fifth wave per SIMD).
-    __shared__ double s_tapc[2 * 4 * 9];
-    if (CPMNF == 0 && t < 72) {
-        const double2 tp = reinterpret_cast<const double2 *>(mf_taps)[8 - t % 9];
-        const int part = (t % 36) / 9;
-        s_tapc[t] = t < 36 ? ((part == 0 || part == 3) ? -tp.y : tp.x) : ((part == 0 || part == 3) ? tp.x : tp.y);
+    // The column parity of a lane does not change with the row when a row holds an even number of columns
+    // (SPS 8: 64; tiles start on even symbols); with 51 (SPS 10) or 25 (SPS 20) it alternates row by row.
+    // Tap components in LDS (as registers they cost a fifth wave per SIMD).
+    __shared__ double s_tapc[2 * 4 * NT];
+    if (CPMNF == 0 && t < 8 * NT) {
+        const double2 tp = reinterpret_cast<const double2 *>(mf_taps)[NT - 1 - t % NT];
+        const int part = (t % (4 * NT)) / NT;
+        s_tapc[t] = t < 4 * NT ? ((part == 0 || part == 3) ? -tp.y : tp.x) : ((part == 0 || part == 3) ? tp.x : tp.y);
     }
-    const int odd_l = (Q.pack_par0 + mq - Q.kshift) & 1;
-    const double *tapc = s_tapc + 9 * (4 * odd_l + mp);
+    const int odd_l = (Q.pack_par0 + mq - Q.kshift) & 1;      // parity of this lane's column in an even row of an even tile-symbol base
     const int slot_l = (mp & 1) ? 4 - mp : mp;                     // packed slot this lane stores: 0, 3, 2, 1
     const double *ring_d = reinterpret_cast<const double *>(s_ring);
 
@@ -697,8 +719,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     const int64_t per_blk = (P.ntiles + gridDim.x - 1) / gridDim.x;
     const int64_t lt0_ = (int64_t)blockIdx.x * per_blk, lt1_ = lt0_ + per_blk < P.ntiles ? lt0_ + per_blk : P.ntiles;
     const int lt0 = (int)lt0_, lt1 = (int)lt1_;       // (the host checks ntiles < 2^31: one scalar register each across the loops)
-    if (lt0 == 0 && P.tile_lo == 0)                           // samples before the burst (row -1 of tile 0): ring row 1 and the group before it
-        for (int k = t; k < 512 + 64 + 9; k += MOD_THREADS) s_ring[(MCB_RING / 512 - 1) * 576 - 9 + k] = make_double2(0.0, 0.0);
+    if (lt0 == 0 && P.tile_lo == 0)                           // samples before the burst (row -1 of tile 0) are zeros: clear the ring
+        for (int k = t; k < G::SLOTS; k += MOD_THREADS) s_ring[k] = make_double2(0.0, 0.0);
     bool run_first = true;
     for (int ltile = lt0; ltile < lt1; ++ltile, run_first = false) {
         const bool run_last = ltile + 1 == lt1;
@@ -745,10 +767,10 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
         // window that ends there reads the copy.
         // the 64 columns whose window starts in row `rho` of this tile (rho = -1 .. 15)
         auto bank_row = [&](int rho) __attribute__((always_inline)) {
-            const int kr = 64 * rho + mq - Q.kshift;                    // column index relative to the tile's first symbol
+            const int kr = CPR * rho + mq - Q.kshift;                   // column index relative to the tile's first symbol
             const int64_t k = sym_base + kr;
-            const bool k_ok = kr >= klo && kr < khi;
-            const int grp = (64 * rho + mq) & (MCB_RING / 8 - 1);       // pad group of the window start
+            const bool k_ok = kr >= klo && kr < khi && (CPR == 64 || mq < CPR);
+            const int grp = ((rho & 1) ? CPR : 0) + (CPR == 64 ? mq : (mq < CPR ? mq : 0));   // pad group of the window start (rho = -1 .. 15)
             const bool odd = ((Q.pack_par0 + kr + (int)(sym_base & 1)) & 1) != 0;
             if constexpr (CPMNF != 0) {
                 // rows of the generic CPM detector: this lane's CPMNF / 4 filters of symbol k
@@ -775,11 +797,13 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                     for (int f = 0; f < FPT; ++f) o[f] = make_double2(zr[f], zi[f]);
                 }
             } else if (sym_taps_i != 0) {
-                const double *xb = ring_d + 2 * (9 * grp) + (mp & 1);
+                const double *xb = ring_d + 2 * (G::GS * grp) + (mp & 1);
+                // (CPR even: the lane's column parity is the same in every row)
+                const double *tapc = s_tapc + NT * (4 * ((CPR & 1) ? (int)odd : odd_l) + mp);
                 double S = 0.0, U = 0.0;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const double x = xb[2 * (j < 8 ? j : 9)];
+#pragma unroll NT <= 11 ? NT : 7                                         // (21 taps at sps 20: three trips of 7 keep the reads in flight within the register budget)
+                for (int j = 0; j < NT; ++j) {
+                    const double x = xb[2 * (j < SPS ? j : G::GS)];
                     S = fma(x, tapc[j], S);
                     U += x;
                 }
@@ -787,15 +811,15 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                 const double val = (mp == 0 || mp == 3) ? U : T;
                 if (k_ok) rows[4 * (k - Q.k_lo) + slot_l] = val;
             } else {
-                // any 3 x 9 bank: lane p keeps the one chain of the packed row it stores
+                // any 3 x (SPS + 1) bank: lane p keeps the one chain of the packed row it stores
                 const int f = mp < 2 ? 1 : (mp == 2 ? 0 : 2);
                 const bool imag = mp == 1 || (mp == 2 && odd) || (mp == 3 && !odd);
-                const double2 *xb = s_ring + 9 * grp;
+                const double2 *xb = s_ring + G::GS * grp;
                 double acc = 0.0;
 #pragma unroll 1
-                for (int j = 0; j < 9; ++j) {
-                    const double2 x = xb[j < 8 ? j : 9];
-                    const double2 tp = s_taps[f * 9 + (8 - j)];
+                for (int j = 0; j < NT; ++j) {
+                    const double2 x = xb[j < SPS ? j : G::GS];
+                    const double2 tp = s_taps[f * NT + (NT - 1 - j)];
                     acc = imag ? fma(x.x, tp.y, fma(x.y, tp.x, acc)) : fma(x.x, tp.x, fma(-x.y, tp.y, acc));
                 }
                 if (k_ok) rows[4 * (k - Q.k_lo) + mp] = acc;
@@ -806,7 +830,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
             const bool EXTRA = u >= MOD_ROWS;                   // (uniform; false for every row but the run's last one)
             double2 x0 = make_double2(0.0, 0.0), x1 = x0;
             bool have_next = true;
-            if (!EXTRA || wave_u == 0) {
+            if ((!EXTRA || wave_u == 0) && active) {
             double Wu = W;
             int refu_a = ref_a, refu_b = ref_b;
             if (EXTRA) {                                        // the next tile's carry and reference counts (fetched here: nothing of row 16 is live across the other rows)
@@ -817,12 +841,12 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
             }
             double ra, rb;
             mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap, P.nh,
-                                 win + 1, refu_a, refu_b, Wu, Th_a, Th_b, 8.0, 0.125, ra, rb);   // (sps = 8 here: P.sps_d, P.inv_sps as literals)
+                                 win + 1, refu_a, refu_b, Wu, Th_a, Th_b, (double)SPS, 1.0 / (double)SPS, ra, rb);   // (P.sps_d, P.inv_sps as literals)
             double2 e0, e1;
             wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
             wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
             // channel (wf_awgn_c128): derotate + Philox AWGN, one block per thread and row
-            const int64_t n0 = tile_base + (int64_t)u * 512 + 2 * t;
+            const int64_t n0 = tile_base + (int64_t)u * RS + 2 * t;
             double g[4];
 #ifdef WF_ABL_MCB_NONOISE   // ablation only
             g[0] = g[1] = g[2] = g[3] = (double)(n0 & 7);
@@ -850,12 +874,20 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
 #ifndef WF_ABL_MCB_NOBAR1   // ablation only (timing; results are wrong)
             wf_lds_barrier();
 #endif
-            const int ia = ((u << 9) + 2 * t - Q.d) & (MCB_RING - 1), ib = (ia + 1) & (MCB_RING - 1);
-            if (!EXTRA || t < 4) {                              // (row 16: its first 8 samples; the lanes above computed on window slots that do not exist)
-                s_ring[ia + (ia >> 3)] = x0;
-                s_ring[ib + (ib >> 3)] = x1;
-                if (ia == 0) s_ring[MCB_RING + MCB_RING / 8] = x0;  // index 2048: read by the window that ends the ring
-                if (ib == 0) s_ring[MCB_RING + MCB_RING / 8] = x1;
+            int ia, ib;                                         // ring indices (sample - d) mod RING of the thread's two samples
+            if (SPS == 8) {
+                ia = ((u << 9) + 2 * t - Q.d) & (G::RING - 1);
+                ib = (ia + 1) & (G::RING - 1);
+            } else {
+                ia = ((u & 1) ? RS : 0) + 2 * t - Q.d;
+                ia += ia < 0 ? G::RING : 0;
+                ib = ia + 1 == G::RING ? 0 : ia + 1;
+            }
+            if (active && (!EXTRA || 2 * t < SPS)) {            // (row 16: its first SPS samples; the lanes above computed on window slots that do not exist)
+                s_ring[ia + ia / SPS] = x0;
+                s_ring[ib + ib / SPS] = x1;
+                if (ia == 0) s_ring[G::GROUPS * G::GS] = x0;    // index RING: read by the window that ends the ring
+                if (ib == 0) s_ring[G::GROUPS * G::GS] = x1;
             }
             // ... and row u is complete after this barrier — one more barrier per row than a four-row
             // ring, 18 KB less LDS (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
@@ -989,7 +1021,7 @@ extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_
 
 // Fused modulator + channel + 3 x 9 bank with detector-packed rows (link fuse bit 3; internal).
 // Returns 1 — not an error — when the configuration is outside the fused kernel (the caller then
-// runs the separate kernels): needs sps 8, a pulse of at most 9 symbols inside the fused
+// runs the separate kernels): needs sps 8, 10 or 20 (CPM rows: 8), a pulse of at most 9 symbols inside the fused
 // modulator's envelope, an even first noise index.
 // Window form (streaming link): tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total symbols,
 // d_symbols[0] = symbol sym_origin (nloc resident), phase carry of the first tile from *d_q_in
@@ -1013,11 +1045,13 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_rows4) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_mf_taps) & 15) == 0,
                "wf_mod_chan_bank: device pointers must be 16-byte aligned");
     mod_params P;
-    if (sps != 8 || (first_index & 1) || first < 0 || first >= 8 || ncols < 1 || k_lo < 0) return 1;
-    if (!mod_setup(P, nsym_total, nh, ntaps, sps, phi0) || P.rs != 2 * MOD_THREADS) return 1;
+    const bool sps_ok = sps == 8 || (cpm_nf == 0 && (sps == 10 || sps == 20));   // kernel instantiations (mcb_geom)
+    if (!sps_ok || (first_index & 1) || first < 0 || first >= sps || ncols < 1 || k_lo < 0) return 1;
+    const int rs_want = sps == 8 ? mcb_geom<8>::RS : (sps == 10 ? mcb_geom<10>::RS : mcb_geom<20>::RS);
+    if (!mod_setup(P, nsym_total, nh, ntaps, sps, phi0) || P.rs != rs_want) return 1;
     const int J = (ntaps + sps - 1) / sps;
     if (J > 9) return 1;
-    WF_REQUIRE(first + (k_lo + ncols - 1) * 8 < P.out_len, "wf_mod_chan_bank: columns run past the burst");
+    WF_REQUIRE(first + (k_lo + ncols - 1) * (int64_t)sps < P.out_len, "wf_mod_chan_bank: columns run past the burst");
     if (ntiles < 0) ntiles = P.ntiles;
     WF_REQUIRE(tile_lo >= 0 && ntiles >= 1 && tile_lo + ntiles <= P.ntiles && ntiles < (int64_t)1 << 31, "wf_mod_chan_bank: bad tile window");
     P.sym_origin = sym_origin;
@@ -1038,15 +1072,18 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     Q.dyn_index = d_dyn_index;
     Q.k_lo = k_lo;
     Q.k_hi = k_lo + ncols;
-    Q.kshift = first >= 4 ? 0 : -1;
-    Q.d = (int)((first - 4 + 8) & 7);
+    // column k's window (sps + 1 taps, "same" convolution: centre tap at sample first + k sps) starts at sample
+    // first + k sps - sps / 2 = sps (k + kshift) + d
+    Q.kshift = first >= sps / 2 ? 0 : -1;
+    Q.d = (int)((first - sps / 2 + sps) % sps);
     Q.pack_par0 = pack_par0 & 1;
     Q.cpm_nh = cpm_nh;
     const int JM = J <= 4 ? 4 : 9;
-    const int win = MOD_ROWS * 64 + JM + 2;
+    const int win = MOD_ROWS * (P.rs / sps) + JM + 2;
+    const int ring_slots = sps == 8 ? mcb_geom<8>::SLOTS : (sps == 10 ? mcb_geom<10>::SLOTS : mcb_geom<20>::SLOTS);
     // (occupancy experiment, LDS padded to force fewer workgroups per CU with the 4-row ring of the
     //  first version: 1 per CU 0.97 ms, 2: 0.63, 3: 0.56 — the 2-row ring's 4 per CU: 0.53)
-    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)MCB_SLOTS * sizeof(double2) + (size_t)nh * (win + 1) * sizeof(int);
+    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)ring_slots * sizeof(double2) + (size_t)nh * (win + 1) * sizeof(int);
     // one run of consecutive tiles per resident workgroup (4 per CU for the SOQPSK form, 3 for the CPM forms)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -1059,6 +1096,8 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
     kern_t k = cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)
+             : sps == 10    ? (JM == 4 ? mod_chan_bank_kernel<4, 0, 10> : mod_chan_bank_kernel<9, 0, 10>)
+             : sps == 20    ? (JM == 4 ? mod_chan_bank_kernel<4, 0, 20> : mod_chan_bank_kernel<9, 0, 20>)
                             : (JM == 4 ? mod_chan_bank_kernel<4, 0> : mod_chan_bank_kernel<9, 0>);
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1076,6 +1115,18 @@ int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, 
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_mf_taps, rot_re, rot_im, sigma, seed, stream_id, first_index, nullptr, first, 0, ncols,
                                    pack_par0, d_rows4, stream, 0, 1, 3);
+}
+
+// Would the one-kernel front end (SOQPSK form: 3 x (sps + 1) bank, detector-packed rows) take this configuration?
+// Exactly the conditions under which wf_mod_chan_bank_window returns 0, without launching anything: the link
+// decides the row layout (32 B packed at sps 10 / 20 only through this kernel) with it.
+int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_ntaps, int64_t first)
+{
+    if (!(sps == 8 || sps == 10 || sps == 20) || mf_ntaps != sps + 1 || first < 0 || first >= sps || nh < 1 || nh > 2) return 0;
+    mod_params P;
+    const int rs_want = sps == 8 ? mcb_geom<8>::RS : (sps == 10 ? mcb_geom<10>::RS : mcb_geom<20>::RS);
+    if (!mod_setup(P, nsym, nh, ntaps, sps, 0.0) || P.rs != rs_want) return 0;
+    return (ntaps + sps - 1) / sps <= 9;
 }
 
 // Would the one-kernel front end take this CPM configuration?  (The answer wf_mod_chan_cpm_rows gives by

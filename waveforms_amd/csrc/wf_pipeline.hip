@@ -72,10 +72,24 @@ static link_layout make_layout(int64_t nsym, int sps, int ntaps, int nfilt, int 
 // so the library does not guess from sigma.  Every launch proves its output either way.
 static int link_warmup(const wf_link_config *cfg) { return cfg->warmup; }
 
-static bool link_packed_rows(const wf_link_config *cfg)
+// (the channel + bank kernel's PACK form exists at 8 samples per symbol only: what the streaming link and the
+//  fallback of the one-shot link can rely on)
+static bool link_packed_rows8(const wf_link_config *cfg)
 {
     return (cfg->fuse & 4) && (cfg->fuse & 2) && cfg->sps == 8 && cfg->mf_nfilt == 3;
 }
+
+// fuse bit 3 (with bits 0 - 2): modulator + channel + pulse-truncation bank in ONE kernel, detector-packed rows —
+// at 8, 10 (the reference's own examples/soqpsk_detection.py:38) and 20 samples per symbol.
+static bool link_one_kernel(const wf_link_config *cfg)
+{
+    if ((cfg->fuse & 15) != 15 || cfg->mf_nfilt != 3 || cfg->sps < 2) return false;
+    int64_t first = (-(int64_t)cfg->timing_offset) % cfg->sps;
+    if (first < 0) first += cfg->sps;
+    return wf_mod_chan_bank_applies(cfg->nsym, 1, cfg->ntaps, cfg->sps, cfg->mf_ntaps, first) != 0;
+}
+
+static bool link_packed_rows(const wf_link_config *cfg) { return link_packed_rows8(cfg) || link_one_kernel(cfg); }
 
 extern "C" int64_t wf_link_workspace_bytes(const wf_link_config *cfg)
 {
@@ -136,12 +150,13 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     // fuse bit 3 (with bits 1 and 2 in effect): modulator, channel and bank in ONE kernel — the clean
     // baseband samples never exist in HBM.  Outside that kernel's envelope the bits below apply.
     bool fused_all = false;
-    if ((cfg->fuse & 8) && (cfg->fuse & 1) && link_packed_rows(cfg) && cfg->mf_ntaps == 9 && L.ncols > 0) {
+    if (link_one_kernel(cfg) && L.ncols > 0) {
         rc = wf_mod_chan_bank_packed(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_mf_taps,
                                      cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, L.first, L.ncols, 0,
                                      mf, stream);
         if (rc < 0) return rc;
-        fused_all = rc == 0;
+        WF_REQUIRE(rc == 0, "wf_link_run: internal: the one-kernel front end refused a configuration wf_mod_chan_bank_applies accepted");
+        fused_all = true;
     }
     if (fused_all) {
         MARK(3); MARK(4); MARK(5); MARK(6);   // the "fir" slot times the whole fused kernel
@@ -182,7 +197,7 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     if (m > cfg->nsym) m = cfg->nsym;
     if (m < 0) m = 0;
     const bool fused_count = false;
-    const bool packed = fused_chan && link_packed_rows(cfg);
+    const bool packed = fused_chan && link_packed_rows8(cfg);
     if (L.ncols > 0) {
         if (packed)   // detector-packed rows: 4 doubles per call (call index of column 0 is 0: even)
             rc = wf_awgn_mf_bank_dyn(ctx, sig, L.npts, rot_re, rot_im, cfg->sigma, cfg->seed, cfg->stream_id, 0, nullptr,
@@ -229,8 +244,10 @@ extern "C" int wf_link_layout(const wf_link_config *cfg, int64_t *info8)
 {
     if (!cfg || !info8 || cfg->nsym < 1 || cfg->sps < 1) return WF_ERR_VALUE;
     const link_layout L = make_layout(cfg->nsym, cfg->sps, cfg->ntaps, cfg->mf_nfilt, 2, cfg->timing_offset);
-    info8[0] = L.ncols; info8[1] = 0; info8[2] = (int64_t)L.off_dbits; info8[3] = (int64_t)L.off_dsyms;
-    info8[4] = (int64_t)L.off_sig; info8[5] = 0; info8[6] = L.npts; info8[7] = (int64_t)L.off_mf;
+    info8[0] = L.ncols; info8[2] = (int64_t)L.off_dbits; info8[3] = (int64_t)L.off_dsyms;
+    info8[4] = (int64_t)L.off_sig; info8[6] = L.npts; info8[7] = (int64_t)L.off_mf;
+    info8[1] = link_one_kernel(cfg) ? 1 : 0;                          // modulator + channel + bank run as ONE kernel
+    info8[5] = link_packed_rows(cfg) ? 32 : 16 * cfg->mf_nfilt;       // bytes per matched-filter row at off(mf)
     return WF_OK;
 }
 
@@ -423,7 +440,7 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
             outp[c][s][(b & 1) ^ flip] = kOut[c][b];
         }
     int rc = WF_OK;
-    const bool packed = link_packed_rows(cfg);
+    const bool packed = link_packed_rows8(cfg);     // (the stream's one-kernel windows are an sps-8 path)
     const double rot_re = cos(-M_PI / 4), rot_im = sin(-M_PI / 4);
     WF_REQUIRE(!steady || (cfg->fuse & 2), "wf_link_stream_steady needs the fused channel (fuse bit 1)");
     if (phases & 1) {

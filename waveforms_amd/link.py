@@ -95,17 +95,16 @@ class SOQPSKLink:
 
     @property
     def row_bytes(self) -> int:
-        """Bytes per matched-filter row in the workspace: 48 (3 complex128), or 32 when fuse bit 2 is
-        in effect (detector-packed rows; 3-filter bank at 8 samples per symbol with the fused channel)."""
-        c = self.cfg
-        packed = (c.fuse & 4) and (c.fuse & 2) and c.sps == 8 and c.mf_nfilt == 3
-        return 32 if packed else 16 * c.mf_nfilt
+        """Bytes per matched-filter row in the workspace: 48 (3 complex128), or 32 when fuse bit 2 is in effect
+        (detector-packed rows: 3-filter bank with the fused channel at 8 samples per symbol, or the one-kernel
+        front end at 8 / 10 / 20)."""
+        return self.layout()["row_bytes"]            # the library's own rule (wf_link_layout)
 
     def layout(self) -> dict:
         """Byte offsets of the intermediates inside ``self.workspace``."""
         info = (ctypes.c_int64 * 8)()
         _hip.check(_hip.lib().wf_link_layout(ctypes.byref(self.cfg), info))
-        keys = ("calls", "first_call", "off_bits", "off_syms", "off_signal", "signal_origin", "signal_len", "off_mf")
+        keys = ("calls", "one_kernel_front_end", "off_bits", "off_syms", "off_signal", "row_bytes", "signal_len", "off_mf")
         return dict(zip(keys, (int(v) for v in info)))
 
     def reset_counts(self) -> None:
@@ -155,7 +154,12 @@ class SOQPSKStream:
     decisions and error counts equal a one-shot :class:`SOQPSKLink` over the whole stream,
     while HBM use is that of one chunk."""
 
-    row_bytes = SOQPSKLink.row_bytes   # same rule: it reads self.cfg only
+    @property
+    def row_bytes(self) -> int:
+        """Bytes per matched-filter row of a chunk: 32 (detector-packed) with fuse bits 1 + 2 at 8 samples per
+        symbol, else 48 (the streaming windows of the one-kernel front end are an sps-8 path)."""
+        c = self.cfg
+        return 32 if (c.fuse & 4) and (c.fuse & 2) and c.sps == 8 and c.mf_nfilt == 3 else 16 * c.mf_nfilt
 
     def __init__(self, total_symbols: int, chunk_symbols: int, sps: int = 8, **kw) -> None:
         # reuse the link's configuration (taps, pulse, PRBS ...) without its one-shot workspace

@@ -759,8 +759,10 @@ def test_empty_inputs_and_error_paths(oracle):
         bank(np.ones(5, dtype=np.complex128))
     with pytest.raises(ValueError):                      # columns past the end
         bank(np.ones(100, dtype=np.complex128), first=0, step=8, ncols=14)
-    with pytest.raises(ValueError):
-        SOQPSKTrellisDetector(length=4).detect(np.zeros((4, 3), dtype=np.complex128))
+    with pytest.raises(ValueError):                      # the batch form covers even window lengths 2 .. 16
+        SOQPSKTrellisDetector(length=5).detect(np.zeros((4, 3), dtype=np.complex128))
+    b4, s4 = SOQPSKTrellisDetector(length=4).detect(np.zeros((0, 3), dtype=np.complex128))
+    assert b4.size == 0 and s4.size == 0
     with pytest.raises(KeyError):
         PNSequence(65)
 

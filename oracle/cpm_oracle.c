@@ -77,8 +77,12 @@ void orc_cpm_mf_rows(const double *r_ri, int64_t npts, const double *taps_ri, in
                 if (t < 0 || t >= npts) continue;
                 const double rr = r_ri[2 * t], ri = r_ri[2 * t + 1];
                 const double tr = T[2 * (f * ntm + k)], ti = T[2 * (f * ntm + k) + 1];
+                /* per tap: the imaginary sample's term, then the real one's — in BOTH sums.  It is the order in
+                 * which v_mfma_f64_16x16x4_f64 runs its k index (a bitwise fma chain, k ascending: measured,
+                 * tools/mfma_f64_probe.hip) over the operand order (Im r_0, Re r_0, Im r_1, ...) the ARTM front end
+                 * feeds it, so the matrix-core kernel and the vector-pipe kernels produce the same bits. */
                 zr = fma(rr, tr, fma(ri, ti, zr));
-                zi = fma(ri, tr, fma(-rr, ti, zi));
+                zi = fma(-rr, ti, fma(ri, tr, zi));
             }
             out_ri[2 * (n * NF + f)] = zr;
             out_ri[2 * (n * NF + f) + 1] = zi;

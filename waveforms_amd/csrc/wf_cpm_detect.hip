@@ -641,14 +641,14 @@ __global__ __launch_bounds__(256) void cpm_mf_rows_kernel(const double2 *__restr
                     const double2 xv = x[k];
                     const double2 tp = c ? tap[1][k] : tap[0][k];
                     zr = fma(xv.x, tp.x, fma(xv.y, tp.y, zr));
-                    zi = fma(xv.y, tp.x, fma(-xv.x, tp.y, zi));
+                    zi = fma(-xv.x, tp.y, fma(xv.y, tp.x, zi));      // (imaginary sample's term first in both sums: cpm_oracle.c)
                 }
             } else {
                 const double2 *tp = s_t + (c * NF + f) * ntm;
                 for (int k = 0; k < ntm; ++k) {
                     const double2 xv = x[k];
                     zr = fma(xv.x, tp[k].x, fma(xv.y, tp[k].y, zr));
-                    zi = fma(xv.y, tp[k].x, fma(-xv.x, tp[k].y, zi));
+                    zi = fma(-xv.x, tp[k].y, fma(xv.y, tp[k].x, zi));
                 }
             }
             out[n * NF + f] = make_double2(zr, zi);

@@ -711,6 +711,44 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     const int slot_l = (mp & 1) ? 4 - mp : mp;                     // packed slot this lane stores: 0, 3, 2, 1
     const double *ring_d = reinterpret_cast<const double *>(s_ring);
 
+    // ---- CPMNF = 16 (ARTM: 16 filters of 9 taps): the bank on the MATRIX cores ------------------------------
+    // Row n of the bank is a real product  [1 x 18] . [18 x 32]:  the 9 window samples as (Im r_0, Re r_0, Im r_1,
+    // ...), the 32 outputs as (Re Z_0, Im Z_0, Re Z_1, ...), so 16 symbols x 32 outputs = two
+    // v_mfma_f64_16x16x4_f64 tiles over K = 20 (18 + 2 zeros): 10 MFMAs per 16 symbols in place of 144 fp64 FMAs
+    // per thread and row on the vector pipe — the same flops at the same peak rate (78.6 TF either way on this
+    // chip), but on a pipe that runs BESIDE the VALU, which the Philox / Box-Muller stream of the other waves
+    // keeps busy.  The instruction accumulates k ascending as a bitwise fma chain (tools/mfma_f64_probe.hip:
+    // 1 024 000 / 1 024 000 elements equal), which is the order cpm_oracle.c states, so the rows are those of the
+    // vector-pipe kernels bit for bit.  The templates alternate with the symbol parity (two modulation indices),
+    // so a wave takes 16 symbols of ONE parity: wave w = (half of the row, parity): columns 32 (w >> 1) + 2 i + (w & 1).
+    // Operand layout (MI355X_MICROARCH.md): A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, D[i][j] in lane
+    // j + 16 (i & 3), register i >> 2.
+#ifndef WF_MCB_MFMA
+#define WF_MCB_MFMA 1
+#endif
+    typedef double mcb_d4 __attribute__((ext_vector_type(4)));
+    constexpr bool USE_MFMA = CPMNF == 16 && WF_MCB_MFMA != 0;
+    double bmat[USE_MFMA ? 10 : 1];                          // B[k-step kk][output block nb], this lane's element
+    const int mf_i = t & 15, mf_kq = (t & 63) >> 4;          // MFMA row / k index of this lane (A), = column / k index (B)
+    if constexpr (USE_MFMA) {
+        wf_lds_barrier();                                    // templates staged above
+        const int par = (wave_u & 1) ^ (Q.kshift & 1);       // modulation-index column of this wave's symbols (tiles start on even symbols)
+        const int colT = Q.cpm_nh == 2 ? par : 0;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int kk = 0; kk < 5; ++kk) {
+                const int c = 4 * kk + mf_kq, tap = c >> 1, o = 16 * nb + mf_i, f = o >> 1;
+                double v = 0.0;
+                if (c < 18) {
+                    const double2 tp = s_taps[(colT * CPMNF + f) * 9 + tap];
+                    // Re Z += Im r . Im T (c even) | Re r . Re T (c odd);   Im Z += Im r . Re T | Re r . (-Im T)
+                    v = (o & 1) == 0 ? ((c & 1) ? tp.x : tp.y) : ((c & 1) ? -tp.y : tp.x);
+                }
+                bmat[nb * 5 + kk] = v;
+            }
+    }
+
     const uint64_t pair0 = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull);
     // A workgroup takes a RUN of consecutive tiles: rows then follow each other across the tile edge in the
     // ring exactly as inside a tile (row 15's last column completes when the next tile's row 0 is in), and
@@ -772,7 +810,34 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
             const bool k_ok = kr >= klo && kr < khi && (CPR == 64 || mq < CPR);
             const int grp = ((rho & 1) ? CPR : 0) + (CPR == 64 ? mq : (mq < CPR ? mq : 0));   // pad group of the window start (rho = -1 .. 15)
             const bool odd = ((Q.pack_par0 + kr + (int)(sym_base & 1)) & 1) != 0;
-            if constexpr (CPMNF != 0) {
+            if constexpr (USE_MFMA) {
+                // this wave's 16 symbols: in-row column 32 (w >> 1) + 2 i + (w & 1); lane = (symbol i, k index kq)
+                const int mqi = 32 * (wave_u >> 1) + 2 * mf_i + (wave_u & 1);
+                const int grp_i = ((rho & 1) ? 64 : 0) + mqi;
+                // A[i][4 kk + kq]: component c = 4 kk + kq of symbol i's window = (c & 1 ? Re : Im) of tap c >> 1
+                const double *xa = ring_d + 2 * (9 * grp_i) + ((mf_kq & 1) ? 0 : 1) + 2 * (mf_kq >> 1);
+                mcb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+                for (int kk = 0; kk < 5; ++kk) {
+                    // taps 2 kk + (kq >> 1): kk < 4 -> slots 0 .. 7; kk = 4: tap 8 sits behind the pad slot (slot 9), taps 9 (c >= 18) are zeros
+                    double a = kk < 4 ? xa[4 * kk] : xa[2 * 9 - 2 * (mf_kq >> 1)];
+                    if (kk == 4 && mf_kq >= 2) a = 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bmat[kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bmat[5 + kk], acc1, 0, 0, 0);
+                }
+                // D[i][j]: this lane holds output j = lane & 15 (+ 16 nb) of symbols i = (lane >> 4) + 4 reg
+                const int jo = mf_i;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int isym = mf_kq + 4 * reg;
+                    const int kr_i = 64 * rho + 32 * (wave_u >> 1) + 2 * isym + (wave_u & 1) - Q.kshift;
+                    if (kr_i >= klo && kr_i < khi) {
+                        double *o = rows + ((sym_base + kr_i) - Q.k_lo) * (2 * CPMNF) + jo;
+                        o[0] = acc0[reg];
+                        o[16] = acc1[reg];
+                    }
+                }
+            } else if constexpr (CPMNF != 0) {
                 // rows of the generic CPM detector: this lane's CPMNF / 4 filters of symbol k
                 constexpr int FPT = CPMNF / 4;
                 const double2 *xb = s_ring + 9 * grp;
@@ -788,7 +853,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                     for (int f = 0; f < FPT; ++f) {
                         const double2 tp = tb_[f * 9 + j];
                         zr[f] = fma(xv.x, tp.x, fma(xv.y, tp.y, zr[f]));
-                        zi[f] = fma(xv.y, tp.x, fma(-xv.x, tp.y, zi[f]));
+                        zi[f] = fma(-xv.x, tp.y, fma(xv.y, tp.x, zi[f]));      // (imaginary sample's term first in both sums: cpm_oracle.c)
                     }
                 }
                 if (k_ok) {

@@ -607,7 +607,7 @@ struct mcb_kargs {
 typedef const __attribute__((address_space(4))) mcb_kargs *mcb_kptr;
 
 template <int JMAX, int CPMNF, int SPS = 8>     // SPS != 8: CPMNF = 0 only (the CPM detector's 9-tap templates are an sps-8 design)
-__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? 3 : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
+__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? (CPMNF == 16 ? 4 : 3) : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
                                                                      const double *__restrict__ hvec_,
                                                                      const double *__restrict__ pulse_,
                                                                      const double *__restrict__ scratch_,
@@ -639,7 +639,14 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     int *s_pi = reinterpret_cast<int *>(s_ring + G::SLOTS);                      // prefix counts of the window's raw symbols
     __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
-    __shared__ double2 s_taps[CPMNF ? 2 * CPMNF * 9 : 3 * NT];
+#ifndef WF_MCB_MFMA
+#define WF_MCB_MFMA 1
+#endif
+    constexpr bool USE_MFMA = CPMNF == 16 && WF_MCB_MFMA != 0;
+    // (matrix-core form: the templates are only needed to build the B operands once, before the first row —
+    //  they are staged in the ring's slots instead of 4.6 KB of their own: 4 workgroups per CU instead of 3)
+    __shared__ double2 s_taps_own[USE_MFMA ? 1 : (CPMNF ? 2 * CPMNF * 9 : 3 * NT)];
+    double2 *const s_taps = USE_MFMA ? s_ring : s_taps_own;
     const int t = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(t) >> 6;      // the same number as a scalar
     wf_stage_tables<1, 0>(s_tab, t, MOD_THREADS);
@@ -723,11 +730,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     // so a wave takes 16 symbols of ONE parity: wave w = (half of the row, parity): columns 32 (w >> 1) + 2 i + (w & 1).
     // Operand layout (MI355X_MICROARCH.md): A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, D[i][j] in lane
     // j + 16 (i & 3), register i >> 2.
-#ifndef WF_MCB_MFMA
-#define WF_MCB_MFMA 1
-#endif
     typedef double mcb_d4 __attribute__((ext_vector_type(4)));
-    constexpr bool USE_MFMA = CPMNF == 16 && WF_MCB_MFMA != 0;
     double bmat[USE_MFMA ? 10 : 1];                          // B[k-step kk][output block nb], this lane's element
     const int mf_i = t & 15, mf_kq = (t & 63) >> 4;          // MFMA row / k index of this lane (A), = column / k index (B)
     if constexpr (USE_MFMA) {
@@ -747,6 +750,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                 }
                 bmat[nb * 5 + kk] = v;
             }
+        wf_lds_barrier();                                    // every lane has its operands: the ring's slots are free again
     }
 
     const uint64_t pair0 = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull);
@@ -1155,7 +1159,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
 #ifndef WF_MCB_RUNS_PER_SLOT
 #define WF_MCB_RUNS_PER_SLOT 4   // same-box A/B at 1e7 symbols: 1 run per slot 0.517 ms, 2: 0.500, 4: 0.478, 5 / 10: 0.486 (finer runs balance better; longer ones save more halo rows)
 #endif
-    const int64_t max_grid = (int64_t)cus * (cpm_nf ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
+    const int64_t max_grid = (int64_t)cus * (cpm_nf == 4 || (cpm_nf == 16 && JM != 4) ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
     const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
     const int grid = (int)((P.ntiles + per_run - 1) / per_run);
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);

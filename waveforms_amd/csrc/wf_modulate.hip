@@ -588,6 +588,9 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm CTRL (
 #ifndef WF_MCB_WAVES
 #define WF_MCB_WAVES 4
 #endif
+#ifndef WF_MCB_CPM_WAVES
+#define WF_MCB_CPM_WAVES 4    // CPM forms with a short pulse: 4 waves per SIMD (<= 128 registers, <= 40 KB LDS per workgroup)
+#endif
 #ifndef WF_MCB_UNROLL
 #define WF_MCB_UNROLL 2
 #endif
@@ -607,7 +610,7 @@ struct mcb_kargs {
 typedef const __attribute__((address_space(4))) mcb_kargs *mcb_kptr;
 
 template <int JMAX, int CPMNF, int SPS = 8>     // SPS != 8: CPMNF = 0 only (the CPM detector's 9-tap templates are an sps-8 design)
-__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? (CPMNF == 16 ? 4 : 3) : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
+__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? WF_MCB_CPM_WAVES : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
                                                                      const double *__restrict__ hvec_,
                                                                      const double *__restrict__ pulse_,
                                                                      const double *__restrict__ scratch_,
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     // The column parity of a lane does not change with the row when a row holds an even number of columns
     // (SPS 8: 64; tiles start on even symbols); with 51 (SPS 10) or 25 (SPS 20) it alternates row by row.
     // Tap components in LDS (as registers they cost a fifth wave per SIMD).
-    __shared__ double s_tapc[2 * 4 * NT];
+    __shared__ double s_tapc[CPMNF == 0 ? 2 * 4 * NT : 1];      // (SOQPSK bank only)
     if (CPMNF == 0 && t < 8 * NT) {
         const double2 tp = reinterpret_cast<const double2 *>(mf_taps)[NT - 1 - t % NT];
         const int part = (t % (4 * NT)) / NT;
@@ -1159,7 +1162,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
 #ifndef WF_MCB_RUNS_PER_SLOT
 #define WF_MCB_RUNS_PER_SLOT 4   // same-box A/B at 1e7 symbols: 1 run per slot 0.517 ms, 2: 0.500, 4: 0.478, 5 / 10: 0.486 (finer runs balance better; longer ones save more halo rows)
 #endif
-    const int64_t max_grid = (int64_t)cus * (cpm_nf == 4 || (cpm_nf == 16 && JM != 4) ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
+    const int64_t max_grid = (int64_t)cus * (cpm_nf && JM != 4 ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
     const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
     const int grid = (int)((P.ntiles + per_run - 1) / per_run);
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);

@@ -42,7 +42,30 @@ def main():
     db = time.perf_counter() - t1
     fresh = SOQPSKTrellisDetector(length=2)
     want = np.array([fresh.iteration(z)[0][0] for z in rows[:2000]])
+    # the C-ABI call alone (preallocated operands, no numpy work per call): what the boundary itself costs
+    import ctypes
+
+    from waveforms_amd import _hip
+
+    cdet = SOQPSKTrellisDetector(length=2)
+    cdet._ensure_state()
+    fn, ctx, st, stream = _hip.lib().wf_viterbi4_iteration_host, _hip.ctx(), cdet._d_state_ptr, _hip.stream()
+    flat = np.ascontiguousarray(rows).view(np.float64).reshape(-1, 6)
+    bits, syms = np.empty(2), np.empty(2)
+    pb, ps, base = bits.ctypes.data, syms.ctypes.data, flat.ctypes.data
+    for k in range(200):
+        fn(ctx, st, 2, 1, base + 48 * k, pb, ps, stream)
+    t2 = time.perf_counter()
+    for k in range(a.calls):
+        fn(ctx, st, 2, 1, base + 48 * k, pb, ps, stream)
+    dc = time.perf_counter() - t2
+    t3 = time.perf_counter()
+    ver = _hip.lib().wf_version
+    for k in range(a.calls):
+        ver()
+    dv = time.perf_counter() - t3
     print(json.dumps({"calls": a.calls, "iteration_us_per_call": round(dt / a.calls * 1e6, 2),
+                      "c_abi_call_us": round(dc / a.calls * 1e6, 2), "empty_ctypes_call_us": round(dv / a.calls * 1e6, 2),
                       "reference_us_per_call": 57.0, "batch_detect_us_per_call_incl_h2d_d2h": round(db / a.calls * 1e6, 4),
                       "iteration_equals_batch": bool(np.array_equal(want.astype(np.uint8), bb[:2000]))}))
 

@@ -8,7 +8,7 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/$tag
 mkdir -p $out
-flags="--steps 2 --warmup 1 --no-cpu-baseline --overlap-streams 0 $*"
+flags="--steps 2 --warmup 1 --no-cpu-baseline --overlap-streams 0 --steady-steps 0 $*"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/p1 -o p1 -- python3 bench.py $flags > /dev/null 2> $out/p1.err
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $out/p2 -o p2 -- python3 bench.py $flags > /dev/null 2> $out/p2.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_TRANS_F --output-format csv -d $out/p3 -o p3 -- python3 bench.py $flags > /dev/null 2> $out/p3.err

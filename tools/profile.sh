@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/$tag
 mkdir -p $out/profiles
 # --overlap-streams 0: only the single-stream timed region, so the per-kernel averages are those of kernels running alone
-flags="--steps 5 --warmup 2 --no-cpu-baseline --overlap-streams 0 $*"
+flags="--steps 5 --warmup 2 --no-cpu-baseline --overlap-streams 0 --steady-steps 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py $flags > $out/profiles/${tag}_bench_under_rocprof.json 2> $out/kt.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python3 bench.py $flags > /dev/null 2> $out/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python3 bench.py $flags > /dev/null 2> $out/write.err
@@ -22,7 +22,8 @@ wc=$(find $out/write -name '*counter_collection.csv' | head -1)
 sc=$(find $out/sq -name '*counter_collection.csv' | head -1)
 cp $ks $out/profiles/${tag}_kernel_stats.csv
 kt=$(find $out/kt -name '*kernel_trace.csv' | head -1)
-python3 tools/pmc_summary.py $tag $ks $fc $wc --sq $sc --trace $kt --nsym 10000000 --sps 8 --out $out/profiles
+sps=8; case " $* " in *" --sps 10 "*) sps=10;; *" --sps 20 "*) sps=20;; esac
+python3 tools/pmc_summary.py $tag $ks $fc $wc --sq $sc --trace $kt --nsym 10000000 --sps $sps --out $out/profiles
 # the bench line committed next to the summary is taken AFTER it, so that its roofline object quotes this
 # very profile (traffic, VALU instructions, shader cycles) and says traffic_profile_matches_build: true
 cp $out/profiles/${tag}_summary.json profiles/

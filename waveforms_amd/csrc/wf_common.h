@@ -66,6 +66,10 @@ struct wf_ctx {
     hipEvent_t *events = nullptr;  // WF_LINK_EVENT_SLOTS x (WF_LINK_STAGES + 1), created lazily
     double *h_iter = nullptr;      // per-symbol detector call: pinned, device-mapped staging (6 in + 2 x 64 out)
     double *d_iter = nullptr;      // ... the device's address of the same memory
+    void *h_mailbox = nullptr;     // per-symbol detector call through the persistent iteration server (wf_viterbi.hip): pinned mailbox,
+    void *d_mailbox = nullptr;     // ... its device address,
+    void *iter_stream = nullptr;   // ... the server's own (non-blocking) stream,
+    const void *iter_last_state = nullptr;   // ... and the detector state the last request was for
 };
 
 static inline hipStream_t wf_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -73,6 +77,7 @@ static inline hipStream_t wf_stream(void *s) { return reinterpret_cast<hipStream
 int wf_ctx_reserve_scan(wf_ctx *ctx, size_t words);
 int wf_ctx_reserve_fsm(wf_ctx *ctx, size_t words);
 int wf_ctx_reserve_mod(wf_ctx *ctx, size_t words);
+int wf_iter_server_stop(wf_ctx *ctx);
 int wf_ctx_reserve_vit(wf_ctx *ctx, size_t words);
 
 // Internal (not exported) forms with device-resident carries, used by the streaming link.

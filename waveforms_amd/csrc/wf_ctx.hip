@@ -44,6 +44,7 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
 {
     if (!c) return WF_OK;
     (void)hipSetDevice(c->device);
+    (void)wf_iter_server_stop(c);           // a persistent iteration server (if any) retires before the device-wide wait
     (void)hipDeviceSynchronize();
     for (auto &kv : c->lfsr) {
         if (kv.second->dev) (void)hipFree(kv.second->dev);
@@ -65,6 +66,8 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_iter) (void)hipHostFree(c->h_iter);
+    if (c->iter_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(c->iter_stream));
+    if (c->h_mailbox) (void)hipHostFree(c->h_mailbox);
     delete c;
     return WF_OK;
 }

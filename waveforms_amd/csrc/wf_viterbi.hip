@@ -18,6 +18,9 @@
 //    reference detector supports (state_exp_term has 4 entries, algorithm.py:30).
 //  * viterbi_iteration_kernel: one literal .iteration() for any window length, detector
 //    state resident in device memory (drop-in for the per-symbol API).
+#include <stdlib.h>
+#include <string.h>
+
 #include "wf_common.h"
 
 #define VIT_THREADS 256
@@ -850,10 +853,11 @@ extern "C" int64_t wf_viterbi4_state_bytes(int length)
     return (length >= 1 && length <= VIT_MAX_LEN) ? (int64_t)sizeof(vit_state) : -1;
 }
 
-__global__ void viterbi_iteration_kernel(vit_state *st, int L, int diff, const double *__restrict__ mf3,
-                                         double *__restrict__ bits_out, double *__restrict__ syms_out)
+// One literal .iteration() (algorithm.py:44-101) by ONE thread.  mf3 / bits_out / syms_out may be host memory the
+// device addresses directly (volatile: the mailbox form below re-reads them on every request).
+__device__ __forceinline__ void vit_iteration_body(vit_state *st, int L, int diff, const volatile double *mf3,
+                                                   volatile double *bits_out, volatile double *syms_out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long i = st->i;
     const int col_now = (int)(((i % 2) + 2) % 2);
     // algorithm.py:57-63: np.roll(-1) then overwrite the last column
@@ -912,6 +916,102 @@ __global__ void viterbi_iteration_kernel(vit_state *st, int L, int diff, const d
     st->i = i + 1;
 }
 
+__global__ void viterbi_iteration_kernel(vit_state *st, int L, int diff, const double *__restrict__ mf3,
+                                         double *__restrict__ bits_out, double *__restrict__ syms_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    vit_iteration_body(st, L, diff, mf3, bits_out, syms_out);
+}
+
+// ---- the per-symbol call without a launch per symbol ---------------------------------------------------
+// examples/soqpsk_detection.py:189-198 calls the detector once per symbol from a Python loop.  A kernel
+// launch + a stream synchronise per call cost 22.7 us (profiles/r02_iteration_bench.json), 2.5x fewer than the
+// reference's 57 us of interpreted Python but all of it launch latency.  Instead ONE single-wave kernel is
+// started by the first call and serves every following call through a mailbox in pinned host memory that the
+// device addresses directly: the host writes the three matched-filter outputs and bumps `req`, the kernel (lane
+// 0 polls with system-scope atomics) runs the iteration on the detector state in device memory, writes the
+// 2 x length results and sets `ack` = `req`; the host spins on `ack`.  Two PCIe round trips per call, no launch.
+// EXIT CONDITIONS (every wave reaches one): `stop` set by the host (context teardown), or no request for
+// VIT_SERVER_IDLE_TICKS of the constant-rate wall clock (10 ms): the kernel then clears `running` and retires;
+// the next call simply starts it again (the detector state lives in device memory, the sequence numbers in the
+// mailbox).  It runs on the context's own stream, so nothing the caller queues waits behind it, and a
+// device-wide synchronise waits for at most the idle time.
+struct vit_mailbox {
+    unsigned long long req, ack, stop, running;      // sequence numbers / flags (each written by ONE side)
+    // the request, 64 bytes read by the device with four independent 16-byte loads (one PCIe round trip):
+    unsigned long long state_ptr;                    // vit_state* of the detector this request is for
+    int length, diff;
+    double mf[6];
+    double bits[VIT_MAX_LEN], syms[VIT_MAX_LEN];     // the answer
+};
+#define VIT_SERVER_IDLE_TICKS 1000000ull             // wall_clock64() ticks at 100 MHz: 10 ms
+
+__global__ void viterbi_iteration_server_kernel(vit_mailbox *mb)
+{
+    // The detector state the requests are for is CACHED in LDS between requests (6.4 KB; a single thread walking it
+    // in device memory paid a ~1 us dependent load per access: 20 .. 30 us per call).  Write-through: what a call
+    // changed (the first `length` columns of the three tables and the counter) goes back to device memory before
+    // the acknowledgement, so the home copy is always current — nothing is written when the server retires, and a
+    // detector whose memory has been freed and handed to a NEW one is never clobbered.  The cache is valid while
+    // the home's call counter equals the cached one (a new, zero-filled detector at the same address does not).
+    __shared__ vit_state s_st;
+    __shared__ double s_out[2 * VIT_MAX_LEN];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    vit_state *home = nullptr;
+    unsigned long long last = __hip_atomic_load(&mb->ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long idle_since = wall_clock64();
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    for (;;) {
+        const unsigned long long seq = __hip_atomic_load(&mb->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (seq != last) {
+            // the request in one burst of loads from host memory
+            const volatile v2d *rq = reinterpret_cast<const volatile v2d *>(&mb->state_ptr);
+            const v2d q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3];
+            const unsigned long long sp = (unsigned long long)__double_as_longlong(q0.x);
+            const long long ld = __double_as_longlong(q0.y);
+            const int L = (int)(ld & 0xFFFFFFFFll), diff = (int)(ld >> 32);
+            double mf[6] = {q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+            vit_state *want = reinterpret_cast<vit_state *>(sp);
+            if (want != home || *(volatile long long *)&want->i != s_st.i) {
+                s_st = *want;
+                home = want;
+            }
+            vit_iteration_body(&s_st, L, diff, mf, s_out, s_out + VIT_MAX_LEN);
+            for (int j = 0; j < L; ++j) {                      // write-through (posted stores: no round trip)
+                for (int b = 0; b < 8; ++b) home->bi_history[b][j] = s_st.bi_history[b][j];
+                for (int q = 0; q < 4; ++q) {
+                    home->metrics[q][j] = s_st.metrics[q][j];
+                    home->path[q][j] = s_st.path[q][j];
+                }
+            }
+            home->i = s_st.i;
+            for (int k = 0; k < L; ++k) {
+                *(volatile double *)&mb->bits[k] = s_out[k];
+                *(volatile double *)&mb->syms[k] = s_out[VIT_MAX_LEN + k];
+            }
+            __hip_atomic_store(&mb->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            last = seq;
+            idle_since = wall_clock64();
+            continue;
+        }
+        if (__hip_atomic_load(&mb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        if (wall_clock64() - idle_since > VIT_SERVER_IDLE_TICKS) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __hip_atomic_store(&mb->running, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Stop the server of a context (teardown; harmless when none is running): it retires within one poll.
+int wf_iter_server_stop(wf_ctx *ctx)
+{
+    if (!ctx || !ctx->h_mailbox) return WF_OK;
+    vit_mailbox *mb = static_cast<vit_mailbox *>(ctx->h_mailbox);
+    __atomic_store_n(&mb->stop, 1ull, __ATOMIC_RELEASE);
+    if (ctx->iter_stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(ctx->iter_stream));
+    __atomic_store_n(&mb->stop, 0ull, __ATOMIC_RELEASE);
+    return WF_OK;
+}
+
 extern "C" int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int differential,
                                      const double *d_mf3_ri, double *d_bits_out, double *d_syms_out,
                                      void *stream)
@@ -937,19 +1037,64 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
     WF_REQUIRE(ctx && d_state && h_mf3_ri && h_bits_out && h_syms_out, "wf_viterbi4_iteration_host: NULL argument");
     WF_REQUIRE(length >= 1 && length <= VIT_MAX_LEN, "wf_viterbi4_iteration_host: length %d", length);
     WF_HIP(hipSetDevice(ctx->device));
-    if (!ctx->h_iter) {
-        WF_HIP(hipHostMalloc(&ctx->h_iter, (6 + 2 * VIT_MAX_LEN) * sizeof(double), hipHostMallocMapped));
-        WF_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->d_iter), ctx->h_iter, 0));
-    }
+    static const bool use_server = [] { const char *e = getenv("WF_ITERATION_SERVER"); return !(e && e[0] == '0'); }();
     hipStream_t s = wf_stream(stream);
-    for (int k = 0; k < 6; ++k) ctx->h_iter[k] = h_mf3_ri[k];
-    hipLaunchKernelGGL(viterbi_iteration_kernel, dim3(1), dim3(64), 0, s, static_cast<vit_state *>(d_state), length,
-                       differential ? 1 : 0, ctx->d_iter, ctx->d_iter + 6, ctx->d_iter + 6 + VIT_MAX_LEN);
-    WF_LAUNCH_CHECK();
-    WF_HIP(hipStreamSynchronize(s));
+    if (!use_server) {      // one launch + one synchronise per call (the round-2 form; kept for A/B and as a fallback)
+        if (!ctx->h_iter) {
+            WF_HIP(hipHostMalloc(&ctx->h_iter, (6 + 2 * VIT_MAX_LEN) * sizeof(double), hipHostMallocMapped));
+            WF_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->d_iter), ctx->h_iter, 0));
+        }
+        for (int k = 0; k < 6; ++k) ctx->h_iter[k] = h_mf3_ri[k];
+        hipLaunchKernelGGL(viterbi_iteration_kernel, dim3(1), dim3(64), 0, s, static_cast<vit_state *>(d_state), length,
+                           differential ? 1 : 0, ctx->d_iter, ctx->d_iter + 6, ctx->d_iter + 6 + VIT_MAX_LEN);
+        WF_LAUNCH_CHECK();
+        WF_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < length; ++k) {
+            h_bits_out[k] = ctx->h_iter[6 + k];
+            h_syms_out[k] = ctx->h_iter[6 + VIT_MAX_LEN + k];
+        }
+        return WF_OK;
+    }
+    if (!ctx->h_mailbox) {
+        WF_HIP(hipHostMalloc(&ctx->h_mailbox, sizeof(vit_mailbox), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ctx->h_mailbox, 0, sizeof(vit_mailbox));
+        WF_HIP(hipHostGetDevicePointer(&ctx->d_mailbox, ctx->h_mailbox, 0));
+        hipStream_t is;
+        WF_HIP(hipStreamCreateWithFlags(&is, hipStreamNonBlocking));
+        ctx->iter_stream = is;
+    }
+    vit_mailbox *mb = static_cast<vit_mailbox *>(ctx->h_mailbox);
+    if (ctx->iter_last_state != d_state) {
+        // a detector this server has not seen: whatever the caller queued on ITS stream to set the state up
+        // (the zero fill of a new detector) must have landed before the server touches it
+        WF_HIP(hipStreamSynchronize(s));
+        ctx->iter_last_state = d_state;
+    }
+    mb->state_ptr = (unsigned long long)(uintptr_t)d_state;
+    mb->length = length;
+    mb->diff = differential ? 1 : 0;
+    for (int k = 0; k < 6; ++k) mb->mf[k] = h_mf3_ri[k];
+    const unsigned long long seq = mb->req + 1;
+    __atomic_store_n(&mb->req, seq, __ATOMIC_RELEASE);
+    for (unsigned long long spins = 0;; ++spins) {
+        if (__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) == seq) break;
+        if (__atomic_load_n(&mb->running, __ATOMIC_ACQUIRE) == 0) {
+            // not started yet, or retired after its idle time (possibly while this request was being posted):
+            // (re)start it — it picks the pending request up from the sequence numbers
+            __atomic_store_n(&mb->running, 1ull, __ATOMIC_RELEASE);
+            hipLaunchKernelGGL(viterbi_iteration_server_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(ctx->iter_stream),
+                               static_cast<vit_mailbox *>(ctx->d_mailbox));
+            WF_LAUNCH_CHECK();
+        }
+        if (spins > 2000000000ull) {        // ~ seconds of spinning: the device is gone or wedged
+            wf_set_error("wf_viterbi4_iteration_host: the iteration server did not answer");
+            return WF_ERR_HIP;
+        }
+        __builtin_ia32_pause();
+    }
     for (int k = 0; k < length; ++k) {
-        h_bits_out[k] = ctx->h_iter[6 + k];
-        h_syms_out[k] = ctx->h_iter[6 + VIT_MAX_LEN + k];
+        h_bits_out[k] = mb->bits[k];
+        h_syms_out[k] = mb->syms[k];
     }
     return WF_OK;
 }

@@ -400,6 +400,23 @@ int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspac
  * channel + filters as one kernel for this configuration), signal samples, off(rows)} */
 int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8);
 
+/* Streaming form of the CPM link (the scheme of wf_link_stream_chunk for the waveforms of BASELINE configs[2]):
+ * a stream of cfg->nsym symbols in chunks of chunk_symbols detector calls, HBM footprint of one chunk; chunk c
+ * makes calls [c*B, (c+1)*B).  Neighbouring context is re-generated as a halo (PRBS leap-ahead, memoryless
+ * mapper, counter-based noise, one modulator tile either side) or carried in d_state
+ * (WF_CPM_STREAM_STATE_BYTES, zero-initialised: detector state + modulator phase carry).  Chunks must be
+ * processed in order; decisions and counts equal wf_cpm_link_run over the whole stream.  chunk_symbols: a
+ * multiple of one modulator tile (wf_mod_tile_geometry) and of 128, at least 4 halos; the configuration must be
+ * one the one-kernel front end takes (fuse bits 1 + 3; wf_cpm_link_layout info8[5]).
+ * wf_cpm_link_stream_layout: info8 = {calls in the chunk, first call index, off(decisions), off(symbols alpha),
+ * global index of symbols[0], calls of the whole stream, symbols per modulator tile, off(rows)}. */
+#define WF_CPM_STREAM_STATE_BYTES 2048
+int64_t wf_cpm_link_stream_workspace_bytes(const wf_cpm_link_config *cfg, int64_t chunk_symbols);
+int wf_cpm_link_stream_layout(const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index, int64_t *info8);
+int wf_cpm_link_stream_chunk(wf_ctx *ctx, const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
+                             void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
+                             int64_t *h_compared, void *stream);
+
 /* ---- data products of the reference's plotting helpers (no plotting) ------------------
  * Welch PSD exactly as Axes.psd / matplotlib.mlab.psd evaluates the call of
  * waveforms/viz/psd.py:36-41 (window d_window of nfft doubles, np.hanning for the reference;

@@ -328,3 +328,34 @@ def test_gpu_cpm_detection_example(oracle):
         res = oracle.cpm_detection_run(sym, pulse, SPS, spec, noise=noise)
         assert got[label] == (res["sym_errors"], res["bit_errors"], res["compared"]), label
     assert got["ARTM multi-h"][1] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waveform,chunk", [("multih", 5120), ("multih", 8192), ("pcmfm", 6144)])
+def test_gpu_cpm_stream_in_chunks_equals_one_shot(waveform, chunk):
+    """wf_cpm_link_stream_chunk: the CPM link over a stream in chunks (detector state and modulator phase carried,
+    everything else re-generated as a halo) makes exactly the one-shot link's decisions and counts — ragged
+    last chunk, with and without noise."""
+    from waveforms_amd.link import CPMLink, CPMStream
+
+    nsym = 4 * chunk + 1777
+    one = CPMLink(nsym, SPS, waveform=waveform)
+    st = CPMStream(nsym, chunk, SPS, waveform=waveform)
+    assert st.nchunks == 5
+    for ebn0, sid in ((None, 0), (6.0, 3)):
+        one.reset_counts()
+        one.run_block(ebn0, seed=4, stream_id=sid)
+        want = one.result()
+        lo = one.layout()
+        want_dec = one.workspace[lo["off_decisions"]:lo["off_decisions"] + lo["calls"]].cpu().numpy()
+        st.reset()
+        got_dec = []
+        for c in range(st.nchunks):
+            st.run_chunk(c, ebn0, seed=4, stream_id=sid)
+            info = st.chunk_info(c)
+            got_dec.append(st.workspace[info["off_decisions"]:info["off_decisions"] + info["calls"]].cpu().numpy())
+        assert st.result() == want
+        assert np.array_equal(np.concatenate(got_dec), want_dec)
+        assert ebn0 is None or want[1] > 0
+    with pytest.raises(ValueError):
+        CPMStream(nsym, 1000, SPS, waveform=waveform)

@@ -927,3 +927,124 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     if (h_compared) *h_compared = m;
     return WF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Streaming form of the CPM link (BASELINE config 5's scheme, wf_pipeline.hip, for the waveforms of
+// configs[2]): the same chain over a stream of cfg->nsym symbols in chunks of `chunk_symbols` detector
+// calls with the HBM footprint of ONE chunk.  Chunk c makes calls [c B, (c+1) B); what it needs from its
+// neighbours is (a) re-generated as a halo — PRBS by leap-ahead, mapper (memoryless), noise by absolute
+// sample index, one modulator tile either side — or (b) carried in a device block of
+// WF_CPM_STREAM_STATE_BYTES: the detector state (WF_CPM_STATE_BYTES: call counter, metrics, tilted phase
+// indices, decision registers) and the 62-bit fixed-point phase carry of the next chunk's first tile.
+// Decisions and counts equal the one-shot wf_cpm_link_run over the whole stream, bit for bit.  Runs the
+// one-kernel front end (fuse bits 1 + 3; sps 8, 4 or 16 filters): other configurations are refused.
+struct cpm_stream_layout {
+    int64_t N, B, tile_len, spt, ntiles_total, halo, ncalls_total, m_total;
+    int64_t k_lo, ncols, ws, nloc, tile_lo, ntiles, q_out_tile;
+    size_t off_bits, off_syms, off_rows, off_dec, total;
+    cpm_link_layout L;
+    bool ok;
+};
+
+static cpm_stream_layout cpm_make_stream_layout(const wf_cpm_link_config *cfg, int64_t B, int64_t c)
+{
+    cpm_stream_layout S{};
+    if (!cpm_make_layout(cfg, S.L) || B <= 0 || c < 0) return S;
+    S.N = cfg->nsym; S.B = B;
+    S.ok = wf_mod_tile_geometry(cfg->sps, cfg->ntaps, cfg->nsym, &S.tile_len, &S.spt, &S.ntiles_total) == 0;
+    if (!S.ok || S.spt <= 0) { S.ok = false; return S; }
+    S.halo = cpm_round_up(S.spt + 48 + cfg->det.D, 16);
+    S.ncalls_total = S.L.ncalls;
+    const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;
+    S.m_total = S.ncalls_total - cfg->det.D + 1 - skip;
+    if (S.m_total < 0) S.m_total = 0;
+    S.ok = B % S.spt == 0 && B % 128 == 0 && B >= 4 * S.halo &&
+           ((cfg->fuse & 8) && (cfg->fuse & 2) &&
+            wf_mod_chan_cpm_rows_applies(cfg->nsym, cfg->det.nh, cfg->ntaps, cfg->sps, S.L.nfilt, S.L.ntm, S.L.start0));
+    S.k_lo = c * B;
+    const int64_t k_hi = S.k_lo + B < S.ncalls_total ? S.k_lo + B : S.ncalls_total;
+    S.ncols = k_hi > S.k_lo ? k_hi - S.k_lo : 0;
+    S.ws = c * B - S.halo > 0 ? c * B - S.halo : 0;
+    const int64_t we = (c + 1) * B + S.halo < S.N ? (c + 1) * B + S.halo : S.N;
+    S.nloc = we > S.ws ? we - S.ws : 0;
+    S.tile_lo = c * B / S.spt - 1 > 0 ? c * B / S.spt - 1 : 0;          // the tile before the chunk too: its last column is the chunk's first
+    int64_t tile_hi = (c + 1) * B / S.spt + 1;
+    if (tile_hi > S.ntiles_total) tile_hi = S.ntiles_total;
+    S.ntiles = tile_hi > S.tile_lo ? tile_hi - S.tile_lo : 0;
+    const int64_t next_tile_lo = (c + 1) * B / S.spt - 1;
+    S.q_out_tile = (next_tile_lo >= S.tile_lo && next_tile_lo < tile_hi) ? next_tile_lo - S.tile_lo : -1;
+    size_t o = 0;
+    const int64_t win = B + 2 * S.halo + 32;
+    S.off_bits = o; o += (size_t)cpm_round_up(win * S.L.bps, 256);
+    S.off_syms = o; o += (size_t)cpm_round_up(win, 256);
+    S.off_rows = o; o += (size_t)cpm_round_up(B * S.L.nfilt * 16, 256);
+    S.off_dec = o;  o += (size_t)cpm_round_up(B + 16, 256);
+    S.total = o;
+    return S;
+}
+
+extern "C" int64_t wf_cpm_link_stream_workspace_bytes(const wf_cpm_link_config *cfg, int64_t chunk_symbols)
+{
+    const cpm_stream_layout S = cpm_make_stream_layout(cfg, chunk_symbols, 0);
+    return S.ok ? (int64_t)S.total : -1;
+}
+
+/* info8 = {calls in the chunk, first call index, off(decisions), off(symbols alpha), global index of symbols[0],
+ *          calls of the whole stream, symbols one modulator tile holds, off(rows)} */
+extern "C" int wf_cpm_link_stream_layout(const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index, int64_t *info8)
+{
+    if (!info8) return WF_ERR_VALUE;
+    const cpm_stream_layout S = cpm_make_stream_layout(cfg, chunk_symbols, chunk_index);
+    if (!S.ok) return WF_ERR_VALUE;
+    info8[0] = S.ncols; info8[1] = S.k_lo; info8[2] = (int64_t)S.off_dec; info8[3] = (int64_t)S.off_syms;
+    info8[4] = S.ws; info8[5] = S.ncalls_total; info8[6] = S.spt; info8[7] = (int64_t)S.off_rows;
+    return WF_OK;
+}
+
+extern "C" int wf_cpm_link_stream_chunk(wf_ctx *ctx, const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
+                                        void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
+                                        int64_t *h_compared, void *stream)
+{
+    WF_REQUIRE(ctx && cfg && d_state && d_workspace && d_counts, "wf_cpm_link_stream_chunk: NULL argument");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_workspace) & 255) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
+               "wf_cpm_link_stream_chunk: workspace must be 256-byte aligned, the carry block 16-byte aligned");
+    const cpm_stream_layout S = cpm_make_stream_layout(cfg, chunk_symbols, chunk_index);
+    WF_REQUIRE(S.ok, "wf_cpm_link_stream_chunk: chunk of %lld calls must be a multiple of the modulator tile (%lld symbols) and of 128 "
+               "and at least 4 halos (%lld), and the configuration one the one-kernel front end takes (fuse bits 1 + 3, sps 8)",
+               (long long)chunk_symbols, (long long)S.spt, (long long)(4 * S.halo));
+    WF_REQUIRE((int64_t)S.total <= workspace_bytes, "wf_cpm_link_stream_chunk: workspace too small");
+    WF_REQUIRE(cfg->d_h && cfg->d_pulse && cfg->d_templates && cfg->d_rot_cs, "wf_cpm_link_stream_chunk: NULL table pointer");
+    if (h_compared) *h_compared = 0;
+    if (S.ncols == 0) return WF_OK;
+    char *w = static_cast<char *>(d_workspace);
+    uint8_t *bits = reinterpret_cast<uint8_t *>(w + S.off_bits);
+    int8_t *syms = reinterpret_cast<int8_t *>(w + S.off_syms);
+    double *rows = reinterpret_cast<double *>(w + S.off_rows);
+    uint8_t *dec = reinterpret_cast<uint8_t *>(w + S.off_dec);
+    char *carry = static_cast<char *>(d_state);
+    uint64_t *q_phase = reinterpret_cast<uint64_t *>(carry + WF_CPM_STATE_BYTES);
+    const int bps = S.L.bps;
+    int rc;
+    if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip + (uint64_t)(S.ws * bps), bits, S.nloc * bps, nullptr, stream)))
+        return rc;
+    // (the mappers are memoryless per symbol; a window starts on a symbol boundary, so the multi-h mapper's parity is 0)
+    if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, S.nloc * bps, 0, 0, 0, syms, stream))) return rc;
+    rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
+                                 S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_templates, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma,
+                                 cfg->seed, cfg->stream_id, 0, nullptr, S.L.start0 + 4, S.k_lo, S.ncols, 0, rows, stream, S.L.nfilt,
+                                 cfg->det.nh, 3);
+    if (rc < 0) return rc;
+    WF_REQUIRE(rc == 0, "wf_cpm_link_stream_chunk: internal: the one-kernel front end refused the window");
+    if ((rc = wf_cpm_viterbi_detect(ctx, &cfg->det, cfg->d_rot_cs, rows, S.ncols, cfg->warmup, dec, carry, stream))) return rc;
+    // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] of the stream are compared
+    const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;
+    const int64_t k_first = skip + cfg->det.D - 1;                      // first call whose decision is compared
+    const int64_t j0 = S.k_lo >= k_first ? 0 : k_first - S.k_lo;
+    const int64_t ncmp = S.ncols - j0;
+    if (ncmp > 0) {
+        const int64_t sym0 = S.k_lo + j0 - cfg->det.D + 1;              // global index of the first reference symbol
+        if ((rc = wf_cpm_count_errors(ctx, dec + j0, syms + (sym0 - S.ws), cfg->det.M, ncmp, d_counts, stream))) return rc;
+        if (h_compared) *h_compared = ncmp;
+    }
+    return WF_OK;
+}

@@ -311,7 +311,7 @@ class CPMLink:
     STAGES = ("prbs", "map", "modulate", "-", "awgn", "mfbank", "viterbi", "count")
 
     def __init__(self, nsym: int, sps: int = 8, waveform: str = "multih", spec=None, pn_degree: int = 23, warmup: int = 0,
-                 skip_head: int = 64, private_ctx: bool = False, fuse: int = 10) -> None:
+                 skip_head: int = 64, private_ctx: bool = False, fuse: int = 10, _no_workspace: bool = False) -> None:
         from .viterbi import cpm
 
         if waveform == "multih":
@@ -340,6 +340,8 @@ class CPMLink:
         cfg.sigma, cfg.seed, cfg.stream_id = 0.0, 1, 0
         cfg.warmup, cfg.skip_head, cfg.event_slot, cfg.fuse = warmup, skip_head, -1, int(fuse)
         self.cfg = cfg
+        if _no_workspace:        # (CPMStream: the one-shot workspace of a long stream is exactly what it avoids)
+            return
         self.workspace_bytes = _hip.lib().wf_cpm_link_workspace_bytes(ctypes.byref(cfg))
         if self.workspace_bytes < 0:
             raise ValueError("invalid link configuration")
@@ -378,6 +380,66 @@ class CPMLink:
         _hip.check(_hip.lib().wf_cpm_link_run(self._ctx, ctypes.byref(c), self.workspace.data_ptr(), self.workspace_bytes,
                                               self.counts.data_ptr(), ctypes.byref(m), _hip.stream()))
         self.compared += m.value
+
+    def result(self) -> tuple[int, int, int]:
+        """(symbol errors, bit errors, symbols compared); raises if a detector chunk was not proven."""
+        return SOQPSKLink.result(self)
+
+
+class CPMStream:
+    """The CPM link (:class:`CPMLink`) over a continuous stream of ``total_symbols`` symbols in chunks of
+    ``chunk_symbols`` detector calls (``wf_cpm_link_stream_chunk``): HBM use of one chunk, the detector state
+    and the modulator phase carried on the device, everything else re-generated as a halo.  Decisions and
+    error counts equal a one-shot :class:`CPMLink` over the whole stream."""
+
+    def __init__(self, total_symbols: int, chunk_symbols: int, sps: int = 8, **kw) -> None:
+        self._proto = CPMLink.__new__(CPMLink)
+        CPMLink.__init__(self._proto, int(total_symbols), sps, _no_workspace=True, **kw)
+        self.cfg, self._ctx, self.sps, self.spec = self._proto.cfg, self._proto._ctx, int(sps), self._proto.spec
+        self.total_symbols, self.chunk_symbols = int(total_symbols), int(chunk_symbols)
+        lib = _hip.lib()
+        nbytes = lib.wf_cpm_link_stream_workspace_bytes(ctypes.byref(self.cfg), self.chunk_symbols)
+        if nbytes < 0:
+            tl, spt, nt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+            lib.wf_mod_tile_geometry(self.sps, self.cfg.ntaps, self.total_symbols, ctypes.byref(tl), ctypes.byref(spt), ctypes.byref(nt))
+            raise ValueError(f"chunk_symbols must be a multiple of {spt.value} (one modulator tile) and of 128 and at least "
+                             f"{4 * (spt.value + 48 + self.spec.D)}, with a configuration the one-kernel front end takes")
+        self.workspace_bytes = nbytes
+        self.workspace = _hip.empty(nbytes, "uint8")
+        self.state = _hip.zeros(2048 // 8, "int64")                 # WF_CPM_STREAM_STATE_BYTES
+        self.counts = _hip.zeros(2, "int64")
+        self.compared = 0
+        self.total_calls = self.chunk_info(0)["stream_calls"]
+        self.nchunks = -(-self.total_calls // self.chunk_symbols)
+
+    def reset(self) -> None:
+        self.state.zero_()
+        self.counts.zero_()
+        self.compared = 0
+
+    def chunk_info(self, c: int) -> dict:
+        info = (ctypes.c_int64 * 8)()
+        _hip.check(_hip.lib().wf_cpm_link_stream_layout(ctypes.byref(self.cfg), self.chunk_symbols, c, info))
+        keys = ("calls", "first_call", "off_decisions", "off_syms", "syms_origin", "stream_calls", "sym_per_tile", "off_rows")
+        return dict(zip(keys, (int(v) for v in info)))
+
+    def run_chunk(self, c: int, ebn0_db: float | None, seed: int = 1, stream_id: int = 0) -> None:
+        from .viterbi.cpm import sigma_for_ebn0 as cpm_sigma
+
+        cfg = self.cfg
+        cfg.sigma = 0.0 if ebn0_db is None else cpm_sigma(ebn0_db, self.sps, self.spec.bits_per_symbol)
+        cfg.seed, cfg.stream_id, cfg.event_slot = seed, stream_id, -1
+        m = ctypes.c_int64(0)
+        _hip.check(_hip.lib().wf_cpm_link_stream_chunk(self._ctx, ctypes.byref(cfg), self.chunk_symbols, c, self.state.data_ptr(),
+                                                       self.workspace.data_ptr(), self.workspace_bytes, self.counts.data_ptr(),
+                                                       ctypes.byref(m), _hip.stream()))
+        self.compared += m.value
+
+    def run(self, ebn0_db: float | None, seed: int = 1, stream_id: int = 0) -> tuple[int, int, int]:
+        self.reset()
+        for c in range(self.nchunks):
+            self.run_chunk(c, ebn0_db, seed, stream_id)
+        return self.result()
 
     def result(self) -> tuple[int, int, int]:
         """(symbol errors, bit errors, symbols compared); raises if a detector chunk was not proven."""

@@ -311,6 +311,12 @@ int wf_link_stream_interior(const wf_link_config *cfg, int64_t chunk_symbols, in
 int wf_link_stream_steady(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, void *d_state,
                           void *d_workspace, int64_t workspace_bytes, int64_t *d_counts, int64_t *h_compared,
                           void *stream);
+/* wf_link_stream_steady in the parts of wf_link_stream_chunk_phase (`phases` bits 0 / 2 / 1), each advancing its
+ * own position word at its end: a PIPELINE of interior chunks on two streams (workspace and wf_ctx per stream,
+ * one event per part) can be captured as ONE hipGraph and replayed. */
+int wf_link_stream_steady_phase(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, void *d_state,
+                                void *d_workspace, int64_t workspace_bytes, int64_t *d_counts, int64_t *h_compared,
+                                int phases, void *stream);
 
 /* ---- generic CPM trellis detector (ARTM multi-h, PCM/FM) ---------------------------
  * The reference has NO detector for these waveforms — only their modulator side

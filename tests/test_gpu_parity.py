@@ -641,6 +641,23 @@ def test_stream_graph_replay_equals_eager_chunks():
             assert want == first
 
 
+@pytest.mark.parametrize("chunks_per_graph", [2, 4])
+def test_stream_captured_two_stream_pipeline_equals_eager_chunks(chunks_per_graph):
+    """The two-stream chunk pipeline with its steady state captured as ONE hipGraph (cross-stream events inside the
+    capture; every part advances its own position word on the device) == the eager chunk-by-chunk run."""
+    from waveforms_amd.link import SOQPSKStream
+
+    chunk = 1 << 15
+    st = SOQPSKStream(13 * chunk + 555, chunk, 8, fuse=15)
+    n_int = st.interior_chunks()
+    assert st.nchunks == 14 and n_int == 11
+    for ebn0 in (3.0, 9.0):
+        want = st.run(ebn0, seed=6, stream_id=4)
+        got = st.run_graph_pipelined(ebn0, seed=6, stream_id=4, chunks_per_graph=chunks_per_graph)
+        assert got == want and want[1] > 0
+        assert st.graph_replays == (n_int - 1) // chunks_per_graph
+
+
 @pytest.mark.parametrize("fuse,chunk", [(15, 1 << 16), (7, 3 << 14), (3, 1 << 15)])
 def test_stream_two_stream_pipeline_equals_sequential_chunks(fuse, chunk):
     """SOQPSKStream.run_pipelined: chunk c's detector + count overlap chunk c + 1's front end on a second

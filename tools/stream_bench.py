@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--pn-degree", type=int, default=31)
     ap.add_argument("--graph", action="store_true", help="replay the steady-state chunk as a hipGraph")
     ap.add_argument("--pipelined", action="store_true", help="consecutive chunks on two streams (detector of chunk c under the front end of c + 1)")
+    ap.add_argument("--graph-pipelined", type=int, default=0, metavar="K", help="the two-stream pipeline with K interior chunks captured as one hipGraph")
     ap.add_argument("--vit-warmup", type=int, default=-1, help="detector chunk warm-up rows (-1: by Eb/N0, waveforms_amd.link.operating_point_warmup; 0: library default)")
     a = ap.parse_args()
     import torch
@@ -34,6 +35,8 @@ def main():
     st.run_chunk(0, a.ebn0)           # warm-up (allocations, code objects)
     torch.cuda.synchronize()
     go = st.run_graph if a.graph else (st.run_pipelined if a.pipelined else st.run)
+    if a.graph_pipelined:
+        go = lambda *args: st.run_graph_pipelined(*args, chunks_per_graph=a.graph_pipelined)   # noqa: E731
     for rep in range(2):              # the first pass also pays the mode's own allocations (second context, graph capture)
         t0 = time.perf_counter()
         se, be, m = go(a.ebn0)
@@ -41,7 +44,7 @@ def main():
         dt = time.perf_counter() - t0
     print(json.dumps({"workload": f"SOQPSK-TG continuous stream, {int(a.total):.3g} symbols @8 sps in {st.nchunks} chunks "
                                   f"of {a.chunk} (PN{a.pn_degree}, {a.detector} detector)",
-                      "mode": "hipGraph replay" if a.graph else ("two-stream chunk pipeline" if a.pipelined else "eager launches"), "Msym_per_s": round(m / dt / 1e6, 1), "seconds": round(dt, 4),
+                      "mode": f"two-stream chunk pipeline captured as hipGraphs of {a.graph_pipelined} chunks" if a.graph_pipelined else "hipGraph replay" if a.graph else ("two-stream chunk pipeline" if a.pipelined else "eager launches"), "Msym_per_s": round(m / dt / 1e6, 1), "seconds": round(dt, 4),
                       "workspace_GB": round(st.workspace_bytes / 1e9, 3), "symbols": m, "bit_errors": be,
                       "ber": be / max(m, 1), "ebn0_db": a.ebn0}))
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "wf_link_stream_chunk_phase": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), c_int, _P]),
     "wf_link_stream_interior": (c_int, [_P, c_int64, c_int64]),
     "wf_link_stream_steady": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
+    "wf_link_stream_steady_phase": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), c_int, _P]),
     "wf_welch_scratch_doubles": (c_int64, [c_int64, c_int]),
     "wf_welch_psd_c128": (c_int, [_P, _P, c_int64, c_int, c_double, _P, c_double, _P, _P, _P]),
     "wf_phase_tree_f64": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_double, _P, _P]),

@@ -322,8 +322,12 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
         ctx->tables_stream = s;
         ctx->tables_pending = true;
     } else if (ctx->tables_pending) {
-        if (hipEventQuery(ctx->tables_event) == hipSuccess) ctx->tables_pending = false;      // landed: nothing to order any more
-        else if (s != ctx->tables_stream) WF_HIP(hipStreamWaitEvent(s, ctx->tables_event, 0));
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap == hipStreamCaptureStatusNone) {            // (inside a capture nothing may be queried or waited for: the caller has
+            if (hipEventQuery(ctx->tables_event) == hipSuccess) ctx->tables_pending = false;   //  synchronised since the upload — see above)
+            else if (s != ctx->tables_stream) WF_HIP(hipStreamWaitEvent(s, ctx->tables_event, 0));
+        }
     }
     enc_params P{columns, states, card, ninp, (int)(i0 % columns), state0, nsym, 0u, 0ull, 0ull};
     const bool small = states <= 4 && tabn <= 16 && columns * ninp <= 4;

@@ -333,12 +333,9 @@ extern "C" int wf_link_stream_layout(const wf_link_config *cfg, int64_t chunk_sy
     return WF_OK;
 }
 
-__global__ void stream_advance_kernel(uint64_t *dyn, uint64_t dskip, uint64_t dindex)
+__global__ void stream_advance_kernel(uint64_t *word, uint64_t by)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        dyn[0] += dskip;
-        dyn[1] += dindex;
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) *word += by;
 }
 
 static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
@@ -376,6 +373,17 @@ extern "C" int wf_link_stream_steady(wf_ctx *ctx, const wf_link_config *cfg, int
 {
     return stream_chunk_impl(ctx, cfg, chunk_symbols, 1, d_state, d_workspace, workspace_bytes, d_counts, h_compared,
                              stream, true);
+}
+
+// The steady-state launch sequence in parts (see wf_link_stream_chunk_phase), for capturing a PIPELINE of
+// interior chunks on two streams as one hipGraph: every part advances its own position word at its end.
+extern "C" int wf_link_stream_steady_phase(wf_ctx *ctx, const wf_link_config *cfg, int64_t chunk_symbols, void *d_state,
+                                           void *d_workspace, int64_t workspace_bytes, int64_t *d_counts, int64_t *h_compared,
+                                           int phases, void *stream)
+{
+    WF_REQUIRE(phases >= 1 && phases <= 7, "wf_link_stream_steady_phase: phases %d", phases);
+    return stream_chunk_impl(ctx, cfg, chunk_symbols, 1, d_state, d_workspace, workspace_bytes, d_counts, h_compared,
+                             stream, true, phases);
 }
 
 // Parts of a chunk for callers that pipeline chunks on two streams (own workspace AND own wf_ctx per
@@ -449,6 +457,10 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
         const int64_t at = S.ws_next - S.ws;
         if ((rc = wf_fsm_encode_core(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, S.nloc, S.ws, 0, enc_state, syms, nullptr,
                                      at <= S.nloc ? enc_state : nullptr, at, stream))) return rc;
+        if (steady) {   // the PRBS position of the next chunk's part 1 (each part advances ITS word: parts of different chunks overlap)
+            hipLaunchKernelGGL(stream_advance_kernel, dim3(1), dim3(64), 0, wf_stream(stream), dyn, (uint64_t)chunk_symbols);
+            WF_LAUNCH_CHECK();
+        }
     }
     // fuse bit 3: modulator + channel + bank of the chunk's tiles in one kernel (no samples in HBM);
     // the tile before the chunk is processed too — its last column is the chunk's first.  Its two
@@ -481,6 +493,11 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
         }
         if (rc) return rc;
     }
+    if (steady && (phases & 4)) {   // the noise counter of the next chunk's part 4
+        hipLaunchKernelGGL(stream_advance_kernel, dim3(1), dim3(64), 0, wf_stream(stream), dyn + 1,
+                           (uint64_t)chunk_symbols * (uint64_t)cfg->sps);
+        WF_LAUNCH_CHECK();
+    }
     if (!(phases & 2)) return WF_OK;
     if (packed)
         rc = wf_viterbi4_detect_packed(ctx, mf, S.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, vit_state, stream);
@@ -495,11 +512,6 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
     if (ncmp > 0) {
         if ((rc = wf_count_errors(ctx, dsyms + j0, syms + (sym0 - S.ws), dbits + j0, bits + (sym0 - S.ws), ncmp, d_counts, stream))) return rc;
         if (h_compared) *h_compared = ncmp;
-    }
-    if (steady) {
-        hipLaunchKernelGGL(stream_advance_kernel, dim3(1), dim3(64), 0, wf_stream(stream), dyn, (uint64_t)chunk_symbols,
-                           (uint64_t)chunk_symbols * (uint64_t)cfg->sps);
-        WF_LAUNCH_CHECK();
     }
     return WF_OK;
 }

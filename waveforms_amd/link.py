@@ -297,6 +297,81 @@ class SOQPSKStream:
             self.run_chunk(c, ebn0_db, seed, stream_id)
         return self.result()
 
+    def run_graph_pipelined(self, ebn0_db: float, seed: int = 1, stream_id: int = 0, chunks_per_graph: int = 8) -> tuple[int, int, int]:
+        """The two-stream chunk pipeline of :meth:`run_pipelined` with its steady state captured as ONE hipGraph:
+        ``chunks_per_graph`` consecutive interior chunks, alternating between two streams (workspace and wf_ctx
+        each), every part (1: PRBS / encoder / carries, 4: modulator + channel + bank, 2: detector + count) ordered
+        behind the same part of the previous chunk by an event inside the capture
+        (``wf_link_stream_steady_phase``: each part advances its own position word on the device)."""
+        torch = _hip.torch()
+        self.reset()
+        cfg = self.cfg
+        cfg.sigma, cfg.seed, cfg.stream_id, cfg.event_slot = sigma_for_ebn0(ebn0_db, self.sps), seed, stream_id, -1
+        if not hasattr(self, "_ws2"):
+            self._ws2 = _hip.empty(self.workspace_bytes, "uint8")
+            self._ctx2 = _hip.new_ctx()
+            self._lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
+        lib, m = _hip.lib(), ctypes.c_int64(0)
+        K = max(2, int(chunks_per_graph) // 2 * 2)
+        n_int = self.interior_chunks()
+        self.run_chunk(0, ebn0_db, seed, stream_id)                 # context 1: first use outside any capture
+        done = 1
+        self.graph_replays = 0
+        if n_int >= 1 + K:
+            # chunk 1 = the first steady call, eagerly on context 2 (its first use; tables, scratch)
+            _hip.check(lib.wf_link_stream_steady_phase(self._ctx2, ctypes.byref(cfg), self.chunk_symbols, self.state.data_ptr(),
+                                                       self._ws2.data_ptr(), self.workspace_bytes, self.counts.data_ptr(),
+                                                       ctypes.byref(m), 7, _hip.stream()))
+            self.compared += m.value
+            done = 2
+            torch.cuda.current_stream().synchronize()
+            key = (cfg.sigma, seed, stream_id, K)               # what the captured launches have baked in
+            cached = getattr(self, "_gp_cache", None)
+            graph = cached[1] if cached and cached[0] == key else None
+            if graph is not None:
+                m.value = cached[2]
+            else:
+              graph = torch.cuda.CUDAGraph()
+              with torch.cuda.graph(graph):
+                  a, b = torch.cuda.current_stream(), self._lanes[1]
+                  b.wait_stream(a)                                    # fork the second lane into the capture
+                  ev = {1: None, 4: None, 2: None}
+                  for i in range(K):
+                      lane, ws, ctx = (a, self.workspace, self._ctx) if i % 2 == 0 else (b, self._ws2, self._ctx2)
+                      with torch.cuda.stream(lane):
+                          for part in (1, 4, 2):
+                              if ev[part] is not None:
+                                  lane.wait_event(ev[part])
+                              _hip.check(lib.wf_link_stream_steady_phase(ctx, ctypes.byref(cfg), self.chunk_symbols, self.state.data_ptr(),
+                                                                         ws.data_ptr(), self.workspace_bytes, self.counts.data_ptr(),
+                                                                         ctypes.byref(m), part, lane.cuda_stream))
+                              ev[part] = torch.cuda.Event()
+                              ev[part].record(lane)
+                  a.wait_stream(b)                                    # join
+              self._gp_cache = (key, graph, m.value)
+            per_chunk = m.value
+            while done + K <= 1 + n_int:
+                graph.replay()
+                self.compared += K * per_chunk
+                done += K
+                self.graph_replays += 1
+        for c in range(done, self.nchunks):
+            if c <= n_int and done > 1:                             # a leftover interior chunk: the position words are live
+                _hip.check(lib.wf_link_stream_steady_phase(self._ctx, ctypes.byref(cfg), self.chunk_symbols, self.state.data_ptr(),
+                                                           self.workspace.data_ptr(), self.workspace_bytes, self.counts.data_ptr(),
+                                                           ctypes.byref(m), 7, _hip.stream()))
+                self.compared += m.value
+            else:
+                self.run_chunk(c, ebn0_db, seed, stream_id)
+        from waveforms_amd import device as dev
+
+        _hip.check(lib.wf_ctx_check(self._ctx2, _hip.stream()))
+        late = dev.viterbi_unmerged(reset=True, ctx=self._ctx2)
+        if late:
+            dev.viterbi_unmerged(reset=True, ctx=self._ctx)
+            raise RuntimeError(f"{late} detector chunk(s) did not merge with the sequential path within the warm-up")
+        return self.result()
+
     def result(self) -> tuple[int, int, int]:
         """Like :meth:`SOQPSKLink.result` (raises if a detector chunk did not merge)."""
         return SOQPSKLink.result(self)

@@ -203,6 +203,9 @@ int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int differenti
  * synchronise through pinned, device-mapped staging owned by the context.  Synchronous. */
 int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length, int differential,
                                const double *h_mf3_ri, double *h_bits_out, double *h_syms_out, void *stream);
+/* Diagnostic: device-side timing of the last request wf_viterbi4_iteration_host's persistent server answered, in
+ * microseconds: {request read from host memory, cache check, the iteration itself, write-through + answer}. */
+int wf_viterbi4_iteration_server_timing(wf_ctx *ctx, double *h_us4);
 
 /* ---- K11: error counting ------------------------------------------------------
  * examples/soqpsk_detection.py:200-209: number of j < m with

@@ -59,13 +59,16 @@ def main():
     for k in range(a.calls):
         fn(ctx, st, 2, 1, base + 48 * k, pb, ps, stream)
     dc = time.perf_counter() - t2
+    us4 = (ctypes.c_double * 4)()
+    _hip.lib().wf_viterbi4_iteration_server_timing(ctx, us4)
     t3 = time.perf_counter()
     ver = _hip.lib().wf_version
     for k in range(a.calls):
         ver()
     dv = time.perf_counter() - t3
     print(json.dumps({"calls": a.calls, "iteration_us_per_call": round(dt / a.calls * 1e6, 2),
-                      "c_abi_call_us": round(dc / a.calls * 1e6, 2), "empty_ctypes_call_us": round(dv / a.calls * 1e6, 2),
+                      "c_abi_call_us": round(dc / a.calls * 1e6, 2),
+                      "server_us_last_request": dict(zip(("request_read", "cache_check", "iteration", "write_through_answer"), (round(v, 2) for v in us4))), "empty_ctypes_call_us": round(dv / a.calls * 1e6, 2),
                       "reference_us_per_call": 57.0, "batch_detect_us_per_call_incl_h2d_d2h": round(db / a.calls * 1e6, 4),
                       "iteration_equals_batch": bool(np.array_equal(want.astype(np.uint8), bb[:2000]))}))
 

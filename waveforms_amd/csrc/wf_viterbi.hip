@@ -18,6 +18,7 @@
 //    reference detector supports (state_exp_term has 4 entries, algorithm.py:30).
 //  * viterbi_iteration_kernel: one literal .iteration() for any window length, detector
 //    state resident in device memory (drop-in for the per-symbol API).
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -923,6 +924,82 @@ __global__ void viterbi_iteration_kernel(vit_state *st, int L, int diff, const d
     vit_iteration_body(st, L, diff, mf3, bits_out, syms_out);
 }
 
+__device__ __forceinline__ void vit_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The same call by one WAVE on a detector state in LDS (the persistent server below): the loops over the 8
+// branches and the 4 end states run across lanes — same operations on the same operands, so the same bits — and
+// only the traceback (a dependent walk) stays with lane 0.  L >= 2 (for L = 1 the reference's in-place stage
+// update reads metrics it has just written: the serial form above keeps that literal).  All 64 lanes call it.
+__device__ __forceinline__ void vit_iteration_wave(vit_state *st, int L, int diff, const double (&mf3)[6], double *bits_out, double *syms_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long i = st->i;
+    const int col_now = (int)(((i % 2) + 2) % 2);
+    double mn = 0.0, mine = 0.0;
+    if (lane < 4) {                                    // algorithm.py:65-67: read before anything is overwritten
+        mn = st->metrics[0][0];
+        for (int s = 1; s < 4; ++s) mn = st->metrics[s][0] < mn ? st->metrics[s][0] : mn;
+        mine = st->metrics[lane][0] - mn;
+    }
+    if (lane < 8) {                                    // algorithm.py:57-63, branch b = lane
+        const int b = lane;
+        for (int j = 0; j + 1 < L; ++j) st->bi_history[b][j] = st->bi_history[b][j + 1];
+        const int oi = kOutIdx[col_now][b];
+        st->bi_history[b][L - 1] = br_inc(b >> 1, mf3[2 * oi], mf3[2 * oi + 1]);
+    }
+    if (lane < 4) {
+        for (int j = 0; j + 1 < L; ++j) st->metrics[lane][j] = 0.0;
+        st->metrics[lane][L - 1] = mine;
+        for (int j = 0; j < L; ++j) st->path[lane][j] = 0;
+    }
+    vit_wave_sync();
+    for (int j = 0; j < L; ++j) {                      // algorithm.py:69-87, end state s = lane
+        const int col = (int)((((i + j - 1) % 2) + 2) % 2);
+        const int jm1 = (j - 1 + L) % L;               // != j for L >= 2: a stage reads the previous stage's column only
+        if (lane < 4) {
+            const int s = lane;
+            int min_k = 0;
+            double min_m = INFINITY;
+            for (int b = 0; b < 8; ++b) {
+                if (br_end(col, b) != s) continue;
+                const double mm = st->metrics[b >> 1][jm1] + st->bi_history[b][j];
+                if (mm < min_m) {
+                    min_m = mm;
+                    min_k = b >> 1;
+                }
+            }
+            st->metrics[s][j] = min_m;
+            st->path[s][j] = (unsigned char)min_k;
+        }
+        vit_wave_sync();
+    }
+    if (lane == 0) {                                   // algorithm.py:90-98
+        int state = 0;
+        for (int s = 1; s < 4; ++s)
+            if (st->metrics[s][L - 1] < st->metrics[state][L - 1]) state = s;
+        for (int j = L - 1; j >= 0; --j) {
+            const int col = (int)((((i + j - 1) % 2) + 2) % 2);
+            const int pred = st->path[state][j];
+            const int b = 2 * pred + (col == 0 ? (state >> 1) : (state & 1));
+            if (br_end(col, b) != state) {
+                bits_out[j] = nan("");
+                syms_out[j] = nan("");
+            } else {
+                bits_out[j] = (double)br_inp(col, b, diff);
+                syms_out[j] = (double)(2 * (int)kOutIdx[col][b] - 2);
+            }
+            state = pred;
+        }
+        st->i = i + 1;
+    }
+    vit_wave_sync();
+}
+
 // ---- the per-symbol call without a launch per symbol ---------------------------------------------------
 // examples/soqpsk_detection.py:189-198 calls the detector once per symbol from a Python loop.  A kernel
 // launch + a stream synchronise per call cost 22.7 us (profiles/r02_iteration_bench.json), 2.5x fewer than the
@@ -938,12 +1015,17 @@ __global__ void viterbi_iteration_kernel(vit_state *st, int L, int diff, const d
 // device-wide synchronise waits for at most the idle time.
 struct vit_mailbox {
     unsigned long long req, ack, stop, running;      // sequence numbers / flags (each written by ONE side)
-    // the request, 64 bytes read by the device with four independent 16-byte loads (one PCIe round trip):
-    unsigned long long state_ptr;                    // vit_state* of the detector this request is for
-    int length, diff;
-    double mf[6];
+    // The request: eight 16-byte chunks {8 bytes of payload, the request's sequence number}, each written by the
+    // host with ONE 16-byte store and read by the device in ONE burst of eight loads — the poll IS the read: a
+    // burst whose eight tags agree on a new number is a complete request (a reader of host memory pays ~4.5 us per
+    // round trip here, so a separate "has something arrived" word would double the latency).
+    // payload: [0] vit_state* of the detector, [1] length | diff << 32, [2..7] the three matched-filter outputs
+    unsigned long long pad_[12];                     // (the chunks start a 128-byte line: ONE wave-wide load fetches them)
+    unsigned long long chunk[8][2];
     double bits[VIT_MAX_LEN], syms[VIT_MAX_LEN];     // the answer
+    unsigned long long t_seen, t_read, t_state, t_body, t_done;   // wall_clock64() ticks (100 MHz) of the last request (tools/iteration_bench.py)
 };
+static_assert(offsetof(vit_mailbox, chunk) == 128, "request chunks must start a 128-byte line");
 #define VIT_SERVER_IDLE_TICKS 1000000ull             // wall_clock64() ticks at 100 MHz: 10 ms
 
 __global__ void viterbi_iteration_server_kernel(vit_mailbox *mb)
@@ -956,49 +1038,90 @@ __global__ void viterbi_iteration_server_kernel(vit_mailbox *mb)
     // the home's call counter equals the cached one (a new, zero-filled detector at the same address does not).
     __shared__ vit_state s_st;
     __shared__ double s_out[2 * VIT_MAX_LEN];
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
     vit_state *home = nullptr;
     unsigned long long last = __hip_atomic_load(&mb->ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned long long idle_since = wall_clock64();
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    for (;;) {
-        const unsigned long long seq = __hip_atomic_load(&mb->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (seq != last) {
-            // the request in one burst of loads from host memory
-            const volatile v2d *rq = reinterpret_cast<const volatile v2d *>(&mb->state_ptr);
-            const v2d q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3];
-            const unsigned long long sp = (unsigned long long)__double_as_longlong(q0.x);
-            const long long ld = __double_as_longlong(q0.y);
-            const int L = (int)(ld & 0xFFFFFFFFll), diff = (int)(ld >> 32);
-            double mf[6] = {q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
-            vit_state *want = reinterpret_cast<vit_state *>(sp);
-            if (want != home || *(volatile long long *)&want->i != s_st.i) {
-                s_st = *want;
+    typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
+    const volatile v2u *rq = reinterpret_cast<const volatile v2u *>(&mb->chunk[0][0]);
+    for (;;) {     // every lane runs the same loop on the same (uniform) values; lane 0 alone writes to the mailbox
+        const unsigned long long t_poll = wall_clock64();
+        // ONE load instruction: lanes 0 .. 7 fetch one 16-byte chunk each = one contiguous 128-byte line (a load of
+        // host memory costs ~1.1 us EACH when issued one after another; 64 lanes issuing eight loads apiece cost 9 us);
+        // the chunks reach every lane as scalars
+        v2u mine = {0, 0};
+        if (lane < 8) mine = rq[lane];
+        auto pick = [&](int k) __attribute__((always_inline)) {
+            v2u r;
+            r.x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine.x >> 32), k) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mine.x, k);
+            r.y = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine.y >> 32), k) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mine.y, k);
+            return r;
+        };
+        const v2u c0 = pick(0), c1 = pick(1), c2 = pick(2), c3 = pick(3), c4 = pick(4), c5 = pick(5), c6 = pick(6), c7 = pick(7);
+        const unsigned long long seq = c0.y;
+        const bool whole = c1.y == seq && c2.y == seq && c3.y == seq && c4.y == seq && c5.y == seq && c6.y == seq && c7.y == seq;
+        if (seq != last && whole) {
+            const unsigned long long t_read = wall_clock64();
+            const int L = (int)(c1.x & 0xFFFFFFFFull), diff = (int)(c1.x >> 32);
+            const double mf[6] = {__longlong_as_double((long long)c2.x), __longlong_as_double((long long)c3.x),
+                                  __longlong_as_double((long long)c4.x), __longlong_as_double((long long)c5.x),
+                                  __longlong_as_double((long long)c6.x), __longlong_as_double((long long)c7.x)};
+            vit_state *want = reinterpret_cast<vit_state *>(c0.x);
+            if (want != home || *(volatile long long *)&want->i != *(volatile long long *)&s_st.i) {
+                vit_wave_sync();
+                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(want);
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(&s_st);
+                for (int k = lane; k < (int)(sizeof(vit_state) / 8); k += 64) dst[k] = src[k];
                 home = want;
+                vit_wave_sync();
             }
-            vit_iteration_body(&s_st, L, diff, mf, s_out, s_out + VIT_MAX_LEN);
-            for (int j = 0; j < L; ++j) {                      // write-through (posted stores: no round trip)
-                for (int b = 0; b < 8; ++b) home->bi_history[b][j] = s_st.bi_history[b][j];
-                for (int q = 0; q < 4; ++q) {
-                    home->metrics[q][j] = s_st.metrics[q][j];
-                    home->path[q][j] = s_st.path[q][j];
-                }
+            const unsigned long long t_state = wall_clock64();
+            if (L >= 2) {
+                vit_iteration_wave(&s_st, L, diff, mf, s_out, s_out + VIT_MAX_LEN);
+            } else {
+                if (lane == 0) vit_iteration_body(&s_st, L, diff, mf, s_out, s_out + VIT_MAX_LEN);
+                vit_wave_sync();
             }
-            home->i = s_st.i;
-            for (int k = 0; k < L; ++k) {
-                *(volatile double *)&mb->bits[k] = s_out[k];
-                *(volatile double *)&mb->syms[k] = s_out[VIT_MAX_LEN + k];
+            const unsigned long long t_body = wall_clock64();
+            // write-through (posted stores: no round trip), lanes over the 16 table rows; then the answer
+            if (lane < 8) for (int j = 0; j < L; ++j) home->bi_history[lane][j] = s_st.bi_history[lane][j];
+            else if (lane < 12) for (int j = 0; j < L; ++j) home->metrics[lane - 8][j] = s_st.metrics[lane - 8][j];
+            else if (lane < 16) for (int j = 0; j < L; ++j) home->path[lane - 12][j] = s_st.path[lane - 12][j];
+            if (lane == 0) home->i = s_st.i;
+            if (lane < L) {
+                *(volatile double *)&mb->bits[lane] = s_out[lane];
+                *(volatile double *)&mb->syms[lane] = s_out[VIT_MAX_LEN + lane];
             }
-            __hip_atomic_store(&mb->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");               // (system scope) every lane's stores before lane 0's acknowledgement
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                mb->t_seen = t_poll; mb->t_read = t_read; mb->t_state = t_state; mb->t_body = t_body; mb->t_done = wall_clock64();
+                __hip_atomic_store(&mb->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             last = seq;
             idle_since = wall_clock64();
             continue;
         }
         if (__hip_atomic_load(&mb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
         if (wall_clock64() - idle_since > VIT_SERVER_IDLE_TICKS) break;
-        __builtin_amdgcn_s_sleep(4);
     }
-    __hip_atomic_store(&mb->running, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) __hip_atomic_store(&mb->running, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Timing of the last served request in microseconds: {request read, state check, body, write-through + answer}
+// (diagnostic for tools/iteration_bench.py; zeros when no server has run).
+extern "C" int wf_viterbi4_iteration_server_timing(wf_ctx *ctx, double *h_us4)
+{
+    WF_REQUIRE(ctx && h_us4, "wf_viterbi4_iteration_server_timing: NULL argument");
+    for (int k = 0; k < 4; ++k) h_us4[k] = 0.0;
+    if (!ctx->h_mailbox) return WF_OK;
+    const vit_mailbox *mb = static_cast<const vit_mailbox *>(ctx->h_mailbox);
+    h_us4[0] = (double)(mb->t_read - mb->t_seen) * 0.01;      // (the poll that found the request: one burst of eight loads)
+    h_us4[1] = (double)(mb->t_state - mb->t_read) * 0.01;
+    h_us4[2] = (double)(mb->t_body - mb->t_state) * 0.01;
+    h_us4[3] = (double)(mb->t_done - mb->t_body) * 0.01;
+    return WF_OK;
 }
 
 // Stop the server of a context (teardown; harmless when none is running): it retires within one poll.
@@ -1031,6 +1154,14 @@ extern "C" int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int
 // matched-filter outputs and the 2 x length results travel through pinned host memory that the
 // device addresses directly, so a call is one kernel launch and one stream synchronise — no
 // device allocation, no separate H2D / D2H copies.  Synchronous.
+// one aligned 16-byte store (host): {lo, hi} — an aligned SSE store is a single 16-byte write on every x86-64 part
+static inline void wf_store16(unsigned long long *p, unsigned long long lo, unsigned long long hi)
+{
+    typedef long long v2ll __attribute__((vector_size(16)));
+    const v2ll v = {(long long)lo, (long long)hi};
+    *reinterpret_cast<volatile v2ll *>(p) = v;
+}
+
 extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length, int differential,
                                           const double *h_mf3_ri, double *h_bits_out, double *h_syms_out, void *stream)
 {
@@ -1070,12 +1201,13 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
         WF_HIP(hipStreamSynchronize(s));
         ctx->iter_last_state = d_state;
     }
-    mb->state_ptr = (unsigned long long)(uintptr_t)d_state;
-    mb->length = length;
-    mb->diff = differential ? 1 : 0;
-    for (int k = 0; k < 6; ++k) mb->mf[k] = h_mf3_ri[k];
     const unsigned long long seq = mb->req + 1;
-    __atomic_store_n(&mb->req, seq, __ATOMIC_RELEASE);
+    mb->req = seq;
+    unsigned long long payload[8];
+    payload[0] = (unsigned long long)(uintptr_t)d_state;
+    payload[1] = (unsigned long long)(unsigned)length | ((unsigned long long)(differential ? 1u : 0u) << 32);
+    memcpy(&payload[2], h_mf3_ri, 6 * sizeof(double));
+    for (int k = 0; k < 8; ++k) wf_store16(&mb->chunk[k][0], payload[k], seq);      // one 16-byte store per chunk: never torn
     for (unsigned long long spins = 0;; ++spins) {
         if (__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) == seq) break;
         if (__atomic_load_n(&mb->running, __ATOMIC_ACQUIRE) == 0) {
@@ -1092,9 +1224,15 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
         }
         __builtin_ia32_pause();
     }
+    bool undefined = false;
     for (int k = 0; k < length; ++k) {
         h_bits_out[k] = mb->bits[k];
         h_syms_out[k] = mb->syms[k];
+        undefined = undefined || h_bits_out[k] != h_bits_out[k];
+    }
+    if (undefined) {        // the reference's reverse_transitions lookup raises KeyError here (model.py:171-174); outputs hold NaN
+        wf_set_error("traceback reached a state pair with no connecting branch");
+        return WF_ERR_KEY;
     }
     return WF_OK;
 }

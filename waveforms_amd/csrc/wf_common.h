@@ -473,6 +473,16 @@ __device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double
 // The two complex Gaussian samples with absolute indices 2*pair and 2*pair + 1: ONE
 // Philox4x32-10 block (counter = pair index, stream id; key = seed), words (x0, x1) for the
 // even sample, (x2, x3) for the odd one.  g = {re0, im0, re1, im1}.
+// The Philox key schedule (20 words: seed + r * Weyl constants) is uniform and loop-invariant; left to the compiler it
+// is hoisted out of a staging loop into 20 SGPRs and pushes as many other uniforms into spill lanes (v_readlane reloads
+// inside the loop).  A seed made opaque at its use is re-derived there by a handful of scalar adds instead.
+__device__ __forceinline__ uint64_t wf_opaque_seed(uint64_t seed)
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    asm volatile("" : "+s"(k0), "+s"(k1));
+    return ((uint64_t)k1 << 32) | k0;
+}
+
 template <class Tabs>
 __device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_id, uint64_t seed, double sigma,
                                                 const Tabs &tb, double g[4])

@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void cpm_mf_rows_kernel(const double2 *__restr
                 const double2 c0 = in0 ? wf_load16_nt(r + b0) : make_double2(0.0, 0.0);
                 const double2 c1 = in1 ? wf_load16_nt(r + b1) : make_double2(0.0, 0.0);
                 double g[4];
-                wf_gaussian_two(pair_lo + (uint64_t)q, P.stream_id, P.seed, P.sigma, wf_tabs_lds<1, 0>{s_tab}, g);
+                wf_gaussian_two(pair_lo + (uint64_t)q, P.stream_id, wf_opaque_seed(P.seed), P.sigma, wf_tabs_lds<1, 0>{s_tab}, g);
                 if (i0 >= 0)
                     s_r[i0] = in0 ? make_double2(fma(c0.x, P.rot_re, fma(-c0.y, P.rot_im, g[0])), fma(c0.x, P.rot_im, fma(c0.y, P.rot_re, g[1])))
                                   : make_double2(0.0, 0.0);

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 for (int it = 0; it < niter; ++it) {
                     const double2 n0 = ld(w0 + 2 * MF_THREADS), n1 = ld(w0 + 2 * MF_THREADS + 1);
                     double g[4];
-                    if (LDS_TABS) wf_gaussian_two(pair, P.stream_id, P.seed, P.sigma, wf_tabs_lds<9, 8>{s_win}, g);
-                    else wf_gaussian_two(pair, P.stream_id, P.seed, P.sigma, wf_tabs_global{}, g);
+                    if (LDS_TABS) wf_gaussian_two(pair, P.stream_id, wf_opaque_seed(P.seed), P.sigma, wf_tabs_lds<9, 8>{s_win}, g);
+                    else wf_gaussian_two(pair, P.stream_id, wf_opaque_seed(P.seed), P.sigma, wf_tabs_global{}, g);
                     const int w1 = w0 + 1;
                     const int q0 = (w0 >= 0 && w0 <= last) ? w0 + (pad ? w0 / step : 0) : dump;
                     const int q1 = (w1 <= last) ? w1 + (pad ? w1 / step : 0) : dump;
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 if (in0 || in1)   // the channel of wf_awgn_c128, on the fly
                 {
                     const uint64_t pr = pair_lo + (uint64_t)((w0 + odd) >> 1);
-                    if (LDS_TABS) wf_gaussian_two(pr, P.stream_id, P.seed, P.sigma, wf_tabs_lds<9, 8>{s_win}, g);
-                    else wf_gaussian_two(pr, P.stream_id, P.seed, P.sigma, wf_tabs_global{}, g);
+                    if (LDS_TABS) wf_gaussian_two(pr, P.stream_id, wf_opaque_seed(P.seed), P.sigma, wf_tabs_lds<9, 8>{s_win}, g);
+                    else wf_gaussian_two(pr, P.stream_id, wf_opaque_seed(P.seed), P.sigma, wf_tabs_global{}, g);
                 }
                 if (w0 >= 0) {
                     const double2 x = in0 ? make_double2(fma(c0.x, P.rot_re, fma(-c0.y, P.rot_im, g[0])),

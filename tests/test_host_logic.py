@@ -244,19 +244,31 @@ def test_bench_gpus_n_self_launches_without_torchrun():
 
 
 def test_link_row_bytes_rule():
-    """Host mirror of wf_pipeline.hip:link_packed_rows — which link configurations carry
-    detector-packed 32 B rows (needs no GPU: it reads the configuration only)."""
+    """wf_link_layout's row rule (wf_pipeline.hip:link_packed_rows / link_one_kernel) — which link configurations
+    carry detector-packed 32 B rows and which run modulator + channel + bank as one kernel (needs no GPU: it reads
+    the configuration only)."""
     from waveforms_amd import _hip
     from waveforms_amd.link import SOQPSKLink
 
-    def rb(fuse, sps=8, ntaps=9, nfilt=3):
+    def rb(fuse, sps=8, mf_ntaps=None, nfilt=3, ntaps=None, timing_offset=-1):
         link = SOQPSKLink.__new__(SOQPSKLink)
         cfg = _hip.LinkConfig()
-        cfg.fuse, cfg.sps, cfg.mf_ntaps, cfg.mf_nfilt = fuse, sps, ntaps, nfilt
+        cfg.nsym, cfg.fuse, cfg.sps, cfg.mf_nfilt = 100_000, fuse, sps, nfilt
+        cfg.mf_ntaps = sps + 1 if mf_ntaps is None else mf_ntaps
+        cfg.ntaps = 8 * sps + 1 if ntaps is None else ntaps           # the SOQPSK-TG pulse
+        cfg.timing_offset = timing_offset
         link.cfg = cfg
-        return link.row_bytes
+        lay = link.layout()
+        assert lay["row_bytes"] == link.row_bytes
+        return link.row_bytes, lay["one_kernel_front_end"]
 
-    assert rb(7) == 32 and rb(6) == 32
-    assert rb(3) == 48 and rb(0) == 48 and rb(5) == 48      # bit 2 needs the fused channel (bit 1)
-    assert rb(7, sps=4) == 48 and rb(7, nfilt=1) == 16          # 3-filter banks at 8 samples per symbol only
-    assert rb(7, ntaps=73) == 32                                # any tap count (the PAM bank)
+    assert rb(7) == (32, 0) and rb(6) == (32, 0)
+    assert rb(3) == (48, 0) and rb(0) == (48, 0) and rb(5) == (48, 0)      # bit 2 needs the fused channel (bit 1)
+    assert rb(7, sps=4) == (48, 0) and rb(7, nfilt=1) == (16, 0)            # channel + bank PACK form: 3-filter banks at 8 samples per symbol only
+    assert rb(7, mf_ntaps=73) == (32, 0)                                    # ... with any tap count (the PAM bank)
+    # fuse 15: the one-kernel front end at 8, 10 and 20 samples per symbol, pulse-truncation bank (sps + 1 taps) only
+    assert rb(15) == (32, 1) and rb(15, sps=10) == (32, 1) and rb(15, sps=20) == (32, 1)
+    assert rb(15, sps=10, timing_offset=-5) == (32, 1)
+    assert rb(15, mf_ntaps=73) == (32, 0)                                   # PAM at 8: separate kernels, packed rows
+    assert rb(15, sps=10, mf_ntaps=91) == (48, 0) and rb(15, sps=16) == (48, 0) and rb(15, sps=4) == (48, 0)
+    assert rb(15, sps=10, ntaps=10 * 10 + 1) == (48, 0)                      # a pulse of more than 9 symbols

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--gpus", type=int, default=0, help="N > 1 without torchrun: start N ranks as child processes")
+    ap.add_argument("--passes", type=int, default=2, help="run the sweep this many times; `seconds` is the last pass")
     ap.add_argument("--json-out", default=None, help="rank 0 also writes its result object to this file")
     a = ap.parse_args()
     lo, hi = (int(v) for v in a.ebn0.split(":"))
@@ -67,18 +68,23 @@ def main():
     rank, world, dist, _ = init_ranks(rehearsal=os.environ.get("WF_BENCH_REHEARSAL") == "1")
     blocks = max(1, int(round(a.symbols_per_point / a.block)))
     plan = SweepPlan(ebn0_db=ebn0, blocks_per_point=blocks, nsym=a.block, seed=a.seed, detector=a.detector, waveform=a.waveform)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    counts = ber_sweep(plan)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # two passes: the first also pays the process's first-use costs (workspace allocations of ~0.8 GB per block in
+    # flight, code-object loads, table uploads); `seconds` is the second pass, the first is reported beside it
+    passes = []
+    for _ in range(max(1, a.passes)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        counts = ber_sweep(plan)
+        torch.cuda.synchronize()
+        passes.append(time.perf_counter() - t0)
+    dt = passes[-1]
     if rank == 0:
         tab = ber_table(ebn0, counts)
         for row in tab:     # errors are counted per symbol and per bit; symbols carry bits_per_symbol bits
             row["ber"] = row["bit_errors"] / max(row["symbols"] * plan.bits_per_symbol, 1)
         for row in tab:
             print(f"Eb/N0 {row['ebn0_db']:5.1f} dB  symbols {row['symbols']:>12d}  SER {row['ser']:.3e}  BER {row['ber']:.3e}")
-        out = {"detector": a.detector, "n_gpus": world, "seconds": round(dt, 3),
+        out = {"detector": a.detector, "n_gpus": world, "seconds": round(dt, 3), "seconds_first_pass": round(passes[0], 3),
                "Msym_per_s": round(int(counts[:, 2].sum()) / dt / 1e6, 1), "table": tab}
         ber = [r["ber"] for r in tab]
         ge, gb = (np.array([]), np.array([]))

@@ -200,7 +200,9 @@ int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int differenti
 
 /* The same call with HOST operands (h_mf3: 3 complex128; outputs `length` doubles each), for the
  * reference's per-symbol loop (examples/soqpsk_detection.py:189-198): one launch + one stream
- * synchronise through pinned, device-mapped staging owned by the context.  Synchronous. */
+ * synchronise through pinned, device-mapped staging owned by the context.  Synchronous.
+ * `d_state` must be initialised (its zero fill complete, not merely enqueued) before the first call
+ * made for it: the call only synchronises `stream` when `d_state` differs from the previous call's. */
 int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length, int differential,
                                const double *h_mf3_ri, double *h_bits_out, double *h_syms_out, void *stream);
 /* Diagnostic: device-side timing of the last request wf_viterbi4_iteration_host's persistent server answered, in

@@ -382,6 +382,25 @@ def test_detector_iteration_api(golden, length):
         assert det.i == 260
 
 
+def test_detector_iteration_fresh_detector_on_a_reused_address(golden):
+    """A detector created right after another one is dropped gets the SAME device address for its state from
+    the caching allocator; the persistent per-symbol server must start it from zeros, not continue the state it
+    still holds for that address (the zero fill has to have landed before the first request is served)."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detect")
+    seen = set()
+    for rep in range(24):
+        det = SOQPSKTrellisDetector(2, differantial_encoding=True)
+        for k in range(3 + rep % 5):
+            b, s = det.iteration(g["triplets"][k])
+            assert np.array_equal(b, g["trip_L2_diff1_bits"][k]), (rep, k)
+            assert np.array_equal(s, g["trip_L2_diff1_syms"][k]), (rep, k)
+        seen.add(det._d_state_ptr)
+        del det
+    assert len(seen) < 24  # the allocator did reuse addresses, so the case was exercised
+
+
 @pytest.mark.parametrize("ebn0", [0.0, 4.0, 10.0])
 def test_detector_chunk_parallel_equals_sequential(oracle, ebn0):
     """Chunk-parallel ACS with warm-up vs the sequential oracle on a long noisy burst —

@@ -46,6 +46,11 @@ HOT = {
     "mod_main_kernel<4, true>": (128, 4),
     # SOQPSK detector: one wave per SIMD by design (three batches of rows in registers)
     "viterbi_batch_kernel<true>": (256, 2),
+    # generic CPM detector: 5 waves per SIMD for the forms with up to 4 filters per call, 4 for ARTM's 16
+    "cpm_viterbi_kernel<2, 2>": (96, 5),
+    "cpm_viterbi_kernel<2, 1>": (96, 5),
+    "cpm_viterbi_kernel<4, 1>": (96, 5),
+    "cpm_viterbi_kernel<4, 2>": (128, 4),
     "fir_kernel<9>": (96, 5),
     "awgn_kernel": (64, 8),
 }

@@ -175,8 +175,26 @@ def ctx() -> int:
             if dev not in _ctxs:
                 out = c_void_p()
                 check(lib().wf_ctx_create(dev, ctypes.byref(out)))
+                if not _ctxs:
+                    import atexit
+
+                    atexit.register(_destroy_default_contexts)
                 _ctxs[dev] = out.value
     return _ctxs[dev]
+
+
+def _destroy_default_contexts() -> None:
+    """At interpreter exit (registered after torch was imported, so it runs before torch's own teardown): destroy
+    the per-device default contexts.  wf_ctx_destroy first retires a persistent iteration server the context may
+    still have running (it would retire by itself within 10 ms of its last request), so the process never exits
+    with one of its kernels on the device."""
+    for dev in list(_ctxs):
+        handle = _ctxs.pop(dev)
+        try:
+            if _lib is not None:
+                _lib.wf_ctx_destroy(handle)
+        except Exception:   # noqa: BLE001 - best effort at shutdown
+            pass
 
 
 def new_ctx() -> int:

@@ -137,11 +137,11 @@ __device__ __forceinline__ void cpm_wave_sync()
 // c - 1's end.  (Until round 3 the start state stayed in five registers per lane for an in-kernel compare.)
 #define CPM_EDGE_WORDS (2 * 16 * 3)
 
-// Waves per SIMD the register allocator is held to: 5 (<= 96 registers) for the binary trellises with
-// up to 4 filters (left alone they took 97 / 98: one register over), 4 (<= 128) for ARTM's 16 filters per
-// call (quaternary, one-symbol filters: 101 — at 96 it spills).
+// Waves per SIMD the register allocator is held to: 5 (<= 96 registers) for the trellises with up to 4 filters
+// per call (binary with a pulse of <= 2 symbols, any alphabet with one-symbol filters: 88 .. 93 registers; left
+// alone they took 97 / 98 / 101), 4 (<= 128) for ARTM's 16 filters per call, 2 for the 64-filter design.
 #ifndef CPM_MIN_WAVES
-#define CPM_MIN_WAVES(M, LP) ((M) == 2 && (LP) <= 2 ? 5 : ((M) == 4 && (LP) == 3 ? 2 : 4))
+#define CPM_MIN_WAVES(M, LP) (((M) == 2 && (LP) <= 2) || (LP) == 1 ? 5 : ((M) == 4 && (LP) == 3 ? 2 : 4))
 #endif
 template <int M_, int LP_>
 __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viterbi_kernel(const double2 *__restrict__ rows,

@@ -63,6 +63,11 @@ class SOQPSKTrellisDetector:
                 raise ValueError(f"unsupported traceback length {self.length}")
             self._d_state = _hip.zeros(nbytes, "uint8")
             self._d_state_ptr = self._d_state.data_ptr()
+            # The zero fill must have LANDED before the first request: the iteration server reads the state from its
+            # own stream, and the allocator may hand out the address of a detector it served before (the C side only
+            # synchronises when the address changes; the server tells a new detector from a cached one by its call
+            # counter, which it can only do once the zeros are there).
+            _hip.torch().cuda.current_stream().synchronize()
             self._iter_fn, self._iter_ctx = _hip.lib().wf_viterbi4_iteration_host, _hip.ctx()
 
     def iteration(

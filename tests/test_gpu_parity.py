@@ -574,7 +574,8 @@ def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
 
 # ------------------------------------------------------------------ streaming (config 5)
 @pytest.mark.parametrize("detector,fuse,chunk", [("PT", 3, 1 << 16), ("PAM", 3, 1 << 15), ("PT", 1, 3 << 14),
-                                                 ("PT", 7, 1 << 16), ("PAM", 7, 1 << 15), ("PT", 15, 1 << 16), ("PT", 15, 3 << 14)])
+                                                 ("PT", 7, 1 << 16), ("PAM", 7, 1 << 15), ("PT", 15, 1 << 16), ("PT", 15, 3 << 14),
+                                                 ("PAM", 15, 1 << 15), ("PAM", 15, 3 << 14)])
 def test_stream_in_chunks_equals_one_shot(detector, fuse, chunk):
     """wf_link_stream_chunk over a stream == wf_link_run over the whole burst: identical
     modulated samples, matched-filter rows, decisions and error counts."""
@@ -906,6 +907,33 @@ def test_one_kernel_front_end_other_sample_rates_rows(oracle, sps, nsym, pulse_n
         odd = (np.arange(calls) & 1) == 1
         want = np.stack([a[:, 1, 0], a[:, 1, 1], np.where(odd, a[:, 0, 1], a[:, 0, 0]), np.where(odd, a[:, 2, 0], a[:, 2, 1])], axis=1)
         np.testing.assert_allclose(b, want, rtol=0, atol=1e-12)
+        for key in ("off_bits", "off_syms"):
+            assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
+
+
+@pytest.mark.parametrize("nsym,pulse_name", [(70_001, "tg"), (1200, "tg"), (300, "tg"), (30_000, "mil"), (2_100_000, "tg")])
+def test_one_kernel_front_end_pam_bank_rows(oracle, nsym, pulse_name):
+    """The one-kernel front end with the PAM bank (3 filters of 73 taps for SOQPSK-TG, 17 for MIL) on the matrix cores:
+    four columns per operand row, K split over the four waves.  Packed rows equal those of the separate kernels
+    (fuse 7: modulator -> channel + 73-tap bank) to rounding — the four partial chains are summed in another order —
+    and decisions and counts are identical; every decimation phase, tile edges, both ends of the burst, bursts
+    shorter than a tile and than a row."""
+    from waveforms_amd.link import SOQPSKLink
+
+    pulse = oracle.freq_pulse_soqpsk_tg(8) if pulse_name == "tg" else oracle.freq_pulse_soqpsk_mil(8)
+    for off in (range(-4, 4) if nsym == 70_001 else (0, -3)):
+        ref = SOQPSKLink(nsym, 8, fuse=7, pulse=pulse, timing_offset=off, detector="PAM")
+        fus = SOQPSKLink(nsym, 8, fuse=15, pulse=pulse, timing_offset=off, detector="PAM")
+        assert (ref.row_bytes, fus.row_bytes) == (32, 32)
+        assert ref.layout()["one_kernel_front_end"] == 0 and fus.layout()["one_kernel_front_end"] == 1
+        for link in (ref, fus):
+            link.run_block(4.0, seed=7, stream_id=9, skip_bits=55)
+        lr, lf = ref.layout(), fus.layout()
+        calls = lr["calls"]
+        a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+        b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+        np.testing.assert_allclose(b, a, rtol=0, atol=2e-12, err_msg=str(off))
+        assert ref.result() == fus.result(), off
         for key in ("off_bits", "off_syms"):
             assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
 

@@ -266,9 +266,11 @@ def test_link_row_bytes_rule():
     assert rb(3) == (48, 0) and rb(0) == (48, 0) and rb(5) == (48, 0)      # bit 2 needs the fused channel (bit 1)
     assert rb(7, sps=4) == (48, 0) and rb(7, nfilt=1) == (16, 0)            # channel + bank PACK form: 3-filter banks at 8 samples per symbol only
     assert rb(7, mf_ntaps=73) == (32, 0)                                    # ... with any tap count (the PAM bank)
-    # fuse 15: the one-kernel front end at 8, 10 and 20 samples per symbol, pulse-truncation bank (sps + 1 taps) only
+    # fuse 15: the one-kernel front end at 8, 10 and 20 samples per symbol with the pulse-truncation bank (sps + 1 taps),
+    # and at 8 with any odd bank of up to 73 taps (the PAM banks: 73 taps for SOQPSK-TG, 17 for MIL)
     assert rb(15) == (32, 1) and rb(15, sps=10) == (32, 1) and rb(15, sps=20) == (32, 1)
     assert rb(15, sps=10, timing_offset=-5) == (32, 1)
-    assert rb(15, mf_ntaps=73) == (32, 0)                                   # PAM at 8: separate kernels, packed rows
+    assert rb(15, mf_ntaps=73) == (32, 1) and rb(15, mf_ntaps=17) == (32, 1)
+    assert rb(15, mf_ntaps=75) == (32, 0) and rb(15, mf_ntaps=72) == (32, 0)    # longer / even banks: separate kernels, packed rows
     assert rb(15, sps=10, mf_ntaps=91) == (48, 0) and rb(15, sps=16) == (48, 0) and rb(15, sps=4) == (48, 0)
     assert rb(15, sps=10, ntaps=10 * 10 + 1) == (48, 0)                      # a pulse of more than 9 symbols

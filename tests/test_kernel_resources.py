@@ -36,6 +36,9 @@ HOT = {
     # the same kernel at the reference examples' own rates (soqpsk_detection.py: 10, pcmfm_test.py: 20)
     "mod_chan_bank_kernel<9, 0, 10>": (128, 4),
     "mod_chan_bank_kernel<9, 0, 20>": (128, 4),
+    # the same kernel with the 73-tap PAM bank on the matrix cores (13 B operands per lane + 8 KB of partial tiles)
+    "mod_chan_bank_kernel<9, -1, 8>": (168, 3),
+    "mod_chan_bank_kernel<4, -1, 8>": (168, 3),
     # CPM front ends (configs[2]): 3 waves per SIMD needs <= 168
     "mod_chan_bank_kernel<4, 16, 8>": (168, 3),
     "mod_chan_bank_kernel<4, 4, 8>": (168, 3),

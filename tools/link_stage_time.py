@@ -16,13 +16,15 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--fuse", type=int, default=-1)
     ap.add_argument("--label", default="")
+    ap.add_argument("--detector", default="PT", choices=["PT", "PAM"])
     a = ap.parse_args()
     import torch
 
     from waveforms_amd.link import CPMLink, SOQPSKLink, operating_point_warmup, soqpsk_warmup_param
 
     if a.waveform == "soqpsk":
-        link = SOQPSKLink(a.nsym, 8, pn_degree=23, warmup=soqpsk_warmup_param(operating_point_warmup("soqpsk", 10.0)), fuse=15 if a.fuse < 0 else a.fuse)
+        link = SOQPSKLink(a.nsym, 8, pn_degree=23, warmup=soqpsk_warmup_param(operating_point_warmup("soqpsk", 10.0)), fuse=15 if a.fuse < 0 else a.fuse,
+                          detector=a.detector)
     else:
         link = CPMLink(a.nsym, 8, waveform=a.waveform, warmup=operating_point_warmup(a.waveform, 10.0), fuse=10 if a.fuse < 0 else a.fuse)
     acc = {}

@@ -97,14 +97,14 @@ int wf_cpm_modulate_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_ori
 int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
                             const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
                             double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
-                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream);
+                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps = 0);
 int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total,
                             const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
                             int64_t tile_lo, int64_t ntiles, const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile,
                             const double *d_mf_taps, double rot_re, double rot_im, double sigma, uint64_t seed,
                             uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index, int64_t first,
                             int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf = 0, int cpm_nh = 1,
-                            int stage = 3);
+                            int stage = 3, int mf_ntaps = 0);
 int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_ntaps, int64_t first);
 int wf_mod_chan_cpm_rows_applies(int64_t nsym, int nh, int ntaps, int sps, int nfilt, int ntm, int64_t start0);
 int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse,

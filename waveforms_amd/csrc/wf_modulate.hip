@@ -546,6 +546,7 @@ struct mcb_params {
     int d;            // (first - 4) mod 8
     int pack_par0;    // parity of the detector call index of column 0 of the burst
     int cpm_nh;       // CPMNF instantiations: number of modulation-index columns of the templates (1 or 2)
+    int mf_ntaps;     // PAM form (CPMNF = -1): taps of the 3-filter bank (odd, <= MCB_PAM_NT)
 };
 
 // Geometry of the 2-row ring per samples-per-symbol SPS (8: the BASELINE configuration; 10: the reference's own
@@ -609,8 +610,10 @@ struct mcb_kargs {
 };
 typedef const __attribute__((address_space(4))) mcb_kargs *mcb_kptr;
 
+#define MCB_PAM_NT 73        // longest bank of the PAM form (the 73-tap PAM bank of SOQPSK-TG at 8 samples per symbol)
+#define MCB_PAM_MIRROR 96    // ring slots behind the wrap copy: samples 0 .. 71 of the ring once more, so a 97-sample operand row never wraps
 template <int JMAX, int CPMNF, int SPS = 8>     // SPS != 8: CPMNF = 0 only (the CPM detector's 9-tap templates are an sps-8 design)
-__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4 ? WF_MCB_CPM_WAVES : 2)) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
+__global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0 ? 3 : (JMAX <= 4 ? WF_MCB_CPM_WAVES : 2))) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
                                                                      const double *__restrict__ hvec_,
                                                                      const double *__restrict__ pulse_,
                                                                      const double *__restrict__ scratch_,
@@ -631,15 +634,23 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     const double *__restrict__ const hvec = ka->hvec;
     const double *__restrict__ const scratch = ka->scratch;
     const double *__restrict__ const mf_taps = ka->mf_taps;
-    static_assert(SPS == 8 || CPMNF == 0, "the CPM detector rows are an sps-8 design");
+    static_assert(SPS == 8 || CPMNF == 0, "the CPM detector rows and the long-bank form are sps-8 designs");
+    constexpr bool PAM = CPMNF < 0;
     using G = mcb_geom<SPS>;
     constexpr int NT = G::NT, RS = G::RS, CPR = G::CPR;
     constexpr bool FULLROW = RS == 2 * MOD_THREADS;                              // every thread owns two samples of a row
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    const int win = MOD_ROWS * CPR + JMAX + 2;
+    // (PAM form: "row 16" runs 74 samples = 10 symbols into the next tile, not one)
+    const int win = MOD_ROWS * CPR + JMAX + 2 + (CPMNF < 0 ? 10 : 0);
     double *s_amp = s_dyn;                                                       // window of symbol amplitudes
     double2 *s_ring = reinterpret_cast<double2 *>(s_dyn + ((win + 1) & ~1));     // noisy samples, 2 rows
-    int *s_pi = reinterpret_cast<int *>(s_ring + G::SLOTS);                      // prefix counts of the window's raw symbols
+    // (PAM form: one pad slot per 32 samples — operand rows 32 samples = 33 slots = 132 words apart: the 16 lanes a
+    //  ds_read_b64 serves together, one per operand row, land 4 banks apart, all different; with the pulse-truncation
+    //  layout's pad per 8 samples, 144 words, every fourth row shared its banks, with a pad per 16 every eighth)
+    constexpr int PG = PAM ? 32 : SPS;                                           // samples per pad group
+    constexpr int RBASE = PAM ? G::RING + G::RING / 32 : G::GROUPS * G::GS;      // slot of ring index RING (the wrap copy / mirror)
+    constexpr int RSLOTS = PAM ? RBASE + MCB_PAM_MIRROR : G::SLOTS;
+    int *s_pi = reinterpret_cast<int *>(s_ring + RSLOTS);                        // prefix counts of the window's raw symbols
     __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
 #ifndef WF_MCB_MFMA
@@ -648,12 +659,14 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     constexpr bool USE_MFMA = CPMNF == 16 && WF_MCB_MFMA != 0;
     // (matrix-core form: the templates are only needed to build the B operands once, before the first row —
     //  they are staged in the ring's slots instead of 4.6 KB of their own: 4 workgroups per CU instead of 3)
-    __shared__ double2 s_taps_own[USE_MFMA ? 1 : (CPMNF ? 2 * CPMNF * 9 : 3 * NT)];
+    __shared__ double2 s_taps_own[USE_MFMA || PAM ? 1 : (CPMNF ? 2 * CPMNF * 9 : 3 * NT)];
     double2 *const s_taps = USE_MFMA ? s_ring : s_taps_own;
     const int t = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(t) >> 6;      // the same number as a scalar
     wf_stage_tables<1, 0>(s_tab, t, MOD_THREADS);
-    if (CPMNF) {
+    if (PAM) {
+        // (the B operands are built from global memory, below)
+    } else if (CPMNF) {
         for (int k = t; k < Q.cpm_nh * CPMNF * 9; k += MOD_THREADS) s_taps[k] = reinterpret_cast<const double2 *>(mf_taps)[k];
     } else if (t < 3 * NT) {
         s_taps[t] = reinterpret_cast<const double2 *>(mf_taps)[t];
@@ -756,6 +769,44 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
         wf_lds_barrier();                                    // every lane has its operands: the ring's slots are free again
     }
 
+    // ---- CPMNF = -1 (PAM form: 3 filters of up to 73 complex taps, detector-packed rows) — also on the matrix cores.
+    // A packed row needs 4 of a column's 6 real outputs, so FOUR consecutive columns share one operand row: row i of
+    // A = the 97 samples from the window start of column 4 i (as Im, Re pairs: K = 194 -> 49 k-steps), the 16 output
+    // columns of B = (shift s = 0 .. 3) x (packed slot o = 0 .. 3), B[c][4 s + o] = the coefficient of window component
+    // c - 16 s in slot o of a column of parity (pack_par0 + s - kshift) & 1, zero outside the bank.  One row of 64
+    // detector columns = ONE 16 x 16 tile: 49 v_mfma_f64_16x16x4_f64 (74 % of them useful flops) in place of 584 fp64
+    // FMAs per column on the vector pipe.  The four waves split K (k-steps w, w + 4, ...; wave 0 takes the 49th: 13
+    // operands of B per lane, registers), leave their partial tiles in LDS and each sums, in the fixed order
+    // ((w0 + w1) + w2) + w3, the 16 columns it stores (register r of D = columns 16 r .. 16 r + 15: 512 B contiguous
+    // per wave) — after the NEXT row barrier, which is there anyway.  Rows therefore differ from the single-chain
+    // banks (mf_bank_kernel and the CPU restatement the tests check it with) in the last bits: the four chains are summed in another order.
+    __shared__ double s_part[PAM ? 4 * 4 * 64 : 1];
+    double bpam[PAM ? 13 : 1];
+    if constexpr (PAM) {
+        const int s_sh = mf_i >> 2, o_sl = mf_i & 3;
+        const int nt = Q.mf_ntaps;
+        const bool odd_col = ((Q.pack_par0 + s_sh - Q.kshift) & 1) != 0;
+        const int f = o_sl < 2 ? 1 : (o_sl == 2 ? 0 : 2);
+        // slot 0 / 1: Re / Im z1;  slot 2: odd ? Im z0 : Re z0;  slot 3: odd ? Re z2 : Im z2
+        const bool want_im = o_sl == 1 || (o_sl == 2 && odd_col) || (o_sl == 3 && !odd_col);
+        const double2 *tg = reinterpret_cast<const double2 *>(mf_taps) + f * nt;
+#pragma unroll
+        for (int n = 0; n < 13; ++n) {
+            const int kk = 4 * n + wave_u;                       // this wave's k-steps: every fourth one
+            const int cc = 4 * kk + mf_kq - 16 * s_sh;           // component of this column's own window
+            double v = 0.0;
+            if (cc >= 0 && cc < 2 * nt && (n < 12 || wave_u == 0)) {
+                const double2 tp = tg[nt - 1 - (cc >> 1)];
+                // component cc: odd = Re x, even = Im x (the imaginary sample's term first, as in every other bank)
+                //   Re z += Re x . Re t + Im x . (-Im t)        Im z += Re x . Im t + Im x . Re t
+                v = want_im ? ((cc & 1) ? tp.y : tp.x) : ((cc & 1) ? tp.x : -tp.y);
+            }
+            bpam[n] = v;
+        }
+        // no uninitialised slot may reach the matrix cores (0 x NaN): rows, pad slots and the mirror start as zeros
+        for (int k = t; k < RSLOTS; k += MOD_THREADS) s_ring[k] = make_double2(0.0, 0.0);
+    }
+
     const uint64_t pair0 = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull);
     // A workgroup takes a RUN of consecutive tiles: rows then follow each other across the tile edge in the
     // ring exactly as inside a tile (row 15's last column completes when the next tile's row 0 is in), and
@@ -765,7 +816,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
     const int64_t lt0_ = (int64_t)blockIdx.x * per_blk, lt1_ = lt0_ + per_blk < P.ntiles ? lt0_ + per_blk : P.ntiles;
     const int lt0 = (int)lt0_, lt1 = (int)lt1_;       // (the host checks ntiles < 2^31: one scalar register each across the loops)
     if (lt0 == 0 && P.tile_lo == 0)                           // samples before the burst (row -1 of tile 0) are zeros: clear the ring
-        for (int k = t; k < G::SLOTS; k += MOD_THREADS) s_ring[k] = make_double2(0.0, 0.0);
+        for (int k = t; k < RSLOTS; k += MOD_THREADS) s_ring[k] = make_double2(0.0, 0.0);
     bool run_first = true;
     for (int ltile = lt0; ltile < lt1; ++ltile, run_first = false) {
         const bool run_last = ltile + 1 == lt1;
@@ -844,6 +895,34 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                         o[16] = acc1[reg];
                     }
                 }
+            } else if constexpr (PAM) {
+                // operand row i = the 97 samples from ring index 512 (rho & 1) + 32 i; this lane's element of k-step
+                // kk = 4 n + w is component 4 kk + kq: sample 8 n + 2 w + (kq >> 1), Im (kq even) or Re (kq odd).  The
+                // sample's slot is index + index / 32, the row starts on a pad-group boundary and 2 w + (kq >> 1) < 8,
+                // so the slot offset of step n is the CONSTANT 8 n + n / 4 behind a per-lane base.
+                const int S0 = ((rho & 1) ? 512 : 0) + 32 * mf_i;
+                const double *xa = ring_d + 2 * (S0 + (S0 >> 5) + 2 * wave_u + (mf_kq >> 1)) + ((mf_kq & 1) ? 0 : 1);
+                mcb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#if defined(WF_ABL_PAM_NOMFMA)      // ablation only (timing): operand reads, no matrix instruction
+#pragma unroll
+                for (int n = 0; n < 12; ++n) acc[n & 3] += xa[2 * (8 * n + n / 4)];
+#elif defined(WF_ABL_PAM_2ACC)      // A/B: two interleaved accumulation chains
+                mcb_d4 acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int n = 0; n < 12; n += 2) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * n + n / 4)], bpam[n], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * (n + 1) + (n + 1) / 4)], bpam[n + 1], acc2, 0, 0, 0);
+                }
+                if (wave_u == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * 12 + 3)], bpam[12], acc, 0, 0, 0);
+                acc += acc2;
+#else
+#pragma unroll
+                for (int n = 0; n < 12; ++n)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * n + n / 4)], bpam[n], acc, 0, 0, 0);
+                if (wave_u == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * 12 + 3)], bpam[12], acc, 0, 0, 0);
+#endif
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) s_part[(4 * wave_u + reg) * 64 + (t & 63)] = acc[reg];
             } else if constexpr (CPMNF != 0) {
                 // rows of the generic CPM detector: this lane's CPMNF / 4 filters of symbol k
                 constexpr int FPT = CPMNF / 4;
@@ -897,6 +976,17 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                 if (k_ok) rows[4 * (k - Q.k_lo) + mp] = acc;
             }
         };
+        // PAM form: the partial tiles of bank_row(rho) summed and stored — register w of D is this wave's
+        auto bank_reduce = [&](int rho) __attribute__((always_inline)) {
+            if constexpr (PAM) {
+                const int ln = t & 63;
+                const double *pp = s_part + (4 * 0 + wave_u) * 64 + ln;
+                const double v = ((pp[0] + pp[4 * 64]) + pp[8 * 64]) + pp[12 * 64];
+                // lane (j = 4 s + o, iq): column 16 w + 4 iq + s of the row, packed slot o: 4 (4 iq + s) + o = the lane index
+                const int kr = 64 * rho + 16 * wave_u + (ln >> 2) - Q.kshift;
+                if (kr >= klo && kr < khi) rows[4 * ((sym_base + kr) - Q.k_lo) + (ln & 3)] = v;
+            }
+        };
         // One row: 512 samples by the 256 threads (EXTRA: "row 16", only what row 15's columns still need).
         auto row_step = [&](const int u) __attribute__((always_inline)) {
             const bool EXTRA = u >= MOD_ROWS;                   // (uniform; false for every row but the run's last one)
@@ -946,6 +1036,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
 #ifndef WF_ABL_MCB_NOBAR1   // ablation only (timing; results are wrong)
             wf_lds_barrier();
 #endif
+            // (PAM form) the partial tiles bank_row(u - 2) left during the previous row step
+            if (PAM && u >= 1 && (u >= 2 || !run_first || (tile == 0 && Q.kshift < 0))) bank_reduce(u - 2);
             int ia, ib;                                         // ring indices (sample - d) mod RING of the thread's two samples
             if (SPS == 8) {
                 ia = ((u << 9) + 2 * t - Q.d) & (G::RING - 1);
@@ -955,11 +1047,17 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
                 ia += ia < 0 ? G::RING : 0;
                 ib = ia + 1 == G::RING ? 0 : ia + 1;
             }
-            if (active && (!EXTRA || 2 * t < SPS)) {            // (row 16: its first SPS samples; the lanes above computed on window slots that do not exist)
-                s_ring[ia + ia / SPS] = x0;
-                s_ring[ib + ib / SPS] = x1;
-                if (ia == 0) s_ring[G::GROUPS * G::GS] = x0;    // index RING: read by the window that ends the ring
-                if (ib == 0) s_ring[G::GROUPS * G::GS] = x1;
+            constexpr int XLEN = PAM ? 74 : SPS;                // samples of the next tile the last columns of a tile look at
+            if (active && (!EXTRA || 2 * t < XLEN)) {           // (row 16: its first XLEN samples; the lanes above computed on window slots that do not exist)
+                s_ring[ia + ia / PG] = x0;
+                s_ring[ib + ib / PG] = x1;
+                if (PAM) {                                      // indices 0 .. 71 once more behind the ring (index RING + i)
+                    if (ia < 72) s_ring[RBASE + ia + ia / PG] = x0;
+                    if (ib < 72) s_ring[RBASE + ib + ib / PG] = x1;
+                } else {
+                    if (ia == 0) s_ring[G::GROUPS * G::GS] = x0;    // index RING: read by the window that ends the ring
+                    if (ib == 0) s_ring[G::GROUPS * G::GS] = x1;
+                }
             }
             // ... and row u is complete after this barrier — one more barrier per row than a four-row
             // ring, 18 KB less LDS (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
@@ -978,6 +1076,10 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (JMAX <= 4
         for (int u = 0; u < nrow; u += 2) {
             row_step(u);
             if (u + 1 < nrow) row_step(u + 1);
+        }
+        if (PAM) {                                              // the last bank_row's partial tiles
+            wf_lds_barrier();
+            bank_reduce(nrow - 2);
         }
     }
 #undef MCB_FRESH
@@ -1105,7 +1207,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             const double *d_mf_taps, double rot_re, double rot_im, double sigma, uint64_t seed,
                             uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index, int64_t first,
                             int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf, int cpm_nh,
-                            int stage)
+                            int stage, int mf_ntaps)
 {
     // stage 1: the two carry kernels only (they also export the phase carry of a stream window);
     // stage 2: the main kernel only, on carries an earlier stage-1 call left in this context's
@@ -1114,6 +1216,11 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_mf_taps && d_rows4, "wf_mod_chan_bank: NULL argument");
     if (cpm_nf != 0 && cpm_nf != 4 && cpm_nf != 16) return 1;
     if (cpm_nf && cpm_nh != 1 && cpm_nh != 2) return 1;
+    // SOQPSK bank: sps + 1 taps = the pulse-truncation form; any other odd length up to MCB_PAM_NT at 8 samples per
+    // symbol = the long-bank (PAM) form on the matrix cores
+    if (mf_ntaps <= 0) mf_ntaps = sps + 1;
+    const bool pam = cpm_nf == 0 && mf_ntaps != sps + 1;
+    if (pam && (sps != 8 || mf_ntaps < 3 || mf_ntaps > MCB_PAM_NT || (mf_ntaps & 1) == 0)) return 1;
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_rows4) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_mf_taps) & 15) == 0,
                "wf_mod_chan_bank: device pointers must be 16-byte aligned");
     mod_params P;
@@ -1146,28 +1253,37 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     Q.k_hi = k_lo + ncols;
     // column k's window (sps + 1 taps, "same" convolution: centre tap at sample first + k sps) starts at sample
     // first + k sps - sps / 2 = sps (k + kshift) + d
-    Q.kshift = first >= sps / 2 ? 0 : -1;
-    Q.d = (int)((first - sps / 2 + sps) % sps);
+    // (any odd bank length: centre tap (mf_ntaps - 1) / 2, window start = first + k sps - (mf_ntaps - 1) / 2)
+    {
+        const int64_t off = first - (cpm_nf ? sps / 2 : (mf_ntaps - 1) / 2);
+        int64_t ks = off / sps;
+        if (off - ks * sps < 0) --ks;
+        Q.kshift = (int)ks;
+        Q.d = (int)(off - ks * sps);
+    }
+    Q.mf_ntaps = mf_ntaps;
     Q.pack_par0 = pack_par0 & 1;
     Q.cpm_nh = cpm_nh;
     const int JM = J <= 4 ? 4 : 9;
-    const int win = MOD_ROWS * (P.rs / sps) + JM + 2;
+    const int win = MOD_ROWS * (P.rs / sps) + JM + 2 + (pam ? 10 : 0);
     const int ring_slots = sps == 8 ? mcb_geom<8>::SLOTS : (sps == 10 ? mcb_geom<10>::SLOTS : mcb_geom<20>::SLOTS);
     // (occupancy experiment, LDS padded to force fewer workgroups per CU with the 4-row ring of the
     //  first version: 1 per CU 0.97 ms, 2: 0.63, 3: 0.56 — the 2-row ring's 4 per CU: 0.53)
-    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)ring_slots * sizeof(double2) + (size_t)nh * (win + 1) * sizeof(int);
+    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)(pam ? mcb_geom<8>::RING + mcb_geom<8>::RING / 32 + MCB_PAM_MIRROR : ring_slots) * sizeof(double2) +
+                       (size_t)nh * (win + 1) * sizeof(int);
     // one run of consecutive tiles per resident workgroup (4 per CU for the SOQPSK form, 3 for the CPM forms)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
 #ifndef WF_MCB_RUNS_PER_SLOT
 #define WF_MCB_RUNS_PER_SLOT 4   // same-box A/B at 1e7 symbols: 1 run per slot 0.517 ms, 2: 0.500, 4: 0.478, 5 / 10: 0.486 (finer runs balance better; longer ones save more halo rows)
 #endif
-    const int64_t max_grid = (int64_t)cus * (cpm_nf && JM != 4 ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
+    const int64_t max_grid = (int64_t)cus * ((cpm_nf && JM != 4) || pam ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
     const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
     const int grid = (int)((P.ntiles + per_run - 1) / per_run);
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
     kern_t k = cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)
+             : pam          ? (JM == 4 ? mod_chan_bank_kernel<4, -1> : mod_chan_bank_kernel<9, -1>)
              : sps == 10    ? (JM == 4 ? mod_chan_bank_kernel<4, 0, 10> : mod_chan_bank_kernel<9, 0, 10>)
              : sps == 20    ? (JM == 4 ? mod_chan_bank_kernel<4, 0, 20> : mod_chan_bank_kernel<9, 0, 20>)
                             : (JM == 4 ? mod_chan_bank_kernel<4, 0> : mod_chan_bank_kernel<9, 0>);
@@ -1182,11 +1298,11 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
 int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
                             const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
                             double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
-                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream)
+                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps)
 {
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_mf_taps, rot_re, rot_im, sigma, seed, stream_id, first_index, nullptr, first, 0, ncols,
-                                   pack_par0, d_rows4, stream, 0, 1, 3);
+                                   pack_par0, d_rows4, stream, 0, 1, 3, mf_ntaps);
 }
 
 // Would the one-kernel front end (SOQPSK form: 3 x (sps + 1) bank, detector-packed rows) take this configuration?
@@ -1194,7 +1310,8 @@ int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, 
 // decides the row layout (32 B packed at sps 10 / 20 only through this kernel) with it.
 int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_ntaps, int64_t first)
 {
-    if (!(sps == 8 || sps == 10 || sps == 20) || mf_ntaps != sps + 1 || first < 0 || first >= sps || nh < 1 || nh > 2) return 0;
+    const bool pam = sps == 8 && mf_ntaps != 9 && mf_ntaps >= 3 && mf_ntaps <= MCB_PAM_NT && (mf_ntaps & 1);   // long-bank form
+    if (!(sps == 8 || sps == 10 || sps == 20) || (mf_ntaps != sps + 1 && !pam) || first < 0 || first >= sps || nh < 1 || nh > 2) return 0;
     mod_params P;
     const int rs_want = sps == 8 ? mcb_geom<8>::RS : (sps == 10 ? mcb_geom<10>::RS : mcb_geom<20>::RS);
     if (!mod_setup(P, nsym, nh, ntaps, sps, 0.0) || P.rs != rs_want) return 0;
@@ -1223,7 +1340,7 @@ int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, con
     if (ntm != 9 || start0 < -4 || start0 > 3 || (nfilt != 4 && nfilt != 16)) return 1;
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_templates, rot_re, rot_im, sigma, seed, stream_id, 0, nullptr, start0 + 4, 0, ncalls, 0,
-                                   d_rows, stream, nfilt, nh, 3);
+                                   d_rows, stream, nfilt, nh, 3, 0);
 }
 
 // Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total

@@ -739,8 +739,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     // ...), the 32 outputs as (Re Z_0, Im Z_0, Re Z_1, ...), so 16 symbols x 32 outputs = two
     // v_mfma_f64_16x16x4_f64 tiles over K = 20 (18 + 2 zeros): 10 MFMAs per 16 symbols in place of 144 fp64 FMAs
     // per thread and row on the vector pipe — the same flops at the same peak rate (78.6 TF either way on this
-    // chip), but on a pipe that runs BESIDE the VALU, which the Philox / Box-Muller stream of the other waves
-    // keeps busy.  The instruction accumulates k ascending as a bitwise fma chain (tools/mfma_f64_probe.hip:
+    // chip; nor does it overlap the other waves' fp64 vector work to any useful degree, see the PAM form below),
+    // but without the 288 LDS operand reads per thread and row those FMAs needed.  The instruction accumulates k ascending as a bitwise fma chain (tools/mfma_f64_probe.hip:
     // 1 024 000 / 1 024 000 elements equal), which is the order cpm_oracle.c states, so the rows are those of the
     // vector-pipe kernels bit for bit.  The templates alternate with the symbol parity (two modulation indices),
     // so a wave takes 16 symbols of ONE parity: wave w = (half of the row, parity): columns 32 (w >> 1) + 2 i + (w & 1).

@@ -15,7 +15,7 @@ from waveforms_amd import _hip
 
 __all__ = ["power_spectral_density", "eye_diagram_data", "phase_tree_data", "cpm_phase_tree_signal",
            "plot_power_spectral_density", "plot_eye_diagram", "plot_phase_tree", "generate_cpm_phase_tree",
-           "plot_constellation", "constellation"]
+           "plot_constellation", "constellation", "constellation_data"]
 
 
 def _dev_c128(signal):
@@ -141,13 +141,22 @@ def generate_cpm_phase_tree(pulse_filter, mod_index, encoder, sps, axis=None):
     return plot_phase_tree(signal=signal, sps=sps, modulo=length, axis=axis)
 
 
-def constellation(signal, sps=8, offset=0, axis=None):
-    """Scatter of the symbol-rate samples (the reference's viz/constellation.py:15-44 — a strided
-    view, no arithmetic to accelerate)."""
+def constellation_data(signal, n: int = 1024):
+    """(re, im) of the first ``n`` samples: the polyline waveforms/viz/constellation.py:36-43 draws (the caller
+    decimates to symbol rate — examples/soqpsk_example.py:168-171 — there is no arithmetic to accelerate)."""
+    pts = np.asarray(signal)[:n]
+    return np.ascontiguousarray(pts.real), np.ascontiguousarray(pts.imag)
+
+
+def constellation(signal, n: int = 1024, color=None, axis=None):
+    """The reference's viz/constellation.py:15-44, same arguments: the first ``n`` samples as a marked polyline."""
     axis = axis or _axes()
-    pts = np.asarray(signal)[offset::sps]
-    axis.scatter(pts.real, pts.imag, s=2)
+    re, im = constellation_data(signal, n)
+    axis.plot(re, im, color=color, alpha=0.2, marker="o")
     axis.set_title("Constellation")
+    axis.set_ylabel("Quadrature [V]")
+    axis.set_xlabel("In-phase [V]")
+    axis.grid(which="both", linestyle=":")
     return axis.figure
 
 

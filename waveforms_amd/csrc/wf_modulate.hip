@@ -595,6 +595,18 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm CTRL (
 #ifndef WF_MCB_UNROLL
 #define WF_MCB_UNROLL 2
 #endif
+// Issue priority (s_setprio): a row is a latency-bound part (amplitude / count reads from LDS, the phase sums, the
+// ring writes, the bank's operand reads) and a throughput-bound part (Philox + Box-Muller: ~45 % of the vector
+// instructions, next to no memory).  With the first at raised priority a wave's LDS round trips start as early as they
+// can and the other waves' noise arithmetic fills the gaps.  Same-box A/B at 1e7 symbols (profiles/r03_ab_prio.log):
+// no priorities 0.4878 / 0.4880 ms, the stretch between the two row barriers raised 0.4816 / 0.4850, everything but
+// the noise raised (mode 2) 0.4813 / 0.4760, only the noise raised 0.4838 / 0.4902.
+#ifndef WF_MCB_PRIO
+#define WF_MCB_PRIO 3
+#endif
+#ifndef WF_MCB_PRIO_MODE
+#define WF_MCB_PRIO_MODE 2
+#endif
 // The kernel's arguments as they lie in the kernarg segment (each at its natural alignment, in order).
 // The kernel reads them THROUGH this view, from a pointer it makes opaque once per tile: left as plain
 // by-value arguments, the ~70 uniform words of the two structs are loaded once at the top and stay live
@@ -1021,7 +1033,17 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
 #ifndef WF_ABL_MCB_HOISTKEYS
                 asm volatile("" : "+s"(k0), "+s"(k1));
 #endif
+#if WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 2
+                __builtin_amdgcn_s_setprio(0);
+#elif WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 3
+                __builtin_amdgcn_s_setprio(WF_MCB_PRIO);
+#endif
                 wf_gaussian_two(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
+#if WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 2
+                __builtin_amdgcn_s_setprio(WF_MCB_PRIO);
+#elif WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 3
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
 #endif
             x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
@@ -1035,6 +1057,9 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             // bank_row(u - 2) ...
 #ifndef WF_ABL_MCB_NOBAR1   // ablation only (timing; results are wrong)
             wf_lds_barrier();
+#endif
+#if WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 1   // A/B: the stretch between the row's barriers (ring writes, bank) at raised issue priority
+            __builtin_amdgcn_s_setprio(WF_MCB_PRIO);
 #endif
             // (PAM form) the partial tiles bank_row(u - 2) left during the previous row step
             if (PAM && u >= 1 && (u >= 2 || !run_first || (tile == 0 && Q.kshift < 0))) bank_reduce(u - 2);
@@ -1066,6 +1091,9 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
 #endif
 #ifndef WF_ABL_MCB_NOBANK   // ablation only
             if (u >= 1 || !run_first || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);   // u = 0: the previous tile's row 15
+#endif
+#if WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 1
+            __builtin_amdgcn_s_setprio(0);
 #endif
         };
         // two rows per trip, ONE copy of the row code: row 16 goes through the same loop body (a separate

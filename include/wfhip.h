@@ -208,6 +208,11 @@ int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length, int diffe
 /* Diagnostic: device-side timing of the last request wf_viterbi4_iteration_host's persistent server answered, in
  * microseconds: {request read from host memory, cache check, the iteration itself, write-through + answer}. */
 int wf_viterbi4_iteration_server_timing(wf_ctx *ctx, double *h_us4);
+/* wf_viterbi4_iteration_host answers BEFORE the detector state has been written back to device memory (about a
+ * microsecond later).  Call this before anything else reads, overwrites or frees a `d_state` that was passed to
+ * it (the next wf_viterbi4_iteration_host call needs nothing: one server, in order).  No-op without a server.
+ * (Reference: the state is the detector object's own arrays, waveforms/viterbi/algorithm.py:36-42.) */
+int wf_viterbi4_iteration_quiesce(wf_ctx *ctx);
 
 /* ---- K11: error counting ------------------------------------------------------
  * examples/soqpsk_detection.py:200-209: number of j < m with

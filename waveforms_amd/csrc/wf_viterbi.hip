@@ -37,7 +37,9 @@
 //   column 0 (even / I): end = (start & 1) + 2*(b & 1)
 //   column 1 (odd  / Q): end = (start & 2) + (b & 1)
 // (model.py:205-230; the diff-encoded trellis :233-258 only relabels the inputs).
-__device__ __constant__ const int8_t kOutIdx[2][8] = {{1, 2, 1, 0, 0, 1, 2, 1}, {1, 0, 2, 1, 1, 2, 0, 1}};
+// {{1, 2, 1, 0, 0, 1, 2, 1}, {1, 0, 2, 1, 1, 2, 0, 1}} as 2-bit fields of one literal: a table in constant memory
+// is a dependent ~0.5 us load each time the per-symbol server (one wave on an idle chip) looks an entry up
+__device__ __forceinline__ int br_out_idx(int col, int b) { return (int)((0x49616419u >> (2 * (8 * col + b))) & 3u); }
 
 __device__ __forceinline__ int br_end(int col, int b)
 {
@@ -636,7 +638,7 @@ __device__ __forceinline__ uint32_t vwin_code(int col, int e, int second, int di
 {
     const int start = col == 0 ? (e & 1) + 2 * second : (e & 2) + second;
     const int b = 2 * start + (col == 0 ? e >> 1 : e & 1);
-    return (uint32_t)br_inp(col, b, diff) | ((uint32_t)kOutIdx[col][b] << 1);
+    return (uint32_t)br_inp(col, b, diff) | ((uint32_t)br_out_idx(col, b) << 1);
 }
 
 template <int COL>
@@ -864,7 +866,7 @@ __device__ __forceinline__ void vit_iteration_body(vit_state *st, int L, int dif
     // algorithm.py:57-63: np.roll(-1) then overwrite the last column
     for (int b = 0; b < 8; ++b) {
         for (int j = 0; j + 1 < L; ++j) st->bi_history[b][j] = st->bi_history[b][j + 1];
-        const int oi = kOutIdx[col_now][b];
+        const int oi = br_out_idx(col_now, b);
         st->bi_history[b][L - 1] = br_inc(b >> 1, mf3[2 * oi], mf3[2 * oi + 1]);
     }
     // algorithm.py:65-67
@@ -910,7 +912,7 @@ __device__ __forceinline__ void vit_iteration_body(vit_state *st, int L, int dif
             syms_out[j] = nan("");
         } else {
             bits_out[j] = (double)br_inp(col, b, diff);
-            syms_out[j] = (double)(2 * (int)kOutIdx[col][b] - 2);
+            syms_out[j] = (double)(2 * (int)br_out_idx(col, b) - 2);
         }
         state = pred;
     }
@@ -949,7 +951,7 @@ __device__ __forceinline__ void vit_iteration_wave(vit_state *st, int L, int dif
     if (lane < 8) {                                    // algorithm.py:57-63, branch b = lane
         const int b = lane;
         for (int j = 0; j + 1 < L; ++j) st->bi_history[b][j] = st->bi_history[b][j + 1];
-        const int oi = kOutIdx[col_now][b];
+        const int oi = br_out_idx(col_now, b);
         st->bi_history[b][L - 1] = br_inc(b >> 1, mf3[2 * oi], mf3[2 * oi + 1]);
     }
     if (lane < 4) {
@@ -962,16 +964,23 @@ __device__ __forceinline__ void vit_iteration_wave(vit_state *st, int L, int dif
         const int col = (int)((((i + j - 1) % 2) + 2) % 2);
         const int jm1 = (j - 1 + L) % L;               // != j for L >= 2: a stage reads the previous stage's column only
         if (lane < 4) {
+            // the two branches that end in state s, in list order (the serial form's `for b ... if (br_end(col, b) != s)
+            // continue` visits exactly these, ascending): column 0: start & 1 = s & 1, b & 1 = s >> 1;
+            // column 1: start & 2 = s & 2, b & 1 = s & 1.  Both operand pairs are fetched before the first compare.
             const int s = lane;
+            const int b0 = col == 0 ? 2 * (s & 1) + (s >> 1) : 2 * (s & 2) + (s & 1);
+            const int b1 = b0 + (col == 0 ? 4 : 2);
+            const double mm0 = st->metrics[b0 >> 1][jm1] + st->bi_history[b0][j];
+            const double mm1 = st->metrics[b1 >> 1][jm1] + st->bi_history[b1][j];
             int min_k = 0;
             double min_m = INFINITY;
-            for (int b = 0; b < 8; ++b) {
-                if (br_end(col, b) != s) continue;
-                const double mm = st->metrics[b >> 1][jm1] + st->bi_history[b][j];
-                if (mm < min_m) {
-                    min_m = mm;
-                    min_k = b >> 1;
-                }
+            if (mm0 < min_m) {
+                min_m = mm0;
+                min_k = b0 >> 1;
+            }
+            if (mm1 < min_m) {
+                min_m = mm1;
+                min_k = b1 >> 1;
             }
             st->metrics[s][j] = min_m;
             st->path[s][j] = (unsigned char)min_k;
@@ -980,8 +989,13 @@ __device__ __forceinline__ void vit_iteration_wave(vit_state *st, int L, int dif
     }
     if (lane == 0) {                                   // algorithm.py:90-98
         int state = 0;
-        for (int s = 1; s < 4; ++s)
-            if (st->metrics[s][L - 1] < st->metrics[state][L - 1]) state = s;
+        {   // (the four final metrics in one batch of reads, then np.argmin's first-minimum rule on registers)
+            const double f0 = st->metrics[0][L - 1], f1 = st->metrics[1][L - 1], f2 = st->metrics[2][L - 1], f3 = st->metrics[3][L - 1];
+            double best = f0;
+            if (f1 < best) { best = f1; state = 1; }
+            if (f2 < best) { best = f2; state = 2; }
+            if (f3 < best) { best = f3; state = 3; }
+        }
         for (int j = L - 1; j >= 0; --j) {
             const int col = (int)((((i + j - 1) % 2) + 2) % 2);
             const int pred = st->path[state][j];
@@ -991,7 +1005,7 @@ __device__ __forceinline__ void vit_iteration_wave(vit_state *st, int L, int dif
                 syms_out[j] = nan("");
             } else {
                 bits_out[j] = (double)br_inp(col, b, diff);
-                syms_out[j] = (double)(2 * (int)kOutIdx[col][b] - 2);
+                syms_out[j] = (double)(2 * (int)br_out_idx(col, b) - 2);
             }
             state = pred;
         }
@@ -1022,7 +1036,11 @@ struct vit_mailbox {
     // payload: [0] vit_state* of the detector, [1] length | diff << 32, [2..7] the three matched-filter outputs
     unsigned long long pad_[12];                     // (the chunks start a 128-byte line: ONE wave-wide load fetches them)
     unsigned long long chunk[8][2];
-    double bits[VIT_MAX_LEN], syms[VIT_MAX_LEN];     // the answer
+    // The answer, tagged the same way: chunk k < length = {bits[k], sequence number}, chunk length + k = {syms[k], ...},
+    // each ONE 16-byte store of the device.  The host takes the answer when all 2 x length tags carry its request's
+    // number — no fence and no acknowledgement word on the way back; the detector state is written through to device
+    // memory AFTER the answer has left (the acknowledgement below only tells the host that this, too, is done).
+    unsigned long long ans[2 * VIT_MAX_LEN][2];
     unsigned long long t_seen, t_read, t_state, t_body, t_done;   // wall_clock64() ticks (100 MHz) of the last request (tools/iteration_bench.py)
 };
 static_assert(offsetof(vit_mailbox, chunk) == 128, "request chunks must start a 128-byte line");
@@ -1084,19 +1102,27 @@ __global__ void viterbi_iteration_server_kernel(vit_mailbox *mb)
                 vit_wave_sync();
             }
             const unsigned long long t_body = wall_clock64();
-            // write-through (posted stores: no round trip), lanes over the 16 table rows; then the answer
+            // the answer first: 2 L tagged 16-byte chunks (lanes 0 .. 2L-1, and again from lane 64 on for L > 32) ...
+            {
+                volatile v2u *an = reinterpret_cast<volatile v2u *>(&mb->ans[0][0]);
+                for (int k = lane; k < 2 * L; k += 64) {
+                    const double v = k < L ? s_out[k] : s_out[VIT_MAX_LEN + (k - L)];
+                    v2u c;
+                    c.x = (unsigned long long)__double_as_longlong(v);
+                    c.y = seq;
+                    an[k] = c;
+                }
+            }
+            const unsigned long long t_ans = wall_clock64();
+            // ... then the write-through (posted stores), lanes over the 16 table rows, and the acknowledgement behind it
             if (lane < 8) for (int j = 0; j < L; ++j) home->bi_history[lane][j] = s_st.bi_history[lane][j];
             else if (lane < 12) for (int j = 0; j < L; ++j) home->metrics[lane - 8][j] = s_st.metrics[lane - 8][j];
             else if (lane < 16) for (int j = 0; j < L; ++j) home->path[lane - 12][j] = s_st.path[lane - 12][j];
             if (lane == 0) home->i = s_st.i;
-            if (lane < L) {
-                *(volatile double *)&mb->bits[lane] = s_out[lane];
-                *(volatile double *)&mb->syms[lane] = s_out[VIT_MAX_LEN + lane];
-            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");               // (system scope) every lane's stores before lane 0's acknowledgement
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
-                mb->t_seen = t_poll; mb->t_read = t_read; mb->t_state = t_state; mb->t_body = t_body; mb->t_done = wall_clock64();
+                mb->t_seen = t_poll; mb->t_read = t_read; mb->t_state = t_state; mb->t_body = t_body; mb->t_done = t_ans;
                 __hip_atomic_store(&mb->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             last = seq;
@@ -1135,6 +1161,7 @@ int wf_iter_server_stop(wf_ctx *ctx)
     return WF_OK;
 }
 
+extern "C" int wf_viterbi4_iteration_quiesce(wf_ctx *ctx);
 extern "C" int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int differential,
                                      const double *d_mf3_ri, double *d_bits_out, double *d_syms_out,
                                      void *stream)
@@ -1142,6 +1169,10 @@ extern "C" int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int
     WF_REQUIRE(ctx && d_state && d_mf3_ri && d_bits_out && d_syms_out, "wf_viterbi4_iteration: NULL argument");
     WF_REQUIRE(length >= 1 && length <= VIT_MAX_LEN, "wf_viterbi4_iteration: length %d", length);
     WF_HIP(hipSetDevice(ctx->device));
+    {   // the state may be one the per-symbol server was asked about: its write-through must be in first
+        const int rq = wf_viterbi4_iteration_quiesce(ctx);
+        if (rq) return rq;
+    }
     hipLaunchKernelGGL(viterbi_iteration_kernel, dim3(1), dim3(64), 0, wf_stream(stream),
                        static_cast<vit_state *>(d_state), length, differential ? 1 : 0, d_mf3_ri,
                        d_bits_out, d_syms_out);
@@ -1160,6 +1191,24 @@ static inline void wf_store16(unsigned long long *p, unsigned long long lo, unsi
     typedef long long v2ll __attribute__((vector_size(16)));
     const v2ll v = {(long long)lo, (long long)hi};
     *reinterpret_cast<volatile v2ll *>(p) = v;
+}
+
+// Wait until the server has written the last served call's state through to device memory (it answers first):
+// before anything else reads or frees a detector state the server may have been asked about.  Harmless without a server.
+extern "C" int wf_viterbi4_iteration_quiesce(wf_ctx *ctx)
+{
+    if (!ctx || !ctx->h_mailbox) return WF_OK;
+    vit_mailbox *mb = static_cast<vit_mailbox *>(ctx->h_mailbox);
+    for (unsigned long long spins = 0; __atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) != mb->req; ++spins) {
+        if (__atomic_load_n(&mb->running, __ATOMIC_ACQUIRE) == 0 || spins > 2000000000ull) {
+            // (a retired server has nothing in flight: it acknowledges before it leaves)
+            if (__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) == mb->req) break;
+            wf_set_error("wf_viterbi4_iteration_quiesce: the iteration server did not acknowledge its last call");
+            return WF_ERR_HIP;
+        }
+        __builtin_ia32_pause();
+    }
+    return WF_OK;
 }
 
 extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length, int differential,
@@ -1208,8 +1257,14 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
     payload[1] = (unsigned long long)(unsigned)length | ((unsigned long long)(differential ? 1u : 0u) << 32);
     memcpy(&payload[2], h_mf3_ri, 6 * sizeof(double));
     for (int k = 0; k < 8; ++k) wf_store16(&mb->chunk[k][0], payload[k], seq);      // one 16-byte store per chunk: never torn
+    const int nans = 2 * length;
     for (unsigned long long spins = 0;; ++spins) {
-        if (__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) == seq) break;
+        // the last chunk first (the device writes them low to high), then every tag
+        if (__atomic_load_n(&mb->ans[nans - 1][1], __ATOMIC_ACQUIRE) == seq) {
+            bool all = true;
+            for (int k = 0; k < nans; ++k) all = all && __atomic_load_n(&mb->ans[k][1], __ATOMIC_ACQUIRE) == seq;
+            if (all) break;
+        }
         if (__atomic_load_n(&mb->running, __ATOMIC_ACQUIRE) == 0) {
             // not started yet, or retired after its idle time (possibly while this request was being posted):
             // (re)start it — it picks the pending request up from the sequence numbers
@@ -1226,8 +1281,10 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
     }
     bool undefined = false;
     for (int k = 0; k < length; ++k) {
-        h_bits_out[k] = mb->bits[k];
-        h_syms_out[k] = mb->syms[k];
+        // (value and tag of a chunk arrive in one 16-byte write; the value is read after its tag matched)
+        const unsigned long long vb = __atomic_load_n(&mb->ans[k][0], __ATOMIC_RELAXED), vs = __atomic_load_n(&mb->ans[length + k][0], __ATOMIC_RELAXED);
+        memcpy(&h_bits_out[k], &vb, 8);
+        memcpy(&h_syms_out[k], &vs, 8);
         undefined = undefined || h_bits_out[k] != h_bits_out[k];
     }
     if (undefined) {        // the reference's reverse_transitions lookup raises KeyError here (model.py:171-174); outputs hold NaN

@@ -47,6 +47,13 @@ class SOQPSKTrellisDetector:
         self._mode = None         # "iteration" or "batch" once the first call has been made
 
     def __del__(self):
+        if getattr(self, "_mode", None) == "iteration" and getattr(self, "_d_state", None) is not None:
+            # the per-symbol server answers before it has written the state back: let that land before the
+            # allocator may hand this memory to somebody else
+            try:
+                self._iter_quiesce(self._iter_ctx)
+            except Exception:      # noqa: BLE001 — interpreter teardown
+                pass
         if getattr(self, "_ctx", None) is not None:
             from waveforms_amd import _hip
 
@@ -69,6 +76,7 @@ class SOQPSKTrellisDetector:
             # counter, which it can only do once the zeros are there).
             _hip.torch().cuda.current_stream().synchronize()
             self._iter_fn, self._iter_ctx = _hip.lib().wf_viterbi4_iteration_host, _hip.ctx()
+            self._iter_quiesce = _hip.lib().wf_viterbi4_iteration_quiesce
 
     def iteration(
         self,

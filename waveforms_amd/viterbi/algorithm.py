@@ -94,16 +94,22 @@ class SOQPSKTrellisDetector:
             self._ensure_state()
             self._iter_stream = _hip.stream()
             self._iter_diff = int(self.differential)
-        L = self.length
+            # operands at fixed host addresses (an ndarray's .ctypes.data builds a helper object per access: three
+            # of them were 1.5 us of a 7.5 us call): the input is copied in, the outputs are copied out
+            self._iter_z = np.zeros(3, dtype=np.complex128)
+            self._iter_out = np.zeros((2, int(self.length)), dtype=np.float64)
+            self._iter_bits, self._iter_syms = self._iter_out[0], self._iter_out[1]      # (views kept: no indexing per call)
+            self._iter_args = (self._iter_ctx, self._d_state_ptr, int(self.length), self._iter_diff, self._iter_z.ctypes.data,
+                               self._iter_bits.ctypes.data, self._iter_syms.ctypes.data, self._iter_stream)
         # one C-ABI call per symbol: host operands in, host results out (a persistent kernel serves the calls
         # through a pinned mailbox: no launch, no torch op, no separate copies); the wrapper itself is kept to a
-        # few attribute reads — at ~8 us per C call Python's share is what is left to trim
-        z = mf_outputs
-        if not (type(z) is np.ndarray and z.dtype == np.complex128 and z.size == 3 and z.flags.c_contiguous):
-            z = np.ascontiguousarray(mf_outputs, dtype=np.complex128).reshape(3)
-        bits, syms = np.empty(L), np.empty(L)
-        rc = self._iter_fn(self._iter_ctx, self._d_state_ptr, L, self._iter_diff, z.ctypes.data, bits.ctypes.data, syms.ctypes.data,
-                           self._iter_stream)
+        # few attribute reads — at ~5 us per C call Python's share is what is left to trim
+        try:
+            self._iter_z[:] = mf_outputs                       # the usual caller: an ndarray of 3 values
+        except ValueError:
+            self._iter_z[:] = np.reshape(mf_outputs, 3)
+        rc = self._iter_fn(*self._iter_args)
+        bits, syms = self._iter_bits.copy(), self._iter_syms.copy()
         if rc:
             from waveforms_amd import _hip
 

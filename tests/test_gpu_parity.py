@@ -401,6 +401,38 @@ def test_detector_iteration_fresh_detector_on_a_reused_address(golden):
     assert len(seen) < 24  # the allocator did reuse addresses, so the case was exercised
 
 
+def test_detector_iteration_from_two_threads(golden):
+    """The per-symbol server's mailbox holds one request: two threads, each stepping its own detector (ctypes
+    calls run without the interpreter lock), take turns inside the C entry point and both get the reference's
+    outputs; afterwards a third detector on the first one's freed state starts from zeros."""
+    import threading
+
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detect")
+    errors = []
+
+    def work(length, diff):
+        try:
+            det = SOQPSKTrellisDetector(length, differantial_encoding=diff)
+            for k in range(260):
+                b, s = det.iteration(g["triplets"][k])
+                if not (np.array_equal(b, g[f"trip_L{length}_diff{int(diff)}_bits"][k]) and np.array_equal(s, g[f"trip_L{length}_diff{int(diff)}_syms"][k])):
+                    errors.append((length, diff, k))
+                    return
+        except Exception as exc:      # noqa: BLE001
+            errors.append((length, diff, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=a) for a in ((2, True), (4, False), (2, False))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    work(6, True)
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("ebn0", [0.0, 4.0, 10.0])
 def test_detector_chunk_parallel_equals_sequential(oracle, ebn0):
     """Chunk-parallel ACS with warm-up vs the sequential oracle on a long noisy burst —

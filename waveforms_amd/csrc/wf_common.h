@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <string>
 
@@ -70,6 +71,7 @@ struct wf_ctx {
     void *d_mailbox = nullptr;     // ... its device address,
     void *iter_stream = nullptr;   // ... the server's own (non-blocking) stream,
     const void *iter_last_state = nullptr;   // ... and the detector state the last request was for
+    std::atomic_flag iter_lock = ATOMIC_FLAG_INIT;   // the mailbox holds ONE request: callers of the per-symbol entry point take turns
 };
 
 static inline hipStream_t wf_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

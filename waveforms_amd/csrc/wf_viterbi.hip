@@ -1235,6 +1235,12 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
         }
         return WF_OK;
     }
+    // one request at a time (Python threads drop the interpreter lock inside a ctypes call)
+    struct turn {
+        std::atomic_flag &f;
+        explicit turn(std::atomic_flag &f_) : f(f_) { while (f.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause(); }
+        ~turn() { f.clear(std::memory_order_release); }
+    } my_turn(ctx->iter_lock);
     if (!ctx->h_mailbox) {
         WF_HIP(hipHostMalloc(&ctx->h_mailbox, sizeof(vit_mailbox), hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->h_mailbox, 0, sizeof(vit_mailbox));

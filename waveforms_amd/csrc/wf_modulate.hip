@@ -600,7 +600,9 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm CTRL (
 // instructions, next to no memory).  With the first at raised priority a wave's LDS round trips start as early as they
 // can and the other waves' noise arithmetic fills the gaps.  Same-box A/B at 1e7 symbols (profiles/r03_ab_prio.log):
 // no priorities 0.4878 / 0.4880 ms, the stretch between the two row barriers raised 0.4816 / 0.4850, everything but
-// the noise raised (mode 2) 0.4813 / 0.4760, only the noise raised 0.4838 / 0.4902.
+// the noise raised (mode 2) 0.4813 / 0.4760, only the noise raised 0.4838 / 0.4902; on a second box mode 2 at priority
+// 3 | 2 | 1 | none: 0.466 / 0.472 | 0.469 / 0.479 | 0.474 / 0.471 | 0.493 / 0.488, and with only the Philox rounds (no memory
+// access at all) at low priority 0.489 / 0.481 against 0.470 / 0.473: the Box-Muller half must stay low, too.
 #ifndef WF_MCB_PRIO
 #define WF_MCB_PRIO 3
 #endif

@@ -1016,11 +1016,34 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 refu_b = P.nh > 1 ? s_pi[win + 1 + lpart + MOD_ROWS * sym_per_row] : 0;
             }
             double ra, rb;
-            mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap, P.nh,
-                                 win + 1, refu_a, refu_b, Wu, Th_a, Th_b, (double)SPS, 1.0 / (double)SPS, ra, rb);   // (P.sps_d, P.inv_sps as literals)
             double2 e0, e1;
-            wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
-            wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
+            // The row's amplitude / count reads are ISSUED FIRST, the noise arithmetic (45 % of the row's vector
+            // instructions, no dependence on them) runs behind them, the phase sums come last: left in program order
+            // (reads, sums, sincos, then the noise) every wave started its row by waiting for LDS.  Same-box A/B at 1e7
+            // symbols: 0.4717 / 0.4786 -> 0.4583 / 0.4531 ms (profiles/r03_ab_loads_first.log).  (Even sps and even c —
+            // every SOQPSK pulse of the reference at 8 / 10 / 20 samples per symbol: both samples of a pair see the same
+            // symbols, 9 reads; wf_mod_chan_bank_applies admits nothing else there.  The 10-samples-per-symbol body keeps
+            // the old order and the general pair form — MIL's 11 taps have c = 5 — and so do the CPM forms: ARTM's
+            // measured 0.711 / 0.715 against 0.684 / 0.700 ms with the new order, PCM/FM's 24-tap pulse has an odd c.)
+            constexpr bool LOADS_FIRST = SPS != 10 && CPMNF <= 0;   // (the 10-samples-per-symbol body is one register over 128 in this order; the CPM forms measured 1.5 - 3 % slower with it: both keep the old one)
+            double am_[JMAX];
+            int pi0_ = 0, pi1_ = 0;
+            if constexpr (!LOADS_FIRST) {
+                mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap, P.nh,
+                                     win + 1, refu_a, refu_b, Wu, Th_a, Th_b, (double)SPS, 1.0 / (double)SPS, ra, rb);
+                wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
+                wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
+            } else {
+                const double *ap = &s_amp[l_top0p1 + u * sym_per_row];
+                const int *pp = &s_pi[(q0 - cq) + u * sym_per_row];
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) am_[j] = ap[-1 - j];
+                pi0_ = pp[0];
+                if (P.nh > 1) pi1_ = pp[win + 1];
+            }
+#ifndef WF_MCB_NO_LOADS_FIRST      // A/B: let the scheduler place the reads
+            if (LOADS_FIRST) __builtin_amdgcn_sched_barrier(0);
+#endif
             // channel (wf_awgn_c128): derotate + Philox AWGN, one block per thread and row
             const int64_t n0 = tile_base + (int64_t)u * RS + 2 * t;
             double g[4];
@@ -1048,6 +1071,26 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
 #endif
             }
 #endif
+#ifndef WF_MCB_NO_LOADS_FIRST
+            if (LOADS_FIRST) __builtin_amdgcn_sched_barrier(0);
+#endif
+            if constexpr (LOADS_FIRST) {
+                // mod_pair_phase with both samples on the same symbols (a1 == a, one count)
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) {
+                    acc0 = fma(Q0[j], am_[j], acc0);
+                    acc1 = fma(Q1[j], am_[j], acc1);
+                }
+                double b0 = fma((double)(pi0_ - refu_a), Th_a, Wu);
+                if (P.nh > 1) b0 = fma((double)(pi1_ - refu_b), Th_b, b0);
+                const double v0 = b0 + acc0, v1 = b0 + acc1;
+                const double kq = floor(v0 * (1.0 / (double)SPS));
+                ra = fma(-kq, (double)SPS, v0);
+                rb = fma(-kq, (double)SPS, v1);
+                wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
+                wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
+            }
             x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
             x1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
             if (EXTRA || !full_tile) {                          // (tile-uniform) samples past the end of the burst are zeros to the bank
@@ -1260,6 +1303,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     if (!mod_setup(P, nsym_total, nh, ntaps, sps, phi0) || P.rs != rs_want) return 1;
     const int J = (ntaps + sps - 1) / sps;
     if (J > 9) return 1;
+    if (cpm_nf == 0 && sps != 10 && ((sps & 1) || (P.c & 1))) return 1;     // SOQPSK forms at 8 / 20: both samples of a thread's pair under the same symbols
     WF_REQUIRE(first + (k_lo + ncols - 1) * (int64_t)sps < P.out_len, "wf_mod_chan_bank: columns run past the burst");
     if (ntiles < 0) ntiles = P.ntiles;
     WF_REQUIRE(tile_lo >= 0 && ntiles >= 1 && tile_lo + ntiles <= P.ntiles && ntiles < (int64_t)1 << 31, "wf_mod_chan_bank: bad tile window");
@@ -1345,6 +1389,7 @@ int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_nt
     mod_params P;
     const int rs_want = sps == 8 ? mcb_geom<8>::RS : (sps == 10 ? mcb_geom<10>::RS : mcb_geom<20>::RS);
     if (!mod_setup(P, nsym, nh, ntaps, sps, 0.0) || P.rs != rs_want) return 0;
+    if (sps != 10 && ((sps & 1) || (P.c & 1))) return 0;      // (the 10-samples-per-symbol body keeps the general pair form)
     return (ntaps + sps - 1) / sps <= 9;
 }
 

@@ -1020,7 +1020,11 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             // The row's amplitude / count reads are ISSUED FIRST, the noise arithmetic (45 % of the row's vector
             // instructions, no dependence on them) runs behind them, the phase sums come last: left in program order
             // (reads, sums, sincos, then the noise) every wave started its row by waiting for LDS.  Same-box A/B at 1e7
-            // symbols: 0.4717 / 0.4786 -> 0.4583 / 0.4531 ms (profiles/r03_ab_loads_first.log).  (Even sps and even c —
+            // symbols: 0.4717 / 0.4786 -> 0.4583 / 0.4531 ms (profiles/r03_ab_loads_first.log; with the three parts
+            // pinned by sched_barrier or left to the scheduler in this source order: 0.4601 / 0.4574 against 0.4572 /
+            // 0.4567 — it is the source order and the shared reads that count, so nothing is pinned; the NEXT row's
+            // Philox block computed behind the second barrier, under the bank's reads: 0.4656 / 0.4700 against 0.4557 /
+            // 0.4553, not kept).  (Even sps and even c —
             // every SOQPSK pulse of the reference at 8 / 10 / 20 samples per symbol: both samples of a pair see the same
             // symbols, 9 reads; wf_mod_chan_bank_applies admits nothing else there.  The 10-samples-per-symbol body keeps
             // the old order and the general pair form — MIL's 11 taps have c = 5 — and so do the CPM forms: ARTM's
@@ -1041,9 +1045,6 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 pi0_ = pp[0];
                 if (P.nh > 1) pi1_ = pp[win + 1];
             }
-#ifndef WF_MCB_NO_LOADS_FIRST      // A/B: let the scheduler place the reads
-            if (LOADS_FIRST) __builtin_amdgcn_sched_barrier(0);
-#endif
             // channel (wf_awgn_c128): derotate + Philox AWGN, one block per thread and row
             const int64_t n0 = tile_base + (int64_t)u * RS + 2 * t;
             double g[4];
@@ -1070,9 +1071,6 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 __builtin_amdgcn_s_setprio(0);
 #endif
             }
-#endif
-#ifndef WF_MCB_NO_LOADS_FIRST
-            if (LOADS_FIRST) __builtin_amdgcn_sched_barrier(0);
 #endif
             if constexpr (LOADS_FIRST) {
                 // mod_pair_phase with both samples on the same symbols (a1 == a, one count)

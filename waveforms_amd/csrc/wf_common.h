@@ -500,6 +500,58 @@ __device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_i
     wf_box_muller32(p.x2, p.x3, sigma, tb, &g[2], &g[3]);
 }
 
+// wf_gaussian_two with the two Box-Muller transforms INTERLEAVED: both log-table entries are fetched together, then
+// both sector entries, so the four dependent table round trips of a Philox block become two (same operations on the
+// same operands as wf_gaussian_two: the same bits).  ALL_UP_FRONT: all four entries right behind the Philox rounds.
+template <bool ALL_UP_FRONT, class Tabs>
+__device__ __forceinline__ void wf_gaussian_two_il(uint64_t pair, uint64_t stream_id, uint64_t seed, double sigma,
+                                                   const Tabs &tb, double g[4])
+{
+    const wf_philox_out p = wf_philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)stream_id,
+                                             (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t xa[2] = {p.x0, p.x2}, xb[2] = {p.x1, p.x3};
+    long long mant[2];
+    int e[2];
+    double2 tl[2], tc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const long long ix = __double_as_longlong((double)xa[q] + 1.0);
+        e[q] = (int)(ix >> 52) - (1023 + 32);
+        mant[q] = ix & 0x000FFFFFFFFFFFFFll;
+        tl[q] = tb.log((int)(mant[q] >> 45));
+    }
+    if (ALL_UP_FRONT) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tc[q] = tb.cis((int)(xb[q] >> 25));
+    }
+    double rad[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double m = __longlong_as_double(mant[q] | 0x3FF0000000000000ll);
+        const double r = fma(m, tl[q].x, -1.0);
+        double pl = fma(r, -1.0 / 6.0, 0.2);
+        pl = fma(r, pl, -0.25);
+        pl = fma(r, pl, 1.0 / 3.0);
+        pl = fma(r, pl, -0.5);
+        pl = fma(r, pl, 1.0);
+        const double de = (double)e[q];
+        const double lg = fmin(fma(de, 6.93147180369123816490e-01, fma(r, pl, tl[q].y) + de * 1.90821492927058770002e-10), 0.0);
+        rad[q] = sigma * wf_sqrt_pos(-2.0 * lg);
+    }
+    if (!ALL_UP_FRONT) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tc[q] = tb.cis((int)(xb[q] >> 25));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ri = (int)(xb[q] & 0x1FFFFFFu) - (1 << 24);
+        double sn, cs;
+        wf_cis_sector(tc[q], (double)ri * (6.28318530717958647692 * 0x1.0p-32), &sn, &cs);
+        g[2 * q] = rad[q] * cs;
+        g[2 * q + 1] = rad[q] * sn;
+    }
+}
+
 __device__ __forceinline__ long long wf_wave_sum_i64(long long v)
 {
 #pragma unroll

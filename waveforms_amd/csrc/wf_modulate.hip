@@ -1066,7 +1066,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
 #endif
 #ifndef WF_MCB_NOISE_IL
 #define WF_MCB_NOISE_IL 2        // the two Box-Muller transforms interleaved, all four table entries fetched right behind the Philox rounds
-#endif                           // (same-box A/B at 1e7 symbols: sequential 0.4580 / 0.4644 ms, table reads in pairs 0.4591 / 0.4588, all four up front 0.4479 / 0.4535)
+#endif                           // (same-box A/B at 1e7 symbols: sequential 0.4580 / 0.4644 ms, table reads in pairs 0.4591 / 0.4588, all four up front 0.4479 / 0.4535;
+                                 //  staged further — Philox + reads, then the phase sums and the sector reads, then the transforms — 0.4640 / 0.4598 against 0.4473 / 0.4536: not kept)
 #if WF_MCB_NOISE_IL > 0
                 wf_gaussian_two_il<WF_MCB_NOISE_IL == 2>(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
 #else

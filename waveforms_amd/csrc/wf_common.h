@@ -64,6 +64,12 @@ struct wf_ctx {
     double *d_vit_edge = nullptr;     // chunk-parallel detector: per-wave start / end metrics (8 doubles each)
     size_t vit_edge_words = 0;
     unsigned long long *d_vit_unmerged = nullptr;   // chunks whose warm-up did not reach the true path metrics
+    // The link's detector call can leave its wave-edge proof (viterbi_verify_kernel: ~1000 compares) to the error
+    // counter that follows it on the same stream — one dependent launch less per block.  Set by the link around the
+    // detector call; whoever finds a pending proof (wf_count_errors, wf_vit_flush_verify) runs it.
+    bool vit_defer_verify = false;
+    const double *vit_pending_edge = nullptr;
+    int64_t vit_pending_nwaves = 0;
     hipEvent_t *events = nullptr;  // WF_LINK_EVENT_SLOTS x (WF_LINK_STAGES + 1), created lazily
     double *h_iter = nullptr;      // per-symbol detector call: pinned, device-mapped staging (6 in + 2 x 64 out)
     double *d_iter = nullptr;      // ... the device's address of the same memory
@@ -108,6 +114,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf = 0, int cpm_nh = 1,
                             int stage = 3, int mf_ntaps = 0);
 int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_ntaps, int64_t first);
+int wf_vit_flush_verify(wf_ctx *ctx, void *stream);   // run a detector proof the link deferred (no-op when none is pending)
 int wf_mod_chan_cpm_rows_applies(int64_t nsym, int nh, int ntaps, int sps, int nfilt, int ntm, int64_t start0);
 int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse,
                          int ntaps, int sps, double phi0, const double *d_templates, int nfilt, int ntm, int64_t start0,

@@ -160,13 +160,15 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     }
     if (fused_all) {
         MARK(3); MARK(4); MARK(5); MARK(6);   // the "fir" slot times the whole fused kernel
-        if ((rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, nullptr, stream))) return rc;
+        ctx->vit_defer_verify = true;      // the error counter below runs the detector's wave-edge proof: one launch less
+        rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, nullptr, stream);
+        ctx->vit_defer_verify = false;
+        if (rc) return rc;
         MARK(7);
         int64_t m_ = L.ncols - length;
         if (m_ > cfg->nsym) m_ = cfg->nsym;
         if (m_ < 0) m_ = 0;
-        if (m_ > 0)
-            if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, stream))) return rc;
+        if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, stream))) return rc;   // (m_ = 0: only the proof)
         MARK(8);
         if (h_compared) *h_compared = m_;
         return WF_OK;

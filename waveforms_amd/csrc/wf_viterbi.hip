@@ -477,6 +477,19 @@ __global__ void viterbi_verify_kernel(const double *__restrict__ edge, int64_t n
     if (bad) atomicAdd(unmerged, 1ull);
 }
 
+int wf_vit_flush_verify(wf_ctx *ctx, void *stream)
+{
+    if (!ctx || !ctx->vit_pending_edge) return WF_OK;
+    const double *edge = ctx->vit_pending_edge;
+    const int64_t nw = ctx->vit_pending_nwaves;
+    ctx->vit_pending_edge = nullptr;
+    ctx->vit_pending_nwaves = 0;
+    hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((nw - 1 + 255) / 256)), dim3(256), 0, wf_stream(stream), edge, nw,
+                       ctx->d_vit_unmerged);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}
+
 __global__ void viterbi_carry_commit_kernel(double *state)
 {
     const int t = threadIdx.x;
@@ -530,9 +543,15 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
                            differential ? 1 : 0, warmup, d_bits, d_syms, d_state, edge, ctx->d_vit_unmerged);
     WF_LAUNCH_CHECK();
     if (nwaves_live > 1) {
-        hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((nwaves_live - 1 + 255) / 256)), dim3(256), 0, s, edge,
-                           nwaves_live, ctx->d_vit_unmerged);
-        WF_LAUNCH_CHECK();
+        if (ctx->vit_defer_verify) {          // the link's error counter, next on this stream, does the compares (wf_count.hip)
+            WF_REQUIRE(ctx->vit_pending_edge == nullptr, "wf_viterbi4_detect: internal: a deferred proof was never run");
+            ctx->vit_pending_edge = edge;
+            ctx->vit_pending_nwaves = nwaves_live;
+        } else {
+            hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((nwaves_live - 1 + 255) / 256)), dim3(256), 0, s, edge,
+                               nwaves_live, ctx->d_vit_unmerged);
+            WF_LAUNCH_CHECK();
+        }
     }
     if (d_state) {
         hipLaunchKernelGGL(viterbi_carry_commit_kernel, dim3(1), dim3(64), 0, s, d_state);

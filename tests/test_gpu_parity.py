@@ -604,6 +604,32 @@ def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
         assert be > 0
 
 
+def test_link_prbs_and_precoder_without_a_scan_equal_the_generic_kernels():
+    """The link's two-launch PRBS + SOQPSK precoder (stretch parities from the PRBS kernel, start state by ballot) against
+    the generic wf_lfsr_generate + three-kernel wf_fsm_encode scan (fuse bit 4): the same bits and symbols, differential
+    and plain trellis, bursts that end inside a 4096-symbol stretch / a 32768-bit PRBS block / a thread's 16 symbols,
+    PRBS offsets, PN23 and PN15; a burst too long for the scan-free form falls back by itself."""
+    from waveforms_amd.link import SOQPSKLink
+
+    for nsym, diff, deg, skip in ((70_001, True, 23, 0), (70_001, False, 23, 12_345), (4096 * 9, True, 15, 7), (32_768 * 3 + 5, True, 23, 1 << 20),
+                                  (300, True, 23, 3), (300, False, 23, 0), (4_200_000, True, 23, 99), (4_200_000, False, 23, 0)):
+        a = SOQPSKLink(nsym, 8, fuse=15, differential=diff, pn_degree=deg)
+        b = SOQPSKLink(nsym, 8, fuse=31, differential=diff, pn_degree=deg)
+        for link in (a, b):
+            link.run_block(6.0, seed=4, stream_id=1, skip_bits=skip)
+        # transmitted bits at the head of the workspace, the precoder's symbols behind them (wf_pipeline.hip: make_layout)
+        off_syms = -(-(nsym + 16) // 256) * 256
+        for name, off in (("bits", 0), ("symbols", off_syms)):
+            x = a.workspace[off:off + nsym].cpu().numpy()
+            y = b.workspace[off:off + nsym].cpu().numpy()
+            assert np.array_equal(x, y), (nsym, diff, deg, skip, name, int(np.argmax(x != y)))
+        assert set(np.unique(a.workspace[off_syms:off_syms + nsym].cpu().numpy().view(np.int8)).tolist()) <= {-2, 0, 2}
+        assert a.result() == b.result()
+    big = SOQPSKLink(8192 * 4096 + 4096, 8, fuse=15)          # one stretch over the limit: generic path, still runs
+    big.run_block(10.0)
+    assert big.result()[2] > 0
+
+
 # ------------------------------------------------------------------ streaming (config 5)
 @pytest.mark.parametrize("detector,fuse,chunk", [("PT", 3, 1 << 16), ("PAM", 3, 1 << 15), ("PT", 1, 3 << 14),
                                                  ("PT", 7, 1 << 16), ("PAM", 7, 1 << 15), ("PT", 15, 1 << 16), ("PT", 15, 3 << 14),

@@ -90,7 +90,11 @@ int wf_ctx_reserve_vit(wf_ctx *ctx, size_t words);
 
 // Internal (not exported) forms with device-resident carries, used by the streaming link.
 int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
-                         const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream);
+                         const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream,
+                         uint32_t *d_sub_par = nullptr);   // d_sub_par: (even | odd << 1) parity of every 4096-bit stretch (see lfsr_kernel)
+// PRBS + the SOQPSK 4-state precoder of the link in two launches (wf_encode.hip); 1 = not this trellis / too long: use the generic calls
+int wf_soqpsk_prbs_encode(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip, const uint8_t *h_next,
+                          const int8_t *h_out, uint8_t *d_bits, int64_t n, int8_t *d_symbols, void *stream, void *mid_event = nullptr);
 int wf_awgn_mf_bank_dyn(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,
                         double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
                         const uint64_t *d_dyn_index, const double *d_taps_ri, int nfilt, int ntaps, int64_t first,

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
                                                               uint64_t mask, uint64_t state,
                                                               uint64_t skip, uint8_t *__restrict__ bits,
                                                               int64_t n, int degree,
-                                                              const uint64_t *__restrict__ dyn_skip)
+                                                              const uint64_t *__restrict__ dyn_skip,
+                                                              uint32_t *__restrict__ sub_par)
 {
     if (dyn_skip) skip += *dyn_skip;   // stream replayed as a graph: the position lives on the device
     __shared__ uint64_t s_tab[64][64];   // all 64 jump matrices (32 KB), staged with parallel loads
@@ -159,6 +160,22 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
         }
     }
     __syncthreads();
+    // Optional by-product for the link's one-launch SOQPSK precoder (wf_encode.hip: soqpsk_emit_kernel): the parity of
+    // the bits at even / odd positions of every 4096-bit stretch (32 threads), bit 0 / bit 1 of one word each — what a
+    // differential encoder carries across that stretch.  (Positions >= n of the last block are junk, and nobody
+    // downstream of the last stretch asks for its parity.)
+    if (sub_par) {
+        static_assert(LFSR_WORDS == 2, "sub-block parities assume 128 bits per thread");
+        const uint64_t w0 = s_words[t * 2], w1 = s_words[t * 2 + 1];
+        const bool pe = ((__popcll(w0 & 0x5555555555555555ull) + __popcll(w1 & 0x5555555555555555ull)) & 1) != 0;
+        const bool po = ((__popcll(w0 & 0xAAAAAAAAAAAAAAAAull) + __popcll(w1 & 0xAAAAAAAAAAAAAAAAull)) & 1) != 0;
+        const unsigned long long be = __builtin_amdgcn_ballot_w64(pe), bo = __builtin_amdgcn_ballot_w64(po);
+        if (lane == 0) {
+            uint32_t *o = sub_par + (size_t)blockIdx.x * (LFSR_BITS_PER_BLOCK / 4096) + 2 * (t >> 6);
+            o[0] = (uint32_t)(__popc((unsigned)be) & 1) | ((uint32_t)(__popc((unsigned)bo) & 1) << 1);
+            o[1] = (uint32_t)(__popc((unsigned)(be >> 32)) & 1) | ((uint32_t)(__popc((unsigned)(bo >> 32)) & 1) << 1);
+        }
+    }
 
     const int64_t blk_byte0 = (int64_t)blockIdx.x * LFSR_BITS_PER_BLOCK;
 #pragma unroll 4
@@ -181,8 +198,6 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
     }
 }
 
-int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
-                         const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream);
 
 extern "C" int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state,
                                 uint64_t skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out,
@@ -192,7 +207,8 @@ extern "C" int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t
 }
 
 int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
-                         const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream)
+                         const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream,
+                         uint32_t *d_sub_par)
 {
     WF_REQUIRE(ctx != nullptr, "wf_lfsr_generate: ctx is NULL");
     if (degree < 2 || degree > 64) {
@@ -215,7 +231,7 @@ int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state,
     const int64_t blocks = (n + LFSR_BITS_PER_BLOCK - 1) / LFSR_BITS_PER_BLOCK;
     WF_REQUIRE(blocks < (1ll << 31), "wf_lfsr_generate: n too large for one launch");
     hipLaunchKernelGGL(lfsr_kernel, dim3((unsigned)blocks), dim3(LFSR_THREADS), 0, wf_stream(stream),
-                       t->dev, mask, state, skip, d_bits, n, degree, d_dyn_skip);
+                       t->dev, mask, state, skip, d_bits, n, degree, d_dyn_skip, d_sub_par);
     WF_LAUNCH_CHECK();
     return WF_OK;
 }

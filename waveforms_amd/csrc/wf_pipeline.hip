@@ -143,9 +143,15 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
 #define MARK(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(stream))); } while (0)
     int rc;
     MARK(0);
-    if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, cfg->nsym, nullptr, stream))) return rc;
-    MARK(1);
-    if ((rc = wf_fsm_encode(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, cfg->nsym, 0, 0, syms, nullptr, stream))) return rc;
+    // PRBS + precoder: two launches when the burst fits the scan-free form (wf_soqpsk_prbs_encode), else the generic four
+    rc = (cfg->fuse & 16) ? 1 : wf_soqpsk_prbs_encode(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, &next[0][0][0], &outp[0][0][0], bits,
+                                                       cfg->nsym, syms, stream, ev ? (void *)ev[1] : nullptr);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+        if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, cfg->nsym, nullptr, stream))) return rc;
+        MARK(1);
+        if ((rc = wf_fsm_encode(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, cfg->nsym, 0, 0, syms, nullptr, stream))) return rc;
+    }
     MARK(2);
     // fuse bit 3 (with bits 1 and 2 in effect): modulator, channel and bank in ONE kernel — the clean
     // baseband samples never exist in HBM.  Outside that kernel's envelope the bits below apply.

@@ -218,7 +218,15 @@ __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viter
             row &= 4095;
 #endif
             const int qq = q < PIECES ? q : 0;
+#ifndef CPM_NO_NT_LOADS    // rows are read once: nontemporal (same-box: ARTM detector 0.7585 / 0.7617 -> 0.7470 / 0.7462 ms, PCM/FM 0.6456 / 0.6473 -> 0.6383 / 0.6406)
+            {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(rows + row * NF + (qq - (qq / NF) * NF)));
+                dst[i] = make_double2(v.x, v.y);
+            }
+#else
             dst[i] = vit_ld16_c(rows + row * NF + (qq - (qq / NF) * NF));
+#endif
         }
     };
     // LDS word index of the slot each of this lane's M candidates goes to (dest = 4 * end state + slot), for

@@ -905,8 +905,13 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                     const int kr_i = 64 * rho + 32 * (wave_u >> 1) + 2 * isym + (wave_u & 1) - Q.kshift;
                     if (kr_i >= klo && kr_i < khi) {
                         double *o = rows + ((sym_base + kr_i) - Q.k_lo) * (2 * CPMNF) + jo;
+#ifndef WF_MCB_NO_NT_STORES   // the rows leave with the nontemporal hint: 2.56 GB per 1e7 symbols that the detector reads back from HBM
+                        __builtin_nontemporal_store(acc0[reg], &o[0]);      // anyway — written normally they sat dirty in the L2s and their write-back met the
+                        __builtin_nontemporal_store(acc1[reg], &o[16]);     // detector's first reads: same-box, detector 0.820 / 0.821 -> 0.754 / 0.761 ms
+#else
                         o[0] = acc0[reg];
                         o[16] = acc1[reg];
+#endif
                     }
                 }
             } else if constexpr (PAM) {
@@ -957,9 +962,17 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                     }
                 }
                 if (k_ok) {
-                    double2 *o = reinterpret_cast<double2 *>(rows) + (k - Q.k_lo) * CPMNF + FPT * mp;
+                    double *o = rows + 2 * ((k - Q.k_lo) * CPMNF + FPT * mp);
 #pragma unroll
-                    for (int f = 0; f < FPT; ++f) o[f] = make_double2(zr[f], zi[f]);
+                    for (int f = 0; f < FPT; ++f) {
+#ifndef WF_MCB_NO_NT_STORES
+                        __builtin_nontemporal_store(zr[f], &o[2 * f]);
+                        __builtin_nontemporal_store(zi[f], &o[2 * f + 1]);
+#else
+                        o[2 * f] = zr[f];
+                        o[2 * f + 1] = zi[f];
+#endif
+                    }
                 }
             } else if (sym_taps_i != 0) {
                 const double *xb = ring_d + 2 * (G::GS * grp) + (mp & 1);
@@ -974,7 +987,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 }
                 const double T = S + mcb_quad_bcast<0xB1>(S);            // quad_perm [1, 0, 3, 2]: vb | vb | va | va
                 const double val = (mp == 0 || mp == 3) ? U : T;
-                if (k_ok) rows[4 * (k - Q.k_lo) + slot_l] = val;
+                if (k_ok) rows[4 * (k - Q.k_lo) + slot_l] = val;        // (32 B rows: the nontemporal hint measured neutral here)
             } else {
                 // any 3 x (SPS + 1) bank: lane p keeps the one chain of the packed row it stores
                 const int f = mp < 2 ? 1 : (mp == 2 ? 0 : 2);

@@ -547,6 +547,7 @@ struct mcb_params {
     int pack_par0;    // parity of the detector call index of column 0 of the burst
     int cpm_nh;       // CPMNF instantiations: number of modulation-index columns of the templates (1 or 2)
     int mf_ntaps;     // PAM form (CPMNF = -1): taps of the 3-filter bank (odd, <= MCB_PAM_NT)
+    int n_long, run_long;   // runs of tiles per workgroup: the first n_long workgroups take run_long tiles each, the rest ONE tile
 };
 
 // Geometry of the 2-row ring per samples-per-symbol SPS (8: the BASELINE configuration; 10: the reference's own
@@ -826,9 +827,12 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     // ring exactly as inside a tile (row 15's last column completes when the next tile's row 0 is in), and
     // only the run's last tile has to compute the 8 samples after it itself (a whole extra row step for
     // wave 0: 6 % of a tile when every tile did it).
-    const int64_t per_blk = (P.ntiles + gridDim.x - 1) / gridDim.x;
-    const int64_t lt0_ = (int64_t)blockIdx.x * per_blk, lt1_ = lt0_ + per_blk < P.ntiles ? lt0_ + per_blk : P.ntiles;
-    const int lt0 = (int)lt0_, lt1 = (int)lt1_;       // (the host checks ntiles < 2^31: one scalar register each across the loops)
+    // Long runs first, single tiles last (workgroups start in index order): the launch drains at the granularity of ONE
+    // tile instead of a whole run, while most tiles still save the extra row a run's last tile computes.
+    const int bx = (int)blockIdx.x;
+    const int lt0 = bx < Q.n_long ? bx * Q.run_long : Q.n_long * Q.run_long + (bx - Q.n_long);
+    const int lt1_ = bx < Q.n_long ? lt0 + Q.run_long : lt0 + 1;
+    const int lt1 = lt1_ < (int)P.ntiles ? lt1_ : (int)P.ntiles;       // (the host checks ntiles < 2^31: one scalar register each across the loops)
     if (lt0 == 0 && P.tile_lo == 0)                           // samples before the burst (row -1 of tile 0) are zeros: clear the ring
         for (int k = t; k < RSLOTS; k += MOD_THREADS) s_ring[k] = make_double2(0.0, 0.0);
     bool run_first = true;
@@ -1367,12 +1371,22 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     // one run of consecutive tiles per resident workgroup (4 per CU for the SOQPSK form, 3 for the CPM forms)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+#ifndef WF_MCB_TAIL_SLOTS_DEFAULT
+#define WF_MCB_TAIL_SLOTS_DEFAULT 1.5   // tiles that go out ONE per workgroup at the end of a launch, in resident-slot-fulls (cus x workgroups per CU):
+#endif                                   // same-box, 1e7 symbols, two passes: 0: 0.4455 / 0.4522 ms | 0.5: 0.4500 / 0.4525 | 1: 0.4436 / 0.4384 | 1.5: 0.4366 / 0.4383 | 2: 0.4374 / 0.4517 | 3: 0.4426 / 0.4530
 #ifndef WF_MCB_RUNS_PER_SLOT
 #define WF_MCB_RUNS_PER_SLOT 4   // same-box A/B at 1e7 symbols: 1 run per slot 0.517 ms, 2: 0.500, 4: 0.478, 5 / 10: 0.486 (finer runs balance better; longer ones save more halo rows)
 #endif
     const int64_t max_grid = (int64_t)cus * ((cpm_nf && JM != 4) || pam ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
     const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
-    const int grid = (int)((P.ntiles + per_run - 1) / per_run);
+    // the last `tail` tiles go out one per workgroup (WF_MCB_TAIL_SLOTS resident-slot-fulls of them; 0 = equal runs throughout)
+    static const double tail_slots = [] { const char *e = getenv("WF_MCB_TAIL_SLOTS"); return e ? atof(e) : WF_MCB_TAIL_SLOTS_DEFAULT; }();
+    // (SOQPSK forms only: PT -1.9 %, PAM -3.8 %; the ARTM form, whose 2.56 GB of row stores bind it, measured + 1.3 % and its detector + 1.5 %)
+    int64_t tail = per_run > 1 && cpm_nf == 0 ? (int64_t)(tail_slots * (double)(max_grid / WF_MCB_RUNS_PER_SLOT)) : 0;
+    if (tail > P.ntiles / 2) tail = P.ntiles / 2;
+    Q.run_long = (int)per_run;
+    Q.n_long = (int)((P.ntiles - tail) / per_run);
+    const int grid = (int)(Q.n_long + (P.ntiles - (int64_t)Q.n_long * per_run));
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
     kern_t k = cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)

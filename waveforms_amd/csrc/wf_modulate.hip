@@ -1377,12 +1377,18 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
 #ifndef WF_MCB_RUNS_PER_SLOT
 #define WF_MCB_RUNS_PER_SLOT 4   // same-box A/B at 1e7 symbols: 1 run per slot 0.517 ms, 2: 0.500, 4: 0.478, 5 / 10: 0.486 (finer runs balance better; longer ones save more halo rows)
 #endif
-    const int64_t max_grid = (int64_t)cus * ((cpm_nf && JM != 4) || pam ? 3 : 4) * WF_MCB_RUNS_PER_SLOT;
+    // (with the single-tile tail below the SOQPSK forms do better on longer runs: 2 per slot = 5 tiles at 1e7 symbols, 0.4352 / 0.4345 ms
+    //  against 0.4418 / 0.4427 for 4 per slot, 0.487 for 1, 0.4515 / 0.4424 for 3)
+#ifndef WF_MCB_RUNS_PER_SLOT_SOQPSK
+#define WF_MCB_RUNS_PER_SLOT_SOQPSK 2
+#endif
+    const int runs_per_slot = cpm_nf ? WF_MCB_RUNS_PER_SLOT : WF_MCB_RUNS_PER_SLOT_SOQPSK;
+    const int64_t max_grid = (int64_t)cus * ((cpm_nf && JM != 4) || pam ? 3 : 4) * runs_per_slot;
     const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
     // the last `tail` tiles go out one per workgroup (WF_MCB_TAIL_SLOTS resident-slot-fulls of them; 0 = equal runs throughout)
     static const double tail_slots = [] { const char *e = getenv("WF_MCB_TAIL_SLOTS"); return e ? atof(e) : WF_MCB_TAIL_SLOTS_DEFAULT; }();
     // (SOQPSK forms only: PT -1.9 %, PAM -3.8 %; the ARTM form, whose 2.56 GB of row stores bind it, measured + 1.3 % and its detector + 1.5 %)
-    int64_t tail = per_run > 1 && cpm_nf == 0 ? (int64_t)(tail_slots * (double)(max_grid / WF_MCB_RUNS_PER_SLOT)) : 0;
+    int64_t tail = per_run > 1 && cpm_nf == 0 ? (int64_t)(tail_slots * (double)(max_grid / runs_per_slot)) : 0;
     if (tail > P.ntiles / 2) tail = P.ntiles / 2;
     Q.run_long = (int)per_run;
     Q.n_long = (int)((P.ntiles - tail) / per_run);

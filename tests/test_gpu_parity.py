@@ -996,6 +996,28 @@ def test_one_kernel_front_end_pam_bank_rows(oracle, nsym, pulse_name):
             assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
 
 
+def test_one_kernel_front_end_random_bursts(capsys):
+    """tools/fuzz_front_end.py for a few seconds: random burst lengths (one row to millions of symbols: the run
+    partition with its single-tile tail, tile edges, ragged ends), decimation phases, both banks and both precoder forms —
+    fuse 15 against fuse 7, rows bitwise (PT) / to 2e-12 (PAM), decisions and counts identical.  (A 90-second run of
+    the same script went through 9689 bursts.)"""
+    import importlib.util
+    import sys
+    from pathlib import Path
+
+    path = Path(__file__).resolve().parent.parent / "tools" / "fuzz_front_end.py"
+    spec = importlib.util.spec_from_file_location("_fuzz_front_end", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = [str(path), "--seconds", "8", "--seed", "11"]
+    try:
+        mod.main()                         # raises AssertionError with the failing configuration
+    finally:
+        sys.argv = argv
+    assert "random bursts: one-kernel front end == separate kernels" in capsys.readouterr().out
+
+
 def test_fused_all_other_timing_offsets_and_generic_taps(oracle):
     """The one-kernel link for every decimation phase (window start anywhere in the symbol) and for
     a 3 x 9 bank WITHOUT the pulse-truncation symmetry (generic MAC path): rows == fuse 7."""

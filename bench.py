@@ -403,6 +403,27 @@ def main() -> None:
             if v_:
                 st["valu_issue_frac"] = v_["valu_issue_frac"]
 
+    steady = None
+    if world == 1 and nstreams == 1 and args.steady_steps > 0:
+        for l in links:
+            l.reset_counts()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for k in range(args.steady_steps):
+            links[0].run_block(args.ebn0, seed=1, stream_id=k & 0xFFFFFFFF, skip_bits=(k % 4096) * args.nsym * bits_per_sym)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        # Over thousands of blocks a chunk of the binary CPM detector can fail its proof at the operating-point
+        # warm-up (PCM/FM, 320 calls: ~7e-8 per chunk); the sweep runner repeats such a block with a doubled warm-up
+        # (waveforms_amd.bert), this loop only times — so the count is REPORTED here and the error total withheld.
+        from waveforms_amd import device as _dev
+        unproven = int(_dev.viterbi_unmerged(reset=True, ctx=links[0]._ctx))
+        s2 = links[0].result()
+        steady = {"steps": args.steady_steps, "seconds": round(dt2, 3), "ms_per_step": round(dt2 / args.steady_steps * 1e3, 4),
+                  "value": round(args.steady_steps * args.nsym / dt2 / 1e6, 2), "unit": "Msym/s",
+                  "bit_errors": int(s2[1]) if unproven == 0 else None, "detector_chunks_unproven": unproven,
+                  "note": "same step, same single stream, outside the driver-timed K steps"}
+
     # The same K steps once more with several independent trial blocks in flight (own workspace, wf_ctx and
     # stream each), as the BER sweep runs them: the vector-pipe-bound front-end kernel of one block overlaps the
     # detector and the small integer kernels of its neighbours.  Reported beside `value`, never instead of it:
@@ -433,28 +454,15 @@ def main() -> None:
         overlapped = {"streams": n2, "value": round(args.steps * args.nsym / dt / 1e6, 2), "unit": "Msym/s",
                       "ms_per_step": round(dt / args.steps * 1e3, 4), "bit_errors": tot[1],
                       "same_blocks_same_counts": tot[1] == be and tot[0] == se}
+        if args.steady_steps > 0:          # ... and, like `steady_state`, over a window long enough for the chip's clock to settle
+            t3 = time.perf_counter()
+            for k in range(args.steady_steps):
+                ostep(k)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t3
+            overlapped["steady_value"] = round(args.steady_steps * args.nsym / dt3 / 1e6, 2)
+            overlapped["steady_steps"] = args.steady_steps
         del extra
-
-    steady = None
-    if world == 1 and nstreams == 1 and args.steady_steps > 0:
-        for l in links:
-            l.reset_counts()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for k in range(args.steady_steps):
-            links[0].run_block(args.ebn0, seed=1, stream_id=k & 0xFFFFFFFF, skip_bits=(k % 4096) * args.nsym * bits_per_sym)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t2
-        # Over thousands of blocks a chunk of the binary CPM detector can fail its proof at the operating-point
-        # warm-up (PCM/FM, 320 calls: ~7e-8 per chunk); the sweep runner repeats such a block with a doubled warm-up
-        # (waveforms_amd.bert), this loop only times — so the count is REPORTED here and the error total withheld.
-        from waveforms_amd import device as _dev
-        unproven = int(_dev.viterbi_unmerged(reset=True, ctx=links[0]._ctx))
-        s2 = links[0].result()
-        steady = {"steps": args.steady_steps, "seconds": round(dt2, 3), "ms_per_step": round(dt2 / args.steady_steps * 1e3, 4),
-                  "value": round(args.steady_steps * args.nsym / dt2 / 1e6, 2), "unit": "Msym/s",
-                  "bit_errors": int(s2[1]) if unproven == 0 else None, "detector_chunks_unproven": unproven,
-                  "note": "same step, same single stream, outside the driver-timed K steps"}
 
     if rank == 0:
         total_sym = args.steps * args.nsym * world

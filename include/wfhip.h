@@ -262,7 +262,7 @@ typedef struct {
                             /* the pulse is outside the kernel: > 9 symbols, sps != 8);  */
                             /* bit 4 (16): PRBS and precoder through the generic kernels */
                             /* (wf_lfsr_generate + the three-kernel wf_fsm_encode scan)   */
-                            /* instead of the link's two-launch form (same bits and      */
+                            /* instead of the link's one-launch form (same bits and      */
                             /* symbols; bursts over 3.3e7 symbols take the generic form) */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
                             /* around every stage into that slot (wf_link_stage_ms)   */

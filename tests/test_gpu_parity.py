@@ -605,7 +605,8 @@ def test_device_link_equals_oracle_chain(oracle, detector, nsym, fuse):
 
 
 def test_link_prbs_and_precoder_without_a_scan_equal_the_generic_kernels():
-    """The link's two-launch PRBS + SOQPSK precoder (stretch parities from the PRBS kernel, start state by ballot) against
+    """The link's one-launch PRBS + SOQPSK precoder (the precoder state in front of every PRBS block is a linear functional
+    of the block's LFSR base state: the host hands it over in the kernel arguments; a ballot inside the block) against
     the generic wf_lfsr_generate + three-kernel wf_fsm_encode scan (fuse bit 4): the same bits and symbols, differential
     and plain trellis, bursts that end inside a 4096-symbol stretch / a 32768-bit PRBS block / a thread's 16 symbols,
     PRBS offsets, PN23 and PN15; a burst too long for the scan-free form falls back by itself."""
@@ -625,7 +626,7 @@ def test_link_prbs_and_precoder_without_a_scan_equal_the_generic_kernels():
             assert np.array_equal(x, y), (nsym, diff, deg, skip, name, int(np.argmax(x != y)))
         assert set(np.unique(a.workspace[off_syms:off_syms + nsym].cpu().numpy().view(np.int8)).tolist()) <= {-2, 0, 2}
         assert a.result() == b.result()
-    big = SOQPSKLink(8192 * 4096 + 4096, 8, fuse=15)          # one stretch over the limit: generic path, still runs
+    big = SOQPSKLink(1024 * 32768 + 4096, 8, fuse=15)         # one PRBS block over the limit: generic path, still runs
     big.run_block(10.0)
     assert big.result()[2] > 0
 

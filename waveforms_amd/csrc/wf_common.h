@@ -39,6 +39,10 @@ enum { WF_FAULT_SCAN_TIMEOUT = 1u };
 struct wf_lfsr_tables {
     uint64_t host[64][64];  // host[j][c] = column c of T^(2^j)
     uint64_t *dev = nullptr;  // same, 64*64 words
+    // linear functionals of a 32768-bit block's base state (wf_lfsr.hip: lfsr_block_functionals): parity of its bits at
+    // even / odd positions, its last bit but one and its last bit
+    uint64_t f_even = 0, f_odd = 0, f_m2 = 0, f_m1 = 0;
+    bool f_ready = false;
 };
 
 struct wf_ctx {
@@ -88,11 +92,12 @@ int wf_ctx_reserve_mod(wf_ctx *ctx, size_t words);
 int wf_iter_server_stop(wf_ctx *ctx);
 int wf_ctx_reserve_vit(wf_ctx *ctx, size_t words);
 
+struct lfsr_emit_args;
 // Internal (not exported) forms with device-resident carries, used by the streaming link.
 int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
                          const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream,
-                         uint32_t *d_sub_par = nullptr);   // d_sub_par: (even | odd << 1) parity of every 4096-bit stretch (see lfsr_kernel)
-// PRBS + the SOQPSK 4-state precoder of the link in two launches (wf_encode.hip); 1 = not this trellis / too long: use the generic calls
+                         const struct lfsr_emit_args *emit = nullptr);   // emit: the link's precoder rides in the same launch (see lfsr_kernel)
+// PRBS + the SOQPSK 4-state precoder of the link in ONE launch (wf_lfsr.hip); 1 = not this trellis / too long: use the generic calls
 int wf_soqpsk_prbs_encode(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip, const uint8_t *h_next,
                           const int8_t *h_out, uint8_t *d_bits, int64_t n, int8_t *d_symbols, void *stream, void *mid_event = nullptr);
 int wf_awgn_mf_bank_dyn(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,

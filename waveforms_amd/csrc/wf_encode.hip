@@ -365,115 +365,6 @@ int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, 
     return WF_OK;
 }
 
-// ------------------------------------------------------------------ the link's precoder without a scan
-// The SOQPSK 4-state / 2-column trellis (model.py:205-258) keeps ONE bit per rail: column 0 replaces state bit 1 by
-// beta = x ^ flip, column 1 replaces bit 0, flip = the bit being replaced (differential form) or 0.  So the state in
-// front of symbol n is no general function composition: differential — the running XOR of the inputs of each rail;
-// plain — the last two inputs.  A thread finds its start state from the parity of the bits before it (the stretch
-// parities the PRBS kernel leaves behind, a ballot inside the block) and walks its 16 symbols through the same
-// tables as enc_emit_kernel: the same symbols, one launch instead of three.
-#define SQ_MAX_SUB 8192        // stretches of 4096 symbols a block may have to fold (3.3e7 symbols); longer bursts take the generic scan
-template <bool DIFF>
-__global__ __launch_bounds__(ENC_THREADS) void soqpsk_emit_kernel(const uint8_t *__restrict__ bits, enc_params P,
-                                                                    const uint32_t *__restrict__ sub_par,
-                                                                    int8_t *__restrict__ symbols)
-{
-    static_assert(ENC_SYM_PER_BLOCK == 4096, "one block per parity stretch of the PRBS kernel");
-    __shared__ unsigned s_w[ENC_THREADS / WF_WAVE + 1];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t sym0 = ((int64_t)blockIdx.x * ENC_THREADS + t) * ENC_SYM_PER_THREAD;
-    int nv;
-    const uint64_t inps = load_inputs(bits, sym0, P.nsym, 1, &nv);            // nibble k = bit sym0 + k (zeros past the end)
-    int st;
-    if (DIFF) {
-        // parities of this thread's bits at even / odd positions (sym0 is even), exclusive prefix over the block ...
-        const bool pe = (__popcll(inps & 0x0101010101010101ull) & 1) != 0;                // nibbles 0, 2, ... , 14
-        const bool po = (__popcll(inps & 0x1010101010101010ull) & 1) != 0;
-        const unsigned long long be = __builtin_amdgcn_ballot_w64(pe), bo = __builtin_amdgcn_ballot_w64(po);
-        const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        unsigned ex = (unsigned)(__popcll(be & lt) & 1) | ((unsigned)(__popcll(bo & lt) & 1) << 1);
-        if (t == 0) s_w[ENC_THREADS / WF_WAVE] = 0;
-        if (lane == 0) s_w[wave] = (unsigned)(__popcll(be) & 1) | ((unsigned)(__popcll(bo) & 1) << 1);
-        // ... and of every stretch before this block (each thread folds its share, the wave by ballots)
-        unsigned acc = 0;
-        for (int64_t k = t; k < (int64_t)blockIdx.x; k += ENC_THREADS) acc ^= sub_par[k];
-        const unsigned long long ae = __builtin_amdgcn_ballot_w64((acc & 1u) != 0), ao = __builtin_amdgcn_ballot_w64((acc & 2u) != 0);
-        __syncthreads();
-        if (lane == 0) atomicXor(&s_w[ENC_THREADS / WF_WAVE], (unsigned)(__popcll(ae) & 1) | ((unsigned)(__popcll(ao) & 1) << 1));
-        for (int w = 0; w < wave; ++w) ex ^= s_w[w];
-        __syncthreads();
-        ex ^= s_w[ENC_THREADS / WF_WAVE];
-        // rail of position parity q: column (col0 + q) & 1; column 0 is state bit 1
-        const unsigned r0 = P.col0 == 0 ? (ex & 1u) : ((ex >> 1) & 1u);   // running XOR of the column-0 inputs
-        const unsigned r1 = P.col0 == 0 ? ((ex >> 1) & 1u) : (ex & 1u);
-        st = (int)((((unsigned)P.state0 >> 1) ^ r0) << 1 | (((unsigned)P.state0 & 1u) ^ r1));
-    } else {
-        // the two inputs before sym0 (sym0 >= 16 here), or the given start state
-        if (sym0 == 0) {
-            st = P.state0;
-        } else {
-            const unsigned x2 = bits[sym0 - 2] & 1u, x1 = bits[sym0 - 1] & 1u;   // positions sym0 - 2 (parity of sym0: column col0), sym0 - 1
-            st = P.col0 == 0 ? (int)((x2 << 1) | x1) : (int)((x1 << 1) | x2);
-        }
-    }
-    if (nv == 0) return;
-    int col = P.col0;                                                         // (sym0 is even: two columns)
-    uint64_t lo = 0, hi = 0;
-    for (int k = 0; k < nv; ++k) {
-        const int inp = (int)((inps >> (4 * k)) & 15ull);
-        const int idx = (col * P.states + st) * P.ninp + inp;
-        const uint64_t o = ((idx < 8 ? P.out_lo : P.out_hi) >> (8 * (idx & 7))) & 0xFFull;
-        if (k < 8) lo |= o << (8 * k); else hi |= o << (8 * (k - 8));
-        st = (int)((P.next2 >> (2 * idx)) & 3u);
-        col ^= 1;
-    }
-    if (nv == ENC_SYM_PER_THREAD) {
-        *reinterpret_cast<ulonglong2 *>(symbols + sym0) = make_ulonglong2(lo, hi);
-    } else {
-        for (int k = 0; k < nv; ++k) symbols[sym0 + k] = (int8_t)(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFF);
-    }
-}
-
-int wf_soqpsk_prbs_encode(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip, const uint8_t *h_next,
-                          const int8_t *h_out, uint8_t *d_bits, int64_t n, int8_t *d_symbols, void *stream, void *mid_event)
-{
-    WF_REQUIRE(ctx && h_next && h_out, "wf_soqpsk_prbs_encode: NULL argument");
-    if (n < 1 || (n + 4095) / 4096 > SQ_MAX_SUB) return 1;
-    // the tables must BE this trellis (next[c][s][x], 2 columns x 4 states x 2 inputs), in one of its two forms
-    int diff = -1;
-    for (int d = 0; d < 2 && diff < 0; ++d) {
-        bool ok = true;
-        for (int c = 0; c < 2 && ok; ++c)
-            for (int s = 0; s < 4 && ok; ++s)
-                for (int x = 0; x < 2 && ok; ++x) {
-                    const int flip = d ? (c == 0 ? (s >> 1) : (s & 1)) : 0, beta = x ^ flip;
-                    ok = h_next[(c * 4 + s) * 2 + x] == (c == 0 ? (s & 1) + 2 * beta : (s & 2) + beta);
-                }
-        if (ok) diff = d;
-    }
-    if (diff < 0) return 1;
-    WF_REQUIRE(d_bits && d_symbols && (reinterpret_cast<uintptr_t>(d_bits) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_symbols) & 15) == 0,
-               "wf_soqpsk_prbs_encode: device pointers must be non-NULL and 16-byte aligned");
-    const int64_t nsub = ((n + 32767) / 32768) * 8;                           // the PRBS kernel writes 8 stretches per block
-    int rc = wf_ctx_reserve_fsm(ctx, (size_t)nsub / 2 + 8);
-    if (rc) return rc;
-    uint32_t *sub_par = reinterpret_cast<uint32_t *>(ctx->d_fsm_scratch);
-    if ((rc = wf_lfsr_generate_dyn(ctx, degree, mask, state, skip, nullptr, d_bits, n, nullptr, stream, sub_par))) return rc;
-    if (mid_event) WF_HIP(hipEventRecord(static_cast<hipEvent_t>(mid_event), wf_stream(stream)));   // (the link's stage timing: PRBS | precoder)
-    enc_params P{2, 4, 1, 2, 0, 0, n, 0u, 0ull, 0ull};
-    for (int k = 0; k < 16; ++k) {
-        P.next2 |= (uint32_t)(h_next[k] & 3) << (2 * k);
-        (k < 8 ? P.out_lo : P.out_hi) |= (uint64_t)(uint8_t)h_out[k] << (8 * (k & 7));
-    }
-    const unsigned nblocks = (unsigned)((n + ENC_SYM_PER_BLOCK - 1) / ENC_SYM_PER_BLOCK);
-    if (diff)
-        hipLaunchKernelGGL(soqpsk_emit_kernel<true>, dim3(nblocks), dim3(ENC_THREADS), 0, wf_stream(stream), d_bits, P, sub_par, d_symbols);
-    else
-        hipLaunchKernelGGL(soqpsk_emit_kernel<false>, dim3(nblocks), dim3(ENC_THREADS), 0, wf_stream(stream), d_bits, P, sub_par, d_symbols);
-    WF_LAUNCH_CHECK();
-    return WF_OK;
-}
-
 extern "C" int wf_fsm_encode(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, int columns,
                              int states, int card, const uint8_t *d_bits, int64_t nbits, int64_t i0,
                              int state0, int8_t *d_symbols, int *h_state_out, void *stream)

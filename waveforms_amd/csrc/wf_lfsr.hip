@@ -89,12 +89,28 @@ __device__ __forceinline__ uint64_t lfsr_wave_xor(uint64_t v)
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
 }
 
+// The link's SOQPSK 4-state / 2-column precoder (model.py:205-258) in the SAME launch.  That trellis keeps ONE bit per rail:
+// column 0 (even symbol index) replaces state bit 1 by beta = x ^ flip, column 1 bit 0, flip = the bit being replaced
+// (differential form) or 0 — so the state in front of symbol n is the running XOR of each rail's inputs, or simply the
+// last two inputs.  For a whole 32768-bit block that is a LINEAR functional of the block's LFSR base state, so the host
+// walks the blocks' base states (one matrix-vector product each) and hands the kernel the state in front of every block
+// in its arguments: no scan, no second launch.  Inside the block a ballot gives every 16-symbol chunk its start state
+// and each thread walks chunks through the trellis tables exactly as enc_emit_kernel does.
+struct lfsr_emit_args {
+    uint64_t start[32];          // precoder state (bit 1 | bit 0) in front of block j: bits 2 j, 2 j + 1 (1024 blocks = 3.3e7 symbols)
+    uint64_t out_lo, out_hi;     // the trellis tables as enc_params carries them: output byte of table entry idx ...
+    uint32_t next2;              // ... and its next state, idx = (column * 4 + state) * 2 + input
+    int differential;
+    int8_t *symbols;             // nullptr: PRBS only
+};
+#define LFSR_EMIT_MAX_BLOCKS 1024
+
 __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__restrict__ jump,
                                                               uint64_t mask, uint64_t state,
                                                               uint64_t skip, uint8_t *__restrict__ bits,
                                                               int64_t n, int degree,
                                                               const uint64_t *__restrict__ dyn_skip,
-                                                              uint32_t *__restrict__ sub_par)
+                                                              const lfsr_emit_args E)
 {
     if (dyn_skip) skip += *dyn_skip;   // stream replayed as a graph: the position lives on the device
     __shared__ uint64_t s_tab[64][64];   // all 64 jump matrices (32 KB), staged with parallel loads
@@ -160,20 +176,61 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
         }
     }
     __syncthreads();
-    // Optional by-product for the link's one-launch SOQPSK precoder (wf_encode.hip: soqpsk_emit_kernel): the parity of
-    // the bits at even / odd positions of every 4096-bit stretch (32 threads), bit 0 / bit 1 of one word each — what a
-    // differential encoder carries across that stretch.  (Positions >= n of the last block are junk, and nobody
-    // downstream of the last stretch asks for its parity.)
-    if (sub_par) {
-        static_assert(LFSR_WORDS == 2, "sub-block parities assume 128 bits per thread");
-        const uint64_t w0 = s_words[t * 2], w1 = s_words[t * 2 + 1];
-        const bool pe = ((__popcll(w0 & 0x5555555555555555ull) + __popcll(w1 & 0x5555555555555555ull)) & 1) != 0;
-        const bool po = ((__popcll(w0 & 0xAAAAAAAAAAAAAAAAull) + __popcll(w1 & 0xAAAAAAAAAAAAAAAAull)) & 1) != 0;
-        const unsigned long long be = __builtin_amdgcn_ballot_w64(pe), bo = __builtin_amdgcn_ballot_w64(po);
-        if (lane == 0) {
-            uint32_t *o = sub_par + (size_t)blockIdx.x * (LFSR_BITS_PER_BLOCK / 4096) + 2 * (t >> 6);
-            o[0] = (uint32_t)(__popc((unsigned)be) & 1) | ((uint32_t)(__popc((unsigned)bo) & 1) << 1);
-            o[1] = (uint32_t)(__popc((unsigned)(be >> 32)) & 1) | ((uint32_t)(__popc((unsigned)(bo >> 32)) & 1) << 1);
+    if (E.symbols) {
+        static_assert(LFSR_WORDS == 2 && LFSR_THREADS == 256, "the precoder phase assumes 128 bits per thread, 2048 chunks per block");
+        __shared__ uint8_t s_st[LFSR_BITS_PER_BLOCK / 16];      // start state of every 16-symbol chunk
+        __shared__ unsigned s_wp[LFSR_THREADS / 64];
+        const unsigned carry = (unsigned)((E.start[blockIdx.x >> 5] >> (2 * (blockIdx.x & 31))) & 3ull);
+        auto bit_at = [&](int p) { return (unsigned)((s_words[p >> 6] >> (p & 63)) & 1ull); };
+        if (E.differential) {
+            const uint64_t w0 = s_words[t * 2], w1 = s_words[t * 2 + 1];
+            const bool pe = ((__popcll(w0 & 0x5555555555555555ull) + __popcll(w1 & 0x5555555555555555ull)) & 1) != 0;
+            const bool po = ((__popcll(w0 & 0xAAAAAAAAAAAAAAAAull) + __popcll(w1 & 0xAAAAAAAAAAAAAAAAull)) & 1) != 0;
+            const unsigned long long be = __builtin_amdgcn_ballot_w64(pe), bo = __builtin_amdgcn_ballot_w64(po);
+            const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+            unsigned st = ((unsigned)(__popcll(be & lt) & 1) << 1) | (unsigned)(__popcll(bo & lt) & 1);   // rails before this thread, inside the wave
+            if (lane == 0) s_wp[t >> 6] = ((unsigned)(__popcll(be) & 1) << 1) | (unsigned)(__popcll(bo) & 1);
+            __syncthreads();
+            for (int w = 0; w < (t >> 6); ++w) st ^= s_wp[w];
+            st ^= carry;                                         // (bit 1: even positions = column 0, bit 0: odd positions)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                s_st[8 * t + c] = (uint8_t)st;
+                const unsigned ch = (unsigned)(((c < 4 ? w0 : w1) >> (16 * (c & 3))) & 0xFFFFull);
+                st ^= ((unsigned)(__popc(ch & 0x5555u) & 1) << 1) | (unsigned)(__popc(ch & 0xAAAAu) & 1);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int p = 128 * t + 16 * c;                  // the two inputs before the chunk: position p - 2 is even (column 0: bit 1)
+                s_st[8 * t + c] = (uint8_t)(p == 0 ? carry : ((bit_at(p - 2) << 1) | bit_at(p - 1)));
+            }
+        }
+        __syncthreads();
+        const int64_t blk0 = (int64_t)blockIdx.x * LFSR_BITS_PER_BLOCK;
+#ifndef LFSR_EMIT_UNROLL
+#define LFSR_EMIT_UNROLL 2
+#endif
+#pragma unroll LFSR_EMIT_UNROLL
+        for (int r = 0; r < LFSR_BITS_PER_BLOCK / (16 * LFSR_THREADS); ++r) {
+            const int c = r * LFSR_THREADS + t, p = 16 * c;
+            const int64_t gi = blk0 + p;
+            if (gi >= n) break;
+            const unsigned x = (unsigned)((s_words[p >> 6] >> (p & 63)) & 0xFFFFull);
+            unsigned st = s_st[c];
+            uint64_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned idx = (((unsigned)(k & 1) * 4u + st) << 1) | ((x >> k) & 1u);
+                const uint64_t o = ((idx < 8 ? E.out_lo : E.out_hi) >> (8 * (idx & 7))) & 0xFFull;
+                if (k < 8) lo |= o << (8 * k); else hi |= o << (8 * (k - 8));
+                st = (E.next2 >> (2 * idx)) & 3u;
+            }
+            if (gi + 16 <= n) {
+                *reinterpret_cast<ulonglong2 *>(E.symbols + gi) = make_ulonglong2(lo, hi);
+            } else {
+                for (int k = 0; k < 16 && gi + k < n; ++k) E.symbols[gi + k] = (int8_t)(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFF);
+            }
         }
     }
 
@@ -208,7 +265,7 @@ extern "C" int wf_lfsr_generate(wf_ctx *ctx, int degree, uint64_t mask, uint64_t
 
 int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip,
                          const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream,
-                         uint32_t *d_sub_par)
+                         const lfsr_emit_args *emit)
 {
     WF_REQUIRE(ctx != nullptr, "wf_lfsr_generate: ctx is NULL");
     if (degree < 2 || degree > 64) {
@@ -231,7 +288,88 @@ int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state,
     const int64_t blocks = (n + LFSR_BITS_PER_BLOCK - 1) / LFSR_BITS_PER_BLOCK;
     WF_REQUIRE(blocks < (1ll << 31), "wf_lfsr_generate: n too large for one launch");
     hipLaunchKernelGGL(lfsr_kernel, dim3((unsigned)blocks), dim3(LFSR_THREADS), 0, wf_stream(stream),
-                       t->dev, mask, state, skip, d_bits, n, degree, d_dyn_skip, d_sub_par);
+                       t->dev, mask, state, skip, d_bits, n, degree, d_dyn_skip, emit ? *emit : lfsr_emit_args{});
     WF_LAUNCH_CHECK();
+    return WF_OK;
+}
+
+// Functionals of one 32768-bit block as seen from its base state (linear over GF(2)): parity of the output bits at
+// even / odd positions, the last bit but one, the last bit.  Bit c of a functional = its value for base state e_c.
+static void lfsr_block_functionals(wf_lfsr_tables *t, uint64_t mask)
+{
+    if (t->f_ready) return;
+    for (int c = 0; c < 64; ++c) {
+        uint64_t s = 1ull << c;
+        unsigned pe = 0, po = 0, m2 = 0, m1 = 0;
+        for (int k = 0; k < LFSR_BITS_PER_BLOCK; ++k) {
+            const unsigned bit = (unsigned)(s & 1ull);
+            s = (s >> 1) ^ (mask & (0ull - (uint64_t)bit));
+            if (k & 1) po ^= bit; else pe ^= bit;
+            if (k == LFSR_BITS_PER_BLOCK - 2) m2 = bit;
+            if (k == LFSR_BITS_PER_BLOCK - 1) m1 = bit;
+        }
+        t->f_even |= (uint64_t)pe << c;
+        t->f_odd |= (uint64_t)po << c;
+        t->f_m2 |= (uint64_t)m2 << c;
+        t->f_m1 |= (uint64_t)m1 << c;
+    }
+    t->f_ready = true;
+}
+
+// PRBS bits AND the link's SOQPSK precoder symbols in one launch (see lfsr_emit_args).  h_next / h_out: the trellis
+// tables [2 columns][4 states][2 inputs]; they must BE that trellis, in its differential or its plain form.
+// Returns 1 — not an error — for any other trellis or a burst of more than LFSR_EMIT_MAX_BLOCKS blocks (3.3e7
+// symbols): the caller then runs wf_lfsr_generate + wf_fsm_encode.
+int wf_soqpsk_prbs_encode(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip, const uint8_t *h_next,
+                          const int8_t *h_out, uint8_t *d_bits, int64_t n, int8_t *d_symbols, void *stream, void *mid_event)
+{
+    WF_REQUIRE(ctx && h_next && h_out, "wf_soqpsk_prbs_encode: NULL argument");
+    const int64_t blocks = (n + LFSR_BITS_PER_BLOCK - 1) / LFSR_BITS_PER_BLOCK;
+    if (n < 1 || blocks > LFSR_EMIT_MAX_BLOCKS || degree < 2 || degree > 64) return 1;
+    int diff = -1;
+    for (int d = 0; d < 2 && diff < 0; ++d) {
+        bool ok = true;
+        for (int c = 0; c < 2 && ok; ++c)
+            for (int s = 0; s < 4 && ok; ++s)
+                for (int x = 0; x < 2 && ok; ++x) {
+                    const int flip = d ? (c == 0 ? (s >> 1) : (s & 1)) : 0, beta = x ^ flip;
+                    ok = h_next[(c * 4 + s) * 2 + x] == (c == 0 ? (s & 1) + 2 * beta : (s & 2) + beta);
+                }
+        if (ok) diff = d;
+    }
+    if (diff < 0) return 1;
+    WF_REQUIRE(d_symbols && (reinterpret_cast<uintptr_t>(d_symbols) & 15) == 0, "wf_soqpsk_prbs_encode: d_symbols must be non-NULL and 16-byte aligned");
+    WF_REQUIRE(degree == 64 || ((mask >> degree) == 0 && (state >> degree) == 0), "wf_soqpsk_prbs_encode: mask/state wider than the register");
+    WF_HIP(hipSetDevice(ctx->device));
+    wf_lfsr_tables *t = get_tables(ctx, mask);
+    if (!t) {
+        wf_set_error("wf_soqpsk_prbs_encode: could not build jump tables");
+        return WF_ERR_NOMEM;
+    }
+    lfsr_block_functionals(t, mask);
+    lfsr_emit_args E{};
+    for (int k = 0; k < 16; ++k) {
+        E.next2 |= (uint32_t)(h_next[k] & 3) << (2 * k);
+        (k < 8 ? E.out_lo : E.out_hi) |= (uint64_t)(uint8_t)h_out[k] << (8 * (k & 7));
+    }
+    E.differential = diff;
+    E.symbols = d_symbols;
+    // the precoder state in front of every block, from the blocks' base states (base_{j+1} = T^32768 base_j)
+    uint64_t base = host_jump(t, state, skip);
+    unsigned st = 0, rails = 0;                                      // link: encoder starts in state 0 at an even symbol index
+    static_assert(LFSR_BITS_PER_BLOCK == 32768, "T^(block) is table 15");
+    for (int64_t j = 0; j < blocks; ++j) {
+        E.start[j >> 5] |= (uint64_t)st << (2 * (j & 31));
+        if (diff) {
+            rails ^= ((unsigned)(__builtin_popcountll(t->f_even & base) & 1) << 1) | (unsigned)(__builtin_popcountll(t->f_odd & base) & 1);
+            st = rails;
+        } else {
+            st = ((unsigned)(__builtin_popcountll(t->f_m2 & base) & 1) << 1) | (unsigned)(__builtin_popcountll(t->f_m1 & base) & 1);
+        }
+        base = host_matvec(t->host[15], base);
+    }
+    const int rc = wf_lfsr_generate_dyn(ctx, degree, mask, state, skip, nullptr, d_bits, n, nullptr, stream, &E);
+    if (rc) return rc;
+    if (mid_event) WF_HIP(hipEventRecord(static_cast<hipEvent_t>(mid_event), wf_stream(stream)));   // (the link's stage timing: PRBS + precoder | nothing)
     return WF_OK;
 }

@@ -209,10 +209,12 @@ def main() -> None:
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"],
                     help="soqpsk: BASELINE configs[1] (the headline metric); multih: configs[2], ARTM multi-h CPM through the "
                          "16-state generic CPM trellis detector; pcmfm: PCM/FM through the same detector family")
-    ap.add_argument("--fuse", type=int, default=15,
+    ap.add_argument("--fuse", type=int, default=47,
                     help="bit 0: fused modulator (FIR + phase scan in one pass); bit 1: AWGN inside the MF bank; "
                          "bit 2: detector-packed 32 B rows between bank and detector; bit 3: modulator + channel + bank in one "
-                         "kernel (no baseband samples in HBM); 0 = every stage its own kernel")
+                         "kernel (no baseband samples in HBM); bit 4: PRBS + precoder through the generic kernels; bit 5: the "
+                         "detector and the error count of a block on the context's side stream, beside the next block's front "
+                         "end (15 = one block after the other); 0 = every stage its own kernel")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent trial blocks in flight on separate HIP streams (own workspace + context each)")
     ap.add_argument("--overlap-streams", type=int, default=3,

@@ -263,7 +263,14 @@ typedef struct {
                             /* bit 4 (16): PRBS and precoder through the generic kernels */
                             /* (wf_lfsr_generate + the three-kernel wf_fsm_encode scan)   */
                             /* instead of the link's one-launch form (same bits and      */
-                            /* symbols; bursts over 3.3e7 symbols take the generic form) */
+                            /* symbols; bursts over 3.3e7 symbols take the generic form); */
+                            /* bit 5 (32, with the one-kernel front end): the detector   */
+                            /* and the error count of a block run on the context's side  */
+                            /* stream and overlap the front end of the NEXT wf_link_run  */
+                            /* on the same context; the workspace then holds two sets of */
+                            /* intermediates (wf_link_workspace_bytes says so), used     */
+                            /* alternately; counts complete after wf_link_join /         */
+                            /* wf_ctx_check on the stream that reads them                 */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
                             /* around every stage into that slot (wf_link_stage_ms)   */
 } wf_link_config;
@@ -276,6 +283,12 @@ int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_workspace, int64
  * `event_slot` (HIP events on the run's own stream).  Synchronises on that slot's
  * final event. */
 int wf_link_stage_ms(wf_ctx *ctx, int event_slot, float *h_ms);
+
+/* `stream` waits for the detectors and error counters that wf_link_run calls with fuse bit 5 left on the context's
+ * side stream: call it (or wf_ctx_check, which includes it) on the stream that will read or reset the counters, or
+ * reuse the workspace for something else.  No-op for a context that never ran a pipelined block.
+ * (Reference: the loop body of examples/soqpsk_detection.py:45-216 is sequential; this is a scheduling call.) */
+int wf_link_join(wf_ctx *ctx, void *stream);
 
 /* Workspace offsets of a wf_link_run block, for callers that want the intermediates:
  * info8 = {ncols, one_kernel, off(detected bits), off(detected symbols), off(signal), row_bytes,

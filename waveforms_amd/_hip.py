@@ -55,6 +55,7 @@ SIGNATURES = {
     "wf_viterbi4_iteration_host": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
     "wf_viterbi4_iteration_server_timing": (c_int, [_P, POINTER(ctypes.c_double)]),
     "wf_viterbi4_iteration_quiesce": (c_int, [_P]),
+    "wf_link_join": (c_int, [_P, _P]),
     "wf_count_errors": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P]),
     "wf_link_workspace_bytes": (c_int64, [_P]),
     "wf_link_run": (c_int, [_P, _P, _P, c_int64, _P, POINTER(c_int64), _P]),

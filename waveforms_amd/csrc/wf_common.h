@@ -75,6 +75,13 @@ struct wf_ctx {
     const double *vit_pending_edge = nullptr;
     int64_t vit_pending_nwaves = 0;
     hipEvent_t *events = nullptr;  // WF_LINK_EVENT_SLOTS x (WF_LINK_STAGES + 1), created lazily
+    // wf_link_run with fuse bit 5: the detector and the error count of a block run on this side stream, beside the front
+    // end of the NEXT block (two sets of intermediates in the workspace, used alternately).  pipe_done[s]: the back end
+    // of the last block that used set s; wf_link_join / wf_ctx_check make the caller's stream wait for both.
+    void *pipe_stream = nullptr;
+    hipEvent_t pipe_front = nullptr, pipe_done[2] = {nullptr, nullptr};
+    bool pipe_done_valid[2] = {false, false};
+    int pipe_set = 0;
     double *h_iter = nullptr;      // per-symbol detector call: pinned, device-mapped staging (6 in + 2 x 64 out)
     double *d_iter = nullptr;      // ... the device's address of the same memory
     void *h_mailbox = nullptr;     // per-symbol detector call through the persistent iteration server (wf_viterbi.hip): pinned mailbox,
@@ -123,7 +130,8 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf = 0, int cpm_nh = 1,
                             int stage = 3, int mf_ntaps = 0);
 int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_ntaps, int64_t first);
-int wf_vit_flush_verify(wf_ctx *ctx, void *stream);   // run a detector proof the link deferred (no-op when none is pending)
+int wf_vit_flush_verify(wf_ctx *ctx, void *stream);
+int wf_link_join_internal(wf_ctx *ctx, void *stream);   // the caller's stream waits for what fuse bit 5 left on the side stream   // run a detector proof the link deferred (no-op when none is pending)
 int wf_mod_chan_cpm_rows_applies(int64_t nsym, int nh, int ntaps, int sps, int nfilt, int ntm, int64_t start0);
 int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse,
                          int ntaps, int sps, double phi0, const double *d_templates, int nfilt, int ntm, int64_t start0,

@@ -54,6 +54,10 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
         for (int k = 0; k < WF_LINK_EVENT_SLOTS * (WF_LINK_STAGES + 1); ++k) (void)hipEventDestroy(c->events[k]);
         delete[] c->events;
     }
+    if (c->pipe_front) (void)hipEventDestroy(c->pipe_front);
+    for (int k = 0; k < 2; ++k)
+        if (c->pipe_done[k]) (void)hipEventDestroy(c->pipe_done[k]);
+    if (c->pipe_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(c->pipe_stream));
     if (c->d_scan) (void)hipFree(c->d_scan);
     if (c->d_fsm_scratch) (void)hipFree(c->d_fsm_scratch);
     if (c->d_mod_scratch) (void)hipFree(c->d_mod_scratch);
@@ -72,9 +76,27 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
     return WF_OK;
 }
 
+int wf_link_join_internal(wf_ctx *c, void *stream)
+{
+    if (!c) return WF_OK;
+    for (int k = 0; k < 2; ++k)
+        if (c->pipe_done_valid[k]) WF_HIP(hipStreamWaitEvent(wf_stream(stream), c->pipe_done[k], 0));
+    return WF_OK;
+}
+
+extern "C" int wf_link_join(wf_ctx *c, void *stream)
+{
+    WF_REQUIRE(c != nullptr, "wf_link_join: ctx is NULL");
+    return wf_link_join_internal(c, stream);
+}
+
 extern "C" int wf_ctx_check(wf_ctx *c, void *stream)
 {
     WF_REQUIRE(c != nullptr, "wf_ctx_check: ctx is NULL");
+    {
+        const int rj = wf_link_join_internal(c, stream);      // (pipelined links: their back ends are part of what is being checked)
+        if (rj) return rj;
+    }
     WF_HIP(hipMemcpyAsync(c->h_fault, c->d_fault, sizeof(unsigned), hipMemcpyDeviceToHost,
                           wf_stream(stream)));
     WF_HIP(hipStreamSynchronize(wf_stream(stream)));

@@ -91,10 +91,17 @@ static bool link_one_kernel(const wf_link_config *cfg)
 
 static bool link_packed_rows(const wf_link_config *cfg) { return link_packed_rows8(cfg) || link_one_kernel(cfg); }
 
+// fuse bit 5 (with the one-kernel front end): the detector and the error count of a block run on the context's side
+// stream, so that they overlap the front end of the NEXT wf_link_run on the same context — consecutive blocks are
+// independent trial blocks, and the front-end kernel (vector-issue-bound) leaves what the detector (HBM-bound, one wave
+// per SIMD) needs.  The workspace then holds two sets of intermediates, used alternately.
+static bool link_pipelined(const wf_link_config *cfg) { return (cfg->fuse & 32) && link_one_kernel(cfg); }
+
 extern "C" int64_t wf_link_workspace_bytes(const wf_link_config *cfg)
 {
     if (!cfg || cfg->nsym < 1 || cfg->sps < 1) return -1;
-    return (int64_t)make_layout(cfg->nsym, cfg->sps, cfg->ntaps, cfg->mf_nfilt, 2, cfg->timing_offset).total;
+    const int64_t one = (int64_t)make_layout(cfg->nsym, cfg->sps, cfg->ntaps, cfg->mf_nfilt, 2, cfg->timing_offset).total;
+    return link_pipelined(cfg) ? 2 * round_up(one, 256) : one;       // fuse bit 5: two sets of intermediates
 }
 
 extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
@@ -109,6 +116,25 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
                (long long)workspace_bytes, (long long)L.total);
     WF_REQUIRE(L.npts >= cfg->mf_ntaps, "wf_link_run: burst shorter than the matched filter");
     char *w = static_cast<char *>(d_workspace);
+    const bool piped = link_pipelined(cfg) && L.ncols > 0;
+    if (piped) {
+        const int64_t set_bytes = round_up((int64_t)L.total, 256);
+        WF_REQUIRE(2 * set_bytes <= workspace_bytes, "wf_link_run: fuse bit 5 needs two sets of intermediates (%lld bytes)", (long long)(2 * set_bytes));
+        WF_HIP(hipSetDevice(ctx->device));
+        if (!ctx->pipe_stream) {
+            hipStream_t ps;
+            WF_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+            ctx->pipe_stream = ps;
+            WF_HIP(hipEventCreateWithFlags(&ctx->pipe_front, hipEventDisableTiming));
+            for (int k = 0; k < 2; ++k) WF_HIP(hipEventCreateWithFlags(&ctx->pipe_done[k], hipEventDisableTiming));
+        }
+        w += (int64_t)ctx->pipe_set * set_bytes;
+        // the set was last used two blocks ago: that block's detector and counter must be done with it
+        if (ctx->pipe_done_valid[ctx->pipe_set]) WF_HIP(hipStreamWaitEvent(wf_stream(stream), ctx->pipe_done[ctx->pipe_set], 0));
+    } else {
+        const int rj = wf_link_join_internal(ctx, stream);      // (a context that ran pipelined blocks before: ordinary stream order from here on)
+        if (rj) return rj;
+    }
     uint8_t *bits = reinterpret_cast<uint8_t *>(w + L.off_bits);
     int8_t *syms = reinterpret_cast<int8_t *>(w + L.off_syms);
     double *freq = reinterpret_cast<double *>(w + L.off_freq);
@@ -165,17 +191,31 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
         fused_all = true;
     }
     if (fused_all) {
-        MARK(3); MARK(4); MARK(5); MARK(6);   // the "fir" slot times the whole fused kernel
+        MARK(3); MARK(4); MARK(5);            // the "fir" slot times the whole fused kernel
+        void *back = stream;                  // the stream the detector and the counter run on
+        if (piped) {
+            back = ctx->pipe_stream;
+            WF_HIP(hipEventRecord(ctx->pipe_front, wf_stream(stream)));
+            WF_HIP(hipStreamWaitEvent(wf_stream(back), ctx->pipe_front, 0));
+        }
+#define MARKB(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(back))); } while (0)
+        MARKB(6);
         ctx->vit_defer_verify = true;      // the error counter below runs the detector's wave-edge proof: one launch less
-        rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, nullptr, stream);
+        rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, nullptr, back);
         ctx->vit_defer_verify = false;
         if (rc) return rc;
-        MARK(7);
+        MARKB(7);
         int64_t m_ = L.ncols - length;
         if (m_ > cfg->nsym) m_ = cfg->nsym;
         if (m_ < 0) m_ = 0;
-        if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, stream))) return rc;   // (m_ = 0: only the proof)
-        MARK(8);
+        if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, back))) return rc;   // (m_ = 0: only the proof)
+        MARKB(8);
+#undef MARKB
+        if (piped) {
+            WF_HIP(hipEventRecord(ctx->pipe_done[ctx->pipe_set], wf_stream(back)));
+            ctx->pipe_done_valid[ctx->pipe_set] = true;
+            ctx->pipe_set ^= 1;
+        }
         if (h_compared) *h_compared = m_;
         return WF_OK;
     }

@@ -89,6 +89,13 @@ class SOQPSKLink:
         self.cfg = cfg
 
     def __del__(self):
+        try:
+            if getattr(self, "cfg", None) is not None and (self.cfg.fuse & 32) and getattr(self, "workspace", None) is not None:
+                # back ends of the last blocks may still be reading the workspace on the side stream
+                _hip.lib().wf_link_join(self._ctx, _hip.stream())
+                _hip.torch().cuda.current_stream().synchronize()
+        except Exception:          # noqa: BLE001 — interpreter teardown
+            pass
         if getattr(self, "_owns_ctx", False):
             _hip.free_ctx(self._ctx)
             self._owns_ctx = False
@@ -108,6 +115,8 @@ class SOQPSKLink:
         return dict(zip(keys, (int(v) for v in info)))
 
     def reset_counts(self) -> None:
+        # (fuse bit 5: earlier blocks' counters may still be running on the context's side stream)
+        _hip.check(_hip.lib().wf_link_join(self._ctx, _hip.stream()))
         self.counts.zero_()
         self.compared = 0
 

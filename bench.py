@@ -257,7 +257,7 @@ def main() -> None:
 
         # detector chunk warm-up rows: by operating point (waveforms_amd.link.operating_point_warmup), or --vit-warmup
         cwu = args.vit_warmup if args.vit_warmup >= 0 else operating_point_warmup(args.waveform, args.ebn0)
-        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1, fuse=args.fuse, warmup=cwu)
+        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1, fuse=args.fuse, warmup=cwu)      # (bits 1, 3, 5 apply)
                  for _ in range(nstreams)]
         bits_per_sym = links[0].spec.bits_per_symbol
     else:

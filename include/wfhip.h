@@ -424,7 +424,11 @@ typedef struct {
     int event_slot;
     int fuse;                 /* bit 1: channel applied inside the matched-filter kernel;         */
                               /* bit 3 (with bit 1, sps 8, 4 or 16 filters): modulator + channel  */
-                              /* + matched-filter rows in one kernel, no samples in HBM           */
+                              /* + matched-filter rows in one kernel, no samples in HBM;          */
+                              /* bit 5 (32): as wf_link_config.fuse bit 5 — the detector and the  */
+                              /* error count of a block on the context's side stream, beside the   */
+                              /* next block's front end; two sets of intermediates in the         */
+                              /* workspace; wf_link_join / wf_ctx_check before the counters are read */
 } wf_cpm_link_config;
 int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg);
 int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,

@@ -359,3 +359,31 @@ def test_gpu_cpm_stream_in_chunks_equals_one_shot(waveform, chunk):
         assert ebn0 is None or want[1] > 0
     with pytest.raises(ValueError):
         CPMStream(nsym, 1000, SPS, waveform=waveform)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waveform", ["multih", "pcmfm"])
+def test_gpu_cpm_link_pipelined_blocks_equal_sequential_blocks(waveform):
+    """wf_cpm_link_config.fuse bit 5: a block's detector and error count on the context's side stream, beside the front
+    end of the next block (two sets of intermediates).  Block for block and in total the counts are those of the
+    sequential link."""
+    from waveforms_amd.link import CPMLink
+
+    nsym = 150_001
+    seq = CPMLink(nsym, SPS, waveform=waveform, fuse=10)
+    pip = CPMLink(nsym, SPS, waveform=waveform, fuse=42, private_ctx=True)
+    assert pip.workspace_bytes >= 2 * seq.workspace_bytes
+    out = []
+    for link in (seq, pip):
+        got = []
+        for k in range(5):
+            link.reset_counts()
+            link.run_block(7.0, seed=2, stream_id=k, skip_bits=31 * k)
+            got.append(link.result())
+        link.reset_counts()
+        for k in range(8):
+            link.run_block(6.0 + (k % 3), seed=9, stream_id=50 + k, skip_bits=k, event_slot=0 if k == 7 else -1)
+        got.append(link.result())
+        out.append(got)
+    assert out[0] == out[1]
+    assert out[0][-1][1] > 0

@@ -843,7 +843,9 @@ static bool cpm_make_layout(const wf_cpm_link_config *cfg, cpm_link_layout &L)
 extern "C" int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg)
 {
     cpm_link_layout L;
-    return cpm_make_layout(cfg, L) ? (int64_t)L.total : -1;
+    if (!cpm_make_layout(cfg, L)) return -1;
+    const int64_t one = ((int64_t)L.total + 255) / 256 * 256;
+    return (cfg->fuse & 32) ? 2 * one : (int64_t)L.total;      // fuse bit 5: two sets of intermediates (see wf_cpm_link_run)
 }
 
 extern "C" int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8)
@@ -869,6 +871,26 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
                (long long)workspace_bytes, (long long)L.total);
     WF_REQUIRE(cfg->d_h && cfg->d_pulse && cfg->d_templates && cfg->d_rot_cs, "wf_cpm_link_run: NULL table pointer");
     char *w = static_cast<char *>(d_workspace);
+    // fuse bit 5: the detector and the error count of a block on the context's side stream, beside the front end of the
+    // next wf_cpm_link_run on this context (as wf_link_run does it: two sets of intermediates, used alternately)
+    const bool piped = (cfg->fuse & 32) != 0 && L.ncalls > 0;
+    if (piped) {
+        const int64_t set_bytes = ((int64_t)L.total + 255) / 256 * 256;
+        WF_REQUIRE(2 * set_bytes <= workspace_bytes, "wf_cpm_link_run: fuse bit 5 needs two sets of intermediates (%lld bytes)", (long long)(2 * set_bytes));
+        WF_HIP(hipSetDevice(ctx->device));
+        if (!ctx->pipe_stream) {
+            hipStream_t ps;
+            WF_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+            ctx->pipe_stream = ps;
+            WF_HIP(hipEventCreateWithFlags(&ctx->pipe_front, hipEventDisableTiming));
+            for (int k = 0; k < 2; ++k) WF_HIP(hipEventCreateWithFlags(&ctx->pipe_done[k], hipEventDisableTiming));
+        }
+        w += (int64_t)ctx->pipe_set * set_bytes;
+        if (ctx->pipe_done_valid[ctx->pipe_set]) WF_HIP(hipStreamWaitEvent(wf_stream(stream), ctx->pipe_done[ctx->pipe_set], 0));
+    } else {
+        const int rj = wf_link_join_internal(ctx, stream);
+        if (rj) return rj;
+    }
     uint8_t *bits = reinterpret_cast<uint8_t *>(w + L.off_bits);
     int8_t *syms = reinterpret_cast<int8_t *>(w + L.off_syms);
     double *sig = reinterpret_cast<double *>(w + L.off_sig);
@@ -921,16 +943,29 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
         if ((rc = wf_cpm_mf_rows_c128(ctx, sig, L.npts, cfg->d_templates, cfg->det.nh, L.nfilt, L.ntm, L.start0, cfg->sps, L.ncalls,
                                       rows, stream))) return rc;
     }
-    MARK(6);
-    if ((rc = wf_cpm_viterbi_detect(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, stream))) return rc;
-    MARK(7);
+    void *back = stream;
+    if (piped) {
+        back = ctx->pipe_stream;
+        WF_HIP(hipEventRecord(ctx->pipe_front, wf_stream(stream)));
+        WF_HIP(hipStreamWaitEvent(wf_stream(back), ctx->pipe_front, 0));
+    }
+#define MARKB(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(back))); } while (0)
+    MARKB(6);
+    if ((rc = wf_cpm_viterbi_detect(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, back))) return rc;
+    MARKB(7);
     // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] are compared
     const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;
     int64_t m = L.ncalls - cfg->det.D + 1 - skip;
     if (m < 0) m = 0;
     if (m > 0)
-        if ((rc = wf_cpm_count_errors(ctx, dec + skip + cfg->det.D - 1, syms + skip, cfg->det.M, m, d_counts, stream))) return rc;
-    MARK(8);
+        if ((rc = wf_cpm_count_errors(ctx, dec + skip + cfg->det.D - 1, syms + skip, cfg->det.M, m, d_counts, back))) return rc;
+    MARKB(8);
+#undef MARKB
+    if (piped) {
+        WF_HIP(hipEventRecord(ctx->pipe_done[ctx->pipe_set], wf_stream(back)));
+        ctx->pipe_done_valid[ctx->pipe_set] = true;
+        ctx->pipe_set ^= 1;
+    }
 #undef MARK
     if (h_compared) *h_compared = m;
     return WF_OK;

@@ -434,6 +434,12 @@ class CPMLink:
         self.compared = 0
 
     def __del__(self):
+        try:
+            if getattr(self, "cfg", None) is not None and (self.cfg.fuse & 32) and getattr(self, "workspace", None) is not None:
+                _hip.lib().wf_link_join(self._ctx, _hip.stream())
+                _hip.torch().cuda.current_stream().synchronize()
+        except Exception:          # noqa: BLE001 — interpreter teardown
+            pass
         if getattr(self, "_owns_ctx", False):
             _hip.free_ctx(self._ctx)
             self._owns_ctx = False
@@ -445,6 +451,7 @@ class CPMLink:
         return dict(zip(keys, (int(v) for v in info)))
 
     def reset_counts(self) -> None:
+        _hip.check(_hip.lib().wf_link_join(self._ctx, _hip.stream()))   # (fuse bit 5: counters of earlier blocks on the side stream)
         self.counts.zero_()
         self.compared = 0
 

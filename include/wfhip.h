@@ -181,6 +181,13 @@ int64_t wf_viterbi4_window_state_bytes(void);
  * *h_count = that counter since the last reset (synchronises `stream`); 0 means every batch call
  * since then reproduced the sequential detector exactly.  Non-zero: re-run with a larger `warmup`. */
 int wf_viterbi4_unmerged(wf_ctx *ctx, int64_t *h_count, int reset, void *stream);
+/* The generic CPM detector (wf_cpm_viterbi_detect) REPAIRS a chunk whose proof failed before it counts it: a second
+ * launch runs the chunk's own calls again from the state the previous chunk ended with, beside the first launch's
+ * trajectory, until the two are bitwise equal, and replaces the decisions up to there; only a chunk whose
+ * trajectories have not met by its end (or the 1025th failed chunk of a launch) is counted by
+ * wf_viterbi4_unmerged.  *h_count = chunks repaired that way since the last reset (synchronises `stream`).
+ * (Build-defined like the proof itself: the reference's detector is one sequential loop, algorithm.py:44-101.) */
+int wf_viterbi_repaired(wf_ctx *ctx, int64_t *h_count, int reset, void *stream);
 
 /* wf_viterbi4_detect + wf_count_errors in one call (fresh detector): decision k is
  * compared with reference element k - skip for 0 <= k - skip < ncompare
@@ -387,8 +394,9 @@ int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsa
  * k, i.e. of symbol n0 + k - D + 1 (n0 = calls already made on d_state; entries with
  * n0 + k < D - 1 are written as 0).  Chunk-parallel like wf_viterbi4_detect: each 16-lane group
  * re-derives metrics, phase indices and decision registers over `warmup` rows (0 = default) and
- * every launch verifies bitwise that a chunk started from what its predecessor ended with
- * (wf_viterbi4_unmerged counts failures).  d_state (WF_CPM_STATE_BYTES, zeroed = fresh detector,
+ * every launch verifies bitwise that a chunk started from what its predecessor ended with,
+ * repairs the chunks for which that failed (wf_viterbi_repaired) and counts what it could not
+ * repair (wf_viterbi4_unmerged).  d_state (WF_CPM_STATE_BYTES, zeroed = fresh detector,
  * may be NULL) carries the detector across calls. */
 #define WF_CPM_STATE_BYTES 1024
 int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs,

@@ -8,6 +8,7 @@ the bit-error rate against the minimum-distance bound — and the HIP kernels mu
 it bit for bit through the C ABI.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -220,13 +221,55 @@ def test_gpu_detector_reports_and_repairs_unmerged_chunks(oracle):
     out = _hip.zeros(40_000, "uint8")
     cfg, rot = cpm.ARTM_16.c_config(), _hip.to_device(cpm.rotation_table(cpm.ARTM_16))
     dev.viterbi_unmerged(reset=True)
-    # 4 rows of warm-up cannot even fill the decision register: the launch must say so
-    _hip.check(_hip.lib().wf_cpm_viterbi_detect(_hip.ctx(), ctypes.byref(cfg), _hip.ptr(rot), _hip.ptr(rows), res["rows"].shape[0], 4,
-                                                _hip.ptr(out), None, _hip.stream()))
-    assert dev.viterbi_unmerged(reset=True) > 0
-    # ... and the host API repeats the call with a longer warm-up until the output is proven
-    got = cpm.CPMTrellisDetector(cpm.ARTM_16).detect(res["rows"], warmup=4)
-    assert np.array_equal(got, res["decisions"])
+    dev.viterbi_repaired(reset=True)
+    n = res["rows"].shape[0]
+
+    def launch(warmup):
+        _hip.check(_hip.lib().wf_cpm_viterbi_detect(_hip.ctx(), ctypes.byref(cfg), _hip.ptr(rot), _hip.ptr(rows), n, warmup,
+                                                    _hip.ptr(out), None, _hip.stream()))
+
+    # 4 rows of warm-up cannot even fill the decision register.  With the repair launch switched off the call must say so ...
+    os.environ["WF_CPM_NO_REPAIR"] = "1"
+    try:
+        launch(4)
+        assert dev.viterbi_unmerged(reset=True) > 0
+        assert dev.viterbi_repaired(reset=True) == 0
+        # ... and the host API repeats the call with a longer warm-up until the output is proven
+        got = cpm.CPMTrellisDetector(cpm.ARTM_16).detect(res["rows"], warmup=4)
+        assert np.array_equal(got, res["decisions"])
+    finally:
+        del os.environ["WF_CPM_NO_REPAIR"]
+    # The call as shipped repairs those chunks itself: their own calls again from the state the previous chunk ended with
+    # until that trajectory meets the first launch's.  Every decision is then the sequential detector's, and proven.
+    launch(4)
+    assert dev.viterbi_unmerged(reset=True) == 0
+    repaired = dev.viterbi_repaired(reset=True)
+    assert repaired >= n // 512, repaired                         # practically every chunk
+    D = cpm.ARTM_16.D
+    assert np.array_equal(_hip.to_host(out)[D - 1:n], res["decisions"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("design", GPU_DESIGNS)
+def test_gpu_short_warmup_repaired_on_device_equals_oracle(oracle, design):
+    """Every trellis shape with a warm-up of 8 calls — far below the merge depth, so most chunks miss it: the
+    repair launch makes the output the sequential detector's all the same (noisy rows with a drift, exact ties,
+    carried state across two calls), or the call says which chunks it could not prove."""
+    from waveforms_amd import _hip, device as dev
+    from waveforms_amd.viterbi import cpm
+
+    spec_o = _spec(oracle, *design, D=32 if design[0] == 2 else 20)
+    spec_p = cpm.CPMDetectorSpec(M=spec_o.M, p=spec_o.p, K=spec_o.K, Lp=spec_o.Lp, NC=spec_o.NC, D=spec_o.D)
+    rng = np.random.default_rng(5)
+    n = 50_001
+    rows = rng.standard_normal((n, spec_o.nfilt)) + 1j * rng.standard_normal((n, spec_o.nfilt))
+    rows[:, 0] += 2.0
+    rows[::333] = 0.0
+    want = oracle.cpm_viterbi(spec_o).run(rows)
+    det = cpm.CPMTrellisDetector(spec_p)
+    got = np.concatenate([det.detect(rows[:20_000], warmup=8), det.detect(rows[20_000:], warmup=8)])
+    assert np.array_equal(got, want)
+    assert dev.viterbi_repaired(reset=True, ctx=det._ctx) > 0
 
 
 @pytest.mark.gpu

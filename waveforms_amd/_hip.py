@@ -46,6 +46,7 @@ SIGNATURES = {
     "wf_awgn_mf_bank_c128": (c_int, [_P, _P, c_int64, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64, _P,
                                      c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
     "wf_viterbi4_unmerged": (c_int, [_P, POINTER(c_int64), c_int, _P]),
+    "wf_viterbi_repaired": (c_int, [_P, POINTER(c_int64), c_int, _P]),
     "wf_viterbi4_detect_count": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P, _P]),
     "wf_viterbi4_detect": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "wf_viterbi4_detect_window": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),

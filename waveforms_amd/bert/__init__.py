@@ -131,7 +131,8 @@ def gpu_block_runner(plan: SweepPlan, streams: int = 3):
     # the context.  The lane reads that word every `check_every` jobs (and at the end): zero -> commit the
     # pending counts; non-zero -> drop them and repeat exactly those jobs one by one with the warm-up doubled
     # until proven (blocks are idempotent: same seed, point, block).  A sweep therefore never loses its counts
-    # to one unproven chunk — at 0 dB the ARTM detector leaves about 2e-6 of its chunks unproven at 256 calls.
+    # to one unproven chunk.  (The generic CPM detector repairs most such chunks itself on the device, wf_viterbi_repaired;
+    # what reaches this path is a chunk whose two trajectories did not meet within the chunk.)
     tables = [_hip.zeros((npts, 2), "int64") for _ in range(n)]
     pend = [_hip.zeros((npts, 2), "int64") for _ in range(n)]
     window: list[list[tuple[int, int]]] = [[] for _ in range(n)]
@@ -142,7 +143,7 @@ def gpu_block_runner(plan: SweepPlan, streams: int = 3):
     if n > 1:   # the tables were zeroed on the current stream
         torch.cuda.current_stream().synchronize()
     if cpm:
-        base_warmup = links[0].cfg.warmup or (384 if links[0].spec.M == 2 else 320)
+        base_warmup = links[0].cfg.warmup or 256       # (what a repeated block starts doubling from; the library's own default is 96 + on-device repair)
     else:
         base_warmup = links[0].cfg.warmup or 31
 

@@ -143,13 +143,19 @@ __device__ __forceinline__ void cpm_wave_sync()
 #ifndef CPM_MIN_WAVES
 #define CPM_MIN_WAVES(M, LP) (((M) == 2 && (LP) <= 2) || (LP) == 1 ? 5 : ((M) == 4 && (LP) == 3 ? 2 : 4))
 #endif
-template <int M_, int LP_>
-__global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viterbi_kernel(const double2 *__restrict__ rows,
-                                                                  const double2 *__restrict__ rot_cs,
-                                                                  uint8_t *__restrict__ out, uint64_t *__restrict__ state,
-                                                                  uint64_t *__restrict__ edge,
-                                                                  unsigned long long *__restrict__ unmerged,
-                                                                  cpm_vit_params P)
+// REPAIR (cpm_repair_kernel) = the second launch of a detector call (see cpm_verify_kernel): one WAVE per chunk whose proof failed.  The
+// chunk's own calls are run again from BOTH states — groups 0 / 2 from the state the first launch started them from
+// (what its warm-up arrived at), groups 1 / 3 from the state the previous chunk ended with (the true one) — until the
+// two are bitwise equal: from there on the first launch's decisions and end state were the sequential detector's, and
+// up to there the second trajectory's decisions replace them.  A pair that has not met by the end of the chunk
+// leaves the chunk counted as unproven.  Most chunks that miss a SHORT warm-up meet within a few dozen calls, so the
+// warm-up can be sized for the typical merge depth instead of its 1e-7 tail.
+#define CPM_REPAIR_CAP 1024     // failed chunks one launch can take (the rest are counted as unproven)
+template <int M_, int LP_, bool REPAIR>
+__device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
+                                                 uint8_t *__restrict__ out, uint64_t *__restrict__ state,
+                                                 uint64_t *__restrict__ edge, unsigned long long *__restrict__ unmerged,
+                                                 const cpm_vit_params &P)
 {
     constexpr int M = M_;
     constexpr int LGM = M_ == 4 ? 2 : 1;
@@ -176,7 +182,16 @@ __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viter
     __syncthreads();
 
     const int64_t n0 = state ? (int64_t)state[CPM_ST_N] : 0;          // calls made before this launch
-    const int64_t chunk = ((int64_t)blockIdx.x * CPM_WAVES + wave) * CPM_GROUPS + g;
+    uint64_t *const fail = edge + P.nchunks * CPM_EDGE_WORDS;         // [0] chunks whose proof failed, [1 ..] which (cpm_verify_kernel)
+    int64_t chunk = ((int64_t)blockIdx.x * CPM_WAVES + wave) * CPM_GROUPS + g;
+    if constexpr (REPAIR) {
+        const int64_t idx = (int64_t)blockIdx.x * CPM_WAVES + wave;
+        const int64_t listed = (int64_t)fail[0] < CPM_REPAIR_CAP ? (int64_t)fail[0] : CPM_REPAIR_CAP;
+        if (idx >= listed) return;                                    // (whole waves; no workgroup barrier below)
+        chunk = (int64_t)fail[1 + idx];
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        fail[0] = 0;
+    }
     const int64_t k_first = chunk * P.CH;                             // first own call (local index)
     const bool live = k_first < P.ncalls;
     const int T = P.W + P.CH;
@@ -205,6 +220,12 @@ __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viter
         hist = state[CPM_ST_H + s];
     }
     uint64_t *const erec = edge + chunk * CPM_EDGE_WORDS;               // (written only when the chunk is live)
+    if constexpr (REPAIR) {
+        const uint64_t *src = (g & 1) ? erec - CPM_EDGE_WORDS + 48 : erec;   // the previous chunk's end | this chunk's start
+        m = active ? __longlong_as_double((long long)src[3 * s]) : INFINITY;
+        r = (int)src[3 * s + 1];
+        hist = src[3 * s + 2];
+    }
 
     // cooperative row fetch: piece q = s + 16 i of the batch's CPM_TB * NF pieces
     auto fetch = [&](int b, double2 (&dst)[PL]) __attribute__((always_inline)) {
@@ -357,7 +378,7 @@ __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viter
         fetch(b + 2 < nbatch ? b + 2 : nbatch - 1, pend);               // issued unconditionally (see wf_viterbi.hip)
         cpm_wave_sync();
         const int t0 = b * CPM_TB;
-        if (t0 == P.W && live) {                                        // the next call is the chunk's first own one
+        if (!REPAIR && t0 == P.W && live) {                             // the next call is the chunk's first own one
             erec[3 * s] = (uint64_t)__double_as_longlong(m);
             erec[3 * s + 1] = (uint64_t)(int64_t)r;
             erec[3 * s + 2] = hist;
@@ -382,6 +403,35 @@ __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viter
         }
         cpm_wave_sync();                                                // batch consumed before the next stash
     };
+    if constexpr (REPAIR) {
+        // (P.W = 0 in this launch: the first batch is the chunk's first own call)
+        const uint64_t hmask = LGM * P.D >= 64 ? ~0ull : ((1ull << (LGM * P.D)) - 1ull);
+        auto met = [&]() __attribute__((always_inline)) {               // both trajectories in bitwise the same state?
+            const int pa = (lane ^ 16) << 2;
+            const long long om = __double_as_longlong(cpm_bperm_f64(pa, m));
+            const int orr = __builtin_amdgcn_ds_bpermute(pa, r);
+            const uint64_t oh = cpm_bperm_u64(pa, hist);
+            const bool diff = active && (om != __double_as_longlong(m) || orr != r || ((oh ^ hist) & hmask) != 0ull);
+            return __builtin_amdgcn_ballot_w64(diff) == 0ull;
+        };
+        int done = 0;
+        bool merged = false;
+        for (int b = 0; b < nbatch && !merged; b += 2) {
+            batch(b, pend0);
+            done = (b + 1) * CPM_TB;
+            merged = met();
+            if (!merged) {
+                batch(b + 1, pend1);
+                done = (b + 2) * CPM_TB;
+                merged = met();
+            }
+        }
+        if (g == 1)                                                     // the true trajectory's decisions up to the meeting point
+            for (int q = s; q < done; q += 16)
+                if (k_first + q < P.ncalls) out[k_first + q] = dec[q];
+        if (lane == 0) atomicAdd(unmerged + (merged ? 1 : 0), 1ull);    // [1]: chunks repaired, [0]: chunks left unproven
+        return;
+    }
     for (int b = 0; b < nbatch; b += 2) {
         batch(b, pend0);
         batch(b + 1, pend1);
@@ -411,10 +461,34 @@ __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viter
     }
 }
 
+template <int M_, int LP_>
+__global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viterbi_kernel(const double2 *__restrict__ rows,
+                                                                  const double2 *__restrict__ rot_cs,
+                                                                  uint8_t *__restrict__ out, uint64_t *__restrict__ state,
+                                                                  uint64_t *__restrict__ edge,
+                                                                  unsigned long long *__restrict__ unmerged,
+                                                                  cpm_vit_params P)
+{
+    cpm_viterbi_body<M_, LP_, false>(rows, rot_cs, out, state, edge, unmerged, P);
+}
+
+template <int M_, int LP_>
+__global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_repair_kernel(const double2 *__restrict__ rows,
+                                                                 const double2 *__restrict__ rot_cs,
+                                                                 uint8_t *__restrict__ out, uint64_t *__restrict__ state,
+                                                                 uint64_t *__restrict__ edge,
+                                                                 unsigned long long *__restrict__ unmerged,
+                                                                 cpm_vit_params P)
+{
+    cpm_viterbi_body<M_, LP_, true>(rows, rot_cs, out, state, edge, unmerged, P);
+}
+
 // Every chunk against its predecessor: thread = (chunk c >= 1, state s); one count per chunk that did NOT start
 // from bitwise the (metric, phase index, last D decisions) chunk c - 1 ended with.
-__global__ void cpm_verify_kernel(const uint64_t *__restrict__ edge, int64_t nchunks, int S, uint64_t hmask,
-                                  unsigned long long *__restrict__ unmerged)
+// repair = 1: failed chunks are LISTED behind the records ([0] how many, [1 ..] which) for the repair launch; only what
+// does not fit the list is counted as unproven here.
+__global__ void cpm_verify_kernel(uint64_t *__restrict__ edge, int64_t nchunks, int S, uint64_t hmask,
+                                  unsigned long long *__restrict__ unmerged, int repair)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t c = idx / 16 + 1;
@@ -426,7 +500,12 @@ __global__ void cpm_verify_kernel(const uint64_t *__restrict__ edge, int64_t nch
     }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
     const int lane = threadIdx.x & 63;
-    if (s == 0 && ((m >> (lane & 48)) & 0xFFFFull)) atomicAdd(unmerged, 1ull);
+    if (s == 0 && ((m >> (lane & 48)) & 0xFFFFull)) {
+        unsigned long long *fail = reinterpret_cast<unsigned long long *>(edge + nchunks * CPM_EDGE_WORDS);
+        const unsigned long long i = repair ? atomicAdd(fail, 1ull) : (unsigned long long)CPM_REPAIR_CAP;
+        if (i < CPM_REPAIR_CAP) fail[1 + i] = (unsigned long long)c;
+        else atomicAdd(unmerged, 1ull);
+    }
 }
 
 __global__ void cpm_carry_commit_kernel(uint64_t *state)
@@ -492,15 +571,16 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
                    (reinterpret_cast<uintptr_t>(d_rot_cs) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
                "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
-    // Default warm-up: the D calls that refill the decision register plus the merge depth of the trellis at
-    // ANY Eb/N0, backed by a RATE (tools/cpm_warmup_scan.py, profiles/r03_cpm_warmup_scan_*.json: 1e6 chunks
-    // per point, 0 .. 12 dB).  ARTM 16-state, chunks left unproven per 1e6: 128 calls 2290 / 409 / 14 / 0 at
-    // 0 / 4 / 6 / 8 dB; 192: 51 / 1 / 0; 256: 1 / 0; 320: 0 anywhere — about 30x fewer per 64 calls, so 320
-    // sits near 1e-7 per chunk at 0 dB.  Binary PCM/FM merges slowly at EVERY Eb/N0 (one bit per call):
-    // 192 calls still leave 2 .. 5 per 1e6 from 2 dB up (422 at 0 dB), 256: 25 at 0 dB and 1 at 6 dB, 320 and
-    // 384 none.  A caller that knows its operating point may pass less (bench.py: ARTM 128 from 8 dB up);
-    // every launch proves its output either way and waveforms.bert repeats a block whose proof failed.
-    int W = warmup ? warmup : (det->M == 2 ? 384 : 320);
+    // Default warm-up.  A chunk that misses its warm-up is REPAIRED by the call's second launch (cpm_repair_kernel),
+    // so the default is sized for the typical merge depth of the trellis, not for its tail, and backed by a scan at
+    // 0 .. 12 dB (tools/cpm_warmup_scan.py, profiles/r03_cpm_repair_scan_*.json: 1.25e6 chunks per point): with
+    // 96 calls ARTM's 16 states leave 1.3 % / 0.4 % / 0.04 % of the chunks to the repair at 0 / 4 / 6 dB (none from
+    // 10 dB up) and binary PCM/FM 2.6 % / 0.1 % / 0.05 % at 0 / 4 / 10 dB — every one of them repaired, none left
+    // unproven; detector time 0.69 - 0.75 ms (ARTM) and 0.49 - 0.54 ms (PCM/FM) per 1e7 calls.  Before the repair
+    // launch existed the defaults had to cover the tail: 320 / 384 calls (0.87 / 0.74 ms).  A caller that knows its
+    // operating point may pass less (waveforms_amd.link.operating_point_warmup: ARTM 48 from 8 dB up, PCM/FM 64);
+    // what the repair cannot settle is counted (wf_viterbi4_unmerged) and waveforms.bert repeats such a block.
+    int W = warmup ? warmup : 96;
     W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
     if (W > 4096) W = 4096;
     // Calls per chunk (a multiple of 64): at least 256 (and 2 W), so the warm-up stays a fraction of
@@ -536,7 +616,7 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     const int64_t nblocks = (nwaves + CPM_WAVES - 1) / CPM_WAVES;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_viterbi_detect: burst too long for one launch");
     P.nchunks = nchunks;
-    rc = wf_ctx_reserve_vit(ctx, (size_t)nchunks * CPM_EDGE_WORDS);
+    rc = wf_ctx_reserve_vit(ctx, (size_t)nchunks * CPM_EDGE_WORDS + 1 + CPM_REPAIR_CAP);
     if (rc) return rc;
     uint64_t *edge = reinterpret_cast<uint64_t *>(ctx->d_vit_edge);
     hipStream_t s = wf_stream(stream);
@@ -552,9 +632,26 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     WF_LAUNCH_CHECK();
     if (nchunks > 1) {
         const uint64_t hmask = P.lgM * P.D >= 64 ? ~0ull : ((1ull << (P.lgM * P.D)) - 1ull);   // only the D decisions still inside the register can reach an output
+        const char *nr = getenv("WF_CPM_NO_REPAIR");                  // (tests of the host-level fallback)
+        const int repair = nr && atoi(nr) ? 0 : 1;
         hipLaunchKernelGGL(cpm_verify_kernel, dim3((unsigned)(((nchunks - 1) * 16 + 255) / 256)), dim3(256), 0, s, edge, nchunks, P.S,
-                           hmask, ctx->d_vit_unmerged);
+                           hmask, ctx->d_vit_unmerged, repair);
         WF_LAUNCH_CHECK();
+        if (repair) {
+            // chunks whose proof failed: their own calls again from the true state until both trajectories meet
+            // (cpm_repair_kernel; every wave leaves at once when nothing is listed)
+            kern_t kr = nullptr;
+            if (P.M == 4) kr = P.Lp == 1 ? cpm_repair_kernel<4, 1> : (P.Lp == 2 ? cpm_repair_kernel<4, 2> : cpm_repair_kernel<4, 3>);
+            else kr = P.Lp == 1 ? cpm_repair_kernel<2, 1> : (P.Lp == 2 ? cpm_repair_kernel<2, 2> : cpm_repair_kernel<2, 3>);
+            if (lds > 48 * 1024)
+                WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            cpm_vit_params Pr = P;
+            Pr.W = 0;
+            hipLaunchKernelGGL(kr, dim3(CPM_REPAIR_CAP / CPM_WAVES), dim3(CPM_THREADS), lds, s, reinterpret_cast<const double2 *>(d_rows_ri),
+                               reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
+                               ctx->d_vit_unmerged, Pr);
+            WF_LAUNCH_CHECK();
+        }
     }
     if (d_state) {
         hipLaunchKernelGGL(cpm_carry_commit_kernel, dim3(1), dim3(64), 0, s, static_cast<uint64_t *>(d_state));

@@ -30,8 +30,8 @@ extern "C" int wf_ctx_create(int device, wf_ctx **out)
     WF_HIP(hipMemset(c->d_fault, 0, 64));
     WF_HIP(hipHostMalloc(&c->h_fault, 64, hipHostMallocDefault));
     WF_HIP(hipMalloc(&c->d_tables, 4096));
-    WF_HIP(hipMalloc(&c->d_vit_unmerged, sizeof(unsigned long long)));
-    WF_HIP(hipMemset(c->d_vit_unmerged, 0, sizeof(unsigned long long)));
+    WF_HIP(hipMalloc(&c->d_vit_unmerged, 2 * sizeof(unsigned long long)));      // [0] chunks left unproven, [1] chunks repaired on the device
+    WF_HIP(hipMemset(c->d_vit_unmerged, 0, 2 * sizeof(unsigned long long)));
     WF_HIP(hipMalloc(&c->d_small, 256));
     WF_HIP(hipHostMalloc(&c->h_small, 256, hipHostMallocDefault));
     *out = c;

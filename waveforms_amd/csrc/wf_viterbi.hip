@@ -584,6 +584,19 @@ extern "C" int wf_viterbi4_unmerged(wf_ctx *ctx, int64_t *h_count, int reset, vo
     return WF_OK;
 }
 
+extern "C" int wf_viterbi_repaired(wf_ctx *ctx, int64_t *h_count, int reset, void *stream)
+{
+    WF_REQUIRE(ctx && h_count, "wf_viterbi_repaired: NULL argument");
+    WF_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = wf_stream(stream);
+    unsigned long long v = 0;
+    WF_HIP(hipMemcpyAsync(&v, ctx->d_vit_unmerged + 1, sizeof(v), hipMemcpyDeviceToHost, s));
+    WF_HIP(hipStreamSynchronize(s));
+    if (reset && v) WF_HIP(hipMemsetAsync(ctx->d_vit_unmerged + 1, 0, sizeof(v), s));
+    *h_count = (int64_t)v;
+    return WF_OK;
+}
+
 int wf_viterbi4_detect_packed(wf_ctx *ctx, const double *d_rows4, int64_t ncalls, int differential, int warmup,
                               uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream)
 {

@@ -190,6 +190,14 @@ def viterbi_unmerged(reset: bool = True, ctx=None) -> int:
     return int(n.value)
 
 
+def viterbi_repaired(reset: bool = True, ctx=None) -> int:
+    """Chunks of the generic CPM detector that missed their warm-up and were repaired on the device since the
+    last reset (``wf_viterbi_repaired``; synchronises): their output is proven like everybody else's."""
+    n = ctypes.c_int64(0)
+    _hip.check(_hip.lib().wf_viterbi_repaired(ctx if ctx is not None else _hip.ctx(), ctypes.byref(n), int(reset), _hip.stream()))
+    return int(n.value)
+
+
 def count_errors(det_syms, ref_syms, det_bits, ref_bits, m: int, counts=None):
     """K11: counts[0] += symbol errors, counts[1] += bit errors over the first m elements."""
     if counts is None:

@@ -27,17 +27,19 @@ def operating_point_warmup(waveform: str, ebn0_db: float | None) -> int:
     """Detector chunk warm-up in ROWS (= detector calls run before a chunk's own first call) for a link at a
     known operating point; 0 = the library default, safe at any Eb/N0.  One table for bench.py and the
     timing tools (tools/link_stage_time.py, tools/stream_bench.py).  Backed by the proof-failure scans
-    (tools/warmup_scan.py, tools/cpm_warmup_scan.py; profiles/r02_warmup_scan.json, r03_cpm_warmup_scan_*.json):
-    SOQPSK 4-state: 16 rows from 6 dB up (0 of 2.5e6 chunks unproven even with 12); ARTM 16-state: 128 from
-    8 dB up (0 of 1e6 chunks); binary PCM/FM merges slowly at every Eb/N0: 320.  Every launch still proves its
-    own output, and ``result()`` raises if a chunk was not proven."""
+    (tools/warmup_scan.py, tools/cpm_warmup_scan.py; profiles/r02_warmup_scan.json, r03_cpm_repair_scan_*.json):
+    SOQPSK 4-state: 16 rows from 6 dB up (0 of 2.5e6 chunks unproven even with 12).  The generic CPM detector
+    repairs the chunks that miss their warm-up on the device (wf_viterbi_repaired), so its warm-up is sized for the
+    typical merge depth, not the tail: ARTM 16-state 48 calls from 8 dB up (0.3 / 0.05 / 0.01 % of the chunks repaired
+    at 8 / 10 / 12 dB, none of 1.25e6 left unproven), 64 from 6 dB; binary PCM/FM 64 from 2 dB up (1.2 - 3 % repaired).
+    Every launch still proves its own output, and ``result()`` raises if a chunk was left unproven."""
     if ebn0_db is None:
         return 0
     if waveform == "soqpsk":
         return 16 if ebn0_db >= 6.0 else 0
     if waveform == "multih":
-        return 128 if ebn0_db >= 8.0 else 0
-    return 320 if ebn0_db >= 8.0 else 0
+        return 48 if ebn0_db >= 8.0 else (64 if ebn0_db >= 6.0 else 0)
+    return 64 if ebn0_db >= 2.0 else 0
 
 
 def soqpsk_warmup_param(rows: int) -> int:

@@ -147,6 +147,12 @@ def gpu_block_runner(plan: SweepPlan, streams: int = 3):
     else:
         base_warmup = links[0].cfg.warmup or 31
 
+    # no warm-up asked for: each Eb/N0 point runs at its own (waveforms_amd.link.operating_point_warmup; 0 = the library's
+    # default where the table has no shorter one) — a block that leaves a chunk unproven is repeated below anyway
+    from waveforms_amd.link import operating_point_warmup, soqpsk_warmup_param
+    point_warmup = [operating_point_warmup(plan.waveform, float(e)) if cpm
+                    else soqpsk_warmup_param(operating_point_warmup("soqpsk", float(e))) for e in plan.ebn0_db]
+
     def launch(k: int, point: int, block: int, warmup: int) -> int:
         link, c = links[k], links[k].cfg
         c.sigma = (cpm_sigma(plan.ebn0_db[point], plan.sps, plan.bits_per_symbol) if cpm
@@ -198,7 +204,7 @@ def gpu_block_runner(plan: SweepPlan, streams: int = 3):
     def run(point: int, block: int) -> None:
         k = issued[0] % n
         issued[0] += 1
-        compared[point] += launch(k, point, block, links[k].cfg.warmup)
+        compared[point] += launch(k, point, block, links[k].cfg.warmup or point_warmup[point])
         window[k].append((point, block))
         if len(window[k]) >= check_every:
             check(k)

@@ -1,6 +1,6 @@
 """SOQPSK-TG BER sweep on the device-resident link (BASELINE config 4).
 
-    python tools/ber_sweep.py [--ebn0 0:12] [--symbols-per-point 1e8] [--block 4194304] [--detector PT]
+    python tools/ber_sweep.py [--ebn0 0:12] [--symbols-per-point 1e8] [--block 10000000] [--detector PT]
     python tools/ber_sweep.py --gpus 8 ...          (starts the 8 ranks itself, as child processes)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/ber_sweep.py ...
 
@@ -45,7 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ebn0", default="0:12")
     ap.add_argument("--symbols-per-point", type=float, default=1e8)
-    ap.add_argument("--block", type=int, default=1 << 22)
+    ap.add_argument("--block", type=int, default=10_000_000, help="symbols per trial block (1e7: BASELINE configs[1]'s block, 10 per point)")
     ap.add_argument("--detector", default="PT")
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"])
     ap.add_argument("--seed", type=int, default=1)

@@ -96,12 +96,14 @@ def init_ranks(rehearsal: bool = False):
     return rank, world, dist, ("cpu" if rehearsal else "cuda")
 
 
-def gpu_block_runner(plan: SweepPlan, streams: int = 3):
-    """Default runner: device-resident SOQPSKLinks; returns (run(point, block), finish()).
-    `streams` trial blocks are kept in flight on separate HIP streams (own workspace, own wf_ctx,
-    own counter table each): the vector-pipe-bound modulator + channel + bank kernel of one block
-    overlaps the latency-bound detector and the small integer kernels of its neighbours — 0.66 ->
-    0.59 ms per 1e7-symbol block with three in flight, identical counts."""
+def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | None = None):
+    """Default runner: device-resident links; returns (run(point, block), finish()).
+    Consecutive trial blocks overlap on the GPU either INSIDE one link (`fuse` bit 5: a block's detector and error
+    count on the context's side stream, beside the next block's front end) or as `streams` blocks in flight on
+    separate HIP streams (own workspace, own wf_ctx, own counter table each).  Defaults, from same-box runs of the
+    13 x 1e8-symbol sweep (tools/sweep_lanes.py; identical counts in every arrangement): SOQPSK one lane with the
+    pipelined link (0.0638 s; three lanes of sequential links 0.0685, three lanes of pipelined links 0.076); the CPM
+    links three lanes of sequential links (PCM/FM 0.1069 s, ARTM 0.1691; one pipelined lane 0.1077 / 0.1722)."""
     import ctypes
 
     from waveforms_amd import _hip, device as dev
@@ -109,18 +111,21 @@ def gpu_block_runner(plan: SweepPlan, streams: int = 3):
     from waveforms_amd.viterbi.cpm import sigma_for_ebn0 as cpm_sigma
 
     torch = _hip.torch()
-    n = max(1, int(streams))
     cpm = plan.waveform != "soqpsk"
+    # (SOQPSK blocks under 2^23 symbols: three lanes again — 2^22-symbol blocks 0.0735 s against 0.0762 for one pipelined lane;
+    #  1e7-symbol blocks, which the front-end kernel's launch shape is tuned for, are the fastest way to run the sweep)
+    n = max(1, int(streams)) if streams is not None else (3 if cpm or plan.nsym < (1 << 23) else 1)
     if cpm:
-        links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, pn_degree=plan.pn_degree, private_ctx=n > 1, warmup=plan.warmup)
+        links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, pn_degree=plan.pn_degree, private_ctx=n > 1, warmup=plan.warmup,
+                         fuse=10 if fuse is None else fuse)
                  for _ in range(n)]
         run_fn = _hip.lib().wf_cpm_link_run
     else:
-        # (fuse bit 4 with several lanes: the link's one-launch PRBS + precoder kernel is few, long workgroups — the right
-        #  trade for ONE block at a time, where every launch boundary is idle time; with three blocks in flight the generic
-        #  kernels fill the machine better: 13 x 1e8 symbols in 0.074 - 0.076 s against 0.078 - 0.079)
+        # (several lanes: sequential links with fuse bit 4 — the link's one-launch PRBS + precoder kernel is few, long
+        #  workgroups, the right trade for ONE block at a time; with three blocks in flight the generic kernels fill the
+        #  machine better: 13 x 1e8 symbols in 0.074 - 0.076 s against 0.078 - 0.079)
         links = [SOQPSKLink(plan.nsym, plan.sps, detector=plan.detector, pn_degree=plan.pn_degree, private_ctx=n > 1, warmup=plan.warmup,
-                            fuse=31 if n > 1 else 15)
+                            fuse=(31 if n > 1 else 47) if fuse is None else fuse)
                  for _ in range(n)]
         run_fn = _hip.lib().wf_link_run
     lanes = [torch.cuda.Stream() for _ in range(n)] if n > 1 else [torch.cuda.current_stream()]

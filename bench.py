@@ -63,6 +63,8 @@ def profile_record(stage: str, nsym: int, sps: int):
         if d.get("nsym") == nsym and d.get("sps") == sps and k:
             rec = {"traffic": int(k["hbm_traffic_bytes"]), "source": path.name, "valu_insts": k.get("valu_insts"),
                    "shader_cycles": k.get("shader_cycles"), "avg_ns": k.get("avg_ns"),
+                   "mfma_insts": k.get("mfma_f64_insts"), "mfma_busy_cycles": k.get("mfma_busy_cycles"),
+                   "mfma_pass_shader_cycles": k.get("mfma_pass_shader_cycles"),
                    "current": bool(now and d.get("build_digest") == now)}
             if best is None or rec["current"] or not best["current"]:
                 best = rec
@@ -96,7 +98,8 @@ def valu_issue(stage: str, rec, launch_ms: float):
         return None
     # mean issue cost of what the loops execute (static mix weighted by loop depth), not of the whole kernel text
     avg = k.get("avg_cycles_per_valu_loop", k["avg_cycles_per_valu"])
-    cycles = rec["valu_insts"] * avg
+    # (SQ_INSTS_VALU counts the matrix instructions too: they are priced below by the cycles the matrix pipe was busy)
+    cycles = (rec["valu_insts"] - (rec.get("mfma_insts") or 0)) * avg
     shader_cycles = rec.get("shader_cycles") or 2.2e9 * launch_ms * 1e-3
     frac = cycles / (mix["simds"] * shader_cycles)
     out = {"valu_issue_frac": round(frac, 4), "valu_wave_insts_per_launch": rec["valu_insts"],
@@ -109,6 +112,13 @@ def valu_issue(stage: str, rec, launch_ms: float):
            "source": f"{rec['source']} + {mix_name} + r02_valu_probe.json"}
     if rec.get("shader_cycles") and rec.get("avg_ns"):
         out["shader_clock_ghz_in_profile"] = round(rec["shader_cycles"] / rec["avg_ns"], 3)
+    if rec.get("mfma_insts") and rec.get("mfma_busy_cycles") and rec.get("mfma_pass_shader_cycles"):
+        # kernels with fp64 matrix tiles (PAM bank, ARTM bank): the matrix pipe's busy cycles of its own counter pass.  A
+        # SIMD does not issue fp64 vector work of its other waves under a running v_mfma_f64 (profiles/r03_mfma_f64_probe.json,
+        # the PAM ablation builds), so the two fractions ADD to the share of the SIMDs' time that is spoken for.
+        mf = rec["mfma_busy_cycles"] / (mix["simds"] * rec["mfma_pass_shader_cycles"])
+        out.update(matrix_pipe_frac=round(mf, 4), mfma_f64_insts_per_launch=rec["mfma_insts"],
+                   mfma_busy_cycles_per_launch=rec["mfma_busy_cycles"], simd_busy_frac=round(frac + mf, 4))
     return out
 
 
@@ -408,6 +418,10 @@ def main() -> None:
         if vfrac > hbm["frac"]:
             roofline.update(bound="valu_issue", achieved=vi["issue_cycles_per_launch"],
                             peak=vi["simds"] * vi["shader_cycles_per_launch"], unit="SIMD issue cycles per launch", frac=vfrac)
+            if vi.get("simd_busy_frac"):
+                # fp64 matrix tiles in the kernel: vector issue + matrix-pipe busy cycles, which exclude each other on a SIMD
+                roofline.update(bound="simd_issue(vector+matrix)", achieved=vi["issue_cycles_per_launch"] + vi["mfma_busy_cycles_per_launch"],
+                                frac=vi["simd_busy_frac"])
         roofline.update(binding=roofline["bound"], binding_frac=roofline["frac"])
     # every stage with a profile record: its own HBM and issue fractions
     for name, st in stages.items():

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--out", default=None, help="output directory (default: profiles/)")
     ap.add_argument("--sq", default=None, help="counter_collection.csv of the SQ_* pass")
     ap.add_argument("--trace", default=None, help="kernel_trace.csv: per-dispatch durations (launch-to-launch spread)")
+    ap.add_argument("--mfma", default=None, help="counter_collection.csv of the matrix-pipe pass (SQ_INSTS_VALU_MFMA_F64, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE)")
     a = ap.parse_args()
     stats = {}
     for r in csv.DictReader(open(a.kernel_stats)):
@@ -76,6 +77,18 @@ def main():
             if m.get("SQ_WAVE_CYCLES"):
                 kernels[k]["frac_wave_cycles_valu_active"] = round(m.get("SQ_ACTIVE_INST_VALU", 0) / m["SQ_WAVE_CYCLES"], 3)
                 kernels[k]["frac_wave_cycles_waiting"] = round(m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"], 3)
+    if a.mfma:
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(a.mfma)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in acc.items():
+            m = {c: statistics.median(v) for c, v in cs.items()}
+            if k in kernels and m.get("SQ_INSTS_VALU_MFMA_F64"):
+                # matrix pipe of this launch, from its OWN counter pass: instructions, the cycles the SIMDs' matrix pipes
+                # were busy (summed over SIMDs) and that pass's shader cycles
+                kernels[k].update(mfma_f64_insts=int(m["SQ_INSTS_VALU_MFMA_F64"]),
+                                  mfma_busy_cycles=int(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)),
+                                  mfma_pass_shader_cycles=int(m.get("GRBM_GUI_ACTIVE", 0) / 8))
     if a.trace:
         per = defaultdict(list)
         for r in csv.DictReader(open(a.trace)):

@@ -299,6 +299,36 @@ def test_gpu_cpm_link_equals_oracle_chain(oracle, waveform, nsym, fuse):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("waveform,ebn0", [("pcmfm", 4.0), ("multih", 8.0)])
+def test_gpu_cpm_link_at_operating_point_warmup_equals_oracle_chain(oracle, waveform, ebn0):
+    """The link as bench.py runs it — chunk warm-up of the operating point (PCM/FM 64 calls, ARTM 48 from 8 dB), where
+    dozens of chunks per block miss the warm-up and are repaired by the detector's second launch — over 2e6 symbols:
+    symbol and bit error counts equal the sequential oracle chain's on the same bits and the same Philox noise."""
+    from waveforms_amd import device as dev
+    from waveforms_amd.link import CPMLink, operating_point_warmup
+
+    nsym = 2_000_000
+    w = operating_point_warmup(waveform, ebn0)
+    assert 0 < w <= 64
+    link = CPMLink(nsym, SPS, waveform=waveform, warmup=w, private_ctx=True)
+    spec = oracle.ARTM_16 if waveform == "multih" else oracle.PCMFM_SPEC
+    pulse = oracle.freq_pulse_multih_irig(SPS) if waveform == "multih" else oracle.freq_pulse_pcmfm(SPS)
+    bps = spec.lgM
+    dev.viterbi_repaired(reset=True, ctx=link._ctx)
+    link.run_block(ebn0, seed=1, stream_id=7)
+    se, be, m = link.result()                                   # (raises if a chunk was left unproven)
+    assert dev.viterbi_repaired(reset=True, ctx=link._ctx) > 0
+    bits = oracle.glfsr_bits(0x420000, 0x7FFFFF, nsym * bps)[0]
+    sym = oracle.multih_mapper(bits)[0] if waveform == "multih" else oracle.pcmfm_mapper(bits)
+    noise = oracle.philox_awgn(oracle.cpm_sigma_for_ebn0(ebn0, SPS, bps), 1, 7, 0, (nsym + 1) * SPS)
+    res = oracle.cpm_detection_run(sym, pulse, SPS, spec, noise=noise)
+    x = (res["decisions"] ^ res["truth"])[64:]
+    assert m == x.size
+    assert (se, be) == (int(np.count_nonzero(x)), int(np.unpackbits(x[:, None], axis=1).sum()))
+    assert be > 0
+
+
+@pytest.mark.gpu
 def test_gpu_multih_full_size_noiseless_and_ber(oracle):
     """BASELINE configs[2] at full size (1e7 quaternary symbols = 2e7 PN23 bits): no noise -> zero errors;
     at 10 dB the link's symbol and bit error counts EQUAL the sequential oracle chain's on the same PN23 bits

@@ -1014,9 +1014,11 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     // (mod_chan_bank_kernel, wf_modulate.hip) — the baseband samples never reach HBM
     bool fused_all = false;
     if ((cfg->fuse & 8) && (cfg->fuse & 2) && L.ncalls > 0) {
+        ctx->mcb_runs_hint = piped ? (L.nfilt == 4 ? 16 : 8) : 0;       // (the detector of the previous block shares the chip: finer runs)
         rc = wf_mod_chan_cpm_rows(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_templates,
                                   L.nfilt, L.ntm, L.start0, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, L.ncalls,
                                   rows, stream);
+        ctx->mcb_runs_hint = 0;
         if (rc < 0) return rc;
         fused_all = rc == 0;
     }

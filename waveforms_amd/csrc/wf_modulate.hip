@@ -1382,7 +1382,10 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
 #ifndef WF_MCB_RUNS_PER_SLOT_SOQPSK
 #define WF_MCB_RUNS_PER_SLOT_SOQPSK 2
 #endif
-    const int runs_per_slot = cpm_nf ? WF_MCB_RUNS_PER_SLOT : WF_MCB_RUNS_PER_SLOT_SOQPSK;
+    // (a pipelined CPM link asks for finer runs, ctx->mcb_runs_hint: its detector runs BESIDE this kernel and gets its
+    //  waves onto a SIMD only when one of this kernel's workgroups leaves.  Steady state of the pipelined links, same box,
+    //  runs per slot 1 | 2 | 4 | 8 | 16: PCM/FM 0.940 | 0.856 | 0.817 | 0.806 | 0.800 ms, ARTM 1.481 | 1.348 | 1.330 | 1.324 | 1.330)
+    const int runs_per_slot = cpm_nf ? (ctx->mcb_runs_hint > 0 ? ctx->mcb_runs_hint : WF_MCB_RUNS_PER_SLOT) : WF_MCB_RUNS_PER_SLOT_SOQPSK;
     const int64_t max_grid = (int64_t)cus * ((cpm_nf && JM != 4) || pam ? 3 : 4) * runs_per_slot;
     const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
     // the last `tail` tiles go out one per workgroup (WF_MCB_TAIL_SLOTS resident-slot-fulls of them; 0 = equal runs throughout)

@@ -273,6 +273,30 @@ def test_gpu_short_warmup_repaired_on_device_equals_oracle(oracle, design):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_repair_fuzz_random_designs_warmups_and_splits(oracle, seed):
+    """Seeded fuzz of the chunk-parallel detector + repair launch against the sequential oracle: a random trellis shape,
+    burst length (ragged ends), warm-up from 8 calls up, drift of the first filter output (how fast survivors merge),
+    exact-tie rows, and the burst cut into 1 .. 3 calls with the state carried between them."""
+    from waveforms_amd.viterbi import cpm
+
+    rng = np.random.default_rng(1000 + seed)
+    design = GPU_DESIGNS[int(rng.integers(len(GPU_DESIGNS)))]
+    spec_o = _spec(oracle, *design, D=int(rng.choice([8, 20, 32])))
+    spec_p = cpm.CPMDetectorSpec(M=spec_o.M, p=spec_o.p, K=spec_o.K, Lp=spec_o.Lp, NC=spec_o.NC, D=spec_o.D)
+    n = int(rng.integers(3_000, 90_000))
+    rows = rng.standard_normal((n, spec_o.nfilt)) + 1j * rng.standard_normal((n, spec_o.nfilt))
+    rows[:, 0] += float(rng.choice([0.0, 0.5, 2.0, 4.0]))
+    rows[::int(rng.integers(50, 700))] = 0.0
+    warm = int(rng.choice([8, 16, 24, 32, 48, 64]))
+    cuts = sorted(int(c) for c in rng.integers(1, n, size=int(rng.integers(0, 3))))
+    want = oracle.cpm_viterbi(spec_o).run(rows)
+    det = cpm.CPMTrellisDetector(spec_p)
+    got = np.concatenate([det.detect(part, warmup=warm) for part in np.split(rows, cuts) if part.shape[0]])
+    assert np.array_equal(got, want), (design, n, warm, cuts)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fuse", [10, 2, 0])
 @pytest.mark.parametrize("waveform,nsym", [("multih", 100_000), ("pcmfm", 60_000), ("multih", 777)])
 def test_gpu_cpm_link_equals_oracle_chain(oracle, waveform, nsym, fuse):

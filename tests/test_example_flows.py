@@ -179,3 +179,18 @@ def test_gpu_soqpsk_example_flow_equals_reference(golden):
         np.testing.assert_allclose(tt, g[f"sq_tree_{label}_t"], rtol=0, atol=1e-13)
         assert traces.shape == g[f"sq_tree_{label}"].shape
         np.testing.assert_allclose(traces, g[f"sq_tree_{label}"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_gpu_figure_examples_render(tmp_path):
+    """examples/waveform_figures.py — the reference's three figure scripts against the same API on the GPU path — runs
+    end to end on a headless box and writes its three PNGs (the arrays behind them are compared above)."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("waveform_figures", Path(__file__).resolve().parent.parent / "examples" / "waveform_figures.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    made = mod.main(["--out", str(tmp_path)])
+    assert [p.name for p in made] == ["irig_comparison.png", "pcmfm_filter_orders.png", "soqpsk_family.png"]
+    assert all(p.stat().st_size > 10_000 for p in made)

@@ -39,9 +39,10 @@ HOT = {
     # the same kernel with the 73-tap PAM bank on the matrix cores (13 B operands per lane + 8 KB of partial tiles)
     "mod_chan_bank_kernel<9, -1, 8>": (168, 3),
     "mod_chan_bank_kernel<4, -1, 8>": (168, 3),
-    # CPM front ends (configs[2]): 3 waves per SIMD needs <= 168
-    "mod_chan_bank_kernel<4, 16, 8>": (168, 3),
-    "mod_chan_bank_kernel<4, 4, 8>": (168, 3),
+    # CPM front ends (configs[2]; the ARTM and PCM/FM pulses are the 4-symbol forms): 4 waves per SIMD, <= 128 registers
+    "mod_chan_bank_kernel<4, 16, 8>": (128, 4),
+    "mod_chan_bank_kernel<4, 4, 8>": (128, 4),
+    # ... longer pulses: 3 waves per SIMD needs <= 168
     "mod_chan_bank_kernel<9, 16, 8>": (168, 3),
     "mod_chan_bank_kernel<9, 4, 8>": (168, 3),
     # stand-alone modulator, SOQPSK-TG (J = 9) and short pulses
@@ -54,6 +55,9 @@ HOT = {
     "cpm_viterbi_kernel<2, 1>": (96, 5),
     "cpm_viterbi_kernel<4, 1>": (96, 5),
     "cpm_viterbi_kernel<4, 2>": (128, 4),
+    # ... its repair launch (same body, one wave per listed chunk): must fit the same LDS / register budget
+    "cpm_repair_kernel<2, 2>": (96, 5),
+    "cpm_repair_kernel<4, 2>": (128, 4),
     "fir_kernel<9>": (96, 5),
     "awgn_kernel": (64, 8),
 }

@@ -433,6 +433,8 @@ typedef struct {
     int fuse;                 /* bit 1: channel applied inside the matched-filter kernel;         */
                               /* bit 3 (with bit 1, sps 8, 4 or 16 filters): modulator + channel  */
                               /* + matched-filter rows in one kernel, no samples in HBM;          */
+                              /* bit 4 (16): PRBS and mapper as two kernels (wf_lfsr_generate +   */
+                              /* wf_symbol_map) instead of the link's one launch (same symbols);  */
                               /* bit 5 (32): as wf_link_config.fuse bit 5 — the detector and the  */
                               /* error count of a block on the context's side stream, beside the   */
                               /* next block's front end; two sets of intermediates in the         */

@@ -469,9 +469,10 @@ def test_gpu_cpm_link_pipelined_blocks_equal_sequential_blocks(waveform):
     nsym = 150_001
     seq = CPMLink(nsym, SPS, waveform=waveform, fuse=10)
     pip = CPMLink(nsym, SPS, waveform=waveform, fuse=42, private_ctx=True)
+    two = CPMLink(nsym, SPS, waveform=waveform, fuse=26, private_ctx=True)      # bit 4: PRBS and mapper as two kernels, not the one launch
     assert pip.workspace_bytes >= 2 * seq.workspace_bytes
     out = []
-    for link in (seq, pip):
+    for link in (seq, pip, two):
         got = []
         for k in range(5):
             link.reset_counts()
@@ -482,5 +483,5 @@ def test_gpu_cpm_link_pipelined_blocks_equal_sequential_blocks(waveform):
             link.run_block(6.0 + (k % 3), seed=9, stream_id=50 + k, skip_bits=k, event_slot=0 if k == 7 else -1)
         got.append(link.result())
         out.append(got)
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2]
     assert out[0][-1][1] > 0

@@ -106,6 +106,8 @@ int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state,
                          const uint64_t *d_dyn_skip, uint8_t *d_bits, int64_t n, uint64_t *h_state_out, void *stream,
                          const struct lfsr_emit_args *emit = nullptr);   // emit: the link's precoder rides in the same launch (see lfsr_kernel)
 // PRBS + the SOQPSK 4-state precoder of the link in ONE launch (wf_lfsr.hip); 1 = not this trellis / too long: use the generic calls
+int wf_lfsr_generate_map(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip, uint8_t *d_bits, int64_t nbits,
+                         int map_kind, int8_t *d_symbols, void *stream);   // PRBS + memoryless CPM mapper in one launch (1: not this mapper)
 int wf_soqpsk_prbs_encode(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip, const uint8_t *h_next,
                           const int8_t *h_out, uint8_t *d_bits, int64_t n, int8_t *d_symbols, void *stream, void *mid_event = nullptr);
 int wf_awgn_mf_bank_dyn(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, double rot_re, double rot_im,

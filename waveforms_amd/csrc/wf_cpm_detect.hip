@@ -1005,10 +1005,18 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
 #define MARK(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(stream))); } while (0)
     int rc;
     MARK(0);
-    if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, L.nbits, nullptr, stream))) return rc;
-    MARK(1);
-    // MultiHSymbolMapper on an even number of bits leaves its parity at 0 (precoder.py:22)
-    if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, L.nbits, 0, 0, 0, syms, stream))) return rc;
+    // PRBS and mapper in one launch (the mappers are memoryless: the PRBS kernel applies them to the bits it holds in LDS);
+    // fuse bit 4 (16), as in wf_link_config: the two generic kernels instead (same bits and symbols)
+    rc = (cfg->fuse & 16) ? 1 : wf_lfsr_generate_map(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, L.nbits, cfg->mapper_kind, syms, stream);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+        if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, L.nbits, nullptr, stream))) return rc;
+        MARK(1);
+        // MultiHSymbolMapper on an even number of bits leaves its parity at 0 (precoder.py:22)
+        if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, L.nbits, 0, 0, 0, syms, stream))) return rc;
+    } else {
+        MARK(1);
+    }
     MARK(2);
     // fuse bit 3 (with bit 1): modulator + channel + matched-filter rows in one kernel
     // (mod_chan_bank_kernel, wf_modulate.hip) — the baseband samples never reach HBM

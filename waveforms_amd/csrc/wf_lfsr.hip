@@ -102,6 +102,8 @@ struct lfsr_emit_args {
     uint32_t next2;              // ... and its next state, idx = (column * 4 + state) * 2 + input
     int differential;
     int8_t *symbols;             // nullptr: PRBS only
+    int map_kind;                // 0: the SOQPSK precoder above; 1 / 2: the memoryless mappers of the CPM link instead (wf_symbol_map
+                                 //    kinds: 1 = bit pairs -> {-3, -1, 1, 3}, first bit the heavier; 2 = bits -> -1 / +1), no carries
 };
 #define LFSR_EMIT_MAX_BLOCKS 1024
 
@@ -176,7 +178,43 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
         }
     }
     __syncthreads();
-    if (E.symbols) {
+    if (E.symbols && E.map_kind) {
+        // the CPM link's mappers (wf_encode.hip: symbol_map_kernel, parity 0) on the block's bits while they are in LDS:
+        // thread t takes 16 bits per pass, chunk-interleaved so that a wave's stores are contiguous
+        const int64_t blk0 = (int64_t)blockIdx.x * LFSR_BITS_PER_BLOCK;
+#pragma unroll 2
+        for (int r = 0; r < LFSR_BITS_PER_BLOCK / (16 * LFSR_THREADS); ++r) {
+            const int p = 16 * (r * LFSR_THREADS + t);
+            const int64_t gi = blk0 + p;
+            if (gi >= n) break;
+            const uint32_t x = (uint32_t)(s_words[p >> 6] >> (p & 63)) & 0xFFFFu;
+            if (E.map_kind == 2) {
+                const uint64_t lo = (((uint64_t)(x & 0xFF) * 0x0101010101010101ull) & 0x8040201008040201ull);
+                const uint64_t hi = (((uint64_t)(x >> 8) * 0x0101010101010101ull) & 0x8040201008040201ull);
+                const uint64_t blo = ((lo + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;   // one byte per bit: 0 / 1
+                const uint64_t bhi = ((hi + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+                const uint64_t vlo = blo | ~(blo * 0xFFull), vhi = bhi | ~(bhi * 0xFFull);          // 2 b - 1: 0x01 / 0xFF
+                if (gi + 16 <= n) {
+                    *reinterpret_cast<ulonglong2 *>(E.symbols + gi) = make_ulonglong2(vlo, vhi);
+                } else {
+                    for (int k = 0; k < 16 && gi + k < n; ++k) E.symbols[gi + k] = (int8_t)(((k < 8 ? vlo : vhi) >> (8 * (k & 7))) & 0xFF);
+                }
+            } else {
+                uint64_t v = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int val = 2 * (2 * (int)((x >> (2 * q)) & 1u) + (int)((x >> (2 * q + 1)) & 1u)) - 3;
+                    v |= (uint64_t)(uint8_t)(int8_t)val << (8 * q);
+                }
+                const int64_t so = gi >> 1, nout = n >> 1;
+                if (so + 8 <= nout) {
+                    *reinterpret_cast<uint64_t *>(E.symbols + so) = v;
+                } else {
+                    for (int k = 0; k < 8 && so + k < nout; ++k) E.symbols[so + k] = (int8_t)((v >> (8 * k)) & 0xFF);
+                }
+            }
+        }
+    } else if (E.symbols) {
         static_assert(LFSR_WORDS == 2 && LFSR_THREADS == 256, "the precoder phase assumes 128 bits per thread, 2048 chunks per block");
         __shared__ uint8_t s_st[LFSR_BITS_PER_BLOCK / 16];      // start state of every 16-symbol chunk
         __shared__ unsigned s_wp[LFSR_THREADS / 64];
@@ -291,6 +329,19 @@ int wf_lfsr_generate_dyn(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state,
                        t->dev, mask, state, skip, d_bits, n, degree, d_dyn_skip, emit ? *emit : lfsr_emit_args{});
     WF_LAUNCH_CHECK();
     return WF_OK;
+}
+
+// PRBS bits AND the CPM link's memoryless symbol mapper (wf_symbol_map kinds 1 / 2 at parity 0) in one launch.
+// Returns 1 — not an error — for any other mapper: the caller runs wf_lfsr_generate + wf_symbol_map.
+int wf_lfsr_generate_map(wf_ctx *ctx, int degree, uint64_t mask, uint64_t state, uint64_t skip, uint8_t *d_bits, int64_t nbits,
+                         int map_kind, int8_t *d_symbols, void *stream)
+{
+    if ((map_kind != 1 && map_kind != 2) || nbits < 1 || (map_kind == 1 && (nbits & 1))) return 1;
+    WF_REQUIRE(d_symbols && (reinterpret_cast<uintptr_t>(d_symbols) & 15) == 0, "wf_lfsr_generate_map: d_symbols must be non-NULL and 16-byte aligned");
+    lfsr_emit_args E{};
+    E.symbols = d_symbols;
+    E.map_kind = map_kind;
+    return wf_lfsr_generate_dyn(ctx, degree, mask, state, skip, nullptr, d_bits, nbits, nullptr, stream, &E);
 }
 
 // Functionals of one 32768-bit block as seen from its base state (linear over GF(2)): parity of the output bits at

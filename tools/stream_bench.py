@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=1 << 22)
     ap.add_argument("--ebn0", type=float, default=10.0)
     ap.add_argument("--detector", default="PT")
+    ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"],
+                    help="multih / pcmfm: the CPM link's stream (CPMStream, eager launches on one stream)")
     ap.add_argument("--pn-degree", type=int, default=31)
     ap.add_argument("--graph", action="store_true", help="replay the steady-state chunk as a hipGraph")
     ap.add_argument("--pipelined", action="store_true", help="consecutive chunks on two streams (detector of chunk c under the front end of c + 1)")
@@ -28,6 +30,24 @@ def main():
     import torch
 
     from waveforms_amd.link import SOQPSKStream
+
+    if a.waveform != "soqpsk":
+        from waveforms_amd.link import CPMStream, operating_point_warmup as opw
+
+        wu = a.vit_warmup if a.vit_warmup >= 0 else opw(a.waveform, a.ebn0)
+        st = CPMStream(int(a.total), a.chunk, 8, waveform=a.waveform, pn_degree=a.pn_degree, warmup=wu)
+        st.run_chunk(0, a.ebn0)
+        torch.cuda.synchronize()
+        for rep in range(2):
+            t0 = time.perf_counter()
+            se, be, m = st.run(a.ebn0)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print(json.dumps({"workload": f"{a.waveform} continuous stream, {int(a.total):.3g} symbols @8 sps in {st.nchunks} chunks of {a.chunk} "
+                                      f"(PN{a.pn_degree}, generic CPM trellis detector)", "mode": "eager launches", "Msym_per_s": round(m / dt / 1e6, 1),
+                          "seconds": round(dt, 4), "workspace_GB": round(st.workspace_bytes / 1e9, 3), "symbols": m, "symbol_errors": se,
+                          "bit_errors": be, "ebn0_db": a.ebn0}))
+        return
 
     from waveforms_amd.link import operating_point_warmup, soqpsk_warmup_param
     wu = soqpsk_warmup_param(a.vit_warmup if a.vit_warmup >= 0 else operating_point_warmup("soqpsk", a.ebn0))    # result() raises if a chunk is unproven

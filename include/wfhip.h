@@ -50,6 +50,12 @@ const char *wf_last_error_string(void);
  * scratch (it grows on demand outside graph capture). */
 int wf_ctx_create(int device, wf_ctx **out);
 int wf_ctx_destroy(wf_ctx *ctx);
+/* Retire a context without freeing it: stops the persistent per-symbol server (SOQPSKTrellisDetector.iteration,
+ * waveforms/viterbi/algorithm.py:57-101, is served by one), drains the side stream of pipelined links and refuses to
+ * start a new server afterwards.  The handle stays valid for wf_link_join / wf_viterbi4_iteration_quiesce /
+ * wf_ctx_destroy — what the reference's objects do from finalisers after interpreter exit began
+ * (examples/soqpsk_detection.py keeps its detector at module level).  Idempotent, synchronous. */
+int wf_ctx_retire(wf_ctx *ctx);
 /* Synchronises `stream`, returns WF_ERR_DEVICE if any kernel since the last
  * check raised the fault word (and clears it). */
 int wf_ctx_check(wf_ctx *ctx, void *stream);

@@ -30,6 +30,7 @@ SIGNATURES = {
     "wf_last_error_string": (c_char_p, []),
     "wf_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "wf_ctx_destroy": (c_int, [_P]),
+    "wf_ctx_retire": (c_int, [_P]),
     "wf_ctx_check": (c_int, [_P, _P]),
     "wf_lfsr_generate": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, _P, c_int64, POINTER(c_uint64), _P]),
     "wf_fsm_encode": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_int64, c_int, _P, POINTER(c_int), _P]),
@@ -187,15 +188,16 @@ def ctx() -> int:
 
 
 def _destroy_default_contexts() -> None:
-    """At interpreter exit (registered after torch was imported, so it runs before torch's own teardown): destroy
-    the per-device default contexts.  wf_ctx_destroy first retires a persistent iteration server the context may
-    still have running (it would retire by itself within 10 ms of its last request), so the process never exits
-    with one of its kernels on the device."""
-    for dev in list(_ctxs):
-        handle = _ctxs.pop(dev)
+    """At interpreter exit (registered after torch was imported, so it runs before torch's own teardown): RETIRE the
+    per-device default contexts — the persistent iteration server a context may still have running leaves the device
+    (it would retire by itself within 10 ms of its last request) and the side stream of pipelined links drains, so the
+    process never exits with one of its kernels on the device.  The contexts are NOT freed: module-level detectors and
+    links (the reference's own examples/soqpsk_detection.py keeps `det` at __main__ level) cached the raw handle and
+    their finalisers run after this hook; process teardown releases the memory."""
+    for handle in list(_ctxs.values()):
         try:
             if _lib is not None:
-                _lib.wf_ctx_destroy(handle)
+                _lib.wf_ctx_retire(handle)
         except Exception:   # noqa: BLE001 - best effort at shutdown
             pass
 

@@ -90,6 +90,7 @@ struct wf_ctx {
     void *iter_stream = nullptr;   // ... the server's own (non-blocking) stream,
     const void *iter_last_state = nullptr;   // ... and the detector state the last request was for
     std::atomic_flag iter_lock = ATOMIC_FLAG_INIT;   // the mailbox holds ONE request: callers of the per-symbol entry point take turns
+    bool iter_closing = false;     // set (under iter_lock) when the context is retired: no new server is started on it
 };
 
 static inline hipStream_t wf_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -1,0 +1,45 @@
+// wf_cpm_detect.h — what the two forms of the generic CPM trellis detector share (wf_cpm_detect.hip: one 16-lane DPP
+// row per chunk, any trellis of up to 16 states; wf_cpm_lanes.hip: one LANE per chunk, trellis known at compile time).
+// Both write the same per-chunk proof records, so one verify kernel and one repair kernel serve either.
+#pragma once
+#include "wf_common.h"
+
+// Device-resident detector state (WF_CPM_STATE_BYTES): words 0..63 current, 64..127 staging.
+//   [0] calls made (as int64), [1..16] metrics (double), [17..32] tilted phase indices r (int64),
+//   [33..48] decision registers (uint64)
+#define CPM_ST_N 0
+#define CPM_ST_M 1
+#define CPM_ST_V 17
+#define CPM_ST_H 33
+#define CPM_ST_STAGE 64
+
+// proof record per CHUNK: [0] the state its own calls started from, [1] the state it ended with; 16 lanes x 3
+// words each (metric, phase index, decision register).  cpm_verify_kernel compares chunk c's start with chunk
+// c - 1's end.
+#define CPM_EDGE_WORDS (2 * 16 * 3)
+#define CPM_REPAIR_CAP 1024     // failed chunks one repair launch can take (the rest are counted as unproven)
+#define CPM_ROT_SIN 128         // rotation table in LDS: cos at [r], sin at [CPM_ROT_SIN + r], r < 2p <= 128
+
+// (M - 1) * sum of K over symbols 0 .. n - Lp, mod 2p: the phase tilt of call n
+__host__ __device__ inline int cpm_tilt(int M, int p, int nh, int K0, int K1, int Lp, int64_t n)
+{
+    const int64_t m = n - Lp + 1;
+    if (m <= 0) return 0;
+    const int per = nh == 2 ? K0 + K1 : K0;
+    int64_t acc = (m / nh) % (2 * p) * per;
+    if (nh == 2 && (m & 1)) acc += K0;
+    return (int)(((int64_t)(M - 1) * (acc % (2 * p))) % (2 * p));
+}
+
+// Lane-per-chunk form (wf_cpm_lanes.hip).  wf_cpm_lanes_plan: 0 and the chunk length / resident-wave geometry when a
+// compiled specialisation exists for this detector, 1 when not (the caller runs the generic kernel).
+struct cpm_lane_plan {
+    int spec;           // which specialisation
+    int ring_batches;   // LDS ring depth in 16 KB batches
+    int waves_per_cu;   // resident waves per CU the ring allows
+    int calls_per_batch;
+};
+int wf_cpm_lanes_plan(const wf_cpm_detector_config *det, cpm_lane_plan *plan);
+int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
+                        int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
+                        void *stream);

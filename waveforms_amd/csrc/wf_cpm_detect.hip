@@ -28,7 +28,7 @@
 
 #include <type_traits>
 
-#include "wf_common.h"
+#include "wf_cpm_detect.h"
 
 #define CPM_THREADS 256
 #define CPM_WAVES (CPM_THREADS / WF_WAVE)
@@ -43,7 +43,7 @@
 // conflicts — and all four groups' writes of one symbol on the same 32 banks: 16 % of the LDS cycles of the
 // ARTM detector and 42 % of the PCM/FM one were bank conflicts, profiles/r03_pmc_cpmvit_*.json.)
 #define CPM_XS 68
-#define CPM_ROT_SIN 128     // rotation table: cos at [r], sin at [CPM_ROT_SIN + r], r < 2p <= 128 (a compile-time distance: one ds_read2_b64)
+// (rotation table: cos at [r], sin at [CPM_ROT_SIN + r], r < 2p <= 128 — a compile-time distance: one ds_read2_b64)
 
 struct cpm_tables {
     // variant kv: 0 / 1 = the symbol leaving the window uses K[0] / K[1]; 2 = it is a virtual
@@ -65,12 +65,7 @@ struct cpm_vit_params {
 
 __device__ __forceinline__ int cpm_tilt_at(const cpm_vit_params &P, int64_t n)   // (M-1) * sum K over symbols 0 .. n-Lp, mod 2p
 {
-    const int64_t m = n - P.Lp + 1;
-    if (m <= 0) return 0;
-    const int per = P.nh == 2 ? P.K0 + P.K1 : P.K0;
-    int64_t acc = (m / P.nh) % (2 * P.p) * per;
-    if (P.nh == 2 && (m & 1)) acc += P.K0;
-    return (int)(((int64_t)(P.M - 1) * (acc % (2 * P.p))) % (2 * P.p));
+    return cpm_tilt(P.M, P.p, P.nh, P.K0, P.K1, P.Lp, n);
 }
 
 // all-reduce min over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1)
@@ -123,19 +118,7 @@ __device__ __forceinline__ void cpm_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Device-resident detector state (WF_CPM_STATE_BYTES): words 0..63 current, 64..127 staging.
-//   [0] calls made (as int64), [1..16] metrics (double), [17..32] tilted phase indices r (int64),
-//   [33..48] decision registers (uint64)
-#define CPM_ST_N 0
-#define CPM_ST_M 1
-#define CPM_ST_V 17
-#define CPM_ST_H 33
-#define CPM_ST_STAGE 64
-
-// proof record per CHUNK: [0] the state its own calls started from, [1] the state it ended with; 16 lanes x 3
-// words each (metric, phase index, decision register).  cpm_verify_kernel compares chunk c's start with chunk
-// c - 1's end.  (Until round 3 the start state stayed in five registers per lane for an in-kernel compare.)
-#define CPM_EDGE_WORDS (2 * 16 * 3)
+// (device-resident detector state and the per-chunk proof records: wf_cpm_detect.h)
 
 // Waves per SIMD the register allocator is held to: 5 (<= 96 registers) for the trellises with up to 4 filters
 // per call (binary with a pulse of <= 2 symbols, any alphabet with one-symbol filters: 88 .. 93 registers; left
@@ -150,7 +133,6 @@ __device__ __forceinline__ void cpm_wave_sync()
 // up to there the second trajectory's decisions replace them.  A pair that has not met by the end of the chunk
 // leaves the chunk counted as unproven.  Most chunks that miss a SHORT warm-up meet within a few dozen calls, so the
 // warm-up can be sized for the typical merge depth instead of its 1e-7 tail.
-#define CPM_REPAIR_CAP 1024     // failed chunks one launch can take (the rest are counted as unproven)
 template <int M_, int LP_, bool REPAIR>
 __device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
                                                  uint8_t *__restrict__ out, uint64_t *__restrict__ state,
@@ -589,15 +571,19 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     // made 1221 workgroups for 1024 slots — a second, almost empty round of the full chain length.
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    // The lane-per-chunk form (wf_cpm_lanes.hip) where a specialisation for this trellis is compiled in: 64 chunks per
+    // wave, as many waves as its LDS ring lets a CU hold — the chunk length that puts the burst into one round of them.
+    cpm_lane_plan lanes{};
+    const bool use_lanes = wf_cpm_lanes_plan(det, &lanes) == 0;
     const int wg_per_cu = CPM_MIN_WAVES(P.M, P.Lp);                 // resident workgroups per CU = waves per SIMD (4 waves per workgroup)
-    const int64_t slots = (int64_t)cus * wg_per_cu * CPM_WAVES * CPM_GROUPS;
+    const int64_t slots = use_lanes ? (int64_t)cus * lanes.waves_per_cu * 64 : (int64_t)cus * wg_per_cu * CPM_WAVES * CPM_GROUPS;
     int64_t ch = (ncalls + slots - 1) / slots;
     ch = (ch + 63) / 64 * 64;
-    if (ch < 256) ch = 256;
+    if (ch < 256) ch = 256;                                        // (room for the repair launch to meet the first launch's trajectory)
     if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
-    if (const char *e = getenv("WF_CPM_CH")) ch = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : ch;   // tuning aid (tools/cpm_vit_time.py)
+    if (const char *e = getenv(use_lanes ? "WF_CPM_LANE_CH" : "WF_CPM_CH")) ch = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : ch;   // tuning aid (tools/cpm_vit_time.py)
     if (ch > 8192) ch = 8192;                                      // decision strips live in LDS; longer bursts take several rounds
-    // (measured at 1e7 ARTM calls, W = 128: 384 calls per chunk 1.07 ms, 512: 1.03, 640: 1.00, 768: 1.19,
+    // (measured at 1e7 ARTM calls, W = 128, row form: 384 calls per chunk 1.07 ms, 512: 1.03, 640: 1.00, 768: 1.19,
     //  1024: 1.28, 1536: 1.68 — longer chunks do less warm-up work but leave fewer waves to hide the
     //  dependent chain of a call)
     P.CH = (int)ch;
@@ -621,15 +607,20 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     uint64_t *edge = reinterpret_cast<uint64_t *>(ctx->d_vit_edge);
     hipStream_t s = wf_stream(stream);
     using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params);
-    kern_t k = nullptr;
-    if (P.M == 4) k = P.Lp == 1 ? cpm_viterbi_kernel<4, 1> : (P.Lp == 2 ? cpm_viterbi_kernel<4, 2> : cpm_viterbi_kernel<4, 3>);
-    else k = P.Lp == 1 ? cpm_viterbi_kernel<2, 1> : (P.Lp == 2 ? cpm_viterbi_kernel<2, 2> : cpm_viterbi_kernel<2, 3>);
-    if (lds > 48 * 1024)
-        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(CPM_THREADS), lds, s, reinterpret_cast<const double2 *>(d_rows_ri),
-                       reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
-                       ctx->d_vit_unmerged, P);
-    WF_LAUNCH_CHECK();
+    if (use_lanes) {
+        rc = wf_cpm_lanes_launch(lanes, det, d_rot_cs, d_rows_ri, ncalls, W, P.CH, nchunks, d_decisions, d_state, edge, stream);
+        if (rc) return rc;
+    } else {
+        kern_t k = nullptr;
+        if (P.M == 4) k = P.Lp == 1 ? cpm_viterbi_kernel<4, 1> : (P.Lp == 2 ? cpm_viterbi_kernel<4, 2> : cpm_viterbi_kernel<4, 3>);
+        else k = P.Lp == 1 ? cpm_viterbi_kernel<2, 1> : (P.Lp == 2 ? cpm_viterbi_kernel<2, 2> : cpm_viterbi_kernel<2, 3>);
+        if (lds > 48 * 1024)
+            WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(CPM_THREADS), lds, s, reinterpret_cast<const double2 *>(d_rows_ri),
+                           reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
+                           ctx->d_vit_unmerged, P);
+        WF_LAUNCH_CHECK();
+    }
     if (nchunks > 1) {
         const uint64_t hmask = P.lgM * P.D >= 64 ? ~0ull : ((1ull << (P.lgM * P.D)) - 1ull);   // only the D decisions still inside the register can reach an output
         const char *nr = getenv("WF_CPM_NO_REPAIR");                  // (tests of the host-level fallback)

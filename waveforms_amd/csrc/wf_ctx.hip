@@ -76,6 +76,18 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
     return WF_OK;
 }
 
+// Retire a context WITHOUT freeing it (interpreter exit): the persistent iteration server leaves the device, the side
+// stream of pipelined links drains, and the handle stays valid — objects that cached it may still call wf_link_join,
+// wf_viterbi4_iteration_quiesce or wf_ctx_destroy from their finalisers.  Idempotent.
+extern "C" int wf_ctx_retire(wf_ctx *c)
+{
+    if (!c) return WF_OK;
+    (void)hipSetDevice(c->device);
+    (void)wf_iter_server_stop(c);
+    if (c->pipe_stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(c->pipe_stream));
+    return WF_OK;
+}
+
 int wf_link_join_internal(wf_ctx *c, void *stream)
 {
     if (!c) return WF_OK;
@@ -153,6 +165,10 @@ int wf_ctx_reserve_mod(wf_ctx *c, size_t words)
 int wf_ctx_reserve_vit(wf_ctx *c, size_t words)
 {
     if (words <= c->vit_edge_words) return WF_OK;
+    {   // a deferred proof points into the block about to be freed: it runs first (only a failed wf_link_run leaves one behind)
+        const int rf = wf_vit_flush_verify(c, nullptr);
+        if (rf) return rf;
+    }
     WF_HIP(hipDeviceSynchronize());
     if (c->d_vit_edge) WF_HIP(hipFree(c->d_vit_edge));
     c->d_vit_edge = nullptr;

@@ -246,10 +246,7 @@ __global__ __launch_bounds__(LFSR_THREADS) void lfsr_kernel(const uint64_t *__re
         }
         __syncthreads();
         const int64_t blk0 = (int64_t)blockIdx.x * LFSR_BITS_PER_BLOCK;
-#ifndef LFSR_EMIT_UNROLL
-#define LFSR_EMIT_UNROLL 2
-#endif
-#pragma unroll LFSR_EMIT_UNROLL
+#pragma unroll 2
         for (int r = 0; r < LFSR_BITS_PER_BLOCK / (16 * LFSR_THREADS); ++r) {
             const int c = r * LFSR_THREADS + t, p = 16 * c;
             const int64_t gi = blk0 + p;

@@ -208,7 +208,10 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
         int64_t m_ = L.ncols - length;
         if (m_ > cfg->nsym) m_ = cfg->nsym;
         if (m_ < 0) m_ = 0;
-        if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, back))) return rc;   // (m_ = 0: only the proof)
+        if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, back))) {   // (m_ = 0: only the proof)
+            (void)wf_vit_flush_verify(ctx, back);    // the counter refused before it took the proof over: the proof still runs
+            return rc;
+        }
         MARKB(8);
 #undef MARKB
         if (piped) {

@@ -22,6 +22,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
 #include "wf_common.h"
 
 #define VIT_THREADS 256
@@ -548,7 +550,10 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     WF_LAUNCH_CHECK();
     if (nwaves_live > 1) {
         if (ctx->vit_defer_verify) {          // the link's error counter, next on this stream, does the compares (wf_count.hip)
-            WF_REQUIRE(ctx->vit_pending_edge == nullptr, "wf_viterbi4_detect: internal: a deferred proof was never run");
+            if (ctx->vit_pending_edge) {      // a proof left behind by a call that failed between detector and counter: it runs now
+                const int rf = wf_vit_flush_verify(ctx, stream);
+                if (rf) return rf;
+            }
             ctx->vit_pending_edge = edge;
             ctx->vit_pending_nwaves = nwaves_live;
         } else {
@@ -1186,15 +1191,41 @@ extern "C" int wf_viterbi4_iteration_server_timing(wf_ctx *ctx, double *h_us4)
     return WF_OK;
 }
 
-// Stop the server of a context (teardown; harmless when none is running): it retires within one poll.
-int wf_iter_server_stop(wf_ctx *ctx)
+// One request at a time, and nothing toggles the mailbox's control words under a request: the per-symbol entry point,
+// the quiesce and the stop all take the context's iteration lock (Python threads drop the interpreter lock inside a
+// ctypes call; a daemon thread may still be inside iteration() when the interpreter exits).
+struct vit_turn {
+    std::atomic_flag &f;
+    explicit vit_turn(std::atomic_flag &f_) : f(f_) { while (f.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause(); }
+    ~vit_turn() { f.clear(std::memory_order_release); }
+};
+
+static inline double vit_now_s()
 {
-    if (!ctx || !ctx->h_mailbox) return WF_OK;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+#define VIT_HOST_SPIN_SECONDS 5.0   // how long the host waits for the server before it reports the device gone
+
+// Stop the server of a context (harmless when none is running): it retires within one poll.  closing: the context
+// is being retired (interpreter exit / destroy) — wf_viterbi4_iteration_host will not start a new server on it.
+static int vit_server_stop_locked(wf_ctx *ctx, bool closing)
+{
+    if (closing) ctx->iter_closing = true;
+    if (!ctx->h_mailbox) return WF_OK;
     vit_mailbox *mb = static_cast<vit_mailbox *>(ctx->h_mailbox);
     __atomic_store_n(&mb->stop, 1ull, __ATOMIC_RELEASE);
     if (ctx->iter_stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(ctx->iter_stream));
     __atomic_store_n(&mb->stop, 0ull, __ATOMIC_RELEASE);
     return WF_OK;
+}
+
+int wf_iter_server_stop(wf_ctx *ctx)
+{
+    if (!ctx) return WF_OK;
+    vit_turn my_turn(ctx->iter_lock);
+    return vit_server_stop_locked(ctx, true);
 }
 
 extern "C" int wf_viterbi4_iteration_quiesce(wf_ctx *ctx);
@@ -1231,12 +1262,13 @@ static inline void wf_store16(unsigned long long *p, unsigned long long lo, unsi
 
 // Wait until the server has written the last served call's state through to device memory (it answers first):
 // before anything else reads or frees a detector state the server may have been asked about.  Harmless without a server.
-extern "C" int wf_viterbi4_iteration_quiesce(wf_ctx *ctx)
+static int vit_quiesce_locked(wf_ctx *ctx)
 {
-    if (!ctx || !ctx->h_mailbox) return WF_OK;
+    if (!ctx->h_mailbox) return WF_OK;
     vit_mailbox *mb = static_cast<vit_mailbox *>(ctx->h_mailbox);
-    for (unsigned long long spins = 0; __atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) != mb->req; ++spins) {
-        if (__atomic_load_n(&mb->running, __ATOMIC_ACQUIRE) == 0 || spins > 2000000000ull) {
+    const double t0 = vit_now_s();
+    for (unsigned spins = 0; __atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) != mb->req; ++spins) {
+        if (__atomic_load_n(&mb->running, __ATOMIC_ACQUIRE) == 0 || ((spins & 0xFFFFu) == 0xFFFFu && vit_now_s() - t0 > VIT_HOST_SPIN_SECONDS)) {
             // (a retired server has nothing in flight: it acknowledges before it leaves)
             if (__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) == mb->req) break;
             wf_set_error("wf_viterbi4_iteration_quiesce: the iteration server did not acknowledge its last call");
@@ -1245,6 +1277,13 @@ extern "C" int wf_viterbi4_iteration_quiesce(wf_ctx *ctx)
         __builtin_ia32_pause();
     }
     return WF_OK;
+}
+
+extern "C" int wf_viterbi4_iteration_quiesce(wf_ctx *ctx)
+{
+    if (!ctx) return WF_OK;
+    vit_turn my_turn(ctx->iter_lock);
+    return vit_quiesce_locked(ctx);
 }
 
 extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length, int differential,
@@ -1265,18 +1304,20 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
                            differential ? 1 : 0, ctx->d_iter, ctx->d_iter + 6, ctx->d_iter + 6 + VIT_MAX_LEN);
         WF_LAUNCH_CHECK();
         WF_HIP(hipStreamSynchronize(s));
+        bool undefined = false;
         for (int k = 0; k < length; ++k) {
             h_bits_out[k] = ctx->h_iter[6 + k];
             h_syms_out[k] = ctx->h_iter[6 + VIT_MAX_LEN + k];
+            undefined = undefined || h_bits_out[k] != h_bits_out[k];
+        }
+        if (undefined) {        // as on the server path below: the reference raises KeyError here (model.py:171-174)
+            wf_set_error("traceback reached a state pair with no connecting branch");
+            return WF_ERR_KEY;
         }
         return WF_OK;
     }
-    // one request at a time (Python threads drop the interpreter lock inside a ctypes call)
-    struct turn {
-        std::atomic_flag &f;
-        explicit turn(std::atomic_flag &f_) : f(f_) { while (f.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause(); }
-        ~turn() { f.clear(std::memory_order_release); }
-    } my_turn(ctx->iter_lock);
+    vit_turn my_turn(ctx->iter_lock);      // one request at a time
+    WF_REQUIRE(!ctx->iter_closing, "wf_viterbi4_iteration_host: the context has been retired (interpreter exit / wf_ctx_retire)");
     if (!ctx->h_mailbox) {
         WF_HIP(hipHostMalloc(&ctx->h_mailbox, sizeof(vit_mailbox), hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->h_mailbox, 0, sizeof(vit_mailbox));
@@ -1300,7 +1341,8 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
     memcpy(&payload[2], h_mf3_ri, 6 * sizeof(double));
     for (int k = 0; k < 8; ++k) wf_store16(&mb->chunk[k][0], payload[k], seq);      // one 16-byte store per chunk: never torn
     const int nans = 2 * length;
-    for (unsigned long long spins = 0;; ++spins) {
+    const double t_post = vit_now_s();
+    for (unsigned spins = 0;; ++spins) {
         // the last chunk first (the device writes them low to high), then every tag
         if (__atomic_load_n(&mb->ans[nans - 1][1], __ATOMIC_ACQUIRE) == seq) {
             bool all = true;
@@ -1315,7 +1357,7 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
                                static_cast<vit_mailbox *>(ctx->d_mailbox));
             WF_LAUNCH_CHECK();
         }
-        if (spins > 2000000000ull) {        // ~ seconds of spinning: the device is gone or wedged
+        if ((spins & 0xFFFFu) == 0xFFFFu && vit_now_s() - t_post > VIT_HOST_SPIN_SECONDS) {   // the device is gone or wedged
             wf_set_error("wf_viterbi4_iteration_host: the iteration server did not answer");
             return WF_ERR_HIP;
         }

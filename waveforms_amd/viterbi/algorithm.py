@@ -101,6 +101,14 @@ class SOQPSKTrellisDetector:
             self._iter_bits, self._iter_syms = self._iter_out[0], self._iter_out[1]      # (views kept: no indexing per call)
             self._iter_args = (self._iter_ctx, self._d_state_ptr, int(self.length), self._iter_diff, self._iter_z.ctypes.data,
                                self._iter_bits.ctypes.data, self._iter_syms.ctypes.data, self._iter_stream)
+        elif self.differential != self._iter_diff or self.length != self._iter_args[2]:
+            # the reference reads these attributes on every call (algorithm.py:62-98): follow a change
+            if int(self.length) != self._iter_args[2]:
+                raise ValueError("the traceback length of a detector cannot change inside a burst (its state arrays are sized by it)")
+            self._iter_diff = int(self.differential)
+            self._iter_args = self._iter_args[:3] + (self._iter_diff,) + self._iter_args[4:]
+        # (the HIP stream is the one current at the FIRST call of the burst: the detector's state is private to this
+        # object and only its own methods touch it, so there is nothing on another stream to order against)
         # one C-ABI call per symbol: host operands in, host results out (a persistent kernel serves the calls
         # through a pinned mailbox: no launch, no torch op, no separate copies); the wrapper itself is kept to a
         # few attribute reads — at ~5 us per C call Python's share is what is left to trim

@@ -158,7 +158,7 @@ def _cpu_trial(job):
     return nsym, time.perf_counter() - t0, res["bit_errors"], res["compared"]
 
 
-def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int, waveform: str = "soqpsk") -> dict:
+def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int, waveform: str = "soqpsk", gpus: int = 1) -> dict:
     """The oracle timed on the host cores of this box, one process per core on independent trial
     blocks, in two forms: `port` = the CPU port of the reference algorithm (C loops +
     numpy), and `faithful_loop` = the reference's own execution form (interpreted per-symbol
@@ -170,7 +170,9 @@ def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int, waveform
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = host_cores
-    cores = max(1, min(usable, 16))          # a 16-core SHARE of the host (what a one-GPU box grants), not all of its cores
+    # a 16-core SHARE of the host per GPU of the job (what a one-GPU box grants; an N-GPU job owns N shares), never more than
+    # this process may run on
+    cores = max(1, min(usable, 16 * max(1, int(gpus))))
     ctx = mp.get_context("spawn")            # never fork a process that has initialised HIP
     out = {}
     with ctx.Pool(cores) as pool:
@@ -190,7 +192,7 @@ def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int, waveform
                 "sample": f"same {waveform} @{sps}sps chain, Eb/N0 {ebn0:.1f} dB, sequential C detector + numpy (the reference has no "
                           f"detector for this waveform: build-defined oracle), PCG64 noise: {o['sample']}"}
     return {"value": out["port"]["value"], "unit": "Msym/s", "cores": cores, "host_cores": host_cores, "kind": "port",
-            "cores_note": f"a {cores}-core share of the host's {host_cores} cores (one process per core), not the whole host",
+            "cores_note": f"min(cores this process may run on, 16 per GPU of the job) = {cores} of the host's {host_cores} cores, one process per core",
             "single_core": out["port"]["single_core"],
             "sample": "same SOQPSK-TG @%dsps chain, Eb/N0 %.1f dB, oracle C loops + numpy, PCG64 noise: %s"
                       % (sps, ebn0, out["port"]["sample"]),
@@ -328,8 +330,28 @@ def main() -> None:
         a_, b_, c_ = l.result()
         se, be, compared = se + a_, be + b_, compared + c_
     counts = torch.tensor([se, be, compared], dtype=torch.int64, device=coll_dev)
+    collective = None
     if dist is not None:
+        own = [int(v) for v in counts.cpu().tolist()]
+        torch.cuda.synchronize()
+        dist.barrier()
+        tc = time.perf_counter()
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)     # the one collective of the job
+        if coll_dev != "cpu":
+            torch.cuda.synchronize()
+        all_reduce_us = (time.perf_counter() - tc) * 1e6
+        # what ran, as the ranks themselves saw it — so that the first real N-GPU run proves its own collective: the
+        # backend, the group size, which physical device each rank drove, every rank's own count (their sum must be the
+        # reduced total) and the wall time of the all-reduce
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = {"rank": rank, "local_device": torch.cuda.current_device(), "name": props.name,
+                 "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+                 "uuid": str(getattr(props, "uuid", "")), "compared": own[2], "bit_errors": own[1]}
+        seen = [None] * world
+        dist.all_gather_object(seen, ident)
+        collective = {"backend": dist.get_backend(), "world_seen": dist.get_world_size(), "all_reduce_us": round(all_reduce_us, 1),
+                      "devices": seen, "sum_of_rank_counts_equals_reduced": sum(d["bit_errors"] for d in seen) == int(counts[1].item()),
+                      "distinct_devices": len({(d["pci"], d["uuid"]) for d in seen})}
     se, be, compared = (int(v) for v in counts.cpu().tolist())
 
     # per-stage kernel time from the HIP events recorded inside the timed region
@@ -433,7 +455,7 @@ def main() -> None:
                 st["valu_issue_frac"] = v_["valu_issue_frac"]
 
     steady = None
-    if world == 1 and nstreams == 1 and args.steady_steps > 0:
+    if nstreams == 1 and args.steady_steps > 0:      # (N > 1: every rank runs its own, reported per rank below)
         for l in links:
             l.reset_counts()
         torch.cuda.synchronize()
@@ -493,6 +515,11 @@ def main() -> None:
             overlapped["steady_steps"] = args.steady_steps
         del extra
 
+    steady_all = None
+    if dist is not None and steady is not None:
+        steady_all = [None] * world
+        dist.all_gather_object(steady_all, {"rank": rank, "ms_per_step": steady["ms_per_step"], "value": steady["value"],
+                                            "detector_chunks_unproven": steady["detector_chunks_unproven"]})
     if rank == 0:
         total_sym = args.steps * args.nsym * world
         out = {
@@ -513,7 +540,7 @@ def main() -> None:
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
                        "fuse": args.fuse, "streams": nstreams,
-                       "detector_warmup_rows": (links[0].cfg.warmup or ("320 (library default)" if args.waveform == "multih" else "384 (library default)")) if cpm
+                       "detector_warmup_rows": (links[0].cfg.warmup or "96 (library default)") if cpm
                                                else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32), "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared * bits_per_sym, 1),
@@ -530,8 +557,11 @@ def main() -> None:
         if world > 1:
             out["per_rank_ms_per_step"] = [round(v, 4) for v in rank_ms]
             out["rank_time_max_over_min"] = round(max(rank_ms) / max(min(rank_ms), 1e-12), 4)
+            out["collective"] = collective
+            if steady_all:
+                out["steady_state_per_rank"] = steady_all
         if not args.no_cpu_baseline:    # rank 0 only, after the timed region, at any N (the other ranks wait at the final barrier)
-            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample, args.waveform)
+            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample, args.waveform, gpus=world)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -20,6 +20,12 @@
  * pulse-truncation idea (examples/soqpsk_detection.py:134-156: sps+1 samples of the phase
  * pulse around its centre), generalised to L' symbols.
  *
+ * RULE (round 4): because this detector is build-defined, a statement in THIS file may be ordered the way a kernel
+ * computes it (round 3 did so once: orc_cpm_mf_rows accumulates in the matrix-pipe instruction's order).  That
+ * licence ends here: nothing in wf_oracle.c / numpy_ref.py / viz_ref.py — the statements pinned by the reference's
+ * goldens, rows a1-a11 and f4 — may ever follow a kernel.  tests/test_oracle_golden.py::
+ * test_golden_pinned_oracle_outputs_are_frozen fails when any of them changes its output on the goldens' inputs.
+ *
  * All file:line citations are relative to /root/reference.
  */
 #include <math.h>

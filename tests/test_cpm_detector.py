@@ -348,7 +348,8 @@ def test_gpu_cpm_link_at_operating_point_warmup_equals_oracle_chain(oracle, wave
     res = oracle.cpm_detection_run(sym, pulse, SPS, spec, noise=noise)
     x = (res["decisions"] ^ res["truth"])[64:]
     assert m == x.size
-    assert (se, be) == (int(np.count_nonzero(x)), int(np.unpackbits(x[:, None], axis=1).sum()))
+    want = (int(np.count_nonzero(x)), int(np.unpackbits(x[:, None], axis=1).sum()))
+    assert (se, be) == want
     assert be > 0
 
 
@@ -379,7 +380,20 @@ def test_gpu_multih_full_size_noiseless_and_ber(oracle):
     del noise
     x = (res["decisions"] ^ res["truth"])[64:]
     assert m == x.size
-    assert (se, be) == (int(np.count_nonzero(x)), int(np.unpackbits(x[:, None], axis=1).sum()))
+    want = (int(np.count_nonzero(x)), int(np.unpackbits(x[:, None], axis=1).sum()))
+    assert (se, be) == want
+    del link
+    # ... and the same in the configuration bench.py times (fuse 42: blocks software-pipelined, the detector of a block
+    # beside the next block's front end; two blocks so that the overlap happens), at bench.py's operating-point warm-up
+    from waveforms_amd.link import operating_point_warmup
+
+    for warmup in (0, operating_point_warmup("multih", 10.0)):
+        piped = CPMLink(nsym, SPS, waveform="multih", fuse=42, warmup=warmup)
+        piped.run_block(10.0, seed=1, stream_id=2)
+        piped.run_block(10.0, seed=1, stream_id=2)
+        se2, be2, m2 = piped.result()                 # (raises if a detector chunk was left unproven)
+        assert (se2, be2, m2) == (2 * want[0], 2 * want[1], 2 * m), warmup
+        del piped
 
 
 @pytest.mark.gpu

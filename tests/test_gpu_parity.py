@@ -805,21 +805,30 @@ def test_stream_config4_full_size_1e9_symbols():
 
 
 def test_link_full_size_equals_oracle_chain_1e7(oracle):
-    """BASELINE configs[1] at full size, once, against the oracle itself (not only fuse-level
-    agreement): 1e7 PN23 symbols through the default fused link (fuse = 7) == oracle.detection_run
-    fed the same Philox noise, count for count."""
+    """BASELINE configs[1] at full size against the oracle itself (not only fuse-level agreement): 1e7 PN23 symbols
+    through the link == oracle.detection_run fed the same Philox noise, count for count — in the configuration
+    bench.py times (fuse = 47: one-kernel front end, blocks software-pipelined; two blocks, so that the second one's
+    front end really runs beside the first one's detector), in the one-block-after-the-other form (15) and in the
+    staged form (7)."""
     from waveforms_amd.link import SOQPSKLink
 
     nsym = 10_000_000
-    link = SOQPSKLink(nsym, 8, fuse=7)
-    link.run_block(10.0, seed=1, stream_id=0)
-    got = link.result()
-    del link
     bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, nsym)
     noise = oracle.philox_awgn(oracle.sigma_for_ebn0(10.0, 8), 1, 0, 0, (nsym + 1) * 8)
     res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise)
-    assert got == (res["sym_errors"], res["bit_errors"], res["compared"])
+    del noise
+    want = (res["sym_errors"], res["bit_errors"], res["compared"])
     assert res["bit_errors"] > 5000
+    for fuse in (47, 15, 7):
+        link = SOQPSKLink(nsym, 8, fuse=fuse)
+        link.run_block(10.0, seed=1, stream_id=0)
+        assert link.result() == want, fuse
+        if fuse & 32:       # the same block again behind the first: its front end overlaps the first block's back end
+            link.reset_counts()
+            link.run_block(10.0, seed=1, stream_id=0)
+            link.run_block(10.0, seed=1, stream_id=0)
+            assert link.result() == (2 * want[0], 2 * want[1], 2 * want[2]), fuse
+        del link
 
 
 # ------------------------------------------------------------------ edge cases
@@ -1095,12 +1104,12 @@ def test_link_full_size_fuse_modes_agree(nsym):
     from waveforms_amd.link import SOQPSKLink
 
     results = {}
-    for fuse in (0, 3, 7, 15):
+    for fuse in (0, 3, 7, 15, 47):
         link = SOQPSKLink(nsym, 8, fuse=fuse)
         link.run_block(10.0, seed=1, stream_id=0)
         results[fuse] = link.result()
         del link
-    assert results[0] == results[3] == results[7] == results[15]
+    assert results[0] == results[3] == results[7] == results[15] == results[47]
     se, be, m = results[7]
     assert m == nsym - 3                  # ncols - length: the example's min_size (examples/soqpsk_detection.py:204)
     ber = be / m

@@ -40,10 +40,20 @@ def test_two_ranks_through_the_real_block_runner_equal_one_rank():
 def test_bench_gpus_2_without_torchrun_rehearsal():
     """`python bench.py --gpus 2` — the command shape the driver uses — starts its own ranks."""
     out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--nsym", "1000000",
-                "--no-cpu-baseline"], {"WF_BENCH_REHEARSAL": "1"})
+                "--no-cpu-baseline", "--steady-steps", "20"], {"WF_BENCH_REHEARSAL": "1"})
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["ber"]["symbols"] == 2 * 3 * (1000000 - 3)
     assert out["value"] > 0 and "roofline" in out
+    # the N > 1 line carries the evidence of its own collective: what backend ran, how many ranks it saw, which device
+    # each rank drove, every rank's own counts (their sum is the reduced total) and every rank's own steady state
+    c = out["collective"]
+    assert c["backend"] == "gloo" and c["world_seen"] == 2 and c["all_reduce_us"] > 0
+    assert [d["rank"] for d in c["devices"]] == [0, 1] and all(d["pci"] and d["compared"] == 3 * (1000000 - 3) for d in c["devices"])
+    assert c["sum_of_rank_counts_equals_reduced"] is True
+    assert sum(d["bit_errors"] for d in c["devices"]) == out["ber"]["bit_errors"]
+    assert c["distinct_devices"] == 1                         # the rehearsal: both ranks on cuda:0 (a real run shows N)
+    per = out["steady_state_per_rank"]
+    assert [p["rank"] for p in per] == [0, 1] and all(p["ms_per_step"] > 0 for p in per)
 
 
 def test_ber_sweep_tool_gpus_2_equals_single_process(tmp_path):
@@ -52,6 +62,8 @@ def test_ber_sweep_tool_gpus_2_equals_single_process(tmp_path):
     two = _run([sys.executable, "tools/ber_sweep.py", "--gpus", "2", *args], {"WF_BENCH_REHEARSAL": "1"})
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert one["counts"] == two["counts"]
+    assert two["collective_backend"] == "gloo" and two["world_seen"] == 2 and two["init_seconds"] >= 0
+    assert one["collective_backend"] is None and one["world_seen"] == 1
 
 
 def test_rccl_all_reduce_of_the_counter_table_world1():

@@ -305,3 +305,25 @@ def test_faithful_loops_chain_reproduces_reference_counts(oracle, golden):
     assert (res["sym_errors"], res["bit_errors"], res["compared"]) == (ref["sym_errors"], ref["bit_errors"], ref["compared"])
     assert np.array_equal(res["det_bits"], ref["det_bits"][2:].astype(np.uint8))
     assert e["sps8_10dB_TG_PT"][2] == 32765
+
+
+# ------------------------------------------------------------------ the golden-pinned statements stay as they are
+def test_golden_pinned_oracle_outputs_are_frozen(oracle):
+    """Every function the tests above check against the reference's goldens (rows a1-a11) keeps returning what it
+    returned when it was pinned: digests of their outputs on fixed inputs (tests/golden/oracle_freeze.json, written by
+    tests/golden/make_oracle_freeze.py).  The build-defined CPM detector statement (oracle/cpm_oracle.c) may be ordered
+    like a kernel and says so in its header; these may not — a reordered accumulation, a changed constant or
+    tie-break shows up here even where a golden is compared with a tolerance."""
+    import importlib.util
+    import json
+
+    from conftest import GOLDEN
+
+    spec = importlib.util.spec_from_file_location("make_oracle_freeze", GOLDEN / "make_oracle_freeze.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.loads((GOLDEN / "oracle_freeze.json").read_text())
+    got = mod.compute()
+    assert got.keys() == want.keys()
+    changed = sorted(k for k in want if got[k] != want[k])
+    assert not changed, f"oracle statements changed their output: {changed}"

@@ -44,7 +44,10 @@ def golden_curve(detector: str):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ebn0", default="0:12")
-    ap.add_argument("--symbols-per-point", type=float, default=1e8)
+    ap.add_argument("--symbols-per-point", type=float, default=1e8,
+                    help="BASELINE configs[3] says 1e8: 1.3e9 symbols = 0.065 s of ONE MI355X, so on 8 GPUs a pass is 8 ms of work "
+                         "per rank against seconds of process start and RCCL bootstrap (reported as init_seconds) — for a "
+                         "strong-scaling curve that measures the GPUs use >= 1e10 per point (>= 6.5 s of work in all)")
     ap.add_argument("--block", type=int, default=10_000_000, help="symbols per trial block (1e7: BASELINE configs[1]'s block, 10 per point)")
     ap.add_argument("--detector", default="PT")
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"])
@@ -64,8 +67,10 @@ def main():
         raise SystemExit(spawn_ranks(str(Path(__file__).resolve()), a.gpus, sys.argv[1:]))
     import torch
 
+    t_start = time.perf_counter()
     # WF_BENCH_REHEARSAL=1: every rank on cuda:0, gloo collectives (N > 1 on a one-GPU box)
-    rank, world, dist, _ = init_ranks(rehearsal=os.environ.get("WF_BENCH_REHEARSAL") == "1")
+    rank, world, dist, coll_dev = init_ranks(rehearsal=os.environ.get("WF_BENCH_REHEARSAL") == "1")
+    init_seconds = time.perf_counter() - t_start       # process-group rendezvous (+ RCCL bootstrap): reported apart from the sweep
     blocks = max(1, int(round(a.symbols_per_point / a.block)))
     plan = SweepPlan(ebn0_db=ebn0, blocks_per_point=blocks, nsym=a.block, seed=a.seed, detector=a.detector, waveform=a.waveform)
     # two passes: the first also pays the process's first-use costs (workspace allocations of ~0.8 GB per block in
@@ -73,10 +78,17 @@ def main():
     passes = []
     for _ in range(max(1, a.passes)):
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()               # every rank starts the pass together ...
         t0 = time.perf_counter()
         counts = ber_sweep(plan)
         torch.cuda.synchronize()
-        passes.append(time.perf_counter() - t0)
+        mine = time.perf_counter() - t0
+        if dist is not None:             # ... and the pass lasts as long as its slowest rank
+            t = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mine = float(t.item())
+        passes.append(mine)
     dt = passes[-1]
     if rank == 0:
         tab = ber_table(ebn0, counts)
@@ -85,6 +97,8 @@ def main():
         for row in tab:
             print(f"Eb/N0 {row['ebn0_db']:5.1f} dB  symbols {row['symbols']:>12d}  SER {row['ser']:.3e}  BER {row['ber']:.3e}")
         out = {"detector": a.detector, "n_gpus": world, "seconds": round(dt, 3), "seconds_first_pass": round(passes[0], 3),
+               "seconds_are": "barrier before the clock, max over ranks", "init_seconds": round(init_seconds, 3),
+               "collective_backend": dist.get_backend() if dist is not None else None, "world_seen": dist.get_world_size() if dist is not None else 1,
                "Msym_per_s": round(int(counts[:, 2].sum()) / dt / 1e6, 1), "table": tab}
         ber = [r["ber"] for r in tab]
         ge, gb = (np.array([]), np.array([]))

@@ -485,17 +485,9 @@ __device__ __forceinline__ void wf_sincos_u32(uint32_t xb, const Tabs &tb, doubl
 template <class Tabs>
 __device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double sigma, const Tabs &tb, double *re, double *im)
 {
-#ifdef WF_ABL_NO_LOG
-    const double r = sigma * ((double)xa + 1.0) * 0x1.0p-32;
-#else
     const double r = sigma * wf_sqrt_pos(-2.0 * wf_log_unit32(xa, tb));
-#endif
     double s, c;
-#ifdef WF_ABL_NO_SINCOS
-    s = (double)xb * 0x1.0p-32; c = 1.0 - s;
-#else
     wf_sincos_u32(xb, tb, &s, &c);
-#endif
     *re = r * c;
     *im = r * s;
 }
@@ -517,13 +509,8 @@ template <class Tabs>
 __device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_id, uint64_t seed, double sigma,
                                                 const Tabs &tb, double g[4])
 {
-#ifdef WF_ABL_NO_PHILOX   // ablation only: NOT a valid generator
-    const wf_philox_out p = {(uint32_t)pair * 2654435761u, (uint32_t)(pair >> 7) ^ (uint32_t)seed,
-                             (uint32_t)pair * 40503u, (uint32_t)stream_id ^ (uint32_t)pair};
-#else
     const wf_philox_out p = wf_philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)stream_id,
                                              (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
-#endif
     wf_box_muller32(p.x0, p.x1, sigma, tb, &g[0], &g[1]);
     wf_box_muller32(p.x2, p.x3, sigma, tb, &g[2], &g[3]);
 }

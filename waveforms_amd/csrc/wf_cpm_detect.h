@@ -42,4 +42,8 @@ struct cpm_lane_plan {
 int wf_cpm_lanes_plan(const wf_cpm_detector_config *det, cpm_lane_plan *plan);
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
                         int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
-                        void *stream);
+                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes);
+// wf_cpm_viterbi_detect for callers that own the memory around the rows (the links: rows sit inside their workspace):
+// slack_*_bytes of it before / behind the array may be READ (never interpreted) by the lane form's row fetch.
+int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
+                             int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes);

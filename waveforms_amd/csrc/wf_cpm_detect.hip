@@ -217,19 +217,12 @@ __device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ row
             const int q = s + 16 * i;
             int64_t row = kb + q / NF;
             row = row < 0 ? 0 : (row >= P.ncalls ? P.ncalls - 1 : row);   // never decoded when clamped
-#ifdef WF_ABL_CPM_SAMEROWS   // ablation only: every chunk reads the same 1 MB of rows (cache-resident)
-            row &= 4095;
-#endif
             const int qq = q < PIECES ? q : 0;
-#ifndef CPM_NO_NT_LOADS    // rows are read once: nontemporal (same-box: ARTM detector 0.7585 / 0.7617 -> 0.7470 / 0.7462 ms, PCM/FM 0.6456 / 0.6473 -> 0.6383 / 0.6406)
             {
                 typedef double v2d __attribute__((ext_vector_type(2)));
                 const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(rows + row * NF + (qq - (qq / NF) * NF)));
                 dst[i] = make_double2(v.x, v.y);
             }
-#else
-            dst[i] = vit_ld16_c(rows + row * NF + (qq - (qq / NF) * NF));
-#endif
         }
     };
     // LDS word index of the slot each of this lane's M candidates goes to (dest = 4 * end state + slot), for
@@ -310,11 +303,7 @@ __device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ row
         const int nr = (int)min(nr_raw, nr_raw - (uint32_t)(2 * P.p));   // mod 2p: the difference wraps to a huge value when nr_raw < 2p
         const uint64_t nh_ = (cpm_bperm_u64(baddr, hist) << LGM) | (uint64_t)u_new;
         double nm = best;      // (lanes that hold no state: metric +inf, candidates parked in their own column, so best = +inf by itself)
-#ifdef WF_ABL_CPM_NOMIN     // ablation only: no 16-lane all-reduce
-        nm -= 0.5 * best;
-#else
         nm -= cpm_row_min(nm);                                          // the minimum becomes exactly 0.0
-#endif
         if (valid) {
             m = nm;
             r = nr;
@@ -543,6 +532,12 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
                                      const double *d_rows_ri, int64_t ncalls, int warmup, uint8_t *d_decisions,
                                      void *d_state, void *stream)
 {
+    return wf_cpm_viterbi_detect_in(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream, 0, 0);
+}
+
+int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
+                             int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes)
+{
     WF_REQUIRE(ctx && det && ncalls >= 0 && warmup >= 0, "wf_cpm_viterbi_detect: bad argument");
     cpm_vit_params P;
     int rc = cpm_build_tables(det, P);
@@ -608,7 +603,7 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     hipStream_t s = wf_stream(stream);
     using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params);
     if (use_lanes) {
-        rc = wf_cpm_lanes_launch(lanes, det, d_rot_cs, d_rows_ri, ncalls, W, P.CH, nchunks, d_decisions, d_state, edge, stream);
+        rc = wf_cpm_lanes_launch(lanes, det, d_rot_cs, d_rows_ri, ncalls, W, P.CH, nchunks, d_decisions, d_state, edge, stream, slack_lo_bytes, slack_hi_bytes);
         if (rc) return rc;
     } else {
         kern_t k = nullptr;
@@ -1049,7 +1044,11 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     }
 #define MARKB(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(back))); } while (0)
     MARKB(6);
-    if ((rc = wf_cpm_viterbi_detect(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, back))) return rc;
+    // (rows sit inside the block's set of intermediates: what lies before them — symbols, the sample region — and behind
+    //  them — the decisions, up to the end of the set — may be read by the lane form's row fetch, so no wave of it clamps)
+    if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, back, (int64_t)L.off_rows,
+                                       (int64_t)(L.total - L.off_rows) - L.ncalls * L.nfilt * 16)))
+        return rc;
     MARKB(7);
     // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] are compared
     const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;

@@ -7,17 +7,19 @@
 // registers of the trellis live in that lane's registers, the trellis permutation is compile-time arithmetic (every array
 // index below is a constant expression, so nothing is indexed dynamically and nothing goes to scratch), the 16 states
 // of a call are independent instruction streams (no cross-lane traffic, no exchange, no wave barrier), and a wave
-// advances 64 chunks per instruction.  Vector instructions per call and chunk: about 9.4 (ARTM, 16 states x 4
-// branches) and 3.6 (PCM/FM, 10 states x 2) against 15.5 and 10.3 in the row form.
+// advances 64 chunks per instruction.  Vector instructions per call and chunk: 10.3 (ARTM, 16 states x 4 branches)
+// and 3.5 (PCM/FM, 10 states x 2) against 15.5 and 10.3 in the row form.
 //
 // Rows reach the lanes through a per-wave LDS ring filled by LDS-DMA (global_load_lds_dwordx4): one instruction moves
-// 1 KiB = the 256 B (16 pieces of 16 B: one ARTM call, four PCM/FM calls) of four consecutive chunks, so HBM sees
-// whole 128 B lines, never a lane-strided gather.  The ring image is lane-linear (the DMA's destination is
-// M0 + lane * 16), so the bank swizzle is applied on the SOURCE side: slot j of chunk c holds piece j ^ (c & 15), and
-// lane c reads piece q at slot q ^ (c & 15) — conflict-free ds_read_b128 (the 16 lanes of a service group hit 16
-// different 4-bank groups).  The DMAs are inline asm (hipcc drains a builtin LDS-DMA with vmcnt(0) before the next
-// ds_read; MI355X guide, "Pipelining across barriers"): R batches in flight per wave, retired by a counted
-// s_waitcnt vmcnt(16 (R - 1)); the ring is private to its wave, so no barrier is involved.
+// 1 KiB = 128 B (8 pieces of 16 B: half an ARTM call, two PCM/FM calls) of eight consecutive chunks, so HBM sees whole
+// 128 B lines, never a lane-strided gather.  A ring slot is 8 KB (8 such instructions: the 64 chunks of the wave); the
+// ring image is lane-linear (the DMA's destination is M0 + lane * 16), so the bank swizzle is applied on the SOURCE
+// side: place j of chunk c holds piece j ^ ((c >> 1) & 7), and lane c reads piece q at place q ^ ((c >> 1) & 7) —
+// conflict-free ds_read_b128 (the 16 lanes of a service group hit 16 different 4-bank groups).  The DMAs are inline asm
+// (hipcc drains a builtin LDS-DMA with vmcnt(0) before the next ds_read; MI355X guide, "Pipelining across barriers"):
+// R slots in flight per wave, retired by a counted s_waitcnt vmcnt(8 (R - 1)); the ring is private to its wave, so no
+// barrier is involved.  The ring is small on purpose — R = 3: 27 KB — because in the pipelined links this kernel runs
+// BESIDE the next block's front end, whose workgroups take 40 KB each: a lane wave has to fit the LDS one of them frees.
 //
 // Arithmetic, tie-breaks and emission are those of the row form and of cpm_oracle.c (the sequential statement kept
 // with the tests), operation for operation: inc = -fma(cos, Re z, sin * Im z), candidate = metric + inc, strict '<'
@@ -31,10 +33,12 @@
 
 #include "wf_cpm_detect.h"
 
-#define LANE_BATCH_BYTES 16384          // one ring slot: 64 chunks x 16 pieces x 16 B
-#define LANE_DMAS 16                    // LDS-DMA instructions per batch (1 KiB each)
+#define LANE_SLOT_PIECES 8              // 16-byte pieces of a chunk per ring slot (one 128-byte line)
+#define LANE_SLOT_BYTES 8192            // one ring slot: 64 chunks x 8 pieces x 16 B
+#define LANE_DMAS 8                     // LDS-DMA instructions per slot (1 KiB each)
 #define LANE_ROT_GAP 2056               // bytes between the cos and the sin column of the rotation table
 #define LANE_ROT_BYTES (LANE_ROT_GAP + 64 * 8)
+#define LANE_LDS_BYTES(R) ((R) * LANE_SLOT_BYTES + LANE_ROT_BYTES)
 
 template <int M_, int LP_, int NC_, int P_, int NH_, int K0_, int K1_>
 struct lane_spec {
@@ -47,8 +51,8 @@ struct lane_spec {
         return r;
     }
     static constexpr int NCORR = ipow(M, LP - 1), MSUB = ipow(M, LP - 2), NF = ipow(M, LP), S = NC * NCORR;
-    static_assert((M == 2 || M == 4) && LP >= 2 && S <= 16 && NF <= 16 && 16 % NF == 0 && P % NC == 0 && 2 * P <= 64,
-                  "lane form: trellis of <= 16 states, <= 16 filters per call, pulse of >= 2 symbols");
+    static_assert((M == 2 || M == 4) && LP >= 2 && S <= 16 && NF >= 4 && NF <= 16 && P % NC == 0 && 2 * P <= 64,
+                  "lane form: trellis of <= 16 states, 4 .. 16 filters per call, pulse of >= 2 symbols");
 };
 
 template <int I, int N, class F>
@@ -115,7 +119,7 @@ __device__ __forceinline__ void lane_dma4(unsigned v0, unsigned v1, unsigned v2,
                  : "memory", "scc");
 }
 
-// One LDS-DMA instruction with a full per-lane address (the waves at either end of the burst, whose rows are clamped).
+// One LDS-DMA instruction with a full per-lane address (the slots at either end of a burst, whose rows are clamped).
 __device__ __forceinline__ void lane_dma1(const void *src, unsigned lds)
 {
     unsigned keep;
@@ -137,6 +141,7 @@ __device__ __forceinline__ void lane_wait_vm()
 
 struct cpm_lane_params {
     int64_t ncalls, nchunks;
+    int64_t slack_lo, slack_hi;     // rows of addressable memory before / behind the row array (0: none promised)
     int CH, W, D;
 };
 
@@ -147,21 +152,21 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                                                          uint64_t *__restrict__ edge, cpm_lane_params P)
 {
     constexpr int S = SP::S, M = SP::M, NF = SP::NF, LGM = SP::LGM, NC = SP::NC, TWO_P = 2 * SP::P;
-    constexpr int B = 16 / NF;                                      // calls per batch
-    static_assert(SP::NH == 1 || (R * B) % 2 == 0, "the leaving symbol's parity must be a constant of the unrolled step");
+    constexpr int UNR = 2;                                           // calls per loop trip: the leaving symbol's parity and every piece's place in its slot are constants
+    static_assert((UNR * NF) % LANE_SLOT_PIECES == 0 && LANE_SLOT_PIECES % M == 0, "a loop trip takes whole slots, a filter group sits inside one");
     static_assert(LANE_DMAS * (R - 1) <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     // Rotation table as two 8-byte columns read by two ds_read_b64 (64-bank mode: the 2p <= 64 entries of a column sit in
     // distinct banks, equal entries are broadcast).  One ds_read2st64_b64 — what the compiler makes of columns 1 KB
     // apart — is served in 32-bank mode, where entries 16 apart collide: 40 % of this kernel's LDS cycles were bank
-    // conflicts (profiles/r04_pmc_lane_*).  LANE_ROT_GAP is neither a ds_read2_b64 nor a ds_read2st64_b64 distance.
-    double *rot_cos = reinterpret_cast<double *>(smem + R * LANE_BATCH_BYTES);
-    double *rot_sin = reinterpret_cast<double *>(smem + R * LANE_BATCH_BYTES + LANE_ROT_GAP);
+    // conflicts (profiles/r04_pmc_lane_first.json).  LANE_ROT_GAP is neither a ds_read2_b64 nor a ds_read2st64_b64 distance.
+    char *const rot_cos = smem + R * LANE_SLOT_BYTES;
+    char *const rot_sin = smem + R * LANE_SLOT_BYTES + LANE_ROT_GAP;
     for (int k = lane; k < TWO_P; k += 64) {
         const double2 e = rot_cs[k];
-        rot_cos[k] = e.x;
-        rot_sin[k] = e.y;
+        reinterpret_cast<double *>(rot_cos)[k] = e.x;
+        reinterpret_cast<double *>(rot_sin)[k] = e.y;
     }
     if (blockIdx.x == 0 && lane == 0) edge[P.nchunks * CPM_EDGE_WORDS] = 0;     // cpm_verify_kernel's list of failed chunks: none yet
     const int64_t n0 = state ? lane_uniform64((int64_t)state[CPM_ST_N]) : 0;    // calls made before this launch
@@ -172,14 +177,18 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     // The step is unrolled with the leaving symbol's parity as a constant: the wave starts its warm-up one call
     // earlier when that makes the parity of its first call 0 (chunk starts and chunk lengths are even).
     const int Weff = P.W + (SP::NH == 2 ? (int)((n0 - P.W - SP::LP + 1) & 1) : 0);
-    const int T = Weff + P.CH;                                       // calls a lane runs
-    const int nb = (T + B - 1) / B;                                  // batches
+    const int T = __builtin_amdgcn_readfirstlane(Weff + P.CH);        // calls a lane runs (uniform, and said so: see fetch)
+    const int nslots = (int)(((int64_t)T * NF + LANE_SLOT_PIECES - 1) / LANE_SLOT_PIECES);
     const int dshift = LGM * (P.D - 1) - (DHI ? 32 : 0);            // inside its 32-bit half
 
-    // detector registers of this chunk
+    // Detector state of this chunk.  (Tried: the decision registers in LDS, [state][lane], the winner's fetched by
+    // address from ONE selected word — rotation offset | register address — instead of two more v_cndmask_b32 per
+    // candidate: 14 % fewer vector instructions, 30 registers less, and 7 % (ARTM) / 22 % (PCM/FM) SLOWER on the same
+    // box: 623 -> 666 us and 236 -> 288 us; the register form stays.)
     double m[S];
-    int r[S];
+    uint32_t r8[S];                                                  // 8 r: byte offset of the survivor's rotation in a table column
     uint64_t h[S];
+    constexpr uint32_t TWO_P8 = 8u * TWO_P;
     {
         const int64_t k_start = chunk == 0 ? 0 : k_first - Weff;     // first call this lane really runs
         const int tilt = cpm_tilt(M, SP::P, SP::NH, SP::K0, SP::K1, SP::LP, n0 + k_start);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
             constexpr int s = decltype(sc)::value;
             m[s] = 0.0;
             const int v = 2 * (s % NC) - tilt;
-            r[s] = v < 0 ? v + TWO_P : v;
+            r8[s] = 8u * (uint32_t)(v < 0 ? v + TWO_P : v);
             h[s] = 0;
         });
     }
@@ -195,19 +204,39 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
         lane_for<0, S>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             m[s] = __longlong_as_double((long long)state[CPM_ST_M + s]);
-            r[s] = (int)state[CPM_ST_V + s];
+            r8[s] = 8u * (uint32_t)state[CPM_ST_V + s];
             h[s] = state[CPM_ST_H + s];
         });
     }
     uint64_t *const erec = edge + chunk * CPM_EDGE_WORDS;            // (written only when the chunk is live)
     uint64_t acc = 0;                                                // decisions of the current group of 8 calls, one byte each
 
+    // What a group of start states (one `corr`) needs: its M filter outputs and the NC rotations of its survivors.
+    struct operands {
+        double2 z[M];
+        double cr[NC], sr[NC];
+    };
+    auto load_rot = [&](auto cc, operands &o) __attribute__((always_inline)) {
+        lane_for<0, NC>([&](auto lc) {
+            constexpr int src = decltype(lc)::value + NC * decltype(cc)::value;
+            o.cr[decltype(lc)::value] = *reinterpret_cast<const double *>(rot_cos + r8[src]);
+            o.sr[decltype(lc)::value] = *reinterpret_cast<const double *>(rot_sin + r8[src]);
+        });
+    };
+    operands first;     // group 0 of the call about to run, requested by the call before it (pipelined calls only)
+
     // One detector call.  KV: the leaving symbol's variant (compile-time); zsrc(f): filter output f of this call.
-    auto step = [&](auto kvc, auto &&zsrc, bool emit, bool emit_ok, int group_pos) __attribute__((always_inline)) {
+    // PIPE: group 0's operands were requested by the previous call (`first`), and this call requests the next one's —
+    // znext(f): filter output f of the NEXT call — before its own tail (normalisation, decision registers, emission):
+    // the tail's ~80 vector instructions hide that round trip, and the slot hand-over (DMA issue + counted wait) that
+    // znext may carry sits there too, instead of in front of a call whose first group then waits for its operands
+    // (profiles/r04_ab_lane_pipe.log).
+    auto step = [&](auto kvc, auto pipec, auto &&zsrc, auto &&znext, bool emit, bool emit_ok, int group_pos) __attribute__((always_inline)) {
         constexpr int KV = decltype(kvc)::value;
+        constexpr bool PIPE = decltype(pipec)::value;
         constexpr int K_old = KV == 2 ? 0 : (KV == 1 ? SP::K1 : SP::K0);
         double nm[S];
-        int nr[S];
+        uint32_t nr8[S];
         uint64_t nh[S];
         // Start states grouped by `corr` (their Lp - 1 previous symbols): a group needs M filter outputs and NC rotations
         // and hands exactly one candidate to each of NC * M end states — in the order of the sequential statement's branch list (start
@@ -216,36 +245,28 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
         // registers for ARTM, a third of them parked in AGPRs, and as many compare masks as the SGPR file holds.)
         // A lane is alone on its SIMD for most of a burst (1e7 calls make ~600 waves for 1024 SIMDs), so nothing but
         // its own instruction stream hides an LDS round trip: the operands of group g + 1 are requested BEFORE group g
-        // is worked (profiles/r04_pmc_lane_*: 29 % of the wave's cycles sat in s_waitcnt lgkmcnt without it).
-        struct operands {
-            double2 z[M];
-            double cr[NC], sr[NC];
-        };
+        // is worked (profiles/r04_pmc_lane_first.json: 29 % of the wave's cycles sat in s_waitcnt lgkmcnt without it).
         auto load_group = [&](auto cc, operands &o) __attribute__((always_inline)) {
             constexpr int corr = decltype(cc)::value;
             lane_for<0, M>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 o.z[u] = zsrc(std::integral_constant<int, u + M * corr>{});
             });
-            lane_for<0, NC>([&](auto lc) {
-                constexpr int src = decltype(lc)::value + NC * corr;
-                o.cr[decltype(lc)::value] = rot_cos[r[src]];
-                o.sr[decltype(lc)::value] = rot_sin[r[src]];
-            });
+            load_rot(cc, o);
         };
         auto run_group = [&](auto self, auto cc, const operands &o) __attribute__((always_inline)) -> void {
             constexpr int corr = decltype(cc)::value;
             constexpr int u_old = corr / SP::MSUB;                   // the symbol leaving the window: slot index of these candidates
             constexpr int inc = (K_old * u_old) % SP::P;
-            constexpr int delta = ((2 * inc - (M - 1) * K_old) % TWO_P + TWO_P) % TWO_P;   // what the branch adds to the TILTED phase index
+            constexpr uint32_t delta8 = 8u * (uint32_t)(((2 * inc - (M - 1) * K_old) % TWO_P + TWO_P) % TWO_P);   // what the branch adds to the TILTED phase index
             operands nx;
             if constexpr (corr + 1 < SP::NCORR) load_group(std::integral_constant<int, corr + 1>{}, nx);
             lane_for<0, NC>([&](auto lc) {
                 constexpr int cls = decltype(lc)::value;
                 constexpr int src = cls + NC * corr;
                 const double cr = o.cr[cls], sr = o.sr[cls];
-                const uint32_t x = (uint32_t)(r[src] + delta);                              // < 4p
-                const int rs = (int)min(x, x - (uint32_t)TWO_P);                          // mod 2p: the difference wraps to a huge value when x < 2p
+                const uint32_t x = r8[src] + delta8;                                        // < 4p (x 8)
+                const uint32_t rs = min(x, x - TWO_P8);                                    // mod 2p: the difference wraps to a huge value when x < 2p
                 lane_for<0, M>([&](auto uc) {
                     constexpr int u = decltype(uc)::value;
                     constexpr int e = (cls + inc) % NC + NC * (u + M * (corr % SP::MSUB));
@@ -253,16 +274,16 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                     const double c = m[src] + inc_m;
                     if constexpr (u_old == 0) {
                         nm[e] = c;
-                        nr[e] = rs;
+                        nr8[e] = rs;
                         nh[e] = h[src];
                     } else {
                         const bool f = c < nm[e];
                         nm[e] = lane_min(nm[e], c);
-                        nr[e] = f ? rs : nr[e];
+                        nr8[e] = f ? rs : nr8[e];
                         nh[e] = f ? h[src] : nh[e];
-                        // (pins the phase select next to its compare: nothing needs nr before the end of the call, so the
+                        // (pins the selects next to their compare: nothing needs them before the end of the call, so the
                         // optimiser sank all 48 of them — and their 48 lane masks, the whole scalar file — below the emission)
-                        asm volatile("" : "+v"(nr[e]));
+                        asm volatile("" : "+v"(nr8[e]), "+v"(nh[e]));
                     }
                 });
                 // (the M candidates of a start state end here for the instruction scheduler: left free, it lines up all
@@ -272,16 +293,23 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
             });
             if constexpr (corr + 1 < SP::NCORR) self(self, std::integral_constant<int, corr + 1>{}, nx);
         };
-        {
+        if constexpr (PIPE) {
+            const operands o0 = first;
+            run_group(run_group, std::integral_constant<int, 0>{}, o0);
+        } else {
             operands o0;
             load_group(std::integral_constant<int, 0>{}, o0);
             run_group(run_group, std::integral_constant<int, 0>{}, o0);
+        }
+        lane_for<0, S>([&](auto sc) { r8[decltype(sc)::value] = nr8[decltype(sc)::value]; });
+        if constexpr (PIPE) {                                        // the next call's first group: its survivors' phases are known now
+            lane_for<0, M>([&](auto uc) { first.z[decltype(uc)::value] = znext(uc); });
+            load_rot(std::integral_constant<int, 0>{}, first);
         }
         const double gmin = lane_tree_min<0, S, S>(nm);
         lane_for<0, S>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             m[s] = nm[s] - gmin;                                     // the minimum becomes exactly 0.0
-            r[s] = nr[s];
             h[s] = (nh[s] << LGM) | (uint64_t)((s / NC) % M);        // the newest symbol of every branch into s
         });
         if (emit) {
@@ -301,145 +329,206 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     };
     using kv2 = std::integral_constant<int, 2>;
 
+    // EVERY lane runs EVERY call of the loop below — the row fetch inside a call is the whole wave's business (a lane
+    // fetches pieces of other lanes' chunks), so no call may sit in divergent control flow.  Lanes whose call is not
+    // theirs to run compute on whatever the clamped rows hold, and what must not see that is kept out of its way:
+    //   - chunk 0 has no warm-up: its lane is handed its true state when its first own call comes up (t == t_first0);
+    //   - a chunk ends where the burst ends: its end record and the carry are written when its last call is done
+    //     (t + 1 == t_hi), not after the loop; decisions past t_hi are never stored;
+    //   - lanes without a chunk fetch a live chunk's rows again and write nothing.
     // Virtual pre-start symbols: the first LP - 1 calls of a fresh burst have no symbol leaving the window (variant 2).
     // Only chunk 0 meets them; it runs them here, straight from global memory, and skips them in the loop.
-    int64_t kmin = 0;
-    if (chunk == 0 && n0 < SP::LP - 1) {
-        kmin = SP::LP - 1 - n0;
-        if (kmin > P.ncalls) kmin = P.ncalls;
-        for (int64_t k = 0; k < kmin; ++k) {
+    const int64_t kmin0 = n0 < SP::LP - 1 ? (SP::LP - 1 - n0 < P.ncalls ? SP::LP - 1 - n0 : P.ncalls) : 0;     // (uniform)
+    if (chunk == 0) {
+        for (int64_t k = 0; k < kmin0; ++k) {
             const double2 *zr = rows + k * NF;
-            step(kv2{}, [&](auto fc) { return zr[decltype(fc)::value]; }, true, n0 + k >= P.D - 1, (int)(k & 7));
+            auto zg = [&](auto fc) { return zr[decltype(fc)::value]; };
+            step(kv2{}, std::false_type{}, zg, zg, true, n0 + k >= P.D - 1, (int)(k & 7));
         }
+        // parked in chunk 0's own start record (nothing else reads that one) until the loop reaches its first call
+        lane_for<0, S>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            erec[3 * s] = (uint64_t)__double_as_longlong(m[s]);
+            erec[3 * s + 1] = (uint64_t)r8[s];
+            erec[3 * s + 2] = h[s];
+        });
     }
-    // Call t of the loop is local call kbase + t.  What a lane may run, as 32-bit bounds on t (64-bit compares per call
-    // cost the loop its scalar registers): [t_lo, t_hi) = inside the burst, live, not run above; t_ok: first call that decides.
+    // Call t of the loop is local call kbase + t.  32-bit bounds on t (64-bit compares per call cost the loop its scalar
+    // registers): t_hi = end of what this lane owns (0: nothing), t_ok = first call whose decision counts.
     const int64_t kbase = k_first - Weff;
     auto clamp_t = [&](int64_t v) __attribute__((always_inline)) { return (int)(v < 0 ? 0 : (v > T ? T : v)); };
-    const int t_lo = clamp_t(kmin - kbase);
+    const int t_first0 = Weff + (int)kmin0;                          // (uniform) chunk 0's first call inside the loop
     const int t_hi = live ? clamp_t(P.ncalls - kbase) : 0;
-    const int t_ok = clamp_t((int64_t)P.D - 1 - n0 - kbase);
+    const int t_ok = max(clamp_t((int64_t)P.D - 1 - n0 - kbase), chunk == 0 ? t_first0 : 0);
     uint8_t *const outp = out + kbase;                               // out[k] = outp[t]
+    const bool owns_last = state && live && k_first + P.CH >= P.ncalls;
 
-    // ---- the ring
+    // ---- the ring.  A lane's rows are one stream of 16-byte pieces, NF per call; slot s of the ring holds pieces
+    // [8 s, 8 s + 8) of every chunk of the wave.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-    const int c0 = lane >> 4, j0 = lane & 15;
-    // (uniform) every row this wave will ever ask for exists: the DMAs take base + per-lane offset, no clamping
-    const bool interior = blockIdx.x > 0 && (chunk0 + 64) * P.CH + B <= P.ncalls;
+    const int c8 = lane >> 3, j8 = lane & 7;
+    // The DMAs take a uniform base + a per-lane offset, nothing per lane is clamped.  That is right while every row the
+    // wave asks for exists: from slot fast_lo (the rows of chunk 0's warm-up lie before the burst) to slot fast_hi (a
+    // burst ends inside, or short of, the last wave's chunks) — outside that range, in the wave at either end of a
+    // burst, every DMA works out and clamps its own row.  (Both waves went through the careful form for ALL their
+    // slots at first: 35 % more instructions per call, and a launch lasts as long as its slowest wave.)  Lanes
+    // without a chunk fetch the wave's last live chunk again.  slack_lo / slack_hi: rows of addressable memory the
+    // caller vouches for before and behind the array (the link's workspace has them: no careful slot at all).
+    const int64_t cg_last = chunk0 + 63 < P.nchunks - 1 ? chunk0 + 63 : P.nchunks - 1;     // last live chunk of the wave
+    int fast_lo, fast_hi;
+    {
+        // slot s reads rows floor(8 s / NF) .. floor((8 s + 7) / NF) of a chunk's stream, i.e. absolute rows kbase(chunk) + those
+        const int64_t need_lo = Weff - chunk0 * P.CH - P.slack_lo;                       // first stream row that is >= -slack_lo for chunk0
+        fast_lo = need_lo <= 0 ? 0 : (int)((need_lo * NF + LANE_SLOT_PIECES - 1) / LANE_SLOT_PIECES);
+        const int64_t room = P.ncalls + P.slack_hi + Weff - cg_last * P.CH;              // stream rows of the last live chunk that exist
+        const int64_t hi = room <= 0 ? -1 : (room * NF) / LANE_SLOT_PIECES - 1;          // last slot that lies wholly inside them
+        fast_hi = hi > 0x3fffffff ? 0x3fffffff : (int)hi;
+    }
+    const double2 *const srow0 = rows + (chunk0 * P.CH - Weff) * NF;     // piece 0 of the wave's first chunk's stream (may lie before the array)
     unsigned voff[LANE_DMAS];
     lane_for<0, LANE_DMAS>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const int c = 4 * i + c0;                                    // chunk of the wave this lane fetches for in DMA i
-        const int q = j0 ^ (c & 15);                                 // ... and which of its 16 pieces
+        int c = 8 * i + c8;                                          // chunk of the wave this lane fetches for in DMA i
+        const int q = j8 ^ ((c >> 1) & 7);                           // ... and which of the slot's 8 pieces
+        c = chunk0 + c <= cg_last ? c : (int)(cg_last - chunk0);
         voff[i] = ((unsigned)c * (unsigned)P.CH * NF + (unsigned)q) * 16u;
     });
-    auto fetch = [&](int b, int slot) __attribute__((always_inline)) {
-        const int bb = b < nb ? b : nb - 1;                          // (past the end: the last batch again — the count of DMAs in flight must not change)
-        const unsigned lds = lds0 + (unsigned)slot * LANE_BATCH_BYTES;
-        if (interior) {
-            const double2 *sb = rows + ((chunk0 * P.CH - Weff + (int64_t)bb * B) * NF);
-            lane_dma4(voff[0], voff[1], voff[2], voff[3], sb, lds);
-            lane_dma4(voff[4], voff[5], voff[6], voff[7], sb, lds + 4096);
-            lane_dma4(voff[8], voff[9], voff[10], voff[11], sb, lds + 8192);
-            lane_dma4(voff[12], voff[13], voff[14], voff[15], sb, lds + 12288);
+    auto fetch = [&](int s, unsigned lds) __attribute__((always_inline)) {
+        const int ss = s < nslots ? s : nslots - 1;                  // (past the end: the last slot again — the count of DMAs in flight must not change)
+        if (ss >= fast_lo && ss <= fast_hi) {
+            // (uniform by construction; said so explicitly — the ring counters are loop-carried through the call lambdas and
+            //  the compiler's divergence analysis gives up on them, handing a VGPR pair to an SGPR operand)
+            const double2 *sb = reinterpret_cast<const double2 *>(lane_uniform64((int64_t)(uintptr_t)(srow0 + (int64_t)ss * LANE_SLOT_PIECES)));
+            const unsigned ld = __builtin_amdgcn_readfirstlane(lds);
+            lane_dma4(voff[0], voff[1], voff[2], voff[3], sb, ld);
+            lane_dma4(voff[4], voff[5], voff[6], voff[7], sb, ld + 4096);
         } else {
-            // (cold: two waves of a burst.  Everything is re-derived from values made opaque here, so that none of it is
-            // hoisted out of the call loop into registers the interior waves would pay for)
-            int cz = c0;
-            unsigned lz = lds;
+            // (cold, and kept small: a rolled loop that re-derives everything from values made opaque here, so that none of
+            // it is unrolled into, or hoisted out of, the call loop at the cost of registers every other slot would pay for)
+            int cz = c8;
+            unsigned lz = __builtin_amdgcn_readfirstlane(lds);
             asm volatile("" : "+v"(cz), "+s"(lz));
-            lane_for<0, LANE_DMAS>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const int c = 4 * i + cz;
-                const int q = j0 ^ (c & 15);
-                int64_t row = (chunk0 + c) * P.CH - Weff + (int64_t)bb * B + q / NF;
-                row = row < 0 ? 0 : (row >= P.ncalls ? P.ncalls - 1 : row);          // never decoded when clamped
-                lane_dma1(rows + row * NF + (q % NF), lz + 1024u * i);
-            });
+#pragma unroll 1
+            for (int i = 0; i < LANE_DMAS; ++i) {
+                const int c = 8 * i + cz;
+                const int q = j8 ^ ((c >> 1) & 7);
+                const int64_t piece = (int64_t)ss * LANE_SLOT_PIECES + q;                // of the chunk's stream
+                int64_t row = (chunk0 + c) * P.CH - Weff + piece / NF;
+                row = row < 0 ? 0 : (row >= P.ncalls ? P.ncalls - 1 : row);              // never decoded when clamped
+                lane_dma1(rows + row * NF + (piece % NF), lz + 1024u * i);
+            }
         }
     };
-    const unsigned lds_lane = (unsigned)lane * 256u + (unsigned)j0 * 16u;           // this chunk's 256 B of a slot, swizzle folded in
+    const unsigned lds_lane = (unsigned)lane * 128u + (unsigned)((lane >> 1) & 7) * 16u;   // this chunk's 128 B of a slot, swizzle folded in
 
-    for (int b = 0; b < R - 1; ++b) fetch(b, b);
-    for (int b0 = 0; b0 < nb; b0 += R) {
-        lane_for<0, R>([&](auto rc) {
-            constexpr int RS = decltype(rc)::value;
-            const int b = b0 + RS;
-            if (b < nb) {
-                fetch(b + R - 1, (RS + R - 1) % R);                  // into the slot batch b - 1 was read from
-                lane_wait_vm<LANE_DMAS * (R - 1)>();                 // batch b has landed (this wave's own DMAs: no barrier)
-                lane_for<0, B>([&](auto tc) {
-                    constexpr int TT = decltype(tc)::value;
-                    constexpr int KV = SP::NH == 2 ? ((RS * B + TT) & 1) : 0;
-                    const int t = b * B + TT;
-                    if (t == Weff && live) {                         // the next call is the chunk's first own one
-                        lane_for<0, S>([&](auto sc) {
-                            constexpr int s = decltype(sc)::value;
-                            erec[3 * s] = (uint64_t)__double_as_longlong(m[s]);
-                            erec[3 * s + 1] = (uint64_t)(int64_t)r[s];
-                            erec[3 * s + 2] = h[s];
+    // ring state (uniform): slot index / ring position of the next fetch and of the next slot to read
+    int s_fetch = 0;
+    unsigned p_fetch = 0, p_read = 0;
+    auto next_pos = [](unsigned p) __attribute__((always_inline)) { return p + 1 == (unsigned)R ? 0u : p + 1; };
+    for (int k = 0; k < R - 1; ++k) {
+        fetch(s_fetch++, lds0 + p_fetch * LANE_SLOT_BYTES);
+        p_fetch = next_pos(p_fetch);
+    }
+    unsigned zbase = 0;                                              // LDS byte offset (from smem) of the slot being read
+    // the next slot: one more fetch goes out (into the position read before this one), the oldest one in flight lands
+    auto acquire = [&]() __attribute__((always_inline)) {
+        fetch(s_fetch++, lds0 + p_fetch * LANE_SLOT_BYTES);
+        p_fetch = next_pos(p_fetch);
+        lane_wait_vm<LANE_DMAS * (R - 1)>();                         // (this wave's own DMAs: no barrier)
+        zbase = p_read * LANE_SLOT_BYTES;
+        p_read = next_pos(p_read);
+    };
+
+    // filter output f of call UC of a loop trip (UC == UNR: call 0 of the next trip — the same places of the next slots)
+    auto zring = [&](auto ucc, auto fc) __attribute__((always_inline)) {
+        constexpr int piece = (decltype(ucc)::value % UNR) * NF + decltype(fc)::value;   // within the loop trip
+        constexpr int q = piece % LANE_SLOT_PIECES;
+        if constexpr (q == 0) acquire();                             // the first piece of a slot: hand-over
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d v = *reinterpret_cast<const v2d *>(smem + zbase + (lds_lane ^ (unsigned)(q * 16)));
+        return make_double2(v.x, v.y);
+    };
+    {   // the first call's first group
+        lane_for<0, M>([&](auto uc) { first.z[decltype(uc)::value] = zring(std::integral_constant<int, 0>{}, uc); });
+        load_rot(std::integral_constant<int, 0>{}, first);
+    }
+    // (t0 is uniform, and said so on every trip: the compiler otherwise carries the counter per lane and runs the whole
+    //  loop under an exec mask it keeps — and spills — in scalar registers)
+    for (int t0 = 0; t0 < T; t0 = __builtin_amdgcn_readfirstlane(t0 + UNR)) {
+        lane_for<0, UNR>([&](auto ucc) {
+            constexpr int UC = decltype(ucc)::value;
+            constexpr int KV = SP::NH == 2 ? (UC & 1) : 0;
+            const int t = t0 + UC;
+            if (t < T) {
+                if (t == Weff && live && chunk != 0) {               // the next call is the chunk's first own one
+                    lane_for<0, S>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        erec[3 * s] = (uint64_t)__double_as_longlong(m[s]);
+                        erec[3 * s + 1] = (uint64_t)(r8[s] >> 3);
+                        erec[3 * s + 2] = h[s];
+                    });
+                }
+                if (blockIdx.x == 0 && t == t_first0 && chunk == 0) {   // chunk 0: its true state, parked above
+                    lane_for<0, S>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        m[s] = __longlong_as_double((long long)erec[3 * s]);
+                        r8[s] = (uint32_t)erec[3 * s + 1];
+                        h[s] = erec[3 * s + 2];
+                    });
+                    load_rot(std::integral_constant<int, 0>{}, first);  // (requested with the phases of the warm-up it never had)
+                }
+                const bool emit = t >= Weff;
+                const int gp = (t - Weff) & 7;
+                step(std::integral_constant<int, KV>{}, std::true_type{}, [&](auto fc) __attribute__((always_inline)) { return zring(ucc, fc); },
+                     [&](auto fc) __attribute__((always_inline)) { return zring(std::integral_constant<int, UC + 1>{}, fc); }, emit, t >= t_ok, gp);
+                if (emit && gp == 7) {                               // a group of 8 decisions is complete (uniform)
+                    if (t < t_hi) {
+                        *reinterpret_cast<uint64_t *>(outp + (t - 7)) = acc;
+                    } else if (t - 7 < t_hi) {                       // the burst ends inside the group
+                        lane_for<0, 7>([&](auto qc) {                // (straight-line: a lane-dependent trip count made the whole call loop divergent)
+                            constexpr int q = decltype(qc)::value;
+                            if (t - 7 + q < t_hi) outp[t - 7 + q] = (uint8_t)(acc >> (8 * q));
                         });
                     }
-                    const bool emit = t >= Weff;
-                    const int gp = (t - Weff) & 7;
-                    if (t >= t_lo && t < t_hi) {
-                        const char *zb = smem + RS * LANE_BATCH_BYTES;
-                        step(std::integral_constant<int, KV>{},
-                             [&](auto fc) {
-                                 constexpr int q = TT * NF + decltype(fc)::value;
-                                 typedef double v2d __attribute__((ext_vector_type(2)));
-                                 const v2d v = *reinterpret_cast<const v2d *>(zb + (lds_lane ^ (unsigned)(q * 16)));
-                                 return make_double2(v.x, v.y);
-                             },
-                             emit, t >= t_ok, gp);
+                    acc = 0;
+                }
+                if (t + 1 == t_hi) {                                 // this chunk's last call: its end record, and the carry if it owns the burst's last call
+                    lane_for<0, S>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        erec[48 + 3 * s] = (uint64_t)__double_as_longlong(m[s]);
+                        erec[48 + 3 * s + 1] = (uint64_t)(r8[s] >> 3);
+                        erec[48 + 3 * s + 2] = h[s];
+                    });
+                    if (owns_last) {
+                        uint64_t *const st = state;
+                        st[CPM_ST_STAGE + CPM_ST_N] = (uint64_t)(n0 + P.ncalls);
+                        lane_for<0, S>([&](auto sc) {
+                            constexpr int s = decltype(sc)::value;
+                            st[CPM_ST_STAGE + CPM_ST_M + s] = (uint64_t)__double_as_longlong(m[s]);
+                            st[CPM_ST_STAGE + CPM_ST_V + s] = (uint64_t)(r8[s] >> 3);
+                            st[CPM_ST_STAGE + CPM_ST_H + s] = h[s];
+                        });
                     }
-                    if (emit && gp == 7 && t < T) {                  // a group of 8 decisions is complete (uniform)
-                        if (t < t_hi) {
-                            *reinterpret_cast<uint64_t *>(outp + (t - 7)) = acc;
-                        } else if (t - 7 < t_hi) {                   // the burst ends inside the group
-                            for (int q = 0; t - 7 + q < t_hi; ++q) outp[t - 7 + q] = (uint8_t)(acc >> (8 * q));
-                        }
-                        acc = 0;
-                    }
-                });
+                }
             }
         });
     }
     lane_wait_vm<0>();
-    // proof record: what this chunk ended with
-    if (live) {
-        lane_for<0, S>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            erec[48 + 3 * s] = (uint64_t)__double_as_longlong(m[s]);
-            erec[48 + 3 * s + 1] = (uint64_t)(int64_t)r[s];
-            erec[48 + 3 * s + 2] = h[s];
-        });
-    }
-    if (state && live && k_first + P.CH >= P.ncalls) {              // the lane that owns the last call
-        state[CPM_ST_STAGE + CPM_ST_N] = (uint64_t)(n0 + P.ncalls);
-        lane_for<0, S>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            state[CPM_ST_STAGE + CPM_ST_M + s] = (uint64_t)__double_as_longlong(m[s]);
-            state[CPM_ST_STAGE + CPM_ST_V + s] = (uint64_t)(int64_t)r[s];
-            state[CPM_ST_STAGE + CPM_ST_H + s] = h[s];
-        });
-    }
 }
 
 // ---- the compiled specialisations: the two waveforms BASELINE configs[2] and SURVEY 8(f3) name
 using lane_artm16 = lane_spec<4, 2, 4, 16, 2, 4, 5>;     // ARTM multi-h CPM, h = {4/16, 5/16}, pulse truncated to 2 symbols, 4 phase classes
 using lane_pcmfm10 = lane_spec<2, 2, 5, 10, 1, 7, 7>;    // PCM/FM, h = 7/10, 5 phase classes
-// Ring depth R (batches of 16 KB in flight per wave) decides how many waves a CU holds (160 KB of LDS) against how far
-// ahead of the detector the rows are fetched.  WF_CPM_LANE_R selects another compiled depth (tuning aid).
-#define LANE_R_ARTM 4
-#define LANE_R_PCMFM 3
+// Ring depth R (slots of 8 KB in flight per wave) decides how much LDS a wave takes against how far ahead of the
+// detector the rows are fetched (ARTM: two slots per call).  WF_CPM_LANE_R selects another compiled depth (tuning aid).
+#define LANE_R_DEFAULT 3
 
-static int lane_ring_depth(int spec)
+static int lane_ring_depth()
 {
-    int r = spec == 0 ? LANE_R_ARTM : LANE_R_PCMFM;
+    int r = LANE_R_DEFAULT;
     if (const char *e = getenv("WF_CPM_LANE_R")) {
         const int v = atoi(e);
-        if (v == 2 || (spec == 0 && v == 4) || (spec == 1 && v == 3)) r = v;
+        if (v == 2 || v == 3 || v == 4) r = v;
     }
     return r;
 }
@@ -452,28 +541,34 @@ int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
     if (d->M == 4 && d->Lp == 2 && d->NC == 4 && d->p == 16 && d->nh == 2 && d->K[0] == 4 && d->K[1] == 5 && d->D >= 17 && d->D <= 32) spec = 0;
     if (d->M == 2 && d->Lp == 2 && d->NC == 5 && d->p == 10 && d->nh == 1 && d->K[0] == 7 && d->D >= 1 && d->D <= 32) spec = 1;
     if (spec < 0) return 1;
-    const int R = lane_ring_depth(spec);
-    int per_cu = (160 * 1024) / (R * LANE_BATCH_BYTES + LANE_ROT_BYTES);
-    if (per_cu > 8) per_cu = 8;
+    const int R = lane_ring_depth();
+    int per_cu = (160 * 1024) / LANE_LDS_BYTES(R);
+    if (per_cu > 4) per_cu = 4;                 // one wave per SIMD: 250 registers (ARTM) leave room for nothing else of this kernel
     *plan = {spec, R, per_cu, spec == 0 ? 1 : 4};
     return 0;
 }
 
+template <class SP, bool DHI>
+static auto lane_pick(int R)
+{
+    using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, cpm_lane_params);
+    return R == 2 ? static_cast<kern_t>(cpm_lane_kernel<SP, 2, DHI>) : (R == 4 ? static_cast<kern_t>(cpm_lane_kernel<SP, 4, DHI>) : static_cast<kern_t>(cpm_lane_kernel<SP, 3, DHI>));
+}
+
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
                         int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
-                        void *stream)
+                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes)
 {
     WF_REQUIRE(chunk_calls >= 64 && chunk_calls % 64 == 0 && warmup >= 0 && warmup % 2 == 0 && chunk_calls > warmup + 1,
                "wf_cpm_lanes: chunk of %d calls, warm-up %d", chunk_calls, warmup);
     WF_REQUIRE((int64_t)64 * chunk_calls * 16 * 16 < (1ll << 32), "wf_cpm_lanes: chunk of %d calls overflows the 32-bit row offsets", chunk_calls);
-    cpm_lane_params P{ncalls, nchunks, chunk_calls, warmup, det->D};
+    int nf = 1;
+    for (int i = 0; i < det->Lp; ++i) nf *= det->M;
+    cpm_lane_params P{ncalls, nchunks, slack_lo_bytes / (16 * nf), slack_hi_bytes / (16 * nf), chunk_calls, warmup, det->D};
     const int64_t nblocks = (nchunks + 63) / 64;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_lanes: burst too long for one launch");
-    const size_t lds = (size_t)plan.ring_batches * LANE_BATCH_BYTES + LANE_ROT_BYTES;
-    using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, cpm_lane_params);
-    kern_t k;
-    if (plan.spec == 0) k = plan.ring_batches == 2 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, 2, true>) : static_cast<kern_t>(cpm_lane_kernel<lane_artm16, 4, true>);
-    else k = plan.ring_batches == 2 ? static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, 2, false>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, 3, false>);
+    const size_t lds = (size_t)LANE_LDS_BYTES(plan.ring_batches);
+    const auto k = plan.spec == 0 ? lane_pick<lane_artm16, true>(plan.ring_batches) : lane_pick<lane_pcmfm10, false>(plan.ring_batches);
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64), lds, wf_stream(stream), reinterpret_cast<const double2 *>(d_rows_ri),

@@ -95,7 +95,6 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
             const int vlo = lo64 > 0 ? (lo64 < P.span ? (int)lo64 : P.span) : 0;
             const int vhi = hi64 < P.span ? (hi64 > 0 ? (int)hi64 : 0) : P.span;
             const double2 *rp = reinterpret_cast<const double2 *>(r) + ws;   // dereferenced only inside [vlo, vhi)
-#ifndef WF_ABL_NO_INTERIOR
             if (vlo == 0 && vhi == P.span) {
                 // interior window (all but the first and last workgroup iterations of a burst): every
                 // offset is a burst sample, so there are no per-lane bounds.  The trip count is
@@ -127,14 +126,9 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                     pair += MF_THREADS;
                 }
             } else
-#endif
             {
             auto fetch = [&](int w) {
-#ifdef WF_ABL_NO_MEM   // ablation only: no global traffic
-                return make_double2((double)w, 1.0);
-#else
                 return (w >= vlo && w < vhi) ? rp[w] : make_double2(0.0, 0.0);
-#endif
             };
             int w0 = 2 * t - odd;                                      // offset of the even half (-1 possible)
             double2 c0 = fetch(w0), c1 = fetch(w0 + 1);
@@ -205,7 +199,6 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 double2 x[NTAPS ? NTAPS : 1];
 #pragma unroll
                 for (int j = 0; j < NTAPS; ++j) x[j] = s_win[base + j + (STEP % 2 == 0 ? j / STEP : 0)];
-#ifndef WF_ABL_NO_SYM
                 if (NF == 3 && sym_taps) {
                     // Pulse-truncation bank: filter 1 is all ones and filter 2 = conj(filter 0) (checked
                     // on the taps themselves, below the kernel's tap staging).  z1 is then a plain sum
@@ -227,7 +220,6 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                     ar[NF - 1] = A + B;
                     ai[NF - 1] = D - C;
                 } else
-#endif
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -265,11 +257,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 }
             } else {
                 int extra = 0, jm = 0;
-#ifdef WF_ABL_NO_MAC
-                for (int j = 0; j < 1; ++j) {
-#else
                 for (int j = 0; j < ntaps; ++j) {
-#endif
                     const double2 x = s_win[base + j + extra];
                     const int tt = ntaps - 1 - j;
 #pragma unroll
@@ -295,9 +283,6 @@ __global__ __launch_bounds__(MF_THREADS) void mf_bank_kernel(const double *__res
                 continue;
             }
             double2 *o = reinterpret_cast<double2 *>(out + 2 * (k * P.nfilt));
-#ifdef WF_ABL_NO_MEM
-            if (ar[0] == 1.2345e300)
-#endif
 #pragma unroll
             for (int f = 0; f < NF; ++f)
                 if ((NTAPS && STEP) || f < P.nfilt) o[f] = make_double2(ar[f], ai[f]);

@@ -92,7 +92,6 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_tile_sums_kernel(const int8_t
             for (int q = 0; q < 8; ++q) acc += (double)(int8_t)(w >> (8 * q)) * h0;
         }
         for (int q = 0; k + q < P.spt && q < 8; ++q) acc += (double)sp[k + q] * h0;   // spt not a multiple of 8
-#ifndef WF_NO_NH2_FAST
     } else if (P.nh == 2 && lo >= 0 && lo + P.spt <= P.nsym && l0 >= 0 && l0 + P.spt <= P.nloc) {
         // interior tile, two alternating modulation indices (ARTM): the same 8-symbols-per-load walk, index by symbol parity
         // (the generic walk below cost 19 us per 1e7 symbols against 7 for the single-index form)
@@ -107,7 +106,6 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_tile_sums_kernel(const int8_t
             for (int q = 0; q < 8; ++q) acc += (double)(int8_t)(w >> (8 * q)) * ((q & 1) ? ho : he);
         }
         for (int q = 0; k + q < P.spt && q < 8; ++q) acc += (double)sp[k + q] * ((q & 1) ? ho : he);
-#endif
     } else {
         for (int k = lane; k < P.spt; k += WF_WAVE) acc += mod_amp(symbols, hvec, P, lo + k);
     }
@@ -493,26 +491,13 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
                 double ra, rb;
                 mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap,
                                      P.nh, win + 1, ref_a, ref_b, W, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb);
-#ifdef WF_ABL_NO_SINCOS
-                e0 = make_double2(ra + 1, ra); e1 = make_double2(rb + 1, rb);
-#else
                 wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
                 wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
-#endif
             }
             // A lane holding two adjacent samples would store 16 B at a 32 B stride (half-filled
             // lines per instruction: 3.9 TB/s against 5.1 for contiguous rows), so the wave's 128
             // samples are transposed through its private LDS strip: each store instruction then
             // writes 64 consecutive samples = 1 KB.  Same wave, in-order LDS: no workgroup barrier.
-#ifdef WF_ABL_PAIR_STORE   // ablation only: 16 B stores at a 32 B lane stride
-            {
-                const int64_t n = tile_base + (int64_t)u * P.rs + 2 * t;
-                double2 *o = reinterpret_cast<double2 *>(out);
-                if (active && n >= P.out_origin && n < P.out_hi) o[n - P.out_origin] = e0;
-                if (active && n + 1 >= P.out_origin && n + 1 < P.out_hi) o[n + 1 - P.out_origin] = e1;
-            }
-            continue;
-#endif
             double2 *xw = s_xp + wave * (2 * WF_WAVE);
             xw[2 * lane] = e0;
             xw[2 * lane + 1] = e1;
@@ -523,9 +508,6 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
             const int col = wave * (2 * WF_WAVE) + lane;                       // sample column inside the row
             const int64_t na = tile_base + (int64_t)u * P.rs + col, nb = na + WF_WAVE;
             double2 *o = reinterpret_cast<double2 *>(out);
-#ifdef WF_ABL_NO_STORE
-            if (xa.x == 1.2345e300 && xb.y == 1.2345e300)
-#endif
             if (full_tile) {   // block-uniform: no per-lane 64-bit window tests
                 if (FULLROW || col < P.rs) wf_store16_nt(o + (na - P.out_origin), xa);
                 if (FULLROW || col + WF_WAVE < P.rs) wf_store16_nt(o + (nb - P.out_origin), xb);
@@ -620,12 +602,7 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm CTRL (
 // the noise raised (mode 2) 0.4813 / 0.4760, only the noise raised 0.4838 / 0.4902; on a second box mode 2 at priority
 // 3 | 2 | 1 | none: 0.466 / 0.472 | 0.469 / 0.479 | 0.474 / 0.471 | 0.493 / 0.488, and with only the Philox rounds (no memory
 // access at all) at low priority 0.489 / 0.481 against 0.470 / 0.473: the Box-Muller half must stay low, too.
-#ifndef WF_MCB_PRIO
-#define WF_MCB_PRIO 3
-#endif
-#ifndef WF_MCB_PRIO_MODE
-#define WF_MCB_PRIO_MODE 2
-#endif
+#define WF_MCB_PRIO 3        // kept form: everything but the noise arithmetic at priority 3
 // The kernel's arguments as they lie in the kernarg segment (each at its natural alignment, in order).
 // The kernel reads them THROUGH this view, from a pointer it makes opaque once per tile: left as plain
 // by-value arguments, the ~70 uniform words of the two structs are loaded once at the top and stay live
@@ -651,14 +628,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                                                                      const double *__restrict__ mf_taps_,
                                                                      double *__restrict__ rows_, mod_params P_, mcb_params Q_)
 {
-#ifdef WF_MCB_BYVALUE   // A/B only: the round-2 form (arguments by value)
-    const mcb_kargs KAv{symbols_, hvec_, pulse_, scratch_, mf_taps_, rows_, P_, Q_};
-    const mcb_kargs *const KA0 = &KAv;
-#define MCB_FRESH(ka) ((void)0)
-#else
     mcb_kptr const KA0 = (mcb_kptr)__builtin_amdgcn_kernarg_segment_ptr();
 #define MCB_FRESH(ka) asm volatile("" : "+s"(ka))
-#endif
     auto ka = KA0;
     const auto &P = ka->P;
     const auto &Q = ka->Q;
@@ -684,10 +655,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     int *s_pi = reinterpret_cast<int *>(s_ring + RSLOTS);                        // prefix counts of the window's raw symbols
     __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
-#ifndef WF_MCB_MFMA
-#define WF_MCB_MFMA 1
-#endif
-    constexpr bool USE_MFMA = CPMNF == 16 && WF_MCB_MFMA != 0;
+    constexpr bool USE_MFMA = CPMNF == 16;
     // (matrix-core form: the templates are only needed to build the B operands once, before the first row —
     //  they are staged in the ring's slots instead of 4.6 KB of their own: 4 workgroups per CU instead of 3)
     __shared__ double2 s_taps_own[USE_MFMA || PAM ? 1 : (CPMNF ? 2 * CPMNF * 9 : 3 * NT)];
@@ -925,13 +893,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                     const int kr_i = 64 * rho + 32 * (wave_u >> 1) + 2 * isym + (wave_u & 1) - Q.kshift;
                     if (kr_i >= klo && kr_i < khi) {
                         double *o = rows + ((sym_base + kr_i) - Q.k_lo) * (2 * CPMNF) + jo;
-#ifndef WF_MCB_NO_NT_STORES   // the rows leave with the nontemporal hint: 2.56 GB per 1e7 symbols that the detector reads back from HBM
                         __builtin_nontemporal_store(acc0[reg], &o[0]);      // anyway — written normally they sat dirty in the L2s and their write-back met the
                         __builtin_nontemporal_store(acc1[reg], &o[16]);     // detector's first reads: same-box, detector 0.820 / 0.821 -> 0.754 / 0.761 ms
-#else
-                        o[0] = acc0[reg];
-                        o[16] = acc1[reg];
-#endif
                     }
                 }
             } else if constexpr (PAM) {
@@ -942,24 +905,10 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 const int S0 = ((rho & 1) ? 512 : 0) + 32 * mf_i;
                 const double *xa = ring_d + 2 * (S0 + (S0 >> 5) + 2 * wave_u + (mf_kq >> 1)) + ((mf_kq & 1) ? 0 : 1);
                 mcb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#if defined(WF_ABL_PAM_NOMFMA)      // ablation only (timing): operand reads, no matrix instruction
-#pragma unroll
-                for (int n = 0; n < 12; ++n) acc[n & 3] += xa[2 * (8 * n + n / 4)];
-#elif defined(WF_ABL_PAM_2ACC)      // A/B: two interleaved accumulation chains
-                mcb_d4 acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int n = 0; n < 12; n += 2) {
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * n + n / 4)], bpam[n], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * (n + 1) + (n + 1) / 4)], bpam[n + 1], acc2, 0, 0, 0);
-                }
-                if (wave_u == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * 12 + 3)], bpam[12], acc, 0, 0, 0);
-                acc += acc2;
-#else
 #pragma unroll
                 for (int n = 0; n < 12; ++n)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * n + n / 4)], bpam[n], acc, 0, 0, 0);
                 if (wave_u == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * 12 + 3)], bpam[12], acc, 0, 0, 0);
-#endif
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) s_part[(4 * wave_u + reg) * 64 + (t & 63)] = acc[reg];
             } else if constexpr (CPMNF != 0) {
@@ -985,13 +934,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                     double *o = rows + 2 * ((k - Q.k_lo) * CPMNF + FPT * mp);
 #pragma unroll
                     for (int f = 0; f < FPT; ++f) {
-#ifndef WF_MCB_NO_NT_STORES
                         __builtin_nontemporal_store(zr[f], &o[2 * f]);
                         __builtin_nontemporal_store(zi[f], &o[2 * f + 1]);
-#else
-                        o[2 * f] = zr[f];
-                        o[2 * f + 1] = zi[f];
-#endif
                     }
                 }
             } else if (sym_taps_i != 0) {
@@ -1081,38 +1025,19 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             // channel (wf_awgn_c128): derotate + Philox AWGN, one block per thread and row
             const int64_t n0 = tile_base + (int64_t)u * RS + 2 * t;
             double g[4];
-#ifdef WF_ABL_MCB_NONOISE   // ablation only
-            g[0] = g[1] = g[2] = g[3] = (double)(n0 & 7);
-#else
             {
                 // The Philox key schedule (20 words: seed + r * Weyl) is uniform and loop-invariant; left to
                 // the compiler it is hoisted into 20 SGPRs and pushes as many other uniforms into spill
                 // lanes (v_readlane reloads in this loop).  Opaque per row => re-derived by scalar adds.
                 uint32_t k0 = (uint32_t)Q.seed, k1 = (uint32_t)(Q.seed >> 32);
-#ifndef WF_ABL_MCB_HOISTKEYS
                 asm volatile("" : "+s"(k0), "+s"(k1));
-#endif
-#if WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 2
                 __builtin_amdgcn_s_setprio(0);
-#elif WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 3
+                // the two Box-Muller transforms interleaved, all four table entries fetched right behind the Philox rounds
+                // (same-box A/B at 1e7 symbols: sequential 0.4580 / 0.4644 ms, table reads in pairs 0.4591 / 0.4588, all four up front 0.4479 / 0.4535;
+                //  staged further — Philox + reads, then the phase sums and the sector reads, then the transforms — 0.4640 / 0.4598 against 0.4473 / 0.4536: not kept)
+                wf_gaussian_two_il<true>(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
                 __builtin_amdgcn_s_setprio(WF_MCB_PRIO);
-#endif
-#ifndef WF_MCB_NOISE_IL
-#define WF_MCB_NOISE_IL 2        // the two Box-Muller transforms interleaved, all four table entries fetched right behind the Philox rounds
-#endif                           // (same-box A/B at 1e7 symbols: sequential 0.4580 / 0.4644 ms, table reads in pairs 0.4591 / 0.4588, all four up front 0.4479 / 0.4535;
-                                 //  staged further — Philox + reads, then the phase sums and the sector reads, then the transforms — 0.4640 / 0.4598 against 0.4473 / 0.4536: not kept)
-#if WF_MCB_NOISE_IL > 0
-                wf_gaussian_two_il<WF_MCB_NOISE_IL == 2>(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
-#else
-                wf_gaussian_two(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
-#endif
-#if WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 2
-                __builtin_amdgcn_s_setprio(WF_MCB_PRIO);
-#elif WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 3
-                __builtin_amdgcn_s_setprio(0);
-#endif
             }
-#endif
             if constexpr (LOADS_FIRST) {
                 // mod_pair_phase with both samples on the same symbols (a1 == a, one count)
                 double acc0 = 0.0, acc1 = 0.0;
@@ -1139,12 +1064,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             }
             // Two-row ring: row u takes the slots of row u - 2, whose last readers are the waves still in
             // bank_row(u - 2) ...
-#ifndef WF_ABL_MCB_NOBAR1   // ablation only (timing; results are wrong)
             wf_lds_barrier();
-#endif
-#if WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 1   // A/B: the stretch between the row's barriers (ring writes, bank) at raised issue priority
-            __builtin_amdgcn_s_setprio(WF_MCB_PRIO);
-#endif
             // (PAM form) the partial tiles bank_row(u - 2) left during the previous row step
             if (PAM && u >= 1 && (u >= 2 || !run_first || (tile == 0 && Q.kshift < 0))) bank_reduce(u - 2);
             int ia, ib;                                         // ring indices (sample - d) mod RING of the thread's two samples
@@ -1170,15 +1090,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             }
             // ... and row u is complete after this barrier — one more barrier per row than a four-row
             // ring, 18 KB less LDS (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
-#ifndef WF_ABL_MCB_NOBAR2   // ablation only
             wf_lds_barrier();
-#endif
-#ifndef WF_ABL_MCB_NOBANK   // ablation only
             if (u >= 1 || !run_first || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);   // u = 0: the previous tile's row 15
-#endif
-#if WF_MCB_PRIO > 0 && WF_MCB_PRIO_MODE == 1
-            __builtin_amdgcn_s_setprio(0);
-#endif
         };
         // two rows per trip, ONE copy of the row code: row 16 goes through the same loop body (a separate
         // inlined copy — or the compiler's remainder loop — is a second 1200-instruction body whose

@@ -287,11 +287,7 @@ __device__ __forceinline__ void vit_comp_to_inc(const vit_comp &c, int col, doub
 __device__ __forceinline__ double2 vit_ld16(const double2 *p)
 {
     typedef double v2d __attribute__((ext_vector_type(2)));
-#ifndef VIT_NO_NT_LOADS    // rows are read once: nontemporal, so the 20 MB of decisions this kernel writes are still in the L2s when the
     const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));   // error counter reads them (same-box: detector 85.6 -> 86.3 us, counter 17.3 -> 15.9)
-#else
-    const v2d v = *reinterpret_cast<const v2d *>(p);
-#endif
     return make_double2(v.x, v.y);
 }
 
@@ -333,10 +329,6 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     auto fetch = [&](int b, double2 dst[NP]) __attribute__((always_inline)) {
         const int64_t rb = g0u * CH - warmup - 1 + (int64_t)b * VIT_S;   // first row of the batch (uniform)
         const double2 *basep = rows + RW * rb;
-#ifdef WF_ABL_NO_MEM   // ablation only
-#pragma unroll
-        for (int u = 0; u < NP; ++u) dst[u] = make_double2((double)(sgw[u] & 7) - 3.5, (double)(sgw[u] & 3) - 1.0);
-#else
         if (rb >= 0 && rb + (int64_t)(WF_WAVE - 1) * CH + VIT_S <= ncalls) {
 #pragma unroll
             for (int u = 0; u < NP; ++u) dst[u] = vit_ld16(basep + RW * CH * (sgw[u] >> 8) + (sgw[u] & 255));
@@ -352,7 +344,6 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
                 dst[u] = vit_ld16(basep + RW * rc + (wi - RW * (wi / RW)));
             }
         }
-#endif
     };
     auto stash = [&](const double2 src[NP]) __attribute__((always_inline)) {
 #pragma unroll
@@ -524,9 +515,6 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     ch = (ch + 15) / 16 * 16;
     if (ch < 32) ch = 32;
     if (ch > 512) ch = 512;
-#ifdef VIT_FORCE_CH
-    ch = VIT_FORCE_CH;
-#endif
     const int64_t nthreads = (ncalls + ch - 1) / ch;
     const int64_t nblocks = (nthreads + VIT_THREADS - 1) / VIT_THREADS;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");

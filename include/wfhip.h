@@ -469,6 +469,15 @@ int wf_cpm_link_stream_layout(const wf_cpm_link_config *cfg, int64_t chunk_symbo
 int wf_cpm_link_stream_chunk(wf_ctx *ctx, const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
                              void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
                              int64_t *h_compared, void *stream);
+/* The same chunk in parts, for callers that pipeline consecutive chunks on two HIP streams (own workspace and own
+ * wf_ctx per stream; wf_link_stream_chunk_phase's numbering): phases bit 0 = PRBS + mapper (depends on nothing),
+ * bit 2 = modulator + channel + matched-filter rows (after this chunk's bit-0 part and the previous chunk's bit-2 part:
+ * the phase carry in d_state), bit 1 = detector + error count (after this chunk's bit-2 part and the previous chunk's
+ * bit-1 part: the detector carry).  7 = wf_cpm_link_stream_chunk.  Replaces, for a stream, the per-call chain of
+ * waveforms/cpm/modulate.py:57-101 + waveforms/noise.py:8-32 + the build-defined detector of wf_cpm_viterbi_detect. */
+int wf_cpm_link_stream_chunk_phase(wf_ctx *ctx, const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
+                                   void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
+                                   int64_t *h_compared, int phases, void *stream);
 
 /* ---- data products of the reference's plotting helpers (no plotting) ------------------
  * Welch PSD exactly as Axes.psd / matplotlib.mlab.psd evaluates the call of

@@ -468,6 +468,9 @@ def test_gpu_cpm_stream_in_chunks_equals_one_shot(waveform, chunk):
         assert st.result() == want
         assert np.array_equal(np.concatenate(got_dec), want_dec)
         assert ebn0 is None or want[1] > 0
+        # ... and as the two-stream chunk pipeline (wf_cpm_link_stream_chunk_phase: the detector of chunk c beside the
+        # front end of chunk c + 1, carries handed over by events)
+        assert st.run_pipelined(ebn0, seed=4, stream_id=sid) == want
     with pytest.raises(ValueError):
         CPMStream(nsym, 1000, SPS, waveform=waveform)
 

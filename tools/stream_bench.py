@@ -38,13 +38,15 @@ def main():
         st = CPMStream(int(a.total), a.chunk, 8, waveform=a.waveform, pn_degree=a.pn_degree, warmup=wu)
         st.run_chunk(0, a.ebn0)
         torch.cuda.synchronize()
+        go = st.run_pipelined if a.pipelined else st.run
         for rep in range(2):
             t0 = time.perf_counter()
-            se, be, m = st.run(a.ebn0)
+            se, be, m = go(a.ebn0)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         print(json.dumps({"workload": f"{a.waveform} continuous stream, {int(a.total):.3g} symbols @8 sps in {st.nchunks} chunks of {a.chunk} "
-                                      f"(PN{a.pn_degree}, generic CPM trellis detector)", "mode": "eager launches", "Msym_per_s": round(m / dt / 1e6, 1),
+                                      f"(PN{a.pn_degree}, generic CPM trellis detector)", "mode": "two-stream chunk pipeline" if a.pipelined else "eager launches",
+                          "Msym_per_s": round(m / dt / 1e6, 1),
                           "seconds": round(dt, 4), "workspace_GB": round(st.workspace_bytes / 1e9, 3), "symbols": m, "symbol_errors": se,
                           "bit_errors": be, "ebn0_db": a.ebn0}))
         return

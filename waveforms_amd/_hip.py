@@ -86,6 +86,7 @@ SIGNATURES = {
     "wf_cpm_link_stream_workspace_bytes": (c_int64, [_P, c_int64]),
     "wf_cpm_link_stream_layout": (c_int, [_P, c_int64, c_int64, POINTER(c_int64)]),
     "wf_cpm_link_stream_chunk": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
+    "wf_cpm_link_stream_chunk_phase": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), c_int, _P]),
 }
 
 

@@ -576,6 +576,10 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
     ch = (ch + 63) / 64 * 64;
     if (ch < 256) ch = 256;                                        // (room for the repair launch to meet the first launch's trajectory)
     if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
+    // (lane form: 64 chunks per wave make the chunks short — 256 calls at 1e7 — and a chunk that missed a short warm-up needs
+    //  room to meet the first launch's trajectory inside its own calls: with 64-call warm-ups and 256-call chunks PCM/FM
+    //  left 3 chunks of 1.2e7 unproven at 10 dB, none with 320 — profiles/r04_lane_chunk_sweep.log)
+    if (use_lanes && ch < 5 * W) ch = (5 * W + 63) / 64 * 64;
     if (const char *e = getenv(use_lanes ? "WF_CPM_LANE_CH" : "WF_CPM_CH")) ch = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : ch;   // tuning aid (tools/cpm_vit_time.py)
     if (ch > 8192) ch = 8192;                                      // decision strips live in LDS; longer bursts take several rounds
     // (measured at 1e7 ARTM calls, W = 128, row form: 384 calls per chunk 1.07 ms, 512: 1.03, 640: 1.00, 768: 1.19,
@@ -1145,6 +1149,19 @@ extern "C" int wf_cpm_link_stream_chunk(wf_ctx *ctx, const wf_cpm_link_config *c
                                         void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
                                         int64_t *h_compared, void *stream)
 {
+    return wf_cpm_link_stream_chunk_phase(ctx, cfg, chunk_symbols, chunk_index, d_state, d_workspace, workspace_bytes, d_counts, h_compared, 7, stream);
+}
+
+// Parts of a chunk for callers that pipeline chunks on two streams (own workspace AND own wf_ctx per stream), numbered
+// like wf_link_stream_chunk_phase: bit 0 = PRBS + mapper (stateless: leap-ahead position, memoryless mapper — depends on
+// nothing); bit 2 = modulator + channel + matched-filter rows (needs this chunk's bit-0 part and the phase carry the
+// previous chunk's bit-2 part left in d_state); bit 1 = detector + error count (needs this chunk's bit-2 part and the
+// detector carry of the previous chunk's bit-1 part).  phases = 7: the whole chunk.
+extern "C" int wf_cpm_link_stream_chunk_phase(wf_ctx *ctx, const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,
+                                              void *d_state, void *d_workspace, int64_t workspace_bytes, int64_t *d_counts,
+                                              int64_t *h_compared, int phases, void *stream)
+{
+    WF_REQUIRE(phases >= 1 && phases <= 7, "wf_cpm_link_stream_chunk_phase: phases %d", phases);
     WF_REQUIRE(ctx && cfg && d_state && d_workspace && d_counts, "wf_cpm_link_stream_chunk: NULL argument");
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_workspace) & 255) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
                "wf_cpm_link_stream_chunk: workspace must be 256-byte aligned, the carry block 16-byte aligned");
@@ -1165,26 +1182,35 @@ extern "C" int wf_cpm_link_stream_chunk(wf_ctx *ctx, const wf_cpm_link_config *c
     uint64_t *q_phase = reinterpret_cast<uint64_t *>(carry + WF_CPM_STATE_BYTES);
     const int bps = S.L.bps;
     int rc;
-    if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip + (uint64_t)(S.ws * bps), bits, S.nloc * bps, nullptr, stream)))
-        return rc;
-    // (the mappers are memoryless per symbol; a window starts on a symbol boundary, so the multi-h mapper's parity is 0)
-    if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, S.nloc * bps, 0, 0, 0, syms, stream))) return rc;
-    rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
-                                 S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_templates, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma,
-                                 cfg->seed, cfg->stream_id, 0, nullptr, S.L.start0 + 4, S.k_lo, S.ncols, 0, rows, stream, S.L.nfilt,
-                                 cfg->det.nh, 3);
-    if (rc < 0) return rc;
-    WF_REQUIRE(rc == 0, "wf_cpm_link_stream_chunk: internal: the one-kernel front end refused the window");
-    if ((rc = wf_cpm_viterbi_detect(ctx, &cfg->det, cfg->d_rot_cs, rows, S.ncols, cfg->warmup, dec, carry, stream))) return rc;
-    // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] of the stream are compared
-    const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;
-    const int64_t k_first = skip + cfg->det.D - 1;                      // first call whose decision is compared
-    const int64_t j0 = S.k_lo >= k_first ? 0 : k_first - S.k_lo;
-    const int64_t ncmp = S.ncols - j0;
-    if (ncmp > 0) {
-        const int64_t sym0 = S.k_lo + j0 - cfg->det.D + 1;              // global index of the first reference symbol
-        if ((rc = wf_cpm_count_errors(ctx, dec + j0, syms + (sym0 - S.ws), cfg->det.M, ncmp, d_counts, stream))) return rc;
-        if (h_compared) *h_compared = ncmp;
+    if (phases & 1) {
+        if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip + (uint64_t)(S.ws * bps), bits, S.nloc * bps, nullptr, stream)))
+            return rc;
+        // (the mappers are memoryless per symbol; a window starts on a symbol boundary, so the multi-h mapper's parity is 0)
+        if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, S.nloc * bps, 0, 0, 0, syms, stream))) return rc;
+    }
+    if (phases & 4) {
+        rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
+                                     S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_templates, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma,
+                                     cfg->seed, cfg->stream_id, 0, nullptr, S.L.start0 + 4, S.k_lo, S.ncols, 0, rows, stream, S.L.nfilt,
+                                     cfg->det.nh, 3);
+        if (rc < 0) return rc;
+        WF_REQUIRE(rc == 0, "wf_cpm_link_stream_chunk: internal: the one-kernel front end refused the window");
+    }
+    if (phases & 2) {
+        // (the rows sit inside the chunk's workspace: symbols before them, decisions behind — see wf_cpm_link_run)
+        if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, S.ncols, cfg->warmup, dec, carry, stream, (int64_t)S.off_rows,
+                                           (int64_t)(S.total - S.off_rows) - S.ncols * S.L.nfilt * 16)))
+            return rc;
+        // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] of the stream are compared
+        const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;
+        const int64_t k_first = skip + cfg->det.D - 1;                  // first call whose decision is compared
+        const int64_t j0 = S.k_lo >= k_first ? 0 : k_first - S.k_lo;
+        const int64_t ncmp = S.ncols - j0;
+        if (ncmp > 0) {
+            const int64_t sym0 = S.k_lo + j0 - cfg->det.D + 1;          // global index of the first reference symbol
+            if ((rc = wf_cpm_count_errors(ctx, dec + j0, syms + (sym0 - S.ws), cfg->det.M, ncmp, d_counts, stream))) return rc;
+            if (h_compared) *h_compared = ncmp;
+        }
     }
     return WF_OK;
 }

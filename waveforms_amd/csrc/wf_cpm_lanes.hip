@@ -51,6 +51,10 @@ struct lane_spec {
         return r;
     }
     static constexpr int NCORR = ipow(M, LP - 1), MSUB = ipow(M, LP - 2), NF = ipow(M, LP), S = NC * NCORR;
+    // calls software-pipelined (see `step`): pays while the carried operands fit the register file — same box, detector
+    // stage of the link, off | on: PCM/FM (10 states) 0.339 / 0.345 | 0.290 / 0.297 ms; ARTM (16 states x 4 branches, 240
+    // registers without it) 0.688 / 0.715 | 0.784 / 0.793 (profiles/r04_ab_lane_switches.log)
+    static constexpr bool PIPE = S * M <= 32;
     static_assert((M == 2 || M == 4) && LP >= 2 && S <= 16 && NF >= 4 && NF <= 16 && P % NC == 0 && 2 * P <= 64,
                   "lane form: trellis of <= 16 states, 4 .. 16 filters per call, pulse of >= 2 symbols");
 };
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     // znext(f): filter output f of the NEXT call — before its own tail (normalisation, decision registers, emission):
     // the tail's ~80 vector instructions hide that round trip, and the slot hand-over (DMA issue + counted wait) that
     // znext may carry sits there too, instead of in front of a call whose first group then waits for its operands
-    // (profiles/r04_ab_lane_pipe.log).
+    // (lane_spec::PIPE).
     auto step = [&](auto kvc, auto pipec, auto &&zsrc, auto &&znext, bool emit, bool emit_ok, int group_pos) __attribute__((always_inline)) {
         constexpr int KV = decltype(kvc)::value;
         constexpr bool PIPE = decltype(pipec)::value;
@@ -281,9 +285,11 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                         nm[e] = lane_min(nm[e], c);
                         nr8[e] = f ? rs : nr8[e];
                         nh[e] = f ? h[src] : nh[e];
-                        // (pins the selects next to their compare: nothing needs them before the end of the call, so the
-                        // optimiser sank all 48 of them — and their 48 lane masks, the whole scalar file — below the emission)
-                        asm volatile("" : "+v"(nr8[e]), "+v"(nh[e]));
+                        // (pins the phase select next to its compare: nothing needs it before the end of the call, so the
+                        // optimiser sank all 48 of them — and their 48 lane masks, the whole scalar file — below the emission.
+                        // Pinning the decision register's two selects as well: 8 scalar spills instead of 12, and 4 % slower
+                        // — profiles/r04_ab_lane_switches.log)
+                        asm volatile("" : "+v"(nr8[e]));
                     }
                 });
                 // (the M candidates of a start state end here for the instruction scheduler: left free, it lines up all
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
         const v2d v = *reinterpret_cast<const v2d *>(smem + zbase + (lds_lane ^ (unsigned)(q * 16)));
         return make_double2(v.x, v.y);
     };
-    {   // the first call's first group
+    if (SP::PIPE) {   // the first call's first group
         lane_for<0, M>([&](auto uc) { first.z[decltype(uc)::value] = zring(std::integral_constant<int, 0>{}, uc); });
         load_rot(std::integral_constant<int, 0>{}, first);
     }
@@ -475,11 +481,11 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                         r8[s] = (uint32_t)erec[3 * s + 1];
                         h[s] = erec[3 * s + 2];
                     });
-                    load_rot(std::integral_constant<int, 0>{}, first);  // (requested with the phases of the warm-up it never had)
+                    if (SP::PIPE) load_rot(std::integral_constant<int, 0>{}, first);  // (requested with the phases of the warm-up it never had)
                 }
                 const bool emit = t >= Weff;
                 const int gp = (t - Weff) & 7;
-                step(std::integral_constant<int, KV>{}, std::true_type{}, [&](auto fc) __attribute__((always_inline)) { return zring(ucc, fc); },
+                step(std::integral_constant<int, KV>{}, std::integral_constant<bool, SP::PIPE>{}, [&](auto fc) __attribute__((always_inline)) { return zring(ucc, fc); },
                      [&](auto fc) __attribute__((always_inline)) { return zring(std::integral_constant<int, UC + 1>{}, fc); }, emit, t >= t_ok, gp);
                 if (emit && gp == 7) {                               // a group of 8 decisions is complete (uniform)
                     if (t < t_hi) {
@@ -519,19 +525,10 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
 // ---- the compiled specialisations: the two waveforms BASELINE configs[2] and SURVEY 8(f3) name
 using lane_artm16 = lane_spec<4, 2, 4, 16, 2, 4, 5>;     // ARTM multi-h CPM, h = {4/16, 5/16}, pulse truncated to 2 symbols, 4 phase classes
 using lane_pcmfm10 = lane_spec<2, 2, 5, 10, 1, 7, 7>;    // PCM/FM, h = 7/10, 5 phase classes
-// Ring depth R (slots of 8 KB in flight per wave) decides how much LDS a wave takes against how far ahead of the
-// detector the rows are fetched (ARTM: two slots per call).  WF_CPM_LANE_R selects another compiled depth (tuning aid).
-#define LANE_R_DEFAULT 3
-
-static int lane_ring_depth()
-{
-    int r = LANE_R_DEFAULT;
-    if (const char *e = getenv("WF_CPM_LANE_R")) {
-        const int v = atoi(e);
-        if (v == 2 || v == 3 || v == 4) r = v;
-    }
-    return r;
-}
+// Ring depth: 3 slots of 8 KB in flight per wave (ARTM: two slots per call).  Same box, detector alone, 2 | 3 | 4 slots:
+// ARTM 724 | 656 | 658 us, PCM/FM 313 | 307 | 313 us (profiles/r04_ab_lane_ring.log) — two slots leave the fetch one
+// slot of lead, four cost a CU a resident wave (and the front end running beside it 8 KB).
+#define LANE_R 3
 
 int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
 {
@@ -541,18 +538,11 @@ int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
     if (d->M == 4 && d->Lp == 2 && d->NC == 4 && d->p == 16 && d->nh == 2 && d->K[0] == 4 && d->K[1] == 5 && d->D >= 17 && d->D <= 32) spec = 0;
     if (d->M == 2 && d->Lp == 2 && d->NC == 5 && d->p == 10 && d->nh == 1 && d->K[0] == 7 && d->D >= 1 && d->D <= 32) spec = 1;
     if (spec < 0) return 1;
-    const int R = lane_ring_depth();
+    constexpr int R = LANE_R;
     int per_cu = (160 * 1024) / LANE_LDS_BYTES(R);
     if (per_cu > 4) per_cu = 4;                 // one wave per SIMD: 250 registers (ARTM) leave room for nothing else of this kernel
     *plan = {spec, R, per_cu, spec == 0 ? 1 : 4};
     return 0;
-}
-
-template <class SP, bool DHI>
-static auto lane_pick(int R)
-{
-    using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, cpm_lane_params);
-    return R == 2 ? static_cast<kern_t>(cpm_lane_kernel<SP, 2, DHI>) : (R == 4 ? static_cast<kern_t>(cpm_lane_kernel<SP, 4, DHI>) : static_cast<kern_t>(cpm_lane_kernel<SP, 3, DHI>));
 }
 
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
@@ -568,7 +558,8 @@ int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config 
     const int64_t nblocks = (nchunks + 63) / 64;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_lanes: burst too long for one launch");
     const size_t lds = (size_t)LANE_LDS_BYTES(plan.ring_batches);
-    const auto k = plan.spec == 0 ? lane_pick<lane_artm16, true>(plan.ring_batches) : lane_pick<lane_pcmfm10, false>(plan.ring_batches);
+    using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, cpm_lane_params);
+    const kern_t k = plan.spec == 0 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R, true>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, LANE_R, false>);
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64), lds, wf_stream(stream), reinterpret_cast<const double2 *>(d_rows_ri),

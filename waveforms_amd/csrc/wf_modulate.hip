@@ -1315,6 +1315,10 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     //  waves onto a SIMD only when one of this kernel's workgroups leaves.  Steady state of the pipelined links, same box,
     //  runs per slot 1 | 2 | 4 | 8 | 16: PCM/FM 0.940 | 0.856 | 0.817 | 0.806 | 0.800 ms, ARTM 1.481 | 1.348 | 1.330 | 1.324 | 1.330)
     const int runs_per_slot = cpm_nf ? (ctx->mcb_runs_hint > 0 ? ctx->mcb_runs_hint : WF_MCB_RUNS_PER_SLOT) : WF_MCB_RUNS_PER_SLOT_SOQPSK;
+    // (round 4, negative: a pipelined CPM link's front end capped at 2 | 2.5 | 3 | 4 | 8 | 16 resident-slot-fulls of workgroups, to
+    //  leave each CU half free for the detector running beside it: ARTM steady 1.87 | 1.69 | 1.53 | 1.50 | 1.35 | 1.31 ms against
+    //  1.32 uncapped, PCM/FM 0.74 | 0.91 | 0.85 | 0.74 | 0.70 | 0.67 against 0.65 — this kernel needs its four waves per SIMD;
+    //  profiles/r04_ab_front_end_grid_cap.log)
     const int64_t max_grid = (int64_t)cus * ((cpm_nf && JM != 4) || pam ? 3 : 4) * runs_per_slot;
     const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
     // the last `tail` tiles go out one per workgroup (WF_MCB_TAIL_SLOTS resident-slot-fulls of them; 0 = equal runs throughout)

@@ -534,6 +534,57 @@ class CPMStream:
             self.run_chunk(c, ebn0_db, seed, stream_id)
         return self.result()
 
+    def run_pipelined(self, ebn0_db: float | None, seed: int = 1, stream_id: int = 0) -> tuple[int, int, int]:
+        """Like :meth:`run` with consecutive chunks alternating between two HIP streams, each with its own workspace and
+        library context (``wf_cpm_link_stream_chunk_phase``, as :meth:`SOQPSKStream.run_pipelined` does it): PRBS + mapper
+        depend on nothing, a chunk's front end waits for the previous chunk's front end (phase carry), its detector for
+        the previous chunk's detector (detector carry) — so the detector of chunk c runs beside the front end of chunk
+        c + 1.  Same decisions and counts as :meth:`run`."""
+        from .viterbi.cpm import sigma_for_ebn0 as cpm_sigma
+
+        torch = _hip.torch()
+        self.reset()
+        cfg = self.cfg
+        cfg.sigma = 0.0 if ebn0_db is None else cpm_sigma(ebn0_db, self.sps, self.spec.bits_per_symbol)
+        cfg.seed, cfg.stream_id, cfg.event_slot = seed, stream_id, -1
+        if getattr(self, "_ws2", None) is None:
+            self._ws2 = _hip.empty(self.workspace_bytes, "uint8")
+            self._ctx2 = _hip.new_ctx()
+            self._lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
+        main = torch.cuda.current_stream()
+        for lane in self._lanes:
+            lane.wait_stream(main)                       # the carry block / counters were zeroed on the caller's stream
+        lib, m = _hip.lib(), ctypes.c_int64(0)
+        done = {4: None, 2: None}
+        for c in range(self.nchunks):
+            lane, ws, ctx = self._lanes[c & 1], (self.workspace, self._ws2)[c & 1], (self._ctx, self._ctx2)[c & 1]
+            with torch.cuda.stream(lane):
+                for part in (1, 4, 2):
+                    if part != 1 and done[part] is not None:
+                        lane.wait_event(done[part])
+                    _hip.check(lib.wf_cpm_link_stream_chunk_phase(ctx, ctypes.byref(cfg), self.chunk_symbols, c, self.state.data_ptr(),
+                                                                  ws.data_ptr(), self.workspace_bytes, self.counts.data_ptr(),
+                                                                  ctypes.byref(m), part, lane.cuda_stream))
+                    if part != 1:
+                        done[part] = torch.cuda.Event()
+                        done[part].record(lane)
+                self.compared += m.value
+        for lane in self._lanes:
+            main.wait_stream(lane)
+        from waveforms_amd import device as dev
+
+        _hip.check(lib.wf_ctx_check(self._ctx2, _hip.stream()))
+        late = dev.viterbi_unmerged(reset=True, ctx=self._ctx2)     # the first context's count is read by result()
+        if late:
+            dev.viterbi_unmerged(reset=True, ctx=self._ctx)
+            raise RuntimeError(f"{late} detector chunk(s) did not merge with the sequential path within the warm-up")
+        return self.result()
+
+    def __del__(self):
+        if getattr(self, "_ctx2", None):
+            _hip.free_ctx(self._ctx2)
+            self._ctx2 = None
+
     def result(self) -> tuple[int, int, int]:
         """(symbol errors, bit errors, symbols compared); raises if a detector chunk was not proven."""
         return SOQPSKLink.result(self)

@@ -266,6 +266,7 @@ def main() -> None:
     cpm = args.waveform != "soqpsk"
     if cpm:
         from waveforms_amd.link import CPMLink
+        from waveforms_amd.viterbi.cpm import detector_kernel_name
 
         # detector chunk warm-up rows: by operating point (waveforms_amd.link.operating_point_warmup), or --vit-warmup
         cwu = args.vit_warmup if args.vit_warmup >= 0 else operating_point_warmup(args.waveform, args.ebn0)
@@ -374,7 +375,7 @@ def main() -> None:
             bps["mod+awgn+mfbank"] = 1 + 16 * nf
             STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<4, {nf}, 8>"
         STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}, {'true' if links[0].cfg.fuse & 2 else 'false'}>",
-                             "viterbi": f"cpm_viterbi_kernel<{links[0].spec.M}, {links[0].spec.Lp}>", "map": "symbol_map_kernel",
+                             "viterbi": detector_kernel_name(links[0].spec), "map": "symbol_map_kernel",
                              "modulate": "mod_main_kernel<4, true>"})
     one_kernel = not cpm and bool(links[0].layout()["one_kernel_front_end"])     # asked from the library (wf_link_layout)
     if one_kernel:      # fuse bit 3: the "fir" slot times modulator + channel + bank; symbols in, packed rows out

@@ -528,6 +528,20 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
     return WF_OK;
 }
 
+// Which form of the detector wf_cpm_viterbi_detect runs for this trellis (bench.py and the profile tools name the
+// kernel they price by it): info4 = {form (0: row form, one 16-lane DPP row per chunk; 1: lane form, one lane per chunk),
+// ring slots of the lane form, 0, 0}.
+extern "C" int wf_cpm_detector_form(const wf_cpm_detector_config *det, int *info4)
+{
+    WF_REQUIRE(det && info4, "wf_cpm_detector_form: NULL argument");
+    cpm_lane_plan lanes{};
+    const bool use_lanes = wf_cpm_lanes_plan(det, &lanes) == 0;
+    info4[0] = use_lanes ? 1 : 0;
+    info4[1] = use_lanes ? lanes.ring_batches : 0;
+    info4[2] = info4[3] = 0;
+    return WF_OK;
+}
+
 extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs,
                                      const double *d_rows_ri, int64_t ncalls, int warmup, uint8_t *d_decisions,
                                      void *d_state, void *stream)

@@ -31,7 +31,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-__all__ = ["CPMDetectorSpec", "ARTM_16", "PCMFM_10", "CPMTrellisDetector", "matched_filter_templates", "rotation_table",
+__all__ = ["CPMDetectorSpec", "ARTM_16", "PCMFM_10", "CPMTrellisDetector", "matched_filter_templates", "rotation_table", "detector_kernel_name",
            "filter_geometry", "sigma_for_ebn0"]
 
 
@@ -74,6 +74,23 @@ class CPMDetectorSpec:
 ARTM_16 = CPMDetectorSpec(M=4, p=16, K=(4, 5), Lp=2, NC=4, D=32)
 # PCMFM_NUMER / DENOM = 7 / 10 (waveforms/cpm/pcmfm/__init__.py:5-6), binary
 PCMFM_10 = CPMDetectorSpec(M=2, p=10, K=(7,), Lp=2, NC=5, D=32)
+
+
+def detector_kernel_name(spec: "CPMDetectorSpec") -> str:
+    """Name (as rocprofv3 prints it) of the kernel ``wf_cpm_viterbi_detect`` runs for ``spec``: asked from the library
+    (``wf_cpm_detector_form``), so that bench.py and the profile tools price the kernel that really runs."""
+    import ctypes
+
+    from waveforms_amd import _hip
+
+    info = (ctypes.c_int * 4)()
+    cfg = spec.c_config()
+    _hip.check(_hip.lib().wf_cpm_detector_form(ctypes.byref(cfg), info))
+    if info[0] == 1:
+        k1 = spec.K[1] if len(spec.K) > 1 else spec.K[0]
+        hi = "true" if spec.bits_per_symbol * (spec.D - 1) >= 32 else "false"
+        return f"cpm_lane_kernel<lane_spec<{spec.M}, {spec.Lp}, {spec.NC}, {spec.p}, {len(spec.K)}, {spec.K[0]}, {k1}>, {info[1]}, {hi}>"
+    return f"cpm_viterbi_kernel<{spec.M}, {spec.Lp}>"
 
 
 def filter_geometry(ntaps: int, sps: int, spec: CPMDetectorSpec, nsym: int) -> dict:

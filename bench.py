@@ -375,7 +375,7 @@ def main() -> None:
             bps["mod+awgn+mfbank"] = 1 + 16 * nf
             STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<4, {nf}, 8>"
         STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}, {'true' if links[0].cfg.fuse & 2 else 'false'}>",
-                             "viterbi": detector_kernel_name(links[0].spec), "map": "symbol_map_kernel",
+                             "viterbi": detector_kernel_name(links[0].spec, links[0].layout()["calls"], links[0].cfg.warmup), "map": "symbol_map_kernel",
                              "modulate": "mod_main_kernel<4, true>"})
     one_kernel = not cpm and bool(links[0].layout()["one_kernel_front_end"])     # asked from the library (wf_link_layout)
     if one_kernel:      # fuse bit 3: the "fir" slot times modulator + channel + bank; symbols in, packed rows out

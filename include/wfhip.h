@@ -405,11 +405,13 @@ int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsa
  * repair (wf_viterbi4_unmerged).  d_state (WF_CPM_STATE_BYTES, zeroed = fresh detector,
  * may be NULL) carries the detector across calls. */
 #define WF_CPM_STATE_BYTES 1024
-/* Which of its two forms wf_cpm_viterbi_detect runs for this trellis: info4[0] = 0 the row form (one 16-lane DPP row per
- * chunk, any trellis of <= 16 states), 1 the lane form (one lane per chunk, trellis compiled in: the ARTM 16-state and
- * PCM/FM 10-state designs of waveforms/cpm/multih, waveforms/cpm/pcmfm); info4[1] = its LDS ring depth.  Both forms
- * make the same decisions, bit for bit (notes/cpm/cpm.md:100-140 is what both implement).  No device work. */
-int wf_cpm_detector_form(const wf_cpm_detector_config *det, int *info4);
+/* Which of its two forms wf_cpm_viterbi_detect runs for this trellis, burst length and warm-up: info4[0] = 0 the row
+ * form (one 16-lane DPP row per chunk, any trellis of <= 16 states), 1 the lane form (one lane per chunk, trellis compiled
+ * in: the ARTM 16-state and PCM/FM 10-state designs of waveforms/cpm/multih, waveforms/cpm/pcmfm; bursts long enough for
+ * its 64 chunks per wave to fill the chip, ~9e6 / ~6.5e6 calls); info4[1] = its LDS ring depth; info4[2] = calls per
+ * chunk; info4[3] = warm-up calls.  Both forms make the same decisions, bit for bit (notes/cpm/cpm.md:100-140 is what both
+ * implement).  No device work. */
+int wf_cpm_detector_form(const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int *info4);
 int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs,
                           const double *d_rows_ri, int64_t ncalls, int warmup, uint8_t *d_decisions,
                           void *d_state, void *stream);

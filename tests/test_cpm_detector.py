@@ -32,6 +32,23 @@ DESIGNS = [  # (M, p, K, Lp, NC): full and reduced trellises, both alphabets, ev
 GPU_DESIGNS = [d for d in DESIGNS if d[4] * d[0] ** (d[3] - 1) <= 16]
 
 
+@pytest.fixture(params=["auto", "lanes", "rows"])
+def detector_form(request):
+    """wf_cpm_viterbi_detect has two forms — one 16-lane row per chunk, one lane per chunk — and picks by burst length
+    (the lane form pays from ~9e6 / ~6.5e6 calls).  The tests below run every size in BOTH (WF_CPM_LANES=1 / 0 forces a
+    form where a lane specialisation exists) and as shipped."""
+    old = os.environ.get("WF_CPM_LANES")
+    if request.param == "auto":
+        os.environ.pop("WF_CPM_LANES", None)
+    else:
+        os.environ["WF_CPM_LANES"] = "1" if request.param == "lanes" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("WF_CPM_LANES", None)
+    else:
+        os.environ["WF_CPM_LANES"] = old
+
+
 # ------------------------------------------------------------------ oracle side (CPU)
 @pytest.mark.parametrize("design", DESIGNS)
 def test_c_detector_equals_independent_python_statement(oracle, design):
@@ -176,7 +193,7 @@ def test_gpu_matched_filter_rows_equal_oracle(oracle, waveform, sps):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ebn0", [0.0, 4.0, 10.0])
-def test_gpu_artm16_decisions_equal_sequential_oracle(oracle, ebn0):
+def test_gpu_artm16_decisions_equal_sequential_oracle(oracle, ebn0, detector_form):
     """BASELINE configs[2]'s detector: 4.2e5 symbols, chunk-parallel on the GPU vs the sequential
     C detector on the same matched-filter rows — every decision identical."""
     from waveforms_amd.viterbi.cpm import ARTM_16, CPMTrellisDetector
@@ -193,7 +210,7 @@ def test_gpu_artm16_decisions_equal_sequential_oracle(oracle, ebn0):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("design", GPU_DESIGNS)
-def test_gpu_every_supported_design_equals_oracle(oracle, design):
+def test_gpu_every_supported_design_equals_oracle(oracle, design, detector_form):
     """Every trellis shape the kernel family accepts (M 2 / 4, Lp 1..3, full and reduced phase
     state, 2 .. 16 states) on noisy rows and on unstructured random rows with exact ties."""
     from waveforms_amd.viterbi import cpm
@@ -212,7 +229,7 @@ def test_gpu_every_supported_design_equals_oracle(oracle, design):
 
 
 @pytest.mark.gpu
-def test_gpu_detector_reports_and_repairs_unmerged_chunks(oracle):
+def test_gpu_detector_reports_and_repairs_unmerged_chunks(oracle, detector_form):
     from waveforms_amd import _hip, device as dev
     from waveforms_amd.viterbi import cpm
 
@@ -251,7 +268,7 @@ def test_gpu_detector_reports_and_repairs_unmerged_chunks(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("design", GPU_DESIGNS)
-def test_gpu_short_warmup_repaired_on_device_equals_oracle(oracle, design):
+def test_gpu_short_warmup_repaired_on_device_equals_oracle(oracle, design, detector_form):
     """Every trellis shape with a warm-up of 8 calls — far below the merge depth, so most chunks miss it: the
     repair launch makes the output the sequential detector's all the same (noisy rows with a drift, exact ties,
     carried state across two calls), or the call says which chunks it could not prove."""
@@ -274,7 +291,7 @@ def test_gpu_short_warmup_repaired_on_device_equals_oracle(oracle, design):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
-def test_gpu_repair_fuzz_random_designs_warmups_and_splits(oracle, seed):
+def test_gpu_repair_fuzz_random_designs_warmups_and_splits(oracle, seed, detector_form):
     """Seeded fuzz of the chunk-parallel detector + repair launch against the sequential oracle: a random trellis shape,
     burst length (ragged ends), warm-up from 8 calls up, drift of the first filter output (how fast survivors merge),
     exact-tie rows, and the burst cut into 1 .. 3 calls with the state carried between them."""
@@ -299,7 +316,7 @@ def test_gpu_repair_fuzz_random_designs_warmups_and_splits(oracle, seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fuse", [10, 2, 0])
 @pytest.mark.parametrize("waveform,nsym", [("multih", 100_000), ("pcmfm", 60_000), ("multih", 777)])
-def test_gpu_cpm_link_equals_oracle_chain(oracle, waveform, nsym, fuse):
+def test_gpu_cpm_link_equals_oracle_chain(oracle, waveform, nsym, fuse, detector_form):
     """wf_cpm_link_run (PRBS -> mapper -> modulate -> Philox AWGN -> rows -> detector -> count)
     against the oracle chain fed the same noise: identical symbol and bit error counts."""
     from waveforms_amd.link import CPMLink
@@ -324,7 +341,7 @@ def test_gpu_cpm_link_equals_oracle_chain(oracle, waveform, nsym, fuse):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("waveform,ebn0", [("pcmfm", 4.0), ("multih", 8.0)])
-def test_gpu_cpm_link_at_operating_point_warmup_equals_oracle_chain(oracle, waveform, ebn0):
+def test_gpu_cpm_link_at_operating_point_warmup_equals_oracle_chain(oracle, waveform, ebn0, detector_form):
     """The link as bench.py runs it — chunk warm-up of the operating point (PCM/FM 64 calls, ARTM 48 from 8 dB), where
     dozens of chunks per block miss the warm-up and are repaired by the detector's second launch — over 2e6 symbols:
     symbol and bit error counts equal the sequential oracle chain's on the same bits and the same Philox noise."""
@@ -443,7 +460,7 @@ def test_gpu_cpm_detection_example(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("waveform,chunk", [("multih", 5120), ("multih", 8192), ("pcmfm", 6144)])
-def test_gpu_cpm_stream_in_chunks_equals_one_shot(waveform, chunk):
+def test_gpu_cpm_stream_in_chunks_equals_one_shot(waveform, chunk, detector_form):
     """wf_cpm_link_stream_chunk: the CPM link over a stream in chunks (detector state and modulator phase carried,
     everything else re-generated as a halo) makes exactly the one-shot link's decisions and counts — ragged
     last chunk, with and without noise."""
@@ -477,7 +494,7 @@ def test_gpu_cpm_stream_in_chunks_equals_one_shot(waveform, chunk):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("waveform", ["multih", "pcmfm"])
-def test_gpu_cpm_link_pipelined_blocks_equal_sequential_blocks(waveform):
+def test_gpu_cpm_link_pipelined_blocks_equal_sequential_blocks(waveform, detector_form):
     """wf_cpm_link_config.fuse bit 5: a block's detector and error count on the context's side stream, beside the front
     end of the next block (two sets of intermediates).  Block for block and in total the counts are those of the
     sequential link."""

@@ -38,6 +38,8 @@ struct cpm_lane_plan {
     int ring_batches;   // LDS ring depth in 16 KB batches
     int waves_per_cu;   // resident waves per CU the ring allows
     int calls_per_batch;
+    double lane_ns_per_call;    // the lane form's time per call of a chunk (a lane runs its chunk alone: independent of the burst)
+    double row_ns_per_call;     // the row form's time per call of the BURST (measured at 1e7 calls; it scales with the burst)
 };
 int wf_cpm_lanes_plan(const wf_cpm_detector_config *det, cpm_lane_plan *plan);
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,

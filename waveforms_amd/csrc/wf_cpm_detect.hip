@@ -528,17 +528,62 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
     return WF_OK;
 }
 
+// Calls per chunk, and which form runs them.  Row form: a multiple of 64, at least 256 (and 2 W) so that the warm-up stays
+// a fraction of the work, otherwise the smallest that puts the whole burst into ONE round of resident workgroups.  Lane
+// form (wf_cpm_lanes.hip, where a specialisation for this trellis is compiled in): 64 chunks per wave, the chunk length that
+// puts the burst into one round of the waves a CU's LDS holds, at least 5 W — a chunk that missed a short warm-up needs
+// room to meet the first launch's trajectory inside its own calls: with 64-call warm-ups and 256-call chunks PCM/FM left
+// 3 chunks of 1.2e7 unproven at 10 dB, none with 320 (profiles/r04_lane_chunk_sweep.log).
+// Which one: a lane runs its chunk alone, so the lane form's time is (chunk + warm-up) x its time per call whatever the
+// burst's length, while the row form's falls with the burst (4 chunks per wave: 16 times the waves).  The two meet near
+// 9e6 (ARTM) and 6.5e6 (PCM/FM) calls; below, the row form runs (a 2^22-call stream chunk: 0.32 against 0.54 ms for
+// ARTM).  WF_CPM_LANES=0 / 1 forces one form (tests run both on every size).
+static int64_t cpm_chunk_calls(const wf_cpm_detector_config *det, int64_t ncalls, int W, int cus, int wg_per_cu, cpm_lane_plan *lanes, bool *use_lanes)
+{
+    auto floor_ch = [&](int64_t ch, bool lane) {
+        ch = (ch + 63) / 64 * 64;
+        if (ch < 256) ch = 256;                                    // (room for the repair launch to meet the first launch's trajectory)
+        if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
+        if (lane && ch < 5 * W) ch = (5 * W + 63) / 64 * 64;
+        return ch;
+    };
+    const int64_t slots_row = (int64_t)cus * wg_per_cu * CPM_WAVES * CPM_GROUPS;
+    int64_t ch = floor_ch((ncalls + slots_row - 1) / slots_row, false);
+    *use_lanes = false;
+    const int have = wf_cpm_lanes_plan(det, lanes);                // 0: a specialisation exists; 2: ... and WF_CPM_LANES=1 forces it
+    if (have == 0 || have == 2) {
+        const int64_t slots_lane = (int64_t)cus * lanes->waves_per_cu * 64;
+        const int64_t ch_lane = floor_ch((ncalls + slots_lane - 1) / slots_lane, true);
+        const double t_lane = lanes->lane_ns_per_call * (double)(ch_lane + W), t_row = lanes->row_ns_per_call * (double)ncalls;
+        if (have == 2 || t_lane < t_row) {
+            *use_lanes = true;
+            ch = ch_lane;
+        }
+    }
+    if (const char *e = getenv(*use_lanes ? "WF_CPM_LANE_CH" : "WF_CPM_CH")) ch = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : ch;   // tuning aid (tools/cpm_vit_time.py)
+    if (ch > 8192) ch = 8192;                                      // decision strips live in LDS; longer bursts take several rounds
+    return ch;
+}
+
 // Which form of the detector wf_cpm_viterbi_detect runs for this trellis (bench.py and the profile tools name the
 // kernel they price by it): info4 = {form (0: row form, one 16-lane DPP row per chunk; 1: lane form, one lane per chunk),
 // ring slots of the lane form, 0, 0}.
-extern "C" int wf_cpm_detector_form(const wf_cpm_detector_config *det, int *info4)
+extern "C" int wf_cpm_detector_form(const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int *info4)
 {
-    WF_REQUIRE(det && info4, "wf_cpm_detector_form: NULL argument");
+    WF_REQUIRE(det && info4 && ncalls >= 0 && warmup >= 0, "wf_cpm_detector_form: bad argument");
+    cpm_vit_params P;
+    const int rc = cpm_build_tables(det, P);
+    if (rc) return rc;
+    int W = warmup ? warmup : 96;
+    W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
+    if (W > 4096) W = 4096;
     cpm_lane_plan lanes{};
-    const bool use_lanes = wf_cpm_lanes_plan(det, &lanes) == 0;
+    bool use_lanes = false;
+    const int64_t ch = cpm_chunk_calls(det, ncalls, W, 256, CPM_MIN_WAVES(P.M, P.Lp), &lanes, &use_lanes);
     info4[0] = use_lanes ? 1 : 0;
     info4[1] = use_lanes ? lanes.ring_batches : 0;
-    info4[2] = info4[3] = 0;
+    info4[2] = (int)ch;
+    info4[3] = W;
     return WF_OK;
 }
 
@@ -583,19 +628,9 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
     // The lane-per-chunk form (wf_cpm_lanes.hip) where a specialisation for this trellis is compiled in: 64 chunks per
     // wave, as many waves as its LDS ring lets a CU hold — the chunk length that puts the burst into one round of them.
     cpm_lane_plan lanes{};
-    const bool use_lanes = wf_cpm_lanes_plan(det, &lanes) == 0;
     const int wg_per_cu = CPM_MIN_WAVES(P.M, P.Lp);                 // resident workgroups per CU = waves per SIMD (4 waves per workgroup)
-    const int64_t slots = use_lanes ? (int64_t)cus * lanes.waves_per_cu * 64 : (int64_t)cus * wg_per_cu * CPM_WAVES * CPM_GROUPS;
-    int64_t ch = (ncalls + slots - 1) / slots;
-    ch = (ch + 63) / 64 * 64;
-    if (ch < 256) ch = 256;                                        // (room for the repair launch to meet the first launch's trajectory)
-    if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
-    // (lane form: 64 chunks per wave make the chunks short — 256 calls at 1e7 — and a chunk that missed a short warm-up needs
-    //  room to meet the first launch's trajectory inside its own calls: with 64-call warm-ups and 256-call chunks PCM/FM
-    //  left 3 chunks of 1.2e7 unproven at 10 dB, none with 320 — profiles/r04_lane_chunk_sweep.log)
-    if (use_lanes && ch < 5 * W) ch = (5 * W + 63) / 64 * 64;
-    if (const char *e = getenv(use_lanes ? "WF_CPM_LANE_CH" : "WF_CPM_CH")) ch = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : ch;   // tuning aid (tools/cpm_vit_time.py)
-    if (ch > 8192) ch = 8192;                                      // decision strips live in LDS; longer bursts take several rounds
+    bool use_lanes = false;
+    const int64_t ch = cpm_chunk_calls(det, ncalls, W, cus, wg_per_cu, &lanes, &use_lanes);
     // (measured at 1e7 ARTM calls, W = 128, row form: 384 calls per chunk 1.07 ms, 512: 1.03, 640: 1.00, 768: 1.19,
     //  1024: 1.28, 1536: 1.68 — longer chunks do less warm-up work but leave fewer waves to hide the
     //  dependent chain of a call)

@@ -76,16 +76,17 @@ ARTM_16 = CPMDetectorSpec(M=4, p=16, K=(4, 5), Lp=2, NC=4, D=32)
 PCMFM_10 = CPMDetectorSpec(M=2, p=10, K=(7,), Lp=2, NC=5, D=32)
 
 
-def detector_kernel_name(spec: "CPMDetectorSpec") -> str:
-    """Name (as rocprofv3 prints it) of the kernel ``wf_cpm_viterbi_detect`` runs for ``spec``: asked from the library
-    (``wf_cpm_detector_form``), so that bench.py and the profile tools price the kernel that really runs."""
+def detector_kernel_name(spec: "CPMDetectorSpec", ncalls: int = 10_000_000, warmup: int = 0) -> str:
+    """Name (as rocprofv3 prints it) of the kernel ``wf_cpm_viterbi_detect`` runs for ``spec`` on a burst of ``ncalls``
+    calls: asked from the library (``wf_cpm_detector_form``), so that bench.py and the profile tools price the kernel
+    that really runs."""
     import ctypes
 
     from waveforms_amd import _hip
 
     info = (ctypes.c_int * 4)()
     cfg = spec.c_config()
-    _hip.check(_hip.lib().wf_cpm_detector_form(ctypes.byref(cfg), info))
+    _hip.check(_hip.lib().wf_cpm_detector_form(ctypes.byref(cfg), int(ncalls), int(warmup), info))
     if info[0] == 1:
         k1 = spec.K[1] if len(spec.K) > 1 else spec.K[0]
         hi = "true" if spec.bits_per_symbol * (spec.D - 1) >= 32 else "false"

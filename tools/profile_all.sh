@@ -1,6 +1,10 @@
+# Every rocprofv3 profile the round commits (GPU box): tools/profile.sh per workload, blocks one after the other
+# (--fuse 15: every kernel alone on the chip).   bash tools/profile_all.sh <round tag, e.g. r04>
 set -e
-bash tools/profile.sh r03_fuse15 --fuse 15 > gpurun_out/p_fuse15.log 2>&1
-bash tools/profile.sh r03_sps10 --sps 10 --fuse 15 > gpurun_out/p_sps10.log 2>&1
-bash tools/profile.sh r03_multih --waveform multih --fuse 15 > gpurun_out/p_multih.log 2>&1
-bash tools/profile.sh r03_pcmfm --waveform pcmfm --fuse 15 > gpurun_out/p_pcmfm.log 2>&1
+tag=${1:-r04}
+bash tools/profile.sh ${tag}_fuse15 --fuse 15 > gpurun_out/p_fuse15.log 2>&1
+bash tools/profile.sh ${tag}_pam --detector PAM --fuse 15 > gpurun_out/p_pam.log 2>&1
+bash tools/profile.sh ${tag}_sps10 --sps 10 --fuse 15 > gpurun_out/p_sps10.log 2>&1
+bash tools/profile.sh ${tag}_multih --waveform multih --fuse 15 > gpurun_out/p_multih.log 2>&1
+bash tools/profile.sh ${tag}_pcmfm --waveform pcmfm --fuse 15 > gpurun_out/p_pcmfm.log 2>&1
 echo ALLDONE

@@ -100,27 +100,25 @@ __device__ __forceinline__ int64_t lane_uniform64(int64_t v)
 }
 
 // Four LDS-DMA instructions: 16 B per lane from sbase + voff (bytes) to LDS lds, lds + 1 KiB, ... (M0 = destination;
-// written and restored inside the statement — the compiler owns M0 everywhere else).  Rows are read once: nt.
-__device__ __forceinline__ void lane_dma4(unsigned v0, unsigned v1, unsigned v2, unsigned v3, const void *sbase, unsigned lds)
+// written and restored inside the statement — the compiler owns M0 everywhere else).  The instruction's immediate offset
+// moves the LDS destination AND the global source (tools/lds_dma_offset_probe.hip: offset:1024 with M0 = 0 puts global
+// byte 1024 at LDS byte 1024), so one M0 serves the four: the caller passes voff_k - 1024 k (+ LANE_DMA_BIAS on the
+// offsets, - LANE_DMA_BIAS on the base: offsets are unsigned).  Rows are read once: nt.
+#define LANE_DMA_BIAS 4096
+__device__ __forceinline__ void lane_dma4(unsigned v0, unsigned v1, unsigned v2, unsigned v3, const void *sbase_biased, unsigned lds)
 {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %6\n\t"
                  "s_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, %5 nt\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %5 nt\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %3, %5 nt\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %4, %5 nt\n\t"
+                 "global_load_lds_dwordx4 %2, %5 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %3, %5 offset:2048 nt\n\t"
+                 "global_load_lds_dwordx4 %4, %5 offset:3072 nt\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds)
-                 : "memory", "scc");
+                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase_biased), "s"(lds)
+                 : "memory");
 }
 
 // One LDS-DMA instruction with a full per-lane address (the slots at either end of a burst, whose rows are clamped).
@@ -397,14 +395,14 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
         int c = 8 * i + c8;                                          // chunk of the wave this lane fetches for in DMA i
         const int q = j8 ^ ((c >> 1) & 7);                           // ... and which of the slot's 8 pieces
         c = chunk0 + c <= cg_last ? c : (int)(cg_last - chunk0);
-        voff[i] = ((unsigned)c * (unsigned)P.CH * NF + (unsigned)q) * 16u;
+        voff[i] = ((unsigned)c * (unsigned)P.CH * NF + (unsigned)q) * 16u + (unsigned)(LANE_DMA_BIAS - 1024 * (i & 3));   // (see lane_dma4)
     });
     auto fetch = [&](int s, unsigned lds) __attribute__((always_inline)) {
         const int ss = s < nslots ? s : nslots - 1;                  // (past the end: the last slot again — the count of DMAs in flight must not change)
         if (ss >= fast_lo && ss <= fast_hi) {
             // (uniform by construction; said so explicitly — the ring counters are loop-carried through the call lambdas and
             //  the compiler's divergence analysis gives up on them, handing a VGPR pair to an SGPR operand)
-            const double2 *sb = reinterpret_cast<const double2 *>(lane_uniform64((int64_t)(uintptr_t)(srow0 + (int64_t)ss * LANE_SLOT_PIECES)));
+            const char *sb = reinterpret_cast<const char *>(lane_uniform64((int64_t)(uintptr_t)(srow0 + (int64_t)ss * LANE_SLOT_PIECES))) - LANE_DMA_BIAS;
             const unsigned ld = __builtin_amdgcn_readfirstlane(lds);
             lane_dma4(voff[0], voff[1], voff[2], voff[3], sb, ld);
             lane_dma4(voff[4], voff[5], voff[6], voff[7], sb, ld + 4096);

@@ -274,3 +274,15 @@ def test_link_row_bytes_rule():
     assert rb(15, mf_ntaps=75) == (32, 0) and rb(15, mf_ntaps=72) == (32, 0)    # longer / even banks: separate kernels, packed rows
     assert rb(15, sps=10, mf_ntaps=91) == (48, 0) and rb(15, sps=16) == (48, 0) and rb(15, sps=4) == (48, 0)
     assert rb(15, sps=10, ntaps=10 * 10 + 1) == (48, 0)                      # a pulse of more than 9 symbols
+
+
+def test_design_status_block_is_generated_from_committed_profiles():
+    """DESIGN.md's status tables are tools/gen_status.py's output for the committed profiles/r04_bench*.json and the built
+    library's code-object notes: a figure there cannot drift from its source (round-3 verdict, weak #9)."""
+    import subprocess
+    import sys
+
+    root = ROOT
+    r = subprocess.run([sys.executable, str(root / "tools" / "gen_status.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (root / "DESIGN.md").stat().st_size <= 25 * 1024

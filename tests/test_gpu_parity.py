@@ -1034,6 +1034,41 @@ def test_one_kernel_front_end_pam_bank_rows(oracle, nsym, pulse_name):
             assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
 
 
+def _packed_from_unpacked(rows3, par0=0):
+    """Detector-packed rows {Re z1, Im z1, a, b} from full [k][3] complex rows: a = Im z0 / Re z0 and b = Re z2 / Im z2
+    for an odd / even detector call (wf_viterbi.hip)."""
+    k = np.arange(rows3.shape[0]) + par0
+    odd = (k & 1) == 1
+    return np.stack([rows3[:, 1].real, rows3[:, 1].imag, np.where(odd, rows3[:, 0].imag, rows3[:, 0].real),
+                     np.where(odd, rows3[:, 2].real, rows3[:, 2].imag)], axis=1)
+
+
+@pytest.mark.parametrize("nsym", [70_001, 2_000, 300])
+def test_one_kernel_front_end_pam_bank_rows_sps10(oracle, nsym):
+    """The reference example's own configuration — 10 samples per symbol (examples/soqpsk_detection.py:38) and the PAM
+    bank of :158-173 (91- and 81-tap rho pulses) — through the one-kernel front end: operand rows of 4 columns x 10 samples
+    on a pad grid of 40, rows of 51 columns whose odd ones start three columns early (mcb_pam_geom).  Packed rows equal
+    the separate kernels' 48-byte rows component for component to rounding; decisions and counts are identical; every
+    decimation phase, tile edges (816 symbols), both ends of the burst, bursts shorter than a tile and than a row."""
+    from waveforms_amd.link import SOQPSKLink
+
+    for off in (range(-5, 5) if nsym == 70_001 else (0, -3, 4)):
+        ref = SOQPSKLink(nsym, 10, fuse=7, timing_offset=off, detector="PAM")
+        fus = SOQPSKLink(nsym, 10, fuse=15, timing_offset=off, detector="PAM")
+        assert (ref.row_bytes, fus.row_bytes) == (48, 32)
+        assert ref.layout()["one_kernel_front_end"] == 0 and fus.layout()["one_kernel_front_end"] == 1
+        for link in (ref, fus):
+            link.run_block(4.0, seed=7, stream_id=9, skip_bits=55)
+        lr, lf = ref.layout(), fus.layout()
+        calls = lr["calls"]
+        a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 48].view(torch_f64()).reshape(calls, 3, 2).cpu().numpy()
+        b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+        np.testing.assert_allclose(b, _packed_from_unpacked(a[..., 0] + 1j * a[..., 1]), rtol=0, atol=2e-12, err_msg=str(off))
+        assert ref.result() == fus.result(), off
+        for key in ("off_bits", "off_syms"):
+            assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
+
+
 def test_one_kernel_front_end_random_bursts(capsys):
     """tools/fuzz_front_end.py for a few seconds: random burst lengths (one row to millions of symbols: the run
     partition with its single-tile tail, tile edges, ragged ends), decimation phases, both banks and both precoder forms —
@@ -1147,13 +1182,14 @@ def test_detector_reports_and_repairs_unmerged_chunks(oracle):
 def test_link_other_sample_rates_equal_oracle(oracle, sps, detector):
     """The link away from the tuned 8-samples-per-symbol path still equals the oracle chain count for count:
     generic bank and staging kernels with unpacked rows (fuse 0 / 7), and with fuse 15 the one-kernel front end at
-    10 samples per symbol (the reference's own examples/soqpsk_detection.py:38) and 20 (examples/pcmfm_test.py:25)."""
+    10 samples per symbol (the reference's own examples/soqpsk_detection.py:38; both its detectors, the PAM bank of
+    :158-173 as matrix tiles) and 20 (examples/pcmfm_test.py:25)."""
     from waveforms_amd.link import SOQPSKLink
 
     nsym = 30_000
     for fuse in (0, 7, 15):
         link = SOQPSKLink(nsym, sps, detector=detector, fuse=fuse)
-        one_kernel = fuse == 15 and detector == "PT" and sps in (8, 10, 20)
+        one_kernel = fuse == 15 and ((detector == "PT" and sps in (8, 10, 20)) or (detector == "PAM" and sps == 10))
         assert link.layout()["one_kernel_front_end"] == int(one_kernel)
         assert link.row_bytes == (32 if one_kernel or (sps == 8 and fuse & 4) else 48)
         link.run_block(5.0, seed=21, stream_id=3, skip_bits=777)

@@ -39,6 +39,8 @@ HOT = {
     # the same kernel with the 73-tap PAM bank on the matrix cores (13 B operands per lane + 8 KB of partial tiles)
     "mod_chan_bank_kernel<9, -1, 8>": (168, 3),
     "mod_chan_bank_kernel<4, -1, 8>": (168, 3),
+    # ... and the reference example's own configuration: sps 10 with the 91-tap PAM bank (16 B operands per lane)
+    "mod_chan_bank_kernel<9, -1, 10>": (168, 3),
     # CPM front ends (configs[2]; the ARTM and PCM/FM pulses are the 4-symbol forms): 4 waves per SIMD, <= 128 registers
     "mod_chan_bank_kernel<4, 16, 8>": (128, 4),
     "mod_chan_bank_kernel<4, 4, 8>": (128, 4),
@@ -120,7 +122,8 @@ def test_no_spill_traffic_inside_nested_loops(table):
     # ... and the sps-10 form of the one-kernel front end keeps its kernarg pointer (2 SGPRs) in a spill lane:
     # read back once per tile and in the set-up loops, never in the row loop.
     ceilings = {"cpm_mf_rows_kernel<": 0, "mf_bank_kernel<3, true": 31, "mf_bank_kernel<8, true": 44, "mf_bank_kernel<8, false": 4,
-                "mod_chan_bank_kernel<4, 0, 10>": 2, "mod_chan_bank_kernel<9, 0, 10>": 2}
+                "mod_chan_bank_kernel<4, 0, 10>": 2, "mod_chan_bank_kernel<9, 0, 10>": 2,
+                "mod_chan_bank_kernel<4, -1, 10>": 2, "mod_chan_bank_kernel<9, -1, 10>": 2}
     bad = {}
     for k, v in table.items():
         cap = next((c for pre, c in ceilings.items() if k.startswith(pre)), None)

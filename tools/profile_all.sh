@@ -5,6 +5,7 @@ tag=${1:-r04}
 bash tools/profile.sh ${tag}_fuse15 --fuse 15 > gpurun_out/p_fuse15.log 2>&1
 bash tools/profile.sh ${tag}_pam --detector PAM --fuse 15 > gpurun_out/p_pam.log 2>&1
 bash tools/profile.sh ${tag}_sps10 --sps 10 --fuse 15 > gpurun_out/p_sps10.log 2>&1
+bash tools/profile.sh ${tag}_pam10 --sps 10 --detector PAM --fuse 15 > gpurun_out/p_pam10.log 2>&1
 bash tools/profile.sh ${tag}_multih --waveform multih --fuse 15 > gpurun_out/p_multih.log 2>&1
 bash tools/profile.sh ${tag}_pcmfm --waveform pcmfm --fuse 15 > gpurun_out/p_pcmfm.log 2>&1
 echo ALLDONE

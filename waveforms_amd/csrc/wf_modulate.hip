@@ -618,9 +618,38 @@ struct mcb_kargs {
 };
 typedef const __attribute__((address_space(4))) mcb_kargs *mcb_kptr;
 
-#define MCB_PAM_NT 73        // longest bank of the PAM form (the 73-tap PAM bank of SOQPSK-TG at 8 samples per symbol)
-#define MCB_PAM_MIRROR 96    // ring slots behind the wrap copy: samples 0 .. 71 of the ring once more, so a 97-sample operand row never wraps
-template <int JMAX, int CPMNF, int SPS = 8>     // SPS != 8: CPMNF = 0 only (the CPM detector's 9-tap templates are an sps-8 design)
+// Geometry of the PAM (long-bank) form per samples-per-symbol: 8 (BASELINE) and 10 (the reference's own
+// examples/soqpsk_detection.py:38 with its better detector, :158-173).  An operand row of the matrix tile = FOUR consecutive
+// columns = 3 SPS + NT samples (97 / 121), one pad slot per PG = 4 SPS samples, operand rows PG samples apart: 33 / 41 slots =
+// 132 / 164 words, i.e. 4 / 36 banks (mod 64) from one row to the next — the 16 lanes a ds_read_b64 serves together, one
+// per operand row, all land on different banks either way.  A row of 512 samples is 16 operand rows exactly; a row of 510 is
+// 12.75: there the ODD rows of the ring start their operand rows QSH = 3 columns early (ring index 480 = 12 PG: on the pad
+// grid again, and an odd shift, so that column 4 i + s - 3 of an odd row — rows hold 51 columns: the parity of a column
+// flips with the row — has the parity of s like column 4 i + s of an even row: ONE set of B operands serves both).  13 / 14
+// operand rows per row of 51 columns; the 2 - 5 columns they compute outside the row are not stored.
+template <int SPS>
+struct mcb_pam_geom {
+    static constexpr int NT = 9 * SPS + 1;                           // longest bank: 73 / 91 taps (rho_0 of SOQPSK-TG)
+    static constexpr int PG = 4 * SPS;                               // samples per pad group = per operand row
+    static constexpr int OPLEN = 3 * SPS + NT;                       // samples an operand row spans
+    static constexpr int NK = (2 * OPLEN + 3) / 4;                   // k-steps (4 components each): 49 / 61
+    static constexpr int NKW = NK / 4;                               // k-steps per wave (wave 0 takes the odd one out)
+    static constexpr int QSH = (mcb_geom<SPS>::CPR & 1) ? 3 : 0;     // columns an odd row's operand rows start early
+    static constexpr int OPROWS = (mcb_geom<SPS>::CPR + QSH + 3) / 4;   // operand rows in use (of 16)
+    static constexpr int XLEN = NT + 1;                              // samples of the next tile the last columns of a tile look at: NT - SPS + d, d < SPS (even count)
+    // an odd row's last operand row starts at RS - QSH SPS + PG (OPROWS - 1) and its last (half-filled) k-step reads sample OPLEN:
+    static constexpr int MIRROR = (PG * (OPROWS - 1) + OPLEN + 1 - QSH * SPS - mcb_geom<SPS>::RS + 7) & ~7;   // ring indices 0 .. MIRROR-1 once more behind the ring (72 / 104)
+    static constexpr int EXT = mcb_geom<SPS>::RING + MIRROR;                                         // extended ring: indices 0 .. EXT-1
+    static constexpr int SLOTS = EXT + EXT / PG + 1;
+    static_assert(NK % 4 == 1, "wave 0 takes exactly one k-step more than the others");
+    static_assert((mcb_geom<SPS>::RS - QSH * SPS) % PG == 0 && PG % 8 == 0, "operand rows start on the pad grid in both rows of the ring");
+    static_assert(((mcb_geom<SPS>::CPR - QSH) & 1) == 0 && OPROWS <= 16, "one B operand set for both row parities");
+};
+static_assert(mcb_pam_geom<8>::NT == 73 && mcb_pam_geom<8>::NK == 49 && mcb_pam_geom<8>::XLEN == 74 && mcb_pam_geom<8>::OPROWS == 16 && mcb_pam_geom<8>::MIRROR == 72, "SPS = 8 PAM geometry");
+static_assert(mcb_pam_geom<10>::NT == 91 && mcb_pam_geom<10>::NK == 61 && mcb_pam_geom<10>::OPROWS == 14 && mcb_pam_geom<10>::MIRROR == 104, "SPS = 10 PAM geometry");
+#define MCB_PAM_NT(sps) (9 * (sps) + 1)
+static inline int mcb_pam_slots(int sps) { return sps == 8 ? mcb_pam_geom<8>::SLOTS : mcb_pam_geom<10>::SLOTS; }
+template <int JMAX, int CPMNF, int SPS = 8>     // SPS != 8: CPMNF <= 0 only (the CPM detector's 9-tap templates are an sps-8 design); CPMNF < 0: SPS 8 / 10
 __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0 ? 3 : (JMAX <= 4 ? WF_MCB_CPM_WAVES : 2))) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
                                                                      const double *__restrict__ hvec_,
                                                                      const double *__restrict__ pulse_,
@@ -636,9 +665,10 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     const double *__restrict__ const hvec = ka->hvec;
     const double *__restrict__ const scratch = ka->scratch;
     const double *__restrict__ const mf_taps = ka->mf_taps;
-    static_assert(SPS == 8 || CPMNF == 0, "the CPM detector rows and the long-bank form are sps-8 designs");
+    static_assert(SPS == 8 || CPMNF == 0 || (CPMNF < 0 && SPS == 10), "the CPM detector rows are an sps-8 design, the long-bank form one for 8 and 10");
     constexpr bool PAM = CPMNF < 0;
     using G = mcb_geom<SPS>;
+    using GP = mcb_pam_geom<PAM ? SPS : 8>;
     constexpr int NT = G::NT, RS = G::RS, CPR = G::CPR;
     constexpr bool FULLROW = RS == 2 * MOD_THREADS;                              // every thread owns two samples of a row
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -646,12 +676,10 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     const int win = MOD_ROWS * CPR + JMAX + 2 + (CPMNF < 0 ? 10 : 0);
     double *s_amp = s_dyn;                                                       // window of symbol amplitudes
     double2 *s_ring = reinterpret_cast<double2 *>(s_dyn + ((win + 1) & ~1));     // noisy samples, 2 rows
-    // (PAM form: one pad slot per 32 samples — operand rows 32 samples = 33 slots = 132 words apart: the 16 lanes a
-    //  ds_read_b64 serves together, one per operand row, land 4 banks apart, all different; with the pulse-truncation
-    //  layout's pad per 8 samples, 144 words, every fourth row shared its banks, with a pad per 16 every eighth)
-    constexpr int PG = PAM ? 32 : SPS;                                           // samples per pad group
-    constexpr int RBASE = PAM ? G::RING + G::RING / 32 : G::GROUPS * G::GS;      // slot of ring index RING (the wrap copy / mirror)
-    constexpr int RSLOTS = PAM ? RBASE + MCB_PAM_MIRROR : G::SLOTS;
+    // (PAM form: one pad slot per 4 SPS samples over the ring AND its mirror, slot(e) = e + e / PG: mcb_pam_geom; with the
+    //  pulse-truncation layout's pad per 8 samples, 144 words, every fourth operand row shared its banks, with a pad per 16 every eighth)
+    constexpr int PG = PAM ? GP::PG : SPS;                                       // samples per pad group
+    constexpr int RSLOTS = PAM ? GP::SLOTS : G::SLOTS;
     int *s_pi = reinterpret_cast<int *>(s_ring + RSLOTS);                        // prefix counts of the window's raw symbols
     __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
@@ -779,22 +807,23 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     // ((w0 + w1) + w2) + w3, the 16 columns it stores (register r of D = columns 16 r .. 16 r + 15: 512 B contiguous
     // per wave) — after the NEXT row barrier, which is there anyway.  Rows therefore differ from the single-chain
     // banks (mf_bank_kernel and the CPU restatement the tests check it with) in the last bits: the four chains are summed in another order.
+    // (SPS 10: 121-sample operand rows, 61 k-steps, B[c][4 s + o] = the coefficient of component c - 20 s; see mcb_pam_geom)
     __shared__ double s_part[PAM ? 4 * 4 * 64 : 1];
-    double bpam[PAM ? 13 : 1];
+    double bpam[PAM ? GP::NKW + 1 : 1];
     if constexpr (PAM) {
         const int s_sh = mf_i >> 2, o_sl = mf_i & 3;
         const int nt = Q.mf_ntaps;
-        const bool odd_col = ((Q.pack_par0 + s_sh - Q.kshift) & 1) != 0;
+        const bool odd_col = ((Q.pack_par0 + s_sh - Q.kshift) & 1) != 0;   // (column 4 i + s of an even row = column 4 i + s - QSH of an odd one)
         const int f = o_sl < 2 ? 1 : (o_sl == 2 ? 0 : 2);
         // slot 0 / 1: Re / Im z1;  slot 2: odd ? Im z0 : Re z0;  slot 3: odd ? Re z2 : Im z2
         const bool want_im = o_sl == 1 || (o_sl == 2 && odd_col) || (o_sl == 3 && !odd_col);
         const double2 *tg = reinterpret_cast<const double2 *>(mf_taps) + f * nt;
 #pragma unroll
-        for (int n = 0; n < 13; ++n) {
+        for (int n = 0; n <= GP::NKW; ++n) {
             const int kk = 4 * n + wave_u;                       // this wave's k-steps: every fourth one
-            const int cc = 4 * kk + mf_kq - 16 * s_sh;           // component of this column's own window
+            const int cc = 4 * kk + mf_kq - 2 * SPS * s_sh;      // component of this column's own window
             double v = 0.0;
-            if (cc >= 0 && cc < 2 * nt && (n < 12 || wave_u == 0)) {
+            if (cc >= 0 && cc < 2 * nt && (n < GP::NKW || wave_u == 0)) {
                 const double2 tp = tg[nt - 1 - (cc >> 1)];
                 // component cc: odd = Re x, even = Im x (the imaginary sample's term first, as in every other bank)
                 //   Re z += Re x . Re t + Im x . (-Im t)        Im z += Re x . Im t + Im x . Re t
@@ -898,17 +927,18 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                     }
                 }
             } else if constexpr (PAM) {
-                // operand row i = the 97 samples from ring index 512 (rho & 1) + 32 i; this lane's element of k-step
-                // kk = 4 n + w is component 4 kk + kq: sample 8 n + 2 w + (kq >> 1), Im (kq even) or Re (kq odd).  The
-                // sample's slot is index + index / 32, the row starts on a pad-group boundary and 2 w + (kq >> 1) < 8,
-                // so the slot offset of step n is the CONSTANT 8 n + n / 4 behind a per-lane base.
-                const int S0 = ((rho & 1) ? 512 : 0) + 32 * mf_i;
-                const double *xa = ring_d + 2 * (S0 + (S0 >> 5) + 2 * wave_u + (mf_kq >> 1)) + ((mf_kq & 1) ? 0 : 1);
+                // operand row i = the 97 (121) samples from ring index RS (rho & 1) + PG i (odd rows of 51 columns: QSH
+                // columns earlier); this lane's element of k-step kk = 4 n + w is component 4 kk + kq: sample
+                // 8 n + 2 w + (kq >> 1), Im (kq even) or Re (kq odd).  The sample's slot is index + index / PG, the row
+                // starts on a pad-group boundary, PG is a multiple of 8 and 2 w + (kq >> 1) < 8, so the slot offset of
+                // step n is the CONSTANT 8 n + 8 n / PG behind a per-lane base.  (Operand rows past OPROWS: row 0 again.)
+                const int S0 = ((rho & 1) ? RS - GP::QSH * SPS : 0) + PG * (GP::OPROWS < 16 && mf_i >= GP::OPROWS ? 0 : mf_i);
+                const double *xa = ring_d + 2 * (S0 + S0 / PG + 2 * wave_u + (mf_kq >> 1)) + ((mf_kq & 1) ? 0 : 1);
                 mcb_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int n = 0; n < 12; ++n)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * n + n / 4)], bpam[n], acc, 0, 0, 0);
-                if (wave_u == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * 12 + 3)], bpam[12], acc, 0, 0, 0);
+                for (int n = 0; n < GP::NKW; ++n)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * n + 8 * n / PG)], bpam[n], acc, 0, 0, 0);
+                if (wave_u == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * GP::NKW + 8 * GP::NKW / PG)], bpam[GP::NKW], acc, 0, 0, 0);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) s_part[(4 * wave_u + reg) * 64 + (t & 63)] = acc[reg];
             } else if constexpr (CPMNF != 0) {
@@ -973,9 +1003,10 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 const int ln = t & 63;
                 const double *pp = s_part + (4 * 0 + wave_u) * 64 + ln;
                 const double v = ((pp[0] + pp[4 * 64]) + pp[8 * 64]) + pp[12 * 64];
-                // lane (j = 4 s + o, iq): column 16 w + 4 iq + s of the row, packed slot o: 4 (4 iq + s) + o = the lane index
-                const int kr = 64 * rho + 16 * wave_u + (ln >> 2) - Q.kshift;
-                if (kr >= klo && kr < khi) rows[4 * ((sym_base + kr) - Q.k_lo) + (ln & 3)] = v;
+                // lane (j = 4 s + o, iq): column 16 w + 4 iq + s (- QSH in an odd row) of the row, packed slot o: 4 (4 iq + s) + o = the lane index
+                const int col = 16 * wave_u + (ln >> 2) - ((rho & 1) ? GP::QSH : 0);
+                const int kr = CPR * rho + col - Q.kshift;
+                if (kr >= klo && kr < khi && (CPR == 64 || (col >= 0 && col < CPR))) rows[4 * ((sym_base + kr) - Q.k_lo) + (ln & 3)] = v;
             }
         };
         // One row: 512 samples by the 256 threads (EXTRA: "row 16", only what row 15's columns still need).
@@ -1076,13 +1107,13 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 ia += ia < 0 ? G::RING : 0;
                 ib = ia + 1 == G::RING ? 0 : ia + 1;
             }
-            constexpr int XLEN = PAM ? 74 : SPS;                // samples of the next tile the last columns of a tile look at
+            constexpr int XLEN = PAM ? GP::XLEN : SPS;          // samples of the next tile the last columns of a tile look at
             if (active && (!EXTRA || 2 * t < XLEN)) {           // (row 16: its first XLEN samples; the lanes above computed on window slots that do not exist)
                 s_ring[ia + ia / PG] = x0;
                 s_ring[ib + ib / PG] = x1;
-                if (PAM) {                                      // indices 0 .. 71 once more behind the ring (index RING + i)
-                    if (ia < 72) s_ring[RBASE + ia + ia / PG] = x0;
-                    if (ib < 72) s_ring[RBASE + ib + ib / PG] = x1;
+                if (PAM) {                                      // indices 0 .. MIRROR-1 once more behind the ring (index RING + i)
+                    if (ia < GP::MIRROR) s_ring[G::RING + ia + (G::RING + ia) / PG] = x0;
+                    if (ib < GP::MIRROR) s_ring[G::RING + ib + (G::RING + ib) / PG] = x1;
                 } else {
                     if (ia == 0) s_ring[G::GROUPS * G::GS] = x0;    // index RING: read by the window that ends the ring
                     if (ib == 0) s_ring[G::GROUPS * G::GS] = x1;
@@ -1245,7 +1276,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     // symbol = the long-bank (PAM) form on the matrix cores
     if (mf_ntaps <= 0) mf_ntaps = sps + 1;
     const bool pam = cpm_nf == 0 && mf_ntaps != sps + 1;
-    if (pam && (sps != 8 || mf_ntaps < 3 || mf_ntaps > MCB_PAM_NT || (mf_ntaps & 1) == 0)) return 1;
+    if (pam && ((sps != 8 && sps != 10) || mf_ntaps < 3 || mf_ntaps > MCB_PAM_NT(sps) || (mf_ntaps & 1) == 0)) return 1;
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_rows4) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_mf_taps) & 15) == 0,
                "wf_mod_chan_bank: device pointers must be 16-byte aligned");
     mod_params P;
@@ -1295,7 +1326,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     const int ring_slots = sps == 8 ? mcb_geom<8>::SLOTS : (sps == 10 ? mcb_geom<10>::SLOTS : mcb_geom<20>::SLOTS);
     // (occupancy experiment, LDS padded to force fewer workgroups per CU with the 4-row ring of the
     //  first version: 1 per CU 0.97 ms, 2: 0.63, 3: 0.56 — the 2-row ring's 4 per CU: 0.53)
-    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)(pam ? mcb_geom<8>::RING + mcb_geom<8>::RING / 32 + MCB_PAM_MIRROR : ring_slots) * sizeof(double2) +
+    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)(pam ? mcb_pam_slots(sps) : ring_slots) * sizeof(double2) +
                        (size_t)nh * (win + 1) * sizeof(int);
     // one run of consecutive tiles per resident workgroup (4 per CU for the SOQPSK form, 3 for the CPM forms)
     int cus = 256;
@@ -1332,7 +1363,8 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
     kern_t k = cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)
-             : pam          ? (JM == 4 ? mod_chan_bank_kernel<4, -1> : mod_chan_bank_kernel<9, -1>)
+             : pam          ? (sps == 10 ? (JM == 4 ? mod_chan_bank_kernel<4, -1, 10> : mod_chan_bank_kernel<9, -1, 10>)
+                                         : (JM == 4 ? mod_chan_bank_kernel<4, -1> : mod_chan_bank_kernel<9, -1>))
              : sps == 10    ? (JM == 4 ? mod_chan_bank_kernel<4, 0, 10> : mod_chan_bank_kernel<9, 0, 10>)
              : sps == 20    ? (JM == 4 ? mod_chan_bank_kernel<4, 0, 20> : mod_chan_bank_kernel<9, 0, 20>)
                             : (JM == 4 ? mod_chan_bank_kernel<4, 0> : mod_chan_bank_kernel<9, 0>);
@@ -1359,7 +1391,7 @@ int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, 
 // decides the row layout (32 B packed at sps 10 / 20 only through this kernel) with it.
 int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_ntaps, int64_t first)
 {
-    const bool pam = sps == 8 && mf_ntaps != 9 && mf_ntaps >= 3 && mf_ntaps <= MCB_PAM_NT && (mf_ntaps & 1);   // long-bank form
+    const bool pam = (sps == 8 || sps == 10) && mf_ntaps != sps + 1 && mf_ntaps >= 3 && mf_ntaps <= MCB_PAM_NT(sps) && (mf_ntaps & 1);   // long-bank form
     if (!(sps == 8 || sps == 10 || sps == 20) || (mf_ntaps != sps + 1 && !pam) || first < 0 || first >= sps || nh < 1 || nh > 2) return 0;
     mod_params P;
     const int rs_want = sps == 8 ? mcb_geom<8>::RS : (sps == 10 ? mcb_geom<10>::RS : mcb_geom<20>::RS);

@@ -142,7 +142,9 @@ def _cpu_trial(job):
     pulse, sigma = oracle.freq_pulse_soqpsk_tg(sps), oracle.sigma_for_ebn0(ebn0, sps)
     if kind.startswith("cpm:"):   # generic CPM detector chain (build-defined; no reference form exists)
         waveform = kind[4:]
-        spec = oracle.ARTM_16 if waveform == "multih" else oracle.PCMFM_SPEC
+        wide = waveform.endswith("64")                   # "multih64": the 64-state ARTM design (same modulator, same filters)
+        waveform = waveform[:-2] if wide else waveform
+        spec = (oracle.ARTM_64 if wide else oracle.ARTM_16) if waveform == "multih" else oracle.PCMFM_SPEC
         bits, _ = oracle.glfsr_bits(0x420000, state, nsym * spec.lgM)
         sym = oracle.multih_mapper(bits)[0] if waveform == "multih" else oracle.pcmfm_mapper(bits)
         pulse = oracle.freq_pulse_multih_irig(sps) if waveform == "multih" else oracle.freq_pulse_pcmfm(sps)
@@ -221,6 +223,9 @@ def main() -> None:
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"],
                     help="soqpsk: BASELINE configs[1] (the headline metric); multih: configs[2], ARTM multi-h CPM through the "
                          "16-state generic CPM trellis detector; pcmfm: PCM/FM through the same detector family")
+    ap.add_argument("--states", type=int, default=16, choices=[16, 64],
+                    help="--waveform multih: 16 = the reduced design BASELINE configs[2] names (Lp 2, NC 4); 64 = every phase state "
+                         "for the two-symbol pulse (Lp 2, NC 16, N_S = p M^(Lp-1): notes/cpm/cpm.md:128-140), 0.2 dB better, one wave per detector")
     ap.add_argument("--fuse", type=int, default=47,
                     help="bit 0: fused modulator (FIR + phase scan in one pass); bit 1: AWGN inside the MF bank; "
                          "bit 2: detector-packed 32 B rows between bank and detector; bit 3: modulator + channel + bank in one "
@@ -269,8 +274,11 @@ def main() -> None:
         from waveforms_amd.viterbi.cpm import detector_kernel_name
 
         # detector chunk warm-up rows: by operating point (waveforms_amd.link.operating_point_warmup), or --vit-warmup
-        cwu = args.vit_warmup if args.vit_warmup >= 0 else operating_point_warmup(args.waveform, args.ebn0)
-        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, private_ctx=nstreams > 1, fuse=args.fuse, warmup=cwu)      # (bits 1, 3, 5 apply)
+        wide = args.waveform == "multih" and args.states == 64
+        cwu = args.vit_warmup if args.vit_warmup >= 0 else (0 if wide else operating_point_warmup(args.waveform, args.ebn0))
+        if wide:
+            from waveforms_amd.viterbi.cpm import ARTM_64
+        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, spec=ARTM_64 if wide else None, private_ctx=nstreams > 1, fuse=args.fuse, warmup=cwu)      # (bits 1, 3, 5 apply)
                  for _ in range(nstreams)]
         bits_per_sym = links[0].spec.bits_per_symbol
     else:
@@ -536,7 +544,7 @@ def main() -> None:
                                     f"{'Multi-h ARTM CPM (IRIG106 Tier II)' if args.waveform == 'multih' else 'PCM/FM'} {args.nsym:.0e} symbols "
                                     f"@{args.sps} sps, modulate + AWGN + {links[0].spec.nfilt} matched filters ({links[0].spec.Lp}-symbol pulse "
                                     f"truncation) + {links[0].spec.nstates}-state trellis detect"
-                                    + (" (BASELINE configs[2])" if args.waveform == "multih" else "")),
+                                    + (" (BASELINE configs[2])" if args.waveform == "multih" and args.states == 16 else "")),
                        "waveform": args.waveform,
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
@@ -562,7 +570,8 @@ def main() -> None:
             if steady_all:
                 out["steady_state_per_rank"] = steady_all
         if not args.no_cpu_baseline:    # rank 0 only, after the timed region, at any N (the other ranks wait at the final barrier)
-            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample, args.waveform, gpus=world)
+            out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample,
+                                                   args.waveform + ("64" if args.waveform == "multih" and args.states == 64 else ""), gpus=world)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

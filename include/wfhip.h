@@ -398,14 +398,17 @@ int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsa
 /* The detector over ncalls rows.  d_rot_cs: 2p pairs (cos, sin)(pi r / p) (caller-computed so that
  * oracle and device rotate with the same doubles).  d_decisions[k] (uint8) = the U decided at call
  * k, i.e. of symbol n0 + k - D + 1 (n0 = calls already made on d_state; entries with
- * n0 + k < D - 1 are written as 0).  Chunk-parallel like wf_viterbi4_detect: each 16-lane group
+ * n0 + k < D - 1 are written as 0).  Trellises of up to 64 states (N_S = NC M^(Lp-1), notes/cpm/cpm.md:128-140: up to 16
+ * in one 16-lane group, 17 .. 64 — the 64-state ARTM design — one wave per detector).
+ * Chunk-parallel like wf_viterbi4_detect: each 16-lane group
  * re-derives metrics, phase indices and decision registers over `warmup` rows (0 = default) and
  * every launch verifies bitwise that a chunk started from what its predecessor ended with,
  * repairs the chunks for which that failed (wf_viterbi_repaired) and counts what it could not
  * repair (wf_viterbi4_unmerged).  d_state (WF_CPM_STATE_BYTES, zeroed = fresh detector,
  * may be NULL) carries the detector across calls. */
-#define WF_CPM_STATE_BYTES 1024
-/* Which of its two forms wf_cpm_viterbi_detect runs for this trellis, burst length and warm-up: info4[0] = 0 the row
+#define WF_CPM_STATE_BYTES 4096
+/* Which of its forms wf_cpm_viterbi_detect runs for this trellis, burst length and warm-up: info4[0] = 2 the wide form
+ * (17 .. 64 states: lane = state, one wave per chunk), 0 the row
  * form (one 16-lane DPP row per chunk, any trellis of <= 16 states), 1 the lane form (one lane per chunk, trellis compiled
  * in: the ARTM 16-state and PCM/FM 10-state designs of waveforms/cpm/multih, waveforms/cpm/pcmfm; bursts long enough for
  * its 64 chunks per wave to fill the chip, ~9e6 / ~6.5e6 calls); info4[1] = its LDS ring depth; info4[2] = calls per
@@ -470,7 +473,7 @@ int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8);
  * one the one-kernel front end takes (fuse bits 1 + 3; wf_cpm_link_layout info8[5]).
  * wf_cpm_link_stream_layout: info8 = {calls in the chunk, first call index, off(decisions), off(symbols alpha),
  * global index of symbols[0], calls of the whole stream, symbols per modulator tile, off(rows)}. */
-#define WF_CPM_STREAM_STATE_BYTES 2048
+#define WF_CPM_STREAM_STATE_BYTES 8192
 int64_t wf_cpm_link_stream_workspace_bytes(const wf_cpm_link_config *cfg, int64_t chunk_symbols);
 int wf_cpm_link_stream_layout(const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index, int64_t *info8);
 int wf_cpm_link_stream_chunk(wf_ctx *ctx, const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,

@@ -28,8 +28,10 @@ def _random_symbols(rng, n, M):
 DESIGNS = [  # (M, p, K, Lp, NC): full and reduced trellises, both alphabets, every filter length
     (4, 16, (4, 5), 2, 4), (4, 16, (4, 5), 2, 16), (4, 16, (4, 5), 3, 16), (4, 16, (4, 5), 1, 16), (4, 16, (4, 5), 3, 1),
     (4, 16, (4, 5), 2, 2), (2, 10, (7,), 2, 5), (2, 10, (7,), 3, 2), (2, 10, (7,), 1, 10), (2, 2, (1,), 1, 2),
+    # 17 .. 64 states (the wide form of the GPU detector: lane = state, one wave per detector)
+    (4, 16, (4, 5), 2, 8), (4, 16, (4, 5), 3, 4), (2, 10, (7,), 3, 10), (2, 16, (7,), 2, 16), (2, 20, (7,), 1, 20),
 ]
-GPU_DESIGNS = [d for d in DESIGNS if d[4] * d[0] ** (d[3] - 1) <= 16]
+GPU_DESIGNS = [d for d in DESIGNS if d[4] * d[0] ** (d[3] - 1) <= 64]
 
 
 @pytest.fixture(params=["auto", "lanes", "rows"])
@@ -209,10 +211,65 @@ def test_gpu_artm16_decisions_equal_sequential_oracle(oracle, ebn0, detector_for
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ebn0", [0.0, 4.0, 10.0])
+def test_gpu_artm64_decisions_equal_sequential_oracle(oracle, ebn0):
+    """The 64-state ARTM design (Lp 2, NC = p = 16: N_S = p M^(Lp-1) of notes/cpm/cpm.md:128-140 for the two-symbol
+    pulse) on the GPU — one wave per detector — against the sequential C detector on the same 16 matched-filter rows per
+    symbol: every decision identical; and it beats the 16-state design on the same received samples."""
+    from waveforms_amd.viterbi.cpm import ARTM_64, CPMTrellisDetector
+
+    sym, res = _noisy_rows(oracle, oracle.ARTM_64, oracle.freq_pulse_multih_irig(SPS), 420_000, ebn0, int(ebn0) + 11)
+    got = CPMTrellisDetector(ARTM_64).detect(res["rows"])
+    assert got.size == res["decisions"].size == 420_000 - 31
+    assert np.array_equal(got, res["decisions"])
+    _, res16 = _noisy_rows(oracle, oracle.ARTM_16, oracle.freq_pulse_multih_irig(SPS), 420_000, ebn0, int(ebn0) + 11)
+    assert res["bit_errors"] < res16["bit_errors"]
+
+
+@pytest.mark.gpu
+def test_gpu_artm64_link_equals_oracle_chain_and_streams(oracle):
+    """The ARTM link with the 64-state detector: same front end (16 filters per symbol), counts equal the oracle chain fed
+    the same noise; pipelined blocks equal sequential ones; the stream in chunks equals the one-shot link; fewer bit
+    errors than the 16-state design on the same block."""
+    from waveforms_amd.link import CPMLink, CPMStream
+    from waveforms_amd.viterbi import cpm
+
+    nsym, ebn0 = 100_000, 6.0
+    link = CPMLink(nsym, SPS, "multih", spec=cpm.ARTM_64, fuse=10)
+    link.run_block(ebn0, seed=1, stream_id=0)
+    se, be, m = link.result()
+    bits = oracle.glfsr_bits(0x420000, 0x7FFFFF, 2 * nsym)[0]
+    sym = oracle.multih_mapper(bits)[0]
+    noise = oracle.philox_awgn(oracle.cpm_sigma_for_ebn0(ebn0, SPS, 2), 1, 0, 0, (nsym + 1) * SPS)
+    res = oracle.cpm_detection_run(sym, oracle.freq_pulse_multih_irig(SPS), SPS, oracle.ARTM_64, noise=noise)
+    x = (res["decisions"] ^ res["truth"])[64:]
+    assert m == x.size and (se, be) == (int(np.count_nonzero(x)), int(np.unpackbits(x[:, None], axis=1).sum())) and be > 0
+    link16 = CPMLink(nsym, SPS, "multih", fuse=10)
+    link16.run_block(ebn0, seed=1, stream_id=0)
+    assert be < link16.result()[1]
+    # two pipelined blocks (detector of block 0 beside the front end of block 1) == two sequential ones
+    seq, pip = CPMLink(nsym, SPS, "multih", spec=cpm.ARTM_64, fuse=10), CPMLink(nsym, SPS, "multih", spec=cpm.ARTM_64, fuse=42)
+    for lk in (seq, pip):
+        for blk in range(2):
+            lk.run_block(ebn0, seed=1, stream_id=blk, skip_bits=blk * nsym * 2)
+    assert seq.result() == pip.result() and seq.result()[2] == 2 * m
+    # the stream in chunks
+    n2 = 4 * 5120 + 1777
+    one = CPMLink(n2, SPS, "multih", spec=cpm.ARTM_64)
+    one.run_block(ebn0, seed=4, stream_id=3)
+    st = CPMStream(n2, 5120, SPS, waveform="multih", spec=cpm.ARTM_64)
+    for c in range(st.nchunks):
+        st.run_chunk(c, ebn0, seed=4, stream_id=3)
+    assert st.result() == one.result() and one.result()[1] > 0
+    assert st.run_pipelined(ebn0, seed=4, stream_id=3) == one.result()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("design", GPU_DESIGNS)
 def test_gpu_every_supported_design_equals_oracle(oracle, design, detector_form):
     """Every trellis shape the kernel family accepts (M 2 / 4, Lp 1..3, full and reduced phase
-    state, 2 .. 16 states) on noisy rows and on unstructured random rows with exact ties."""
+    state, 2 .. 64 states: up to 16 in one DPP row or one lane, 17 .. 64 one wave per detector) on noisy rows and on
+    unstructured random rows with exact ties."""
     from waveforms_amd.viterbi import cpm
 
     spec_o = _spec(oracle, *design, D=32 if design[0] == 2 else 20)

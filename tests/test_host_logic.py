@@ -267,12 +267,15 @@ def test_link_row_bytes_rule():
     assert rb(7, sps=4) == (48, 0) and rb(7, nfilt=1) == (16, 0)            # channel + bank PACK form: 3-filter banks at 8 samples per symbol only
     assert rb(7, mf_ntaps=73) == (32, 0)                                    # ... with any tap count (the PAM bank)
     # fuse 15: the one-kernel front end at 8, 10 and 20 samples per symbol with the pulse-truncation bank (sps + 1 taps),
-    # and at 8 with any odd bank of up to 73 taps (the PAM banks: 73 taps for SOQPSK-TG, 17 for MIL)
+    # and at 8 / 10 with any odd bank of up to 73 / 91 taps (the PAM banks: 73 taps for SOQPSK-TG, 17 for MIL; 91 at the
+    # reference example's own 10 samples per symbol)
     assert rb(15) == (32, 1) and rb(15, sps=10) == (32, 1) and rb(15, sps=20) == (32, 1)
     assert rb(15, sps=10, timing_offset=-5) == (32, 1)
     assert rb(15, mf_ntaps=73) == (32, 1) and rb(15, mf_ntaps=17) == (32, 1)
     assert rb(15, mf_ntaps=75) == (32, 0) and rb(15, mf_ntaps=72) == (32, 0)    # longer / even banks: separate kernels, packed rows
-    assert rb(15, sps=10, mf_ntaps=91) == (48, 0) and rb(15, sps=16) == (48, 0) and rb(15, sps=4) == (48, 0)
+    assert rb(15, sps=10, mf_ntaps=91) == (32, 1) and rb(15, sps=10, mf_ntaps=21) == (32, 1)
+    assert rb(15, sps=10, mf_ntaps=93) == (48, 0) and rb(15, sps=20, mf_ntaps=181) == (48, 0)
+    assert rb(15, sps=16) == (48, 0) and rb(15, sps=4) == (48, 0)
     assert rb(15, sps=10, ntaps=10 * 10 + 1) == (48, 0)                      # a pulse of more than 9 symbols
 
 

@@ -64,6 +64,8 @@ HOT = {
     # binary trellis fits two (and the LDS a front-end workgroup frees when it runs beside one)
     "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true>": (256, 2),
     "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 3, false>": (168, 3),
+    # ... its wide form (17 .. 64 states, lane = state, one wave per detector): issue-bound, wants every wave it can get
+    "cpm_wide_kernel<4, 2, false>": (72, 7),
     "fir_kernel<9>": (96, 5),
     "awgn_kernel": (64, 8),
 }

@@ -10,5 +10,6 @@ python3 bench.py --detector PAM --no-cpu-baseline > $out/${tag}_bench_pam.json
 python3 bench.py --sps 10 --no-cpu-baseline > $out/${tag}_bench_sps10.json
 python3 bench.py --sps 10 --detector PAM --no-cpu-baseline > $out/${tag}_bench_pam10.json
 python3 bench.py --waveform multih --no-cpu-baseline > $out/${tag}_bench_multih.json
+python3 bench.py --waveform multih --states 64 --no-cpu-baseline > $out/${tag}_bench_multih64.json
 python3 bench.py --waveform pcmfm --no-cpu-baseline > $out/${tag}_bench_pcmfm.json
 echo LINESDONE

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--block", type=int, default=10_000_000, help="symbols per trial block (1e7: BASELINE configs[1]'s block, 10 per point)")
     ap.add_argument("--detector", default="PT")
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"])
+    ap.add_argument("--states", type=int, default=16, choices=[16, 64], help="--waveform multih: the 16-state design of BASELINE configs[2] or the 64-state one")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--gpus", type=int, default=0, help="N > 1 without torchrun: start N ranks as child processes")
     ap.add_argument("--passes", type=int, default=2, help="run the sweep this many times; `seconds` is the last pass")
@@ -72,7 +73,7 @@ def main():
     rank, world, dist, coll_dev = init_ranks(rehearsal=os.environ.get("WF_BENCH_REHEARSAL") == "1")
     init_seconds = time.perf_counter() - t_start       # process-group rendezvous (+ RCCL bootstrap): reported apart from the sweep
     blocks = max(1, int(round(a.symbols_per_point / a.block)))
-    plan = SweepPlan(ebn0_db=ebn0, blocks_per_point=blocks, nsym=a.block, seed=a.seed, detector=a.detector, waveform=a.waveform)
+    plan = SweepPlan(ebn0_db=ebn0, blocks_per_point=blocks, nsym=a.block, seed=a.seed, detector=a.detector, waveform=a.waveform, states=a.states)
     # two passes: the first also pays the process's first-use costs (workspace allocations of ~0.8 GB per block in
     # flight, code-object loads, table uploads); `seconds` is the second pass, the first is reported beside it
     passes = []
@@ -111,7 +112,7 @@ def main():
             d2 = {"multih": 1.2957297551846658}.get(a.waveform)
             if d2:
                 out["min_distance_bound"] = [0.5 * math.erfc(math.sqrt(d2 * 10 ** (e / 10.0) / 2.0)) for e in ebn0]
-            out["detector"] = f"generic CPM trellis detector ({a.waveform})"
+            out["detector"] = f"generic CPM trellis detector ({a.waveform}{', 64 states' if a.states == 64 else ''})"
         for target in (1e-3, 1e-4):
             try:
                 mine = ebn0_at_ber(ebn0, ber, target)

@@ -7,5 +7,6 @@ bash tools/profile.sh ${tag}_pam --detector PAM --fuse 15 > gpurun_out/p_pam.log
 bash tools/profile.sh ${tag}_sps10 --sps 10 --fuse 15 > gpurun_out/p_sps10.log 2>&1
 bash tools/profile.sh ${tag}_pam10 --sps 10 --detector PAM --fuse 15 > gpurun_out/p_pam10.log 2>&1
 bash tools/profile.sh ${tag}_multih --waveform multih --fuse 15 > gpurun_out/p_multih.log 2>&1
+bash tools/profile.sh ${tag}_multih64 --waveform multih --states 64 --fuse 15 > gpurun_out/p_multih64.log 2>&1
 bash tools/profile.sh ${tag}_pcmfm --waveform pcmfm --fuse 15 > gpurun_out/p_pcmfm.log 2>&1
 echo ALLDONE

@@ -28,6 +28,7 @@ class SweepPlan:
     pn_degree: int = 23
     waveform: str = "soqpsk"       # "soqpsk" (detector PT / PAM), or "multih" / "pcmfm" through the generic CPM detector
     warmup: int = 0                # detector chunk warm-up (0: library default); unproven chunks are repaired by the runner
+    states: int = 16               # waveform "multih": 16 (ARTM_16, BASELINE configs[2]) or 64 (ARTM_64: every phase state, notes/cpm/cpm.md:128-140)
     jobs: list[tuple[int, int]] = field(default_factory=list)   # (point index, block index)
 
     def __post_init__(self):
@@ -116,8 +117,11 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
     #  1e7-symbol blocks, which the front-end kernel's launch shape is tuned for, are the fastest way to run the sweep)
     n = max(1, int(streams)) if streams is not None else (3 if cpm or plan.nsym < (1 << 23) else 1)
     if cpm:
-        links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, pn_degree=plan.pn_degree, private_ctx=n > 1, warmup=plan.warmup,
-                         fuse=10 if fuse is None else fuse)
+        from waveforms_amd.viterbi.cpm import ARTM_64
+
+        wide = plan.waveform == "multih" and plan.states == 64
+        links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, spec=ARTM_64 if wide else None, pn_degree=plan.pn_degree, private_ctx=n > 1,
+                         warmup=plan.warmup, fuse=10 if fuse is None else fuse)
                  for _ in range(n)]
         run_fn = _hip.lib().wf_cpm_link_run
     else:
@@ -155,7 +159,7 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
     # no warm-up asked for: each Eb/N0 point runs at its own (waveforms_amd.link.operating_point_warmup; 0 = the library's
     # default where the table has no shorter one) — a block that leaves a chunk unproven is repeated below anyway
     from waveforms_amd.link import operating_point_warmup, soqpsk_warmup_param
-    point_warmup = [operating_point_warmup(plan.waveform, float(e)) if cpm
+    point_warmup = [(0 if plan.states == 64 else operating_point_warmup(plan.waveform, float(e))) if cpm
                     else soqpsk_warmup_param(operating_point_warmup("soqpsk", float(e))) for e in plan.ebn0_db]
 
     def launch(k: int, point: int, block: int, warmup: int) -> int:

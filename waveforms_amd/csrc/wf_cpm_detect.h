@@ -4,7 +4,8 @@
 #pragma once
 #include "wf_common.h"
 
-// Device-resident detector state (WF_CPM_STATE_BYTES): words 0..63 current, 64..127 staging.
+// Device-resident detector state (WF_CPM_STATE_BYTES), trellises of up to 16 states: words 0..63 current, 64..127 staging
+// (17 .. 64 states: the wide layout of wf_cpm_wide.hip in the same block).
 //   [0] calls made (as int64), [1..16] metrics (double), [17..32] tilted phase indices r (int64),
 //   [33..48] decision registers (uint64)
 #define CPM_ST_N 0
@@ -49,3 +50,10 @@ int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config 
 // slack_*_bytes of it before / behind the array may be READ (never interpreted) by the lane form's row fetch.
 int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
                              int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes);
+
+// Wide form (wf_cpm_wide.hip): trellises of 17 .. 64 states, lane = state, one wave = one detector.  Proof records of
+// 2 x 64 x 3 words per chunk, detector state in the wide layout of WF_CPM_STATE_BYTES.
+int wf_cpm_wide_applies(const wf_cpm_detector_config *det);
+int64_t wf_cpm_wide_chunk_calls(int64_t ncalls, int W, int cus);
+int wf_cpm_wide_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
+                       int warmup, uint8_t *d_decisions, void *d_state, void *stream);

@@ -501,7 +501,7 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
     for (int i = 2; i < Lp; ++i) msub *= M;
     for (int i = 0; i < Lp; ++i) NF *= M;
     const int S = NC * ncorr;
-    WF_REQUIRE(S <= 16, "wf_cpm: %d states (at most 16 = one DPP row)", S);
+    WF_REQUIRE(S <= 16, "wf_cpm: %d states (one DPP row holds 16, the wide form 64)", S);
     for (int i = 0; i < d->nh; ++i) WF_REQUIRE(d->K[i] >= 0 && d->K[i] < p, "wf_cpm: K[%d] = %d outside [0, p)", i, d->K[i]);
     P.M = M; P.lgM = lgM; P.p = p; P.nh = d->nh; P.K0 = d->K[0]; P.K1 = d->nh == 2 ? d->K[1] : d->K[0];
     P.Lp = Lp; P.NC = NC; P.D = d->D; P.S = S; P.NF = NF;
@@ -571,6 +571,16 @@ static int64_t cpm_chunk_calls(const wf_cpm_detector_config *det, int64_t ncalls
 extern "C" int wf_cpm_detector_form(const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int *info4)
 {
     WF_REQUIRE(det && info4 && ncalls >= 0 && warmup >= 0, "wf_cpm_detector_form: bad argument");
+    if (wf_cpm_wide_applies(det)) {                                // 17 .. 64 states: lane = state, one wave per chunk
+        int W = warmup ? warmup : 160;
+        W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
+        if (W > 4096) W = 4096;
+        info4[0] = 2;
+        info4[1] = 0;
+        info4[2] = (int)wf_cpm_wide_chunk_calls(ncalls, W, 256);
+        info4[3] = W;
+        return WF_OK;
+    }
     cpm_vit_params P;
     const int rc = cpm_build_tables(det, P);
     if (rc) return rc;
@@ -598,8 +608,15 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
                              int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes)
 {
     WF_REQUIRE(ctx && det && ncalls >= 0 && warmup >= 0, "wf_cpm_viterbi_detect: bad argument");
+    const bool wide = wf_cpm_wide_applies(det) != 0;               // 17 .. 64 states: wf_cpm_wide.hip
     cpm_vit_params P;
-    int rc = cpm_build_tables(det, P);
+    if (wide) {
+        WF_REQUIRE((det->nh == 1 || det->nh == 2) && det->p >= 1 && det->p <= 64 && det->p % det->NC == 0 && det->D >= 1 &&
+                       det->D * (det->M == 4 ? 2 : 1) <= 64,
+                   "wf_cpm: unsupported detector (M %d Lp %d nh %d p %d NC %d D %d)", det->M, det->Lp, det->nh, det->p, det->NC, det->D);
+        for (int i = 0; i < det->nh; ++i) WF_REQUIRE(det->K[i] >= 0 && det->K[i] < det->p, "wf_cpm: K[%d] = %d outside [0, p)", i, det->K[i]);
+    }
+    int rc = wide ? WF_OK : cpm_build_tables(det, P);
     if (rc) return rc;
     if (ncalls == 0) return WF_OK;
     WF_REQUIRE(d_rot_cs && d_rows_ri && d_decisions, "wf_cpm_viterbi_detect: NULL device pointer");
@@ -607,6 +624,7 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
                    (reinterpret_cast<uintptr_t>(d_rot_cs) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
                "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
+    if (wide) return wf_cpm_wide_detect(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream);
     // Default warm-up.  A chunk that misses its warm-up is REPAIRED by the call's second launch (cpm_repair_kernel),
     // so the default is sized for the typical merge depth of the trellis, not for its tail, and backed by a scan at
     // 0 .. 12 dB (tools/cpm_warmup_scan.py, profiles/r03_cpm_repair_scan_*.json: 1.25e6 chunks per point): with

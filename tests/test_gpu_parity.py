@@ -1151,6 +1151,25 @@ def test_link_full_size_fuse_modes_agree(nsym):
     assert 5.5e-4 < ber < 8.0e-4          # reference at 10 dB: 6.8e-4 (tests/golden/ber_golden*.csv)
 
 
+def test_link_full_size_reference_example_configuration_fuse_modes_agree():
+    """The reference example's own configuration at BASELINE size: 10 samples per symbol (examples/soqpsk_detection.py:38)
+    and its better detector, the PAM bank (:158-173), 1e7 symbols — every stage its own kernel, the fused modulator +
+    channel-in-bank, the one-kernel front end (91-tap bank as matrix tiles) and its block-pipelined form give the same
+    counts; the BER is the PAM detector's at 10 dB (2.8e-4 at 8 samples per symbol: the PAM columns of tests/golden/ber_golden*.csv)."""
+    from waveforms_amd.link import SOQPSKLink
+
+    nsym, results = 10_000_000, {}
+    for fuse in (0, 7, 15, 47):
+        link = SOQPSKLink(nsym, 10, fuse=fuse, detector="PAM")
+        assert link.layout()["one_kernel_front_end"] == int(fuse >= 15)
+        link.run_block(10.0, seed=1, stream_id=0)
+        results[fuse] = link.result()
+        del link
+    assert results[0] == results[7] == results[15] == results[47]
+    se, be, m = results[15]
+    assert m > nsym - 16 and 2.0e-4 < be / m < 3.6e-4
+
+
 def test_detector_reports_and_repairs_unmerged_chunks(oracle):
     """The chunk-parallel kernel proves its own output: every launch checks that each chunk started
     from bitwise the metrics its predecessor ended with.  Ordinary inputs never trip it; rows built

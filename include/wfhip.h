@@ -171,10 +171,11 @@ int wf_awgn_mf_bank_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsamp, 
 int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int differential,
                        int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state,
                        void *stream);
-/* The same for ANY even window `length` in 2 .. 16 (waveforms/viterbi/algorithm.py:19-42: `length` is a free
- * parameter; window loop :69-87, depth-`length` traceback :90-98; the reference's stage / history sections only
- * agree for even lengths): for every row, element [0] of what .iteration() returns — the stage-0 branch of the
- * path that ends in the first arg-min state after `length` - 1 stages of look-ahead.  Chunk-parallel with the
+/* The same for ANY window `length` in 1 .. 64 (waveforms/viterbi/algorithm.py:19-42: `length` is a free
+ * parameter; window loop :69-87, depth-`length` traceback :90-98).  Odd lengths included, literally: there the
+ * reference pairs a row's increments (:57-63, section i % 2) with the branches of the other section (:69-87), and
+ * at length 1 the stage updates its metrics column in place.  For every row, element [0] of what .iteration()
+ * returns — the stage-0 branch of the path that ends in the first arg-min state after `length` - 1 stages of look-ahead.  Chunk-parallel with the
  * same on-device proof (wf_viterbi4_unmerged).  d_state (may be NULL): wf_viterbi4_window_state_bytes() bytes,
  * zero-initialised = a fresh detector, carried across calls of the same length. */
 int wf_viterbi4_detect_window(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int length, int differential,

@@ -508,12 +508,62 @@ def test_window_detector_chunk_parallel_equals_sequential(oracle, length, ebn0):
     assert np.array_equal(b2, res["det_bits"][:300_000]) and np.array_equal(s2, res["det_syms"][:300_000])
 
 
-def test_window_detector_rejects_odd_and_long_lengths():
+def test_window_detector_rejects_lengths_outside_1_to_64():
     from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
 
-    for length in (3, 18):
+    for length in (0, 65):
         with pytest.raises(ValueError):
             SOQPSKTrellisDetector(length).detect(np.zeros((8, 3), dtype=np.complex128))
+
+
+@pytest.mark.parametrize("length", [1, 3, 5, 7, 9, 17, 18, 24, 33, 64])
+@pytest.mark.parametrize("diff", [True, False])
+def test_window_detector_batch_odd_and_long_lengths_on_reference_triplets(golden, length, diff):
+    """detect() for the window lengths outside the even 2 .. 16 range against what the reference's own .iteration()
+    returned (element [0] of each call; tests/golden/detect_lengths.npz): odd lengths — the reference pairs a row's
+    increments with the other section's branches, algorithm.py:57-63 against :69-87 —, length 1 (in-place stage) and
+    windows up to 64; in one call and in pieces, and the per-symbol iteration() path on the first rows."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detect_lengths")
+    want_b, want_s = g[f"L{length}_diff{int(diff)}_bits0"], g[f"L{length}_diff{int(diff)}_syms0"]
+    trip = g["triplets"][:want_b.size]
+    bits, syms = SOQPSKTrellisDetector(length, differantial_encoding=diff).detect(trip)
+    assert np.array_equal(bits, want_b) and np.array_equal(syms, want_s)
+    det = SOQPSKTrellisDetector(length, differantial_encoding=diff)
+    cuts = [0, 1, 2, 5, 131, 1000, 1333, want_b.size]
+    parts = [det.detect(trip[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert det.i == want_b.size
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), want_b)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), want_s)
+    det = SOQPSKTrellisDetector(length, differantial_encoding=diff)
+    for k in range(120):
+        b, s = det.iteration(trip[k])
+        assert b[0] == want_b[k] and s[0] == want_s[k], k
+        if f"L{length}_diff{int(diff)}_bits" in g:
+            assert np.array_equal(b, g[f"L{length}_diff{int(diff)}_bits"][k]) and np.array_equal(s, g[f"L{length}_diff{int(diff)}_syms"][k]), k
+
+
+@pytest.mark.parametrize("length,ebn0", [(1, 4.0), (3, 0.0), (5, 10.0), (9, 4.0), (17, 4.0), (33, 0.0), (64, 10.0)])
+def test_window_detector_odd_and_long_lengths_chunk_parallel_equals_sequential(oracle, length, ebn0):
+    """1.2e6 noisy rows at the window lengths outside the even 2 .. 16 range: the chunk-parallel kernel's decisions are
+    bit-identical to the sequential oracle's (which equals the reference on the goldens above), and a warm-up that
+    cannot merge is noticed and repaired."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+    from waveforms_amd import _hip, device as dev
+
+    n = 1_200_000
+    bits, _ = oracle.glfsr_bits(0x420000, 0x7FFFFF, n)
+    noise = oracle.philox_awgn(oracle.sigma_for_ebn0(ebn0, 8), 5, 100 + length, 0, (n + 1) * 8)
+    res = oracle.detection_run(bits, oracle.freq_pulse_soqpsk_tg(8), 0.25, 8, None, noise=noise, length=length)
+    got_b, got_s = SOQPSKTrellisDetector(length).detect(res["mf_rows"])
+    assert np.array_equal(got_b, res["det_bits"]) and np.array_equal(got_s, res["det_syms"])
+    rows = _hip.to_device(np.ascontiguousarray(res["mf_rows"][:300_000]))
+    dev.viterbi_unmerged(reset=True)
+    dev.viterbi_detect_window(rows, length, warmup=2)
+    assert dev.viterbi_unmerged(reset=True) > 0
+    b2, s2 = SOQPSKTrellisDetector(length).detect(res["mf_rows"][:300_000], warmup=2)
+    assert np.array_equal(b2, res["det_bits"][:300_000]) and np.array_equal(s2, res["det_syms"][:300_000])
 
 
 def test_count_errors():
@@ -892,8 +942,10 @@ def test_empty_inputs_and_error_paths(oracle):
         bank(np.ones(5, dtype=np.complex128))
     with pytest.raises(ValueError):                      # columns past the end
         bank(np.ones(100, dtype=np.complex128), first=0, step=8, ncols=14)
-    with pytest.raises(ValueError):                      # the batch form covers even window lengths 2 .. 16
-        SOQPSKTrellisDetector(length=5).detect(np.zeros((4, 3), dtype=np.complex128))
+    with pytest.raises(ValueError):                      # the batch form covers window lengths 1 .. 64, like iteration()
+        SOQPSKTrellisDetector(length=65).detect(np.zeros((4, 3), dtype=np.complex128))
+    b5, s5 = SOQPSKTrellisDetector(length=5).detect(np.zeros((0, 3), dtype=np.complex128))
+    assert b5.size == 0 and s5.size == 0
     b4, s4 = SOQPSKTrellisDetector(length=4).detect(np.zeros((0, 3), dtype=np.complex128))
     assert b4.size == 0 and s4.size == 0
     with pytest.raises(KeyError):

@@ -228,6 +228,23 @@ def test_detector_on_random_triplets(oracle, golden, length, diff):
     assert np.array_equal(np.concatenate((a, b)), fb[:, 0])
 
 
+@pytest.mark.parametrize("length", [1, 3, 5, 7, 9, 17, 18, 24, 33, 64])
+@pytest.mark.parametrize("diff", [True, False])
+def test_detector_on_random_triplets_odd_and_long_lengths(oracle, golden, length, diff):
+    """algorithm.py:19-42 takes any window length: odd ones (a row's increments and the stage that consumes them come
+    from different trellis sections), 1 (the stage updates its column in place) and windows up to 64 — against what the
+    reference's own .iteration() returned (tests/golden/make_detect_lengths_golden.py)."""
+    g = golden("detect_lengths")
+    want_b, want_s = g[f"L{length}_diff{int(diff)}_bits0"], g[f"L{length}_diff{int(diff)}_syms0"]
+    trip = g["triplets"][:want_b.size]
+    if f"L{length}_diff{int(diff)}_bits" in g:
+        fb, fs = oracle.ViterbiOracle(length, diff).run(trip, full=True)
+        assert np.array_equal(fb, g[f"L{length}_diff{int(diff)}_bits"]) and np.array_equal(fs, g[f"L{length}_diff{int(diff)}_syms"])
+    v = oracle.ViterbiOracle(length, diff)
+    a, b = v.run(trip[:777]), v.run(trip[777:])
+    assert np.array_equal(np.concatenate((a[0], b[0])), want_b) and np.array_equal(np.concatenate((a[1], b[1])), want_s)
+
+
 def test_end_to_end_error_counts(oracle, golden):
     """The reference's published result (images/soqpsk_pam.png) and the
     sps-8 operating point of BASELINE.md §2, reproduced by the oracle."""

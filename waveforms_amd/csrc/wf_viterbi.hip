@@ -612,10 +612,14 @@ extern "C" int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int6
 }
 
 // ------------------------------------------------------------------------------------
-// Batch detector for any EVEN window length 2 <= L <= VWIN_MAX_LEN (algorithm.py:19-42: `length` is a
-// free parameter of the reference; its window loop :69-87 and depth-`length` traceback :90-98 are
-// only self-consistent for even lengths — odd ones use different trellis sections for a row's
-// increments and for its ACS stage).  What one .iteration() call k does, restated:
+// Batch detector for any window length 1 <= L <= VWIN_MAX_LEN (algorithm.py:19-42: `length` is a
+// free parameter of the reference).  Its window loop :69-87 and depth-`length` traceback :90-98 are
+// only self-consistent for even lengths: for an odd one the 8 increments of a row were computed, by list
+// position, from the branch list of the OTHER trellis section than the stage that consumes them (:57-63
+// uses section i % 2 at the call the row arrives, :69-87 section (i + j - 1) % 2 for the row of call
+// i - L + 1 + j) — a well-defined recurrence all the same, restated literally by vwin_acs_mis below; and
+// for L = 1 the single stage reads and writes the same metrics column, state by state, in place (:76-87).
+// What one .iteration() call k does, restated:
 //   - the window holds the rows of calls k-L+1 .. k (a row's 8 branch increments are 4 signed
 //     components of it, vit_comp; rows before the burst are zeros = the zero-initialised history),
 //   - entering metrics e = C - min(C), C = the stage-0 metrics the PREVIOUS call produced (:65-67),
@@ -632,13 +636,15 @@ extern "C" int wf_viterbi4_detect_count(wf_ctx *ctx, const double *d_mf_ri, int6
 // ended with, and vwin_verify_kernel counts the chunks whose start is not BITWISE the predecessor's
 // end (wf_viterbi4_unmerged) — the condition under which every decision is the sequential detector's.
 // The window lives in a lane-private LDS ring of L rows (33 16-byte slots per lane at most: an odd
-// stride, so the lanes' ds_read_b128 hit different banks); stage loops are rolled, so one kernel
-// serves every even L.  Carry block (d_state, VWIN_STATE_DOUBLES doubles, zeros = a fresh detector):
-// [0] calls made, [1..4] C, [8 + 4 q ..] components of the row of call i-L+1+q, q < L-1; staging at +128.
+// stride, so the lanes' ds_read_b128 hit different banks; 128 lanes per workgroup up to L = 16, 64 above: 132 KB at
+// L = 64); stage loops are rolled, so one kernel
+// serves every L.  Carry block (d_state, VWIN_STATE_DOUBLES doubles, zeros = a fresh detector):
+// [0] calls made, [1..4] C, [8 + 4 q ..] components of the row of call i-L+1+q, q < L-1; staging at +VWIN_STAGE.
 #define VWIN_THREADS 128
-#define VWIN_MAX_LEN 16
-#define VWIN_STATE_DOUBLES 256
-#define VWIN_STAGE 128
+#define VWIN_MAX_LEN VIT_MAX_LEN
+#define VWIN_STATE_DOUBLES 1024
+#define VWIN_STAGE 512
+static_assert(8 + 4 * (VWIN_MAX_LEN - 1) <= VWIN_STAGE, "carry block");
 
 template <int COL>
 __device__ __forceinline__ void vwin_acs(const double m[4], const vit_comp &q, double out[4], bool lt[4])
@@ -692,6 +698,52 @@ __device__ __forceinline__ void vwin_stage(double m[4], uint32_t d[4], const vit
     }
 }
 
+// Odd window lengths: stage section CS consumes the increments a row got, by LIST POSITION, from section 1 - CS
+// (algorithm.py:74 zips `branches` of one section with a history column filled from the other, :57-63).  List
+// position b of either section starts in state b >> 1; its increment Re(state_exp_term[start] * mf[idx(out)]) under
+// section CR, as a signed component of the row (vit_comp, picked by the row's OWN section):
+//   CR 0: -i1, -b, -r1, -a, +a, +r1, +b, +i1        CR 1: -i1, -a, -b, -r1, +r1, +b, +a, +i1
+// The two positions that end in state e under CS, in list order: CS 0: b = 2 s + (e >> 1), s = (e & 1), (e & 1) + 2;
+// CS 1: b = 2 s + (e & 1), s = (e & 2), (e & 2) + 1.  INPLACE (L = 1): the stage reads and writes ONE metrics
+// column, state by state (:76-87 with (j - 1) % 1 == j): states 1 .. 3 see the new values of the states before them.
+template <int CR>
+__device__ __forceinline__ double vwin_inc(int b, const vit_comp &q)
+{
+    if (CR == 0) {
+        switch (b) {
+        case 0: return -q.i1; case 1: return -q.b; case 2: return -q.r1; case 3: return -q.a;
+        case 4: return q.a; case 5: return q.r1; case 6: return q.b; default: return q.i1;
+        }
+    }
+    switch (b) {
+    case 0: return -q.i1; case 1: return -q.a; case 2: return -q.b; case 3: return -q.r1;
+    case 4: return q.r1; case 5: return q.b; case 6: return q.a; default: return q.i1;
+    }
+}
+
+template <int CS, bool INPLACE>
+__device__ __forceinline__ void vwin_stage_mis(double m[4], uint32_t d[4], const vit_comp &q, bool first, int diff)
+{
+    constexpr int CR = 1 - CS;
+    double o[4];
+    uint32_t n[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int sa = CS == 0 ? (e & 1) : (e & 2), sb = CS == 0 ? (e & 1) + 2 : (e & 2) + 1;
+        const int ba = 2 * sa + (CS == 0 ? e >> 1 : e & 1), bb = 2 * sb + (CS == 0 ? e >> 1 : e & 1);
+        const double ma = INPLACE && sa < e ? o[sa] : m[sa], mb = INPLACE && sb < e ? o[sb] : m[sb];
+        const double fa = ma + vwin_inc<CR>(ba, q), fb = mb + vwin_inc<CR>(bb, q);
+        const bool lt = fb < fa;                  // strict '<': the first listed branch keeps a tie (algorithm.py:79-83)
+        o[e] = lt ? fb : fa;
+        n[e] = first ? (lt ? vwin_code(CS, e, 1, diff) : vwin_code(CS, e, 0, diff)) : (lt ? d[sb] : d[sa]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        m[e] = o[e];
+        d[e] = n[e];
+    }
+}
+
 __global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const double2 *__restrict__ rows, int64_t ncalls, int L, int CH, int W,
                                                                        int diff, uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
                                                                        double *__restrict__ state, double *__restrict__ erec)
@@ -699,7 +751,7 @@ __global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const doub
     extern __shared__ __attribute__((aligned(16))) double2 s_ring[];
     const int stride = 2 * L + 1;                                     // 16-byte slots per lane (odd)
     double2 *ring = s_ring + (size_t)threadIdx.x * stride;
-    const int64_t chunk = (int64_t)blockIdx.x * VWIN_THREADS + threadIdx.x;
+    const int64_t chunk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t a = chunk * CH;
     const bool live = a < ncalls;
     const int64_t i0 = state ? (int64_t)state[0] : 0;                 // calls made before this launch
@@ -745,7 +797,8 @@ __global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const doub
         for (int q = 1; q < L; ++q) put(ks - L + q, comps(ks - L + q));
     vit_comp nxt = comps(ks);
     const int nsteps = W + CH;                                        // common trip count; a lane is active while k < kend
-    const int par = (int)((i0 + 1) & 1);                              // section of stage 0 at step t: (i0 + ks + t - L + 1) & 1, ks and L even
+    const int par = (int)((i0 + 1) & 1);                              // section of stage 0 at step t: (i0 + ks + t - 1) & 1 (algorithm.py:71 at j = 0), ks even
+    const bool mis = (L & 1) != 0;                                    // odd L: a row's increments come from the other section than its stage
     for (int t = 0; t < nsteps; ++t) {
         const int64_t k = ks + t;
         const bool act = live && k < kend;                            // (no barrier below: inactive lanes just idle)
@@ -761,20 +814,42 @@ __global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const doub
         uint32_t d[4] = {0u, 0u, 0u, 0u};
         int q = slot(k - L + 1);
         const bool odd0 = ((par + t) & 1) != 0;                       // wave-uniform
-        // stages in (stage 0's section, the other one) pairs: L is even
-        for (int j = 0; j < L; j += 2) {
+        // stages in (stage 0's section, the other one) pairs, and for an odd L one more of stage 0's section
+        for (int j = 0; j + 1 < L; j += 2) {
             const vit_comp r0 = get(q);
             q = q + 1 == L ? 0 : q + 1;
             const vit_comp r1 = get(q);
             q = q + 1 == L ? 0 : q + 1;
-            if (!odd0) {
-                vwin_stage<0>(m, d, r0, j == 0, diff);
+            if (!mis) {
+                if (!odd0) {
+                    vwin_stage<0>(m, d, r0, j == 0, diff);
+                    if (j == 0) { C[0] = m[0]; C[1] = m[1]; C[2] = m[2]; C[3] = m[3]; }
+                    vwin_stage<1>(m, d, r1, false, diff);
+                } else {
+                    vwin_stage<1>(m, d, r0, j == 0, diff);
+                    if (j == 0) { C[0] = m[0]; C[1] = m[1]; C[2] = m[2]; C[3] = m[3]; }
+                    vwin_stage<0>(m, d, r1, false, diff);
+                }
+            } else if (!odd0) {
+                vwin_stage_mis<0, false>(m, d, r0, j == 0, diff);
                 if (j == 0) { C[0] = m[0]; C[1] = m[1]; C[2] = m[2]; C[3] = m[3]; }
-                vwin_stage<1>(m, d, r1, false, diff);
+                vwin_stage_mis<1, false>(m, d, r1, false, diff);
             } else {
-                vwin_stage<1>(m, d, r0, j == 0, diff);
+                vwin_stage_mis<1, false>(m, d, r0, j == 0, diff);
                 if (j == 0) { C[0] = m[0]; C[1] = m[1]; C[2] = m[2]; C[3] = m[3]; }
-                vwin_stage<0>(m, d, r1, false, diff);
+                vwin_stage_mis<0, false>(m, d, r1, false, diff);
+            }
+        }
+        if (mis) {
+            const vit_comp r0 = get(q);
+            if (L == 1) {
+                if (!odd0) vwin_stage_mis<0, true>(m, d, r0, true, diff);
+                else vwin_stage_mis<1, true>(m, d, r0, true, diff);
+                C[0] = m[0]; C[1] = m[1]; C[2] = m[2]; C[3] = m[3];
+            } else if (!odd0) {
+                vwin_stage_mis<0, false>(m, d, r0, false, diff);
+            } else {
+                vwin_stage_mis<1, false>(m, d, r0, false, diff);
             }
         }
         if (k >= a) {
@@ -820,17 +895,14 @@ __global__ void vwin_verify_kernel(const double *__restrict__ erec, int64_t nchu
 
 __global__ void vwin_carry_commit_kernel(double *state, int n)
 {
-    const int t = threadIdx.x;
-    if (t < n) state[t] = state[VWIN_STAGE + t];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) state[t] = state[VWIN_STAGE + t];
 }
 
 extern "C" int wf_viterbi4_detect_window(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int length, int differential,
                                          int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream)
 {
     WF_REQUIRE(ctx && ncalls >= 0 && warmup >= 0, "wf_viterbi4_detect_window: bad argument");
-    WF_REQUIRE(length >= 2 && length <= VWIN_MAX_LEN && length % 2 == 0,
-               "wf_viterbi4_detect_window: window length %d (even lengths 2 .. %d: the reference's stage / history sections only agree for even lengths)",
-               length, VWIN_MAX_LEN);
+    WF_REQUIRE(length >= 1 && length <= VWIN_MAX_LEN, "wf_viterbi4_detect_window: window length %d (1 .. %d)", length, VWIN_MAX_LEN);
     if (ncalls == 0) return WF_OK;
     WF_REQUIRE(d_mf_ri && d_bits && d_syms, "wf_viterbi4_detect_window: NULL device pointer");
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_mf_ri) & 15) == 0, "wf_viterbi4_detect_window: rows must be 16-byte aligned");
@@ -846,15 +918,16 @@ extern "C" int wf_viterbi4_detect_window(wf_ctx *ctx, const double *d_mf_ri, int
     if (ch < 4 * W) ch = 4 * W;
     if (ch > (1 << 20)) ch = 1 << 20;
     const int64_t nchunks = (ncalls + ch - 1) / ch;
-    const int64_t nblocks = (nchunks + VWIN_THREADS - 1) / VWIN_THREADS;
+    const int threads = length <= 16 ? VWIN_THREADS : 64;               // lanes per workgroup: the window ring is (2 L + 1) x 16 B of LDS per lane
+    const int64_t nblocks = (nchunks + threads - 1) / threads;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect_window: burst too long for one launch");
     int rc = wf_ctx_reserve_vit(ctx, (size_t)nchunks * 8);
     if (rc) return rc;
     hipStream_t s = wf_stream(stream);
-    const size_t lds = (size_t)VWIN_THREADS * (2 * length + 1) * sizeof(double2);
+    const size_t lds = (size_t)threads * (2 * length + 1) * sizeof(double2);
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(viterbi_window_kernel, dim3((unsigned)nblocks), dim3(VWIN_THREADS), lds, s, reinterpret_cast<const double2 *>(d_mf_ri),
+    hipLaunchKernelGGL(viterbi_window_kernel, dim3((unsigned)nblocks), dim3(threads), lds, s, reinterpret_cast<const double2 *>(d_mf_ri),
                        ncalls, length, (int)ch, W, differential ? 1 : 0, d_bits, d_syms, d_state, ctx->d_vit_edge);
     WF_LAUNCH_CHECK();
     if (nchunks > 1) {

@@ -170,7 +170,7 @@ def viterbi_detect(mf_rows, differential: bool = True, warmup: int = 0, state=No
 
 
 def viterbi_detect_window(mf_rows, length: int, differential: bool = True, warmup: int = 0, state=None, ctx=None):
-    """K8-K10 for any even window ``length`` (2 .. 16) -> (bits u8[ncalls], symbols i8[ncalls]) on device;
+    """K8-K10 for any window ``length`` (1 .. 64, odd ones as the reference pairs them) -> (bits u8[ncalls], symbols i8[ncalls]) on device;
     ``state``: float64[wf_viterbi4_window_state_bytes() / 8] carry (zeros = a fresh detector) or None."""
     ncalls = int(mf_rows.shape[0])
     bits = _hip.empty(ncalls + 16, "uint8")

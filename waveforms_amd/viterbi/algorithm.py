@@ -4,11 +4,11 @@
 the GPU with the detector state resident in HBM (csrc/wf_viterbi.hip,
 viterbi_iteration_kernel), any window ``length``.  ``detect`` is the batch form the
 MI355X path is built for: a whole burst of matched-filter rows in one launch
-(chunk-parallel ACS + traceback), any EVEN ``length`` from 2 to 16 (length 2: the kernel the link
-runs; 4 .. 16: a window kernel with ``length`` - 1 stages of look-ahead per row), returning for
-every row exactly what ``iteration(row)[...][0]`` would; it is stateful like ``iteration``
-(successive calls continue the same burst through a device-resident carry).  Odd lengths stay on
-``iteration``: the reference's stage and history sections only agree for even ones.
+(chunk-parallel ACS + traceback), any ``length`` from 1 to 64 like ``iteration`` (length 2: the kernel the link
+runs; the others: a window kernel with ``length`` - 1 stages of look-ahead per row), returning for
+every row exactly what ``iteration(row)[...][0]`` would — for odd lengths too, where the reference pairs a
+row's increments with the other trellis section's branches (algorithm.py:57-63 against :69-87): restated
+literally; it is stateful like ``iteration`` (successive calls continue the same burst through a device-resident carry).
 """
 from __future__ import annotations
 
@@ -133,8 +133,8 @@ class SOQPSKTrellisDetector:
         from waveforms_amd import _hip
 
         L = int(self.length)
-        if L < 2 or L > 16 or L % 2:
-            raise ValueError("batch detection implements even window lengths 2 .. 16 (use iteration() for the others)")
+        if L < 1 or L > 64:
+            raise ValueError(f"unsupported traceback length {L} (1 .. 64, as for iteration())")
         if self._mode == "iteration":
             raise ValueError("this detector has been driven through iteration(); use one API per burst")
         self._mode = "batch"

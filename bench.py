@@ -36,7 +36,7 @@ def stage_bytes_per_symbol(sps: int, nfilt: int = 3) -> dict:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 
 # stage -> kernel that dominates it (names as rocprofv3 prints them)
-STAGE_KERNEL = {"fir": "fir_kernel<9>", "phase": "phase_kernel", "modulate": "mod_main_kernel<9, true>",
+STAGE_KERNEL = {"fir": "fir_kernel<9>", "phase": "phase_kernel", "modulate": "mod_main_kernel<9, true, false>",
                 "awgn": "awgn_kernel", "mfbank": "mf_bank_kernel<3, false, 8, 9>", "awgn+mfbank": "mf_bank_kernel<3, true, 8, 9>",
                 "viterbi": "viterbi_batch_kernel<false>", "count": "count_errors_kernel", "prbs": "lfsr_kernel",
                 "encode": "enc_reduce_kernel"}
@@ -384,7 +384,7 @@ def main() -> None:
             STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<4, {nf}, 8>"
         STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}, {'true' if links[0].cfg.fuse & 2 else 'false'}>",
                              "viterbi": detector_kernel_name(links[0].spec, links[0].layout()["calls"], links[0].cfg.warmup), "map": "symbol_map_kernel",
-                             "modulate": "mod_main_kernel<4, true>"})
+                             "modulate": "mod_main_kernel<4, true, false>"})
     one_kernel = not cpm and bool(links[0].layout()["one_kernel_front_end"])     # asked from the library (wf_link_layout)
     if one_kernel:      # fuse bit 3: the "fir" slot times modulator + channel + bank; symbols in, packed rows out
         acc["mod+awgn+mfbank"] = acc.pop("fir")

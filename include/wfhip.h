@@ -113,7 +113,8 @@ int wf_phase_cexp_f64(wf_ctx *ctx, const double *d_freq, int64_t n, int sps, dou
  * tile carries come from a symbol-rate prefix sum instead of an inter-workgroup scan.
  * Same results as wf_upsample_fir_f64 followed by wf_phase_cexp_f64 (to rounding).
  * Returns 1 — not an error — when the configuration is outside the fused kernel's
- * envelope (signal shorter than the pulse, pulse longer than 33 symbols or than a tile);
+ * envelope (signal shorter than the pulse, pulse longer than 33 symbols or than a tile, more than 8
+ * modulation indices — modulate.py:91-92 cycles any number: symbol i takes d_h[i mod nh]);
  * the caller then runs the two stage kernels. */
 int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
                          const double *d_pulse, int ntaps, int sps, double phi0, double *d_out_ri,

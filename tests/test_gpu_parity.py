@@ -189,8 +189,11 @@ def test_frequency_and_phase_modulate(oracle, golden):
     (8, "mil", (0.25,), (-2, 0, 2), 50_000), (8, "multih", (4 / 16, 5 / 16), (-3, -1, 1, 3), 200_001),
     (8, "pcmfm", (0.7,), (-1, 1), 100_000), (5, "pcmfm", (0.7,), (-1, 1), 33_333), (20, "pcmfm", (0.7,), (-1, 1), 20_000),
     (8, "b", (0.25,), (-2, 0, 2), 70_000), (8, "tg", (0.25,), (-2, 0, 2), 600), (4, "tg", (0.3,), (-2, 0, 2), 5_000),
-    # three modulation indices: outside the one-pass kernel's prefix counts (<= 2) -> it declines, the stage kernels run
-    (8, "tg", (0.25, 0.3, 0.35), (-2, 0, 2), 20_000),
+    # three and more modulation indices (modulate.py:91-92 cycles any N_h): one set of prefix counts per index class in the
+    # one-pass kernel up to 8; nine: it declines and the stage kernels run
+    (8, "tg", (0.25, 0.3, 0.35), (-2, 0, 2), 20_000), (8, "multih", (4 / 16, 5 / 16, 6 / 16), (-3, -1, 1, 3), 150_001),
+    (5, "tg", (0.25, 0.3, 0.35, 0.4, 0.45), (-2, 0, 2), 40_003), (10, "pcmfm", (0.7, 0.5, 0.6, 0.65, 0.55, 0.45, 0.35, 0.75), (-1, 1), 77_777),
+    (8, "tg", (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9), (-2, 0, 2), 20_000),
     # odd sps and an even-length pulse: sample pairs that straddle a symbol edge (the `wrap` lanes of mod_pair_phase)
     (5, "tg", (0.25,), (-2, 0, 2), 40_001), (7, "multih", (4 / 16, 5 / 16), (-3, -1, 1, 3), 30_000)])
 def test_fused_modulator_equals_stage_kernels_and_oracle(oracle, sps, pulse_name, hs, alphabet, nsym):
@@ -212,6 +215,13 @@ def test_fused_modulator_equals_stage_kernels_and_oracle(oracle, sps, pulse_name
     assert np.abs(staged - want).max() < FLOAT_ATOL
     assert np.abs(fused - want).max() < FLOAT_ATOL
     assert np.abs(fused - staged).max() < 1e-10
+    # which form ran: the one-pass kernel takes up to 8 modulation indices
+    from waveforms_amd import device as dev
+    hv = _hip.to_device(np.atleast_1d(np.asarray(hs, dtype=np.float64)))
+    out = _hip.empty((want.size, 2), "float64")
+    rc = _hip.lib().wf_cpm_modulate_c128(_hip.ctx(), _hip.ptr(d_sym), nsym, _hip.ptr(hv), len(hs), _hip.ptr(_hip.to_device(pulse)),
+                                         int(pulse.size), sps, float(np.pi / 4), _hip.ptr(out), _hip.stream())
+    assert rc == (0 if len(hs) <= 8 else 1)
 
 
 def test_baseline_config0_pcmfm_1e4(oracle):

@@ -48,8 +48,8 @@ HOT = {
     "mod_chan_bank_kernel<9, 16, 8>": (168, 3),
     "mod_chan_bank_kernel<9, 4, 8>": (168, 3),
     # stand-alone modulator, SOQPSK-TG (J = 9) and short pulses
-    "mod_main_kernel<9, true>": (168, 3),
-    "mod_main_kernel<4, true>": (128, 4),
+    "mod_main_kernel<9, true, false>": (168, 3),
+    "mod_main_kernel<4, true, false>": (128, 4),
     # SOQPSK detector: one wave per SIMD by design (three batches of rows in registers)
     "viterbi_batch_kernel<true>": (256, 2),
     # generic CPM detector: 5 waves per SIMD for the forms with up to 4 filters per call, 4 for ARTM's 16
@@ -126,9 +126,12 @@ def test_no_spill_traffic_inside_nested_loops(table):
     ceilings = {"cpm_mf_rows_kernel<": 0, "mf_bank_kernel<3, true": 31, "mf_bank_kernel<8, true": 44, "mf_bank_kernel<8, false": 4,
                 "mod_chan_bank_kernel<4, 0, 10>": 2, "mod_chan_bank_kernel<9, 0, 10>": 2,
                 "mod_chan_bank_kernel<4, -1, 10>": 2, "mod_chan_bank_kernel<9, -1, 10>": 2}
+    # ... and the stand-alone modulator's form for three or more modulation indices (no waveform of the reference has
+    # them; modulate.py:91-92 allows it): its per-class staging loops carry the class bookkeeping in spill lanes.
+    many_h = lambda k: k.startswith("mod_main_kernel<") and k.endswith(", true>")
     bad = {}
     for k, v in table.items():
-        cap = next((c for pre, c in ceilings.items() if k.startswith(pre)), None)
+        cap = 17 if many_h(k) else next((c for pre, c in ceilings.items() if k.startswith(pre)), None)
         if cap is not None:
             assert v.get("sgpr_spill_count", 0) <= cap and v.get("vgpr_spill_count", 0) == 0, (k, v)
             continue

@@ -26,6 +26,7 @@
 #define MOD_MAX_PART 40
 #define MOD_SCAN_TAPS 2048   // taps staged in LDS by the carry kernel
 #define MOD_SCAN_PER 16      // tiles per thread the carry kernel keeps in registers
+#define MOD_MAX_NH 8         // modulation indices the one-pass modulator cycles (modulate.py:91-92 takes any N_h; the fused front ends: <= 2)
 
 struct mod_params {
     int64_t nsym, out_len, ntiles;
@@ -315,7 +316,7 @@ __device__ __forceinline__ int mod_wave_incl_scan_i32(int v)
 }
 
 // Called by all MOD_THREADS threads; leaves with a barrier (window and counts visible).  s_wtot: 2 * MOD_WAVES ints.
-template <class PT>   // PT: mod_params, or the same struct read through the kernarg segment (constant address space)
+template <bool MANY_H = false, class PT>   // PT: mod_params, or the same struct read through the kernarg segment (constant address space); MANY_H: more than two modulation indices allowed
 __device__ __forceinline__ void mod_stage_window(const int8_t *__restrict__ symbols, const double *__restrict__ hvec,
                                                  const PT &P, int64_t m0, int win, double *s_amp, int *s_pi, int *s_wtot,
                                                  int t = threadIdx.x)
@@ -327,6 +328,39 @@ __device__ __forceinline__ void mod_stage_window(const int8_t *__restrict__ symb
     const int64_t l0 = m0 - P.sym_origin;
     const bool inner = m0 >= 0 && m0 + win <= P.nsym && l0 >= 0 && l0 + win <= P.nloc;
     const int8_t *sp = symbols + l0;
+    if (MANY_H && P.nh > 2) {
+        // Any number of modulation indices (modulate.py:91-92: symbol i takes h[i mod N_h]): one set of prefix counts per
+        // index class, built class by class with the same block scan — only the stand-alone modulator comes here.
+        const int nh = P.nh;
+        int c0 = (int)(m0 % nh);
+        c0 += c0 < 0 ? nh : 0;                                  // class of window symbol 0 (m0 < 0 in tile 0)
+        auto sym_g = [&](int k) __attribute__((always_inline)) { return inner ? (int)sp[k] : mod_sym_raw(symbols, P, m0 + k); };
+        for (int e = 0; e < per; ++e) {
+            const int k = k0 + e;
+            if (k < win) s_amp[k] = (double)sym_g(k) * hvec[(c0 + k) % nh];
+        }
+        for (int c = 0; c < nh; ++c) {
+            int sa = 0;
+            for (int e = 0; e < per; ++e) {
+                const int k = k0 + e;
+                if (k < win && (c0 + k) % nh == c) sa += sym_g(k);
+            }
+            const int ia = mod_wave_incl_scan_i32(sa);
+            if (lane == 63) s_wtot[wave] = ia;
+            wf_lds_barrier();
+            int ra = ia - sa;
+            for (int w = 0; w < wave; ++w) ra += s_wtot[w];
+            for (int e = 0; e < per; ++e) {
+                const int k = k0 + e;
+                if (k <= win) {
+                    s_pi[c * (win + 1) + k] = ra;
+                    if (k < win && (c0 + k) % nh == c) ra += sym_g(k);
+                }
+            }
+            wf_lds_barrier();                                   // s_wtot is free again; after the last class: window and counts visible
+        }
+        return;
+    }
     const int par0 = P.nh > 1 ? (int)(m0 & 1) : 0;              // (nh <= 2) class of window symbol k = (par0 + k) & (nh - 1)
     const double h0 = hvec[0], h1 = P.nh > 1 ? hvec[1] : 0.0;
     auto sym_at = [&](int k) __attribute__((always_inline)) { return inner ? (int)sp[k] : mod_sym_raw(symbols, P, m0 + k); };
@@ -372,10 +406,13 @@ __device__ __forceinline__ void mod_stage_window(const int8_t *__restrict__ symb
 //   a  = &s_amp[index of the newest symbol under the first sample, + 1]      (the old FIR's window top)
 //   pi = &s_pi[index of the first symbol NOT yet elapsed for the first sample]  (= q0 - cq + row offset)
 // wrap: the second sample already sees the next symbol (per lane; any_wrap: some lane of the kernel does).
+// nh > 2 (stand-alone modulator only): classes 2 .. nh-1 take their reference counts from pi_ref[c pstride] (= s_pi of
+// class c at the tile-edge index) and their index from hv[c]; T = sum of the taps.
 template <int JMAX>
 __device__ __forceinline__ void mod_pair_phase(const double (&Q0)[JMAX], const double (&Q1)[JMAX], const double *a, const int *pi,
                                                int wrap, bool any_wrap, int nh, int pstride, int ref_a, int ref_b, double W,
-                                               double Th_a, double Th_b, double sps_d, double inv_sps, double &ra, double &rb)
+                                               double Th_a, double Th_b, double sps_d, double inv_sps, double &ra, double &rb,
+                                               const int *pi_ref = nullptr, const double *hv = nullptr, double T = 0.0)
 {
     const double *a1 = any_wrap ? a + wrap : a;
     double acc0 = 0.0, acc1 = 0.0;
@@ -386,10 +423,14 @@ __device__ __forceinline__ void mod_pair_phase(const double (&Q0)[JMAX], const d
     }
     double b0 = fma((double)(pi[0] - ref_a), Th_a, W);
     if (nh > 1) b0 = fma((double)(pi[pstride] - ref_b), Th_b, b0);
+    if (nh > 2)
+        for (int c = 2; c < nh; ++c) b0 = fma((double)(pi[c * pstride] - pi_ref[c * pstride]), T * hv[c], b0);
     double b1 = b0;
     if (any_wrap) {
         b1 = fma((double)(pi[wrap] - ref_a), Th_a, W);
         if (nh > 1) b1 = fma((double)(pi[pstride + wrap] - ref_b), Th_b, b1);
+        if (nh > 2)
+            for (int c = 2; c < nh; ++c) b1 = fma((double)(pi[c * pstride + wrap] - pi_ref[c * pstride]), T * hv[c], b1);
     }
     const double v0 = b0 + acc0, v1 = b1 + acc1;
     // one reduction mod sps per pair (the second sample is a single frequency-pulse value further); a
@@ -416,7 +457,8 @@ struct mod_kargs {
 };
 typedef const __attribute__((address_space(4))) mod_kargs *mod_kptr;
 
-template <int JMAX, bool FULLROW>
+// MANY_H: three or more modulation indices (launched for those only: its uniform class bookkeeping costs the common forms scalar spills).
+template <int JMAX, bool FULLROW, bool MANY_H = false>
 __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(const int8_t *__restrict__ symbols_,
                                                                 const double *__restrict__ hvec_,
                                                                 const double *__restrict__ pulse_,
@@ -477,7 +519,7 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
         const int64_t mp1_lo = sym_base + cq - JMAX + 1;
         const bool full_tile = tile_base >= P.out_origin && tile_base + tile_len <= P.out_hi;
         wf_lds_barrier();                                 // the previous tile's rows are done with the window
-        mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot, tp);
+        mod_stage_window<MANY_H>(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot, tp);
         // carry into the tile: T * S(symbols fully elapsed at the tile edge) - K0, fixed point, from the
         // scan kernel (tile 0: -K0, the head truncation; a stream window: the previous window's export)
         const double W = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
@@ -490,7 +532,8 @@ __global__ __launch_bounds__(MOD_THREADS, MOD_MIN_WAVES) void mod_main_kernel(co
             if (active) {
                 double ra, rb;
                 mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap,
-                                     P.nh, win + 1, ref_a, ref_b, W, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb);
+                                     MANY_H ? P.nh : (P.nh > 1 ? 2 : 1), win + 1, ref_a, ref_b, W, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb,
+                                     MANY_H ? &s_pi[lpart] : nullptr, hvec, T);
                 wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
                 wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
             }
@@ -1144,11 +1187,12 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
 // Geometry shared by the one-shot entry point and the streaming link.
-static bool mod_setup(mod_params &P, int64_t nsym, int nh, int ntaps, int sps, double phi0)
+static bool mod_setup(mod_params &P, int64_t nsym, int nh, int ntaps, int sps, double phi0, int max_nh = 2)
 {
     // outside 2 <= sps <= 256 the row length below is 0 (or the lcm divides by 0): not a
     // configuration of the fused kernel.  P is left in a defined state for callers that read it.
-    if (sps < 2 || sps > 256 || ntaps < 1 || nsym < 1 || nh < 1 || nh > 2) {      // (prefix counts: one or two modulation indices)
+    // (prefix counts: one set per modulation index — the one-kernel front ends keep two, the stand-alone modulator MOD_MAX_NH)
+    if (sps < 2 || sps > 256 || ntaps < 1 || nsym < 1 || nh < 1 || nh > max_nh) {
         P = mod_params{};
         P.sps = sps;
         P.ntaps = ntaps;
@@ -1219,7 +1263,8 @@ static int mod_launch(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols,
         const size_t win = (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2);                                   \
         const size_t lds = ((win + 1) & ~(size_t)1) * sizeof(double) + (size_t)P.nh * (win + 1) * sizeof(int); \
         using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, double *, mod_params); \
-        const kern_t k = P.rs == 2 * MOD_THREADS ? mod_main_kernel<JM, true> : mod_main_kernel<JM, false>; \
+        const kern_t k = P.nh > 2 ? (P.rs == 2 * MOD_THREADS ? mod_main_kernel<JM, true, true> : mod_main_kernel<JM, false, true>) \
+                                  : (P.rs == 2 * MOD_THREADS ? mod_main_kernel<JM, true> : mod_main_kernel<JM, false>); \
         if (lds > 48 * 1024)                                                                             \
             WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(k, dim3(grid), dim3(MOD_THREADS), lds, s, d_symbols, d_h, d_pulse, scratch, d_out_ri, P); \
@@ -1245,7 +1290,7 @@ extern "C" int wf_cpm_modulate_c128(wf_ctx *ctx, const int8_t *d_symbols, int64_
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0, "wf_cpm_modulate_c128: d_out alignment");
     WF_HIP(hipSetDevice(ctx->device));
     mod_params P;
-    if (!mod_setup(P, nsym, nh, ntaps, sps, phi0)) return 1;  // caller falls back to the two stage kernels
+    if (!mod_setup(P, nsym, nh, ntaps, sps, phi0, MOD_MAX_NH)) return 1;  // caller falls back to the two stage kernels
     return mod_launch(ctx, P, d_symbols, d_h, d_pulse, d_out_ri, nullptr, nullptr, stream);
 }
 

@@ -398,8 +398,10 @@ static __device__ __constant__ double2 kWfLogTab[128] = {
 // (vector loads through L1), or a copy in LDS with entry i at p[i * STRIDE + OFF] (log) and
 // p[(128 + i) * STRIDE + OFF] (sincos).  Kernels that also store in their main loop want LDS:
 // vmcnt is shared by loads and stores, so a global table load waits for older stores.
+// log(i) = {1 / c_i, -2 ln c_i}: the radius wants -2 ln u, and a factor of -2 carried by the constants (exact: a power of
+// two) is one multiply per Gaussian pair less than applying it to the result — the same bits.
 struct wf_tabs_global {
-    __device__ __forceinline__ double2 log(int i) const { return kWfLogTab[i]; }
+    __device__ __forceinline__ double2 log(int i) const { const double2 v = kWfLogTab[i]; return make_double2(v.x, -2.0 * v.y); }
     __device__ __forceinline__ double2 cis(int i) const { return kWfCisTab[i]; }
 };
 template <int STRIDE, int OFF>
@@ -411,33 +413,39 @@ struct wf_tabs_lds {
 template <int STRIDE, int OFF>
 __device__ __forceinline__ void wf_stage_tables(double2 *p, int t, int nthreads)   // caller synchronises
 {
-    for (int k = t; k < 256; k += nthreads) p[k * STRIDE + OFF] = k < 128 ? kWfLogTab[k] : kWfCisTab[k - 128];
+    for (int k = t; k < 256; k += nthreads)
+        p[k * STRIDE + OFF] = k < 128 ? make_double2(kWfLogTab[k].x, -2.0 * kWfLogTab[k].y) : kWfCisTab[k - 128];
+}
+
+// -2 ln((xa + 1) 2^-32) >= +0: the series of the comment above with every constant scaled by -2 (exact), so the result is
+// bit for bit -2 x what the unscaled series gives.
+__device__ __forceinline__ double wf_neg2log_series(double m, int e, double2 tc)
+{
+    const double r = fma(m, tc.x, -1.0);
+    double p = fma(r, 2.0 / 6.0, -0.4);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, -2.0 / 3.0);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, -2.0);
+    const double de = (double)e;
+    // u <= 1, so the true value is >= 0: clamp the rounding of ln(1) (xa = 2^32 - 1)
+    return fmax(fma(de, -2.0 * 6.93147180369123816490e-01, fma(r, p, tc.y) + de * (-2.0 * 1.90821492927058770002e-10)), 0.0);
 }
 
 template <class Tabs>
-__device__ __forceinline__ double wf_log_unit32(uint32_t xa, const Tabs &tb)
+__device__ __forceinline__ double wf_neg2log_unit32(uint32_t xa, const Tabs &tb)
 {
     const double x = (double)xa + 1.0;                              // 1 .. 2^32, exact
     const long long ix = __double_as_longlong(x);
     const int e = (int)(ix >> 52) - (1023 + 32);
     const long long mant = ix & 0x000FFFFFFFFFFFFFll;
-    const double m = __longlong_as_double(mant | 0x3FF0000000000000ll);
-    const double2 tc = tb.log((int)(mant >> 45));
-    const double r = fma(m, tc.x, -1.0);
-    double p = fma(r, -1.0 / 6.0, 0.2);
-    p = fma(r, p, -0.25);
-    p = fma(r, p, 1.0 / 3.0);
-    p = fma(r, p, -0.5);
-    p = fma(r, p, 1.0);
-    const double de = (double)e;
-    // u <= 1, so the true value is <= 0: clamp the rounding of ln(1) (xa = 2^32 - 1)
-    return fmin(fma(de, 6.93147180369123816490e-01, fma(r, p, tc.y) + de * 1.90821492927058770002e-10), 0.0);
+    return wf_neg2log_series(__longlong_as_double(mant | 0x3FF0000000000000ll), e, tb.log((int)(mant >> 45)));
 }
 
 // sqrt(a) for a normal-range double a >= +0: v_rsq_f64 seed, one Goldschmidt step, then one
 // Newton correction on the exactly computed residual (< 1 ulp).  a = 0 gives 0 (the seed's
 // argument is floored).  The caller must not pass a negative a: -2 ln(u) for u = 1 once rounded
-// to -4e-19 and a * rsq(tiny) turned it into 1e133 — wf_log_unit32 clamps its result to <= 0.
+// to -4e-19 and a * rsq(tiny) turned it into 1e133 — wf_neg2log_series clamps its result to >= 0.
 __device__ __forceinline__ double wf_sqrt_pos(double a)   // a >= +0.0 (the caller's log is clamped to <= 0)
 {
     const double y = __builtin_amdgcn_rsq(fmax(a, 0x1.0p-1000));   // relative error <= 2^-23
@@ -485,7 +493,7 @@ __device__ __forceinline__ void wf_sincos_u32(uint32_t xb, const Tabs &tb, doubl
 template <class Tabs>
 __device__ __forceinline__ void wf_box_muller32(uint32_t xa, uint32_t xb, double sigma, const Tabs &tb, double *re, double *im)
 {
-    const double r = sigma * wf_sqrt_pos(-2.0 * wf_log_unit32(xa, tb));
+    const double r = sigma * wf_sqrt_pos(wf_neg2log_unit32(xa, tb));
     double s, c;
     wf_sincos_u32(xb, tb, &s, &c);
     *re = r * c;
@@ -542,16 +550,7 @@ __device__ __forceinline__ void wf_gaussian_two_il(uint64_t pair, uint64_t strea
     double rad[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const double m = __longlong_as_double(mant[q] | 0x3FF0000000000000ll);
-        const double r = fma(m, tl[q].x, -1.0);
-        double pl = fma(r, -1.0 / 6.0, 0.2);
-        pl = fma(r, pl, -0.25);
-        pl = fma(r, pl, 1.0 / 3.0);
-        pl = fma(r, pl, -0.5);
-        pl = fma(r, pl, 1.0);
-        const double de = (double)e[q];
-        const double lg = fmin(fma(de, 6.93147180369123816490e-01, fma(r, pl, tl[q].y) + de * 1.90821492927058770002e-10), 0.0);
-        rad[q] = sigma * wf_sqrt_pos(-2.0 * lg);
+        rad[q] = sigma * wf_sqrt_pos(wf_neg2log_series(__longlong_as_double(mant[q] | 0x3FF0000000000000ll), e[q], tl[q]));
     }
     if (!ALL_UP_FRONT) {
 #pragma unroll

@@ -394,7 +394,8 @@ def main() -> None:
         bps["viterbi"] = 32 + 2
         jm = 4 if -(-links[0].cfg.ntaps // args.sps) <= 4 else 9
         # (a bank other than the sps + 1 pulse-truncation taps — the 73-tap PAM bank — is the kernel's matrix-core form)
-        form = 0 if links[0].cfg.mf_ntaps == args.sps + 1 else -1
+        # (... its factored form -2 when the link handed the bank over as two real filters + a 3 x 2 combination: wf_link_config.d_mf_factor)
+        form = 0 if links[0].cfg.mf_ntaps == args.sps + 1 else (-2 if links[0].cfg.d_mf_factor else -1)
         STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<{jm}, {form}, {args.sps}>"
         STAGE_KERNEL["viterbi"] = "viterbi_batch_kernel<true>"
     elif not cpm and args.fuse & 1:   # the "fir" event slot times the fused modulator: symbols in, c128 out

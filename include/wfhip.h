@@ -288,6 +288,15 @@ typedef struct {
                             /* wf_ctx_check on the stream that reads them                 */
     int event_slot;         /* -1: off; 0..WF_LINK_EVENT_SLOTS-1: record HIP events    */
                             /* around every stage into that slot (wf_link_stage_ms)   */
+    const double *d_mf_factor; /* device, optional (NULL: none): a long bank (the PAM    */
+                            /* detector's, mf_ntaps != sps + 1) FACTORED as the reference */
+                            /* computes it (examples/soqpsk_detection.py:158-173): two    */
+                            /* real filters b_0, b_1 (mf_ntaps doubles each) and the 3 x 2 */
+                            /* complex combination G (12 doubles, G[s][k] as re, im), with */
+                            /* d_mf_taps[s] == sum_k G[s][k] b_k.  The one-kernel front end */
+                            /* then runs two real filters instead of three complex ones    */
+                            /* (a third fewer matrix instructions); every other path reads */
+                            /* d_mf_taps.  The caller vouches for the identity.            */
 } wf_link_config;
 #define WF_LINK_EVENT_SLOTS 64
 #define WF_LINK_STAGES 8    /* prbs, encode, fir, phase, awgn, mfbank, viterbi, count */

@@ -1081,19 +1081,39 @@ def test_one_kernel_front_end_pam_bank_rows(oracle, nsym, pulse_name):
     pulse = oracle.freq_pulse_soqpsk_tg(8) if pulse_name == "tg" else oracle.freq_pulse_soqpsk_mil(8)
     for off in (range(-4, 4) if nsym == 70_001 else (0, -3)):
         ref = SOQPSKLink(nsym, 8, fuse=7, pulse=pulse, timing_offset=off, detector="PAM")
-        fus = SOQPSKLink(nsym, 8, fuse=15, pulse=pulse, timing_offset=off, detector="PAM")
-        assert (ref.row_bytes, fus.row_bytes) == (32, 32)
-        assert ref.layout()["one_kernel_front_end"] == 0 and fus.layout()["one_kernel_front_end"] == 1
-        for link in (ref, fus):
-            link.run_block(4.0, seed=7, stream_id=9, skip_bits=55)
-        lr, lf = ref.layout(), fus.layout()
-        calls = lr["calls"]
-        a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
-        b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
-        np.testing.assert_allclose(b, a, rtol=0, atol=2e-12, err_msg=str(off))
-        assert ref.result() == fus.result(), off
-        for key in ("off_bits", "off_syms"):
-            assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
+        # both forms of the bank stage: factored (two real rho filters + the pseudo-symbol weights, as the reference computes
+        # it: what a link runs) and the three complex filters (any long bank)
+        for factored in (True, False):
+            fus = SOQPSKLink(nsym, 8, fuse=15, pulse=pulse, timing_offset=off, detector="PAM", factor_bank=factored)
+            assert bool(fus.cfg.d_mf_factor) == factored
+            assert (ref.row_bytes, fus.row_bytes) == (32, 32)
+            assert ref.layout()["one_kernel_front_end"] == 0 and fus.layout()["one_kernel_front_end"] == 1
+            ref.reset_counts()
+            for link in (ref, fus):
+                link.run_block(4.0, seed=7, stream_id=9, skip_bits=55)
+            lr, lf = ref.layout(), fus.layout()
+            calls = lr["calls"]
+            a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+            b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+            np.testing.assert_allclose(b, a, rtol=0, atol=2e-12, err_msg=str((off, factored)))
+            assert ref.result() == fus.result(), (off, factored)
+            for key in ("off_bits", "off_syms"):
+                assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
+    # a factorisation found from the taps alone (SVD basis of their real row space: not the rho pulses) serves as well
+    from waveforms_amd import _hip
+    from waveforms_amd.filters.matched import factor_long_bank, pack_bank_factors, pam_matched_filter_taps
+    fus = SOQPSKLink(nsym, 8, fuse=15, pulse=pulse, detector="PAM", factor_bank=False)
+    fus._d_factor = _hip.to_device(pack_bank_factors(*factor_long_bank(pam_matched_filter_taps(pulse, 0.25, 8))))
+    fus.cfg.d_mf_factor = fus._d_factor.data_ptr()
+    ref = SOQPSKLink(nsym, 8, fuse=7, pulse=pulse, detector="PAM")
+    for link in (ref, fus):
+        link.run_block(4.0, seed=7, stream_id=9, skip_bits=55)
+    lr, lf = ref.layout(), fus.layout()
+    calls = lr["calls"]
+    a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+    b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+    np.testing.assert_allclose(b, a, rtol=0, atol=2e-12)
+    assert ref.result() == fus.result()
 
 
 def _packed_from_unpacked(rows3, par0=0):
@@ -1116,19 +1136,22 @@ def test_one_kernel_front_end_pam_bank_rows_sps10(oracle, nsym):
 
     for off in (range(-5, 5) if nsym == 70_001 else (0, -3, 4)):
         ref = SOQPSKLink(nsym, 10, fuse=7, timing_offset=off, detector="PAM")
-        fus = SOQPSKLink(nsym, 10, fuse=15, timing_offset=off, detector="PAM")
-        assert (ref.row_bytes, fus.row_bytes) == (48, 32)
-        assert ref.layout()["one_kernel_front_end"] == 0 and fus.layout()["one_kernel_front_end"] == 1
-        for link in (ref, fus):
-            link.run_block(4.0, seed=7, stream_id=9, skip_bits=55)
-        lr, lf = ref.layout(), fus.layout()
-        calls = lr["calls"]
-        a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 48].view(torch_f64()).reshape(calls, 3, 2).cpu().numpy()
-        b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
-        np.testing.assert_allclose(b, _packed_from_unpacked(a[..., 0] + 1j * a[..., 1]), rtol=0, atol=2e-12, err_msg=str(off))
-        assert ref.result() == fus.result(), off
-        for key in ("off_bits", "off_syms"):
-            assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
+        for factored in (True, False):     # (the factored form: operand rows of 8 columns x 10 samples, one plane each, pad grid of 80)
+            fus = SOQPSKLink(nsym, 10, fuse=15, timing_offset=off, detector="PAM", factor_bank=factored)
+            assert bool(fus.cfg.d_mf_factor) == factored
+            assert (ref.row_bytes, fus.row_bytes) == (48, 32)
+            assert ref.layout()["one_kernel_front_end"] == 0 and fus.layout()["one_kernel_front_end"] == 1
+            ref.reset_counts()
+            for link in (ref, fus):
+                link.run_block(4.0, seed=7, stream_id=9, skip_bits=55)
+            lr, lf = ref.layout(), fus.layout()
+            calls = lr["calls"]
+            a = ref.workspace[lr["off_mf"]:lr["off_mf"] + calls * 48].view(torch_f64()).reshape(calls, 3, 2).cpu().numpy()
+            b = fus.workspace[lf["off_mf"]:lf["off_mf"] + calls * 32].view(torch_f64()).reshape(calls, 4).cpu().numpy()
+            np.testing.assert_allclose(b, _packed_from_unpacked(a[..., 0] + 1j * a[..., 1]), rtol=0, atol=2e-12, err_msg=str((off, factored)))
+            assert ref.result() == fus.result(), (off, factored)
+            for key in ("off_bits", "off_syms"):
+                assert np.array_equal(ref.workspace[lr[key]:lr[key] + calls].cpu().numpy(), fus.workspace[lf[key]:lf[key] + calls].cpu().numpy())
 
 
 def test_one_kernel_front_end_random_bursts(capsys):

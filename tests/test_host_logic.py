@@ -289,3 +289,28 @@ def test_design_status_block_is_generated_from_committed_profiles():
     r = subprocess.run([sys.executable, str(root / "tools" / "gen_status.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (root / "DESIGN.md").stat().st_size <= 25 * 1024
+
+
+def test_long_bank_factorisation():
+    """The PAM bank's two forms on the host: ``pam_bank_factors`` (the reference's own: rho pulses and conj(pseudo symbols),
+    examples/soqpsk_detection.py:158-173) reproduces ``pam_matched_filter_taps``; ``factor_long_bank`` finds a two-filter
+    form from the taps alone and refuses a bank that has none; the packed buffer is b_0, b_1, then the weights."""
+    from waveforms_amd.cpm.soqpsk import freq_pulse_soqpsk_mil, freq_pulse_soqpsk_tg
+    from waveforms_amd.filters.matched import factor_long_bank, pack_bank_factors, pam_bank_factors, pam_matched_filter_taps
+
+    for sps, pulse in ((8, freq_pulse_soqpsk_tg(8)), (10, freq_pulse_soqpsk_tg(10)), (8, freq_pulse_soqpsk_mil(8))):
+        taps = pam_matched_filter_taps(pulse, 0.25, sps)
+        basis, w = pam_bank_factors(pulse, 0.25, sps)
+        assert basis.shape == (2, taps.shape[1]) and w.shape == (3, 2) and basis.dtype == np.float64
+        assert np.abs(w @ basis - taps).max() < 1e-15
+        b2, w2 = factor_long_bank(taps)
+        assert np.abs(w2 @ b2 - taps).max() < 1e-13 and abs(np.dot(b2[0], b2[1])) < 1e-12
+        buf = pack_bank_factors(basis, w)
+        n = taps.shape[1]
+        assert buf.size == 2 * n + 12 and np.array_equal(buf[:n], basis[0]) and np.array_equal(buf[n:2 * n], basis[1])
+        assert buf[2 * n + 2 * (2 * 1 + 0)] == w[1, 0].real and buf[2 * n + 2 * (2 * 2 + 1) + 1] == w[2, 1].imag
+    rng = np.random.default_rng(5)
+    assert factor_long_bank(rng.standard_normal((3, 73)) + 1j * rng.standard_normal((3, 73))) is None
+    assert factor_long_bank(np.ones((2, 9))) is None
+    with pytest.raises(ValueError):
+        pack_bank_factors(np.ones((3, 9)), np.ones((3, 2)))

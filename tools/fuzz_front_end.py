@@ -26,8 +26,9 @@ def main():
         diff = bool(rng.integers(0, 2))
         ebn0 = float(rng.choice([2.0, 6.0, 10.0]))
         kw = dict(detector=det, timing_offset=off, differential=diff)
+        factored = bool(rng.integers(0, 2))      # PAM: the bank as two real filters + weights (what a link runs by default), or as three complex filters
         try:
-            ref, fus = SOQPSKLink(nsym, sps, fuse=7, **kw), SOQPSKLink(nsym, sps, fuse=15, **kw)
+            ref, fus = SOQPSKLink(nsym, sps, fuse=7, **kw), SOQPSKLink(nsym, sps, fuse=15, factor_bank=factored, **kw)
         except ValueError:
             continue            # burst shorter than the matched filter
         seed, sid, skip = int(rng.integers(1, 1 << 30)), int(rng.integers(0, 1 << 20)), int(rng.integers(0, 1 << 22))
@@ -42,7 +43,7 @@ def main():
             z = x.reshape(calls, 3, 2)
             odd = (np.arange(calls) & 1) == 1
             x = np.stack([z[:, 1, 0], z[:, 1, 1], np.where(odd, z[:, 0, 1], z[:, 0, 0]), np.where(odd, z[:, 2, 0], z[:, 2, 1])], axis=1).reshape(-1)
-        kw = dict(kw, sps=sps)
+        kw = dict(kw, sps=sps, factored=factored)
         if det == "PT" and sps == 8:     # (at sps 10 the separate bank kernel runs plain fma chains, the one-kernel form the shared sums: rounding apart)
             assert np.array_equal(x.view(np.int64), y.view(np.int64)), ("rows", nsym, kw)
         else:

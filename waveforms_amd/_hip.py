@@ -116,7 +116,7 @@ class LinkConfig(ctypes.Structure):
         ("skip", c_uint64), ("differential", c_int), ("d_h", c_void_p), ("d_pulse", c_void_p),
         ("ntaps", c_int), ("d_mf_taps", c_void_p), ("mf_ntaps", c_int), ("mf_nfilt", c_int),
         ("timing_offset", c_int), ("sigma", c_double), ("seed", c_uint64), ("stream_id", c_uint64),
-        ("warmup", c_int), ("fuse", c_int), ("event_slot", c_int),
+        ("warmup", c_int), ("fuse", c_int), ("event_slot", c_int), ("d_mf_factor", c_void_p),
     ]
 
 

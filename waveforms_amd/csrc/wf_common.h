@@ -82,6 +82,7 @@ struct wf_ctx {
     hipEvent_t pipe_front = nullptr, pipe_done[2] = {nullptr, nullptr};
     bool pipe_done_valid[2] = {false, false};
     int pipe_set = 0;
+    const double *mcb_pam_factor = nullptr;   // set by a link around its front-end launch: the long (PAM) bank factored into two real filters + a 3 x 2 complex combination (wf_link_config.d_mf_factor), or NULL
     int mcb_runs_hint = 0;         // runs of tiles per resident slot for the one-kernel CPM front end (0: its default); set by the pipelined CPM link
     double *h_iter = nullptr;      // per-symbol detector call: pinned, device-mapped staging (6 in + 2 x 64 out)
     double *d_iter = nullptr;      // ... the device's address of the same memory

@@ -670,28 +670,34 @@ typedef const __attribute__((address_space(4))) mcb_kargs *mcb_kptr;
 // grid again, and an odd shift, so that column 4 i + s - 3 of an odd row — rows hold 51 columns: the parity of a column
 // flips with the row — has the parity of s like column 4 i + s of an even row: ONE set of B operands serves both).  13 / 14
 // operand rows per row of 51 columns; the 2 - 5 columns they compute outside the row are not stored.
-template <int SPS>
+template <int SPS, int SH = 4>
 struct mcb_pam_geom {
     static constexpr int NT = 9 * SPS + 1;                           // longest bank: 73 / 91 taps (rho_0 of SOQPSK-TG)
-    static constexpr int PG = 4 * SPS;                               // samples per pad group = per operand row
-    static constexpr int OPLEN = 3 * SPS + NT;                       // samples an operand row spans
-    static constexpr int NK = (2 * OPLEN + 3) / 4;                   // k-steps (4 components each): 49 / 61
+    static constexpr int PG = SH * SPS;                              // samples per pad group = per operand row
+    static constexpr int OPLEN = (SH - 1) * SPS + NT;                // samples an operand row spans
+    static constexpr int NK = SH == 4 ? (2 * OPLEN + 3) / 4 : (OPLEN + 3) / 4;   // k-steps (4 components each): 49 / 61; factored form (one plane per operand row): 33 / 41
     static constexpr int NKW = NK / 4;                               // k-steps per wave (wave 0 takes the odd one out)
     static constexpr int QSH = (mcb_geom<SPS>::CPR & 1) ? 3 : 0;     // columns an odd row's operand rows start early
-    static constexpr int OPROWS = (mcb_geom<SPS>::CPR + QSH + 3) / 4;   // operand rows in use (of 16)
+    static constexpr int OPROWS = (mcb_geom<SPS>::CPR + QSH + SH - 1) / SH;   // operand rows in use (of 16; factored form: of 8 per plane)
     static constexpr int XLEN = NT + 1;                              // samples of the next tile the last columns of a tile look at: NT - SPS + d, d < SPS (even count)
-    // an odd row's last operand row starts at RS - QSH SPS + PG (OPROWS - 1) and its last (half-filled) k-step reads sample OPLEN:
-    static constexpr int MIRROR = (PG * (OPROWS - 1) + OPLEN + 1 - QSH * SPS - mcb_geom<SPS>::RS + 7) & ~7;   // ring indices 0 .. MIRROR-1 once more behind the ring (72 / 104)
+    // an odd row's last operand row starts at RS - QSH SPS + PG (OPROWS - 1) and its last (half-filled) k-step reads sample OPLEN
+    // (factored form: its last k-step reads samples up to 4 NK - 1):
+    static constexpr int LASTREAD = SH == 4 ? OPLEN + 1 : 4 * NK;
+    static constexpr int MIRROR = (PG * (OPROWS - 1) + LASTREAD - QSH * SPS - mcb_geom<SPS>::RS + 7) & ~7;   // ring indices 0 .. MIRROR-1 once more behind the ring (72 / 104)
     static constexpr int EXT = mcb_geom<SPS>::RING + MIRROR;                                         // extended ring: indices 0 .. EXT-1
     static constexpr int SLOTS = EXT + EXT / PG + 1;
     static_assert(NK % 4 == 1, "wave 0 takes exactly one k-step more than the others");
-    static_assert((mcb_geom<SPS>::RS - QSH * SPS) % PG == 0 && PG % 8 == 0, "operand rows start on the pad grid in both rows of the ring");
-    static_assert(((mcb_geom<SPS>::CPR - QSH) & 1) == 0 && OPROWS <= 16, "one B operand set for both row parities");
+    static_assert((mcb_geom<SPS>::RS - QSH * SPS) % PG == 0 && PG % (SH == 4 ? 8 : 16) == 0, "operand rows start on the pad grid in both rows of the ring");
+    static_assert((SH == 4 ? (((mcb_geom<SPS>::CPR - QSH) & 1) == 0 && OPROWS <= 16) : OPROWS <= 8), "one B operand set for both row parities");
 };
 static_assert(mcb_pam_geom<8>::NT == 73 && mcb_pam_geom<8>::NK == 49 && mcb_pam_geom<8>::XLEN == 74 && mcb_pam_geom<8>::OPROWS == 16 && mcb_pam_geom<8>::MIRROR == 72, "SPS = 8 PAM geometry");
 static_assert(mcb_pam_geom<10>::NT == 91 && mcb_pam_geom<10>::NK == 61 && mcb_pam_geom<10>::OPROWS == 14 && mcb_pam_geom<10>::MIRROR == 104, "SPS = 10 PAM geometry");
+static_assert(mcb_pam_geom<8, 8>::NK == 33 && mcb_pam_geom<8, 8>::OPROWS == 8 && mcb_pam_geom<8, 8>::MIRROR == 72 && mcb_pam_geom<10, 8>::NK == 41 && mcb_pam_geom<10, 8>::OPROWS == 7 && mcb_pam_geom<10, 8>::MIRROR == 104, "factored PAM geometry");
 #define MCB_PAM_NT(sps) (9 * (sps) + 1)
-static inline int mcb_pam_slots(int sps) { return sps == 8 ? mcb_pam_geom<8>::SLOTS : mcb_pam_geom<10>::SLOTS; }
+static inline int mcb_pam_slots(int sps, bool factored)
+{
+    return factored ? (sps == 8 ? mcb_pam_geom<8, 8>::SLOTS : mcb_pam_geom<10, 8>::SLOTS) : (sps == 8 ? mcb_pam_geom<8>::SLOTS : mcb_pam_geom<10>::SLOTS);
+}
 template <int JMAX, int CPMNF, int SPS = 8>     // SPS != 8: CPMNF <= 0 only (the CPM detector's 9-tap templates are an sps-8 design); CPMNF < 0: SPS 8 / 10
 __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0 ? 3 : (JMAX <= 4 ? WF_MCB_CPM_WAVES : 2))) void mod_chan_bank_kernel(const int8_t *__restrict__ symbols_,
                                                                      const double *__restrict__ hvec_,
@@ -709,9 +715,11 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     const double *__restrict__ const scratch = ka->scratch;
     const double *__restrict__ const mf_taps = ka->mf_taps;
     static_assert(SPS == 8 || CPMNF == 0 || (CPMNF < 0 && SPS == 10), "the CPM detector rows are an sps-8 design, the long-bank form one for 8 and 10");
+    static_assert(CPMNF >= -2, "CPMNF: -1 long bank of 3 complex filters, -2 the same bank given as two real filters + a 3 x 2 complex combination");
     constexpr bool PAM = CPMNF < 0;
+    constexpr bool PAM2 = CPMNF == -2;                 // the factored long bank (below)
     using G = mcb_geom<SPS>;
-    using GP = mcb_pam_geom<PAM ? SPS : 8>;
+    using GP = mcb_pam_geom<PAM ? SPS : 8, PAM2 ? 8 : 4>;
     constexpr int NT = G::NT, RS = G::RS, CPR = G::CPR;
     constexpr bool FULLROW = RS == 2 * MOD_THREADS;                              // every thread owns two samples of a row
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -851,9 +859,44 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     // per wave) — after the NEXT row barrier, which is there anyway.  Rows therefore differ from the single-chain
     // banks (mf_bank_kernel and the CPU restatement the tests check it with) in the last bits: the four chains are summed in another order.
     // (SPS 10: 121-sample operand rows, 61 k-steps, B[c][4 s + o] = the coefficient of component c - 20 s; see mcb_pam_geom)
+    // ---- CPMNF = -2: the same bank FACTORED, as the reference computes it (examples/soqpsk_detection.py:158-173): two REAL
+    // filters b_0, b_1 (the rho pulses, or any basis of the real row space of the three complex filters) and
+    // z_s = sum_k G[s][k] (b_k * r) — mf_taps then holds b_0, b_1 (mf_ntaps doubles each) and G (3 x 2 complex).  A real filter
+    // needs one PLANE of the samples per output, so an operand row is the Re or the Im parts of the 7 SPS + NT samples from the
+    // window start of column 8 i: A rows 0 .. 7 = Re planes of 8 operand rows (8 columns apart), rows 8 .. 15 = their Im planes;
+    // the 16 columns of B = (shift s = 0 .. 7) x (filter k), B[c][2 s + k] = tap c - SPS s of b_k.  33 (41 at sps 10) k-steps of
+    // 4 samples instead of 49 (61) of 2: a third of the matrix instructions gone (each is 64 cycles of its SIMD).  D then
+    // holds Re / Im of b_k * r per column; the quad that stores a column's packed row gathers its four reals (DPP) and every
+    // lane forms the slot it stores: 4 multiply-adds against the 2 x 4 x 4 coefficient table s_gt (by column parity).
+    __shared__ double s_gt[PAM2 ? 2 * 4 * 4 : 1];
+    if constexpr (PAM2) {
+        if (t < 32) {
+            const int odd_c = t >> 4, o = (t >> 2) & 3, comp = t & 3, kf = comp >> 1;     // comp: Re b_0*r, Im b_0*r, Re b_1*r, Im b_1*r
+            // slot 0 / 1: Re / Im z1;  slot 2: odd ? Im z0 : Re z0;  slot 3: odd ? Re z2 : Im z2
+            const int sh = o < 2 ? 1 : (o == 2 ? 0 : 2);
+            const bool want_im = o == 1 || (o == 2 && odd_c) || (o == 3 && !odd_c);
+            const double *gp = mf_taps + 2 * Q.mf_ntaps + 2 * (2 * sh + kf);
+            const double gre = gp[0], gim = gp[1];
+            // Re z = sum_k Re G Re y_k - Im G Im y_k;   Im z = sum_k Im G Re y_k + Re G Im y_k
+            s_gt[t] = want_im ? ((comp & 1) ? gre : gim) : ((comp & 1) ? -gim : gre);
+        }
+    }
     __shared__ double s_part[PAM ? 4 * 4 * 64 : 1];
     double bpam[PAM ? GP::NKW + 1 : 1];
-    if constexpr (PAM) {
+    if constexpr (PAM2) {
+        const int s_sh = mf_i >> 1, kf = mf_i & 1;
+        const int nt = Q.mf_ntaps;
+        const double *bf = mf_taps + kf * nt;
+#pragma unroll
+        for (int n = 0; n <= GP::NKW; ++n) {
+            const int kk = 4 * n + wave_u;                       // this wave's k-steps: every fourth one
+            const int cc = 4 * kk + mf_kq - SPS * s_sh;          // sample of this column's own window
+            double v = 0.0;
+            if (cc >= 0 && cc < nt && (n < GP::NKW || wave_u == 0)) v = bf[nt - 1 - cc];
+            bpam[n] = v;
+        }
+        for (int k = t; k < RSLOTS; k += MOD_THREADS) s_ring[k] = make_double2(0.0, 0.0);
+    } else if constexpr (PAM) {
         const int s_sh = mf_i >> 2, o_sl = mf_i & 3;
         const int nt = Q.mf_ntaps;
         const bool odd_col = ((Q.pack_par0 + s_sh - Q.kshift) & 1) != 0;   // (column 4 i + s of an even row = column 4 i + s - QSH of an odd one)
@@ -969,6 +1012,20 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                         __builtin_nontemporal_store(acc1[reg], &o[16]);     // detector's first reads: same-box, detector 0.820 / 0.821 -> 0.754 / 0.761 ms
                     }
                 }
+            } else if constexpr (PAM2) {
+                // A row i: operand row i & 7 (the samples from ring index RS (rho & 1) [- QSH SPS] + PG (i & 7)), plane i >> 3 (Re | Im);
+                // this lane's element of k-step kk = 4 n + w is sample 4 kk + kq = 16 n + (4 w + kq): PG is a multiple of 16 and
+                // 4 w + kq < 16, so its slot offset is the constant 16 n + 16 n / PG behind a per-lane base.
+                const int ri = mf_i & 7;
+                const int S0 = ((rho & 1) ? RS - GP::QSH * SPS : 0) + PG * (GP::OPROWS < 8 && ri >= GP::OPROWS ? 0 : ri);
+                const double *xa = ring_d + 2 * (S0 + S0 / PG + 4 * wave_u + mf_kq) + (mf_i >> 3);
+                mcb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int n = 0; n < GP::NKW; ++n)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (16 * n + 16 * n / PG)], bpam[n], acc, 0, 0, 0);
+                if (wave_u == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (16 * GP::NKW + 16 * GP::NKW / PG)], bpam[GP::NKW], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) s_part[(4 * wave_u + reg) * 64 + (t & 63)] = acc[reg];
             } else if constexpr (PAM) {
                 // operand row i = the 97 (121) samples from ring index RS (rho & 1) + PG i (odd rows of 51 columns: QSH
                 // columns earlier); this lane's element of k-step kk = 4 n + w is component 4 kk + kq: sample
@@ -1042,7 +1099,23 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
         };
         // PAM form: the partial tiles of bank_row(rho) summed and stored — register w of D is this wave's
         auto bank_reduce = [&](int rho) __attribute__((always_inline)) {
-            if constexpr (PAM) {
+            if constexpr (PAM2) {
+                // D[i][j] sits in lane j + 16 (i & 3), register i >> 2, i = operand row + 8 plane, j = 2 shift + filter.  This wave
+                // stores tile columns 16 w .. 16 w + 15 (operand rows 2 w, 2 w + 1), a quad per column; lane p of the quad first
+                // sums, over the four waves' partial tiles in the fixed order ((w0 + w1) + w2) + w3, component p of its column:
+                // p = 0: Re b_0*r, 1: Im b_0*r, 2: Re b_1*r, 3: Im b_1*r — then forms packed slot p from the quad's four.
+                const int ln = t & 63, tc = 16 * wave_u + (ln >> 2), p4 = ln & 3;
+                const int ri = tc >> 3, reg = (ri >> 2) + 2 * (p4 & 1), lsrc = 2 * (tc & 7) + (p4 >> 1) + 16 * (ri & 3);
+                const double *pp = s_part + reg * 64 + lsrc;
+                const double v = ((pp[0] + pp[4 * 64]) + pp[8 * 64]) + pp[12 * 64];
+                const double y0r = mcb_quad_bcast<0x00>(v), y0i = mcb_quad_bcast<0x55>(v), y1r = mcb_quad_bcast<0xAA>(v), y1i = mcb_quad_bcast<0xFF>(v);
+                const int col = tc - ((rho & 1) ? GP::QSH : 0);
+                const int kr = CPR * rho + col - Q.kshift;
+                const int odd_c = (Q.pack_par0 + kr + (int)(sym_base & 1)) & 1;
+                const double *gt = s_gt + 16 * odd_c + 4 * p4;
+                const double out = fma(gt[3], y1i, fma(gt[2], y1r, fma(gt[1], y0i, gt[0] * y0r)));
+                if (kr >= klo && kr < khi && (CPR == 64 || (col >= 0 && col < CPR))) rows[4 * ((sym_base + kr) - Q.k_lo) + p4] = out;
+            } else if constexpr (PAM) {
                 const int ln = t & 63;
                 const double *pp = s_part + (4 * 0 + wave_u) * 64 + ln;
                 const double v = ((pp[0] + pp[4 * 64]) + pp[8 * 64]) + pp[12 * 64];
@@ -1371,7 +1444,13 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     const int ring_slots = sps == 8 ? mcb_geom<8>::SLOTS : (sps == 10 ? mcb_geom<10>::SLOTS : mcb_geom<20>::SLOTS);
     // (occupancy experiment, LDS padded to force fewer workgroups per CU with the 4-row ring of the
     //  first version: 1 per CU 0.97 ms, 2: 0.63, 3: 0.56 — the 2-row ring's 4 per CU: 0.53)
-    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)(pam ? mcb_pam_slots(sps) : ring_slots) * sizeof(double2) +
+    // the long bank in factored form (the caller's link handed the factorisation over): the kernel then reads ITS buffer as mf_taps
+    const bool pam2 = pam && ctx->mcb_pam_factor != nullptr;
+    if (pam2) {
+        WF_REQUIRE((reinterpret_cast<uintptr_t>(ctx->mcb_pam_factor) & 7) == 0, "wf_mod_chan_bank: the bank's factorisation must be 8-byte aligned");
+        d_mf_taps = ctx->mcb_pam_factor;
+    }
+    const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)(pam ? mcb_pam_slots(sps, pam2) : ring_slots) * sizeof(double2) +
                        (size_t)nh * (win + 1) * sizeof(int);
     // one run of consecutive tiles per resident workgroup (4 per CU for the SOQPSK form, 3 for the CPM forms)
     int cus = 256;
@@ -1408,6 +1487,8 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
     kern_t k = cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)
+             : pam2         ? (sps == 10 ? (JM == 4 ? mod_chan_bank_kernel<4, -2, 10> : mod_chan_bank_kernel<9, -2, 10>)
+                                         : (JM == 4 ? mod_chan_bank_kernel<4, -2> : mod_chan_bank_kernel<9, -2>))
              : pam          ? (sps == 10 ? (JM == 4 ? mod_chan_bank_kernel<4, -1, 10> : mod_chan_bank_kernel<9, -1, 10>)
                                          : (JM == 4 ? mod_chan_bank_kernel<4, -1> : mod_chan_bank_kernel<9, -1>))
              : sps == 10    ? (JM == 4 ? mod_chan_bank_kernel<4, 0, 10> : mod_chan_bank_kernel<9, 0, 10>)

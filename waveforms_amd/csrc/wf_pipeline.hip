@@ -183,9 +183,11 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     // baseband samples never exist in HBM.  Outside that kernel's envelope the bits below apply.
     bool fused_all = false;
     if (link_one_kernel(cfg) && L.ncols > 0) {
+        ctx->mcb_pam_factor = cfg->d_mf_factor;       // (a long bank handed over in factored form: two real filters + a 3 x 2 combination)
         rc = wf_mod_chan_bank_packed(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_mf_taps,
                                      cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, L.first, L.ncols, 0,
                                      mf, stream, cfg->mf_ntaps);
+        ctx->mcb_pam_factor = nullptr;
         if (rc < 0) return rc;
         WF_REQUIRE(rc == 0, "wf_link_run: internal: the one-kernel front end refused a configuration wf_mod_chan_bank_applies accepted");
         fused_all = true;
@@ -520,10 +522,12 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
     // (any bank the kernel takes at 8 samples per symbol: the 9-tap pulse-truncation bank, or an odd-length bank of up to 73 taps)
     if ((cfg->fuse & 8) && packed && (phases & 5) && wf_mod_chan_bank_applies(S.N, 1, cfg->ntaps, cfg->sps, cfg->mf_ntaps, S.first)) {
         const int stage = ((phases & 1) ? 1 : 0) | ((phases & 4) ? 2 : 0);
+        ctx->mcb_pam_factor = cfg->d_mf_factor;
         rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
                                      S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_mf_taps, rot_re, rot_im, cfg->sigma, cfg->seed,
                                      cfg->stream_id, 0, steady ? dyn + 1 : nullptr, S.first, S.k_lo, S.ncols, 0, mf, stream, 0, 1, stage,
                                      cfg->mf_ntaps);
+        ctx->mcb_pam_factor = nullptr;
         if (rc < 0) return rc;
         fused_all = rc == 0;
     }

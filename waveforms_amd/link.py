@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _hip
 from .cpm.soqpsk import freq_pulse_soqpsk_tg
-from .filters.matched import pam_matched_filter_taps, pt_matched_filter_taps
+from .filters.matched import pack_bank_factors, pam_bank_factors, pam_matched_filter_taps, pt_matched_filter_taps
 from .glfsr.pn import generate_mask
 
 
@@ -59,18 +59,25 @@ class SOQPSKLink:
 
     def _configure(self, nsym: int, sps: int = 8, pulse=None, mod_index: float = 0.25, detector: str = "PT",
                    pn_degree: int = 23, differential: bool = True, timing_offset: int | None = None,
-                   warmup: int = 0, fuse: int = 15, private_ctx: bool = False) -> None:
+                   warmup: int = 0, fuse: int = 15, private_ctx: bool = False, factor_bank: bool = True) -> None:
         self.nsym, self.sps = int(nsym), int(sps)
         # a link that runs on its own stream next to other links needs its own scratch
         self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()
         self._owns_ctx = bool(private_ctx)
         pulse = freq_pulse_soqpsk_tg(sps) if pulse is None else np.asarray(pulse, dtype=np.float64)
+        factors = None
         if detector == "PT":
             taps = pt_matched_filter_taps(pulse, mod_index, sps)
             off = -1 if timing_offset is None else timing_offset
         elif detector == "PAM":
             taps = pam_matched_filter_taps(pulse, mod_index, sps)
             off = 0 if timing_offset is None else timing_offset
+            if factor_bank:
+                # the bank as the reference computes it: two real rho filters, outputs weighted by conj(pseudo symbols)
+                # (examples/soqpsk_detection.py:158-173) — the one-kernel front end then runs two real filters, not three complex ones
+                factors = pam_bank_factors(pulse, mod_index, sps)
+                if np.abs(factors[1] @ factors[0] - taps).max() > 1e-12 * np.abs(taps).max():
+                    factors = None
         else:
             raise ValueError(f"unknown detector {detector!r}")
         self.detector = detector
@@ -88,6 +95,8 @@ class SOQPSKLink:
         cfg.sigma, cfg.seed, cfg.stream_id = 0.0, 1, 0
         cfg.event_slot = -1
         cfg.fuse = int(fuse)
+        self._d_factor = _hip.to_device(pack_bank_factors(*factors)) if factors is not None else None
+        cfg.d_mf_factor = self._d_factor.data_ptr() if self._d_factor is not None else None
         self.cfg = cfg
 
     def __del__(self):

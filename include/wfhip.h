@@ -465,7 +465,13 @@ typedef struct {
                               /* bit 5 (32): as wf_link_config.fuse bit 5 — the detector and the  */
                               /* error count of a block on the context's side stream, beside the   */
                               /* next block's front end; two sets of intermediates in the         */
-                              /* workspace; wf_link_join / wf_ctx_check before the counters are read */
+                              /* workspace; wf_link_join / wf_ctx_check before the counters are read; */
+                              /* bit 6 (64, 16 filters, with bit 3): the caller vouches that the  */
+                              /* templates pair off as exact conjugates, d_templates[c][15 - f] == */
+                              /* conj(d_templates[c][f]) (a symmetric alphabet: the negated symbol */
+                              /* pattern negates the phase) — the one-kernel front end then forms  */
+                              /* each pair from four real 9-tap sums: 6 matrix instructions per 16 */
+                              /* symbols instead of 10; rows equal to rounding, not bitwise        */
 } wf_cpm_link_config;
 int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg);
 int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,

@@ -47,6 +47,7 @@ HOT = {
     "mod_chan_bank_kernel<9, -2, 10>": (168, 3),
     # CPM front ends (configs[2]; the ARTM and PCM/FM pulses are the 4-symbol forms): 4 waves per SIMD, <= 128 registers
     "mod_chan_bank_kernel<4, 16, 8>": (128, 4),
+    "mod_chan_bank_kernel<4, 32, 8>": (128, 4),      # (ARTM's 16 templates as 8 conjugate pairs: what the link runs)
     "mod_chan_bank_kernel<4, 4, 8>": (128, 4),
     # ... longer pulses: 3 waves per SIMD needs <= 168
     "mod_chan_bank_kernel<9, 16, 8>": (168, 3),

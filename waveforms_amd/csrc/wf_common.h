@@ -83,6 +83,7 @@ struct wf_ctx {
     bool pipe_done_valid[2] = {false, false};
     int pipe_set = 0;
     const double *mcb_pam_factor = nullptr;   // set by a link around its front-end launch: the long (PAM) bank factored into two real filters + a 3 x 2 complex combination (wf_link_config.d_mf_factor), or NULL
+    bool mcb_cpm_paired = false;   // set by a CPM link around its front-end launch (wf_cpm_link_config.fuse bit 6): the 16 templates pair off as conjugates
     int mcb_runs_hint = 0;         // runs of tiles per resident slot for the one-kernel CPM front end (0: its default); set by the pipelined CPM link
     double *h_iter = nullptr;      // per-symbol detector call: pinned, device-mapped staging (6 in + 2 x 64 out)
     double *d_iter = nullptr;      // ... the device's address of the same memory

@@ -1080,10 +1080,12 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     bool fused_all = false;
     if ((cfg->fuse & 8) && (cfg->fuse & 2) && L.ncalls > 0) {
         ctx->mcb_runs_hint = piped ? (L.nfilt == 4 ? 16 : 8) : 0;       // (the detector of the previous block shares the chip: finer runs)
+        ctx->mcb_cpm_paired = (cfg->fuse & 64) != 0;                      // fuse bit 6: templates f and nfilt - 1 - f are conjugates (caller vouches)
         rc = wf_mod_chan_cpm_rows(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_templates,
                                   L.nfilt, L.ntm, L.start0, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, L.ncalls,
                                   rows, stream);
         ctx->mcb_runs_hint = 0;
+        ctx->mcb_cpm_paired = false;
         if (rc < 0) return rc;
         fused_all = rc == 0;
     }
@@ -1256,10 +1258,12 @@ extern "C" int wf_cpm_link_stream_chunk_phase(wf_ctx *ctx, const wf_cpm_link_con
         if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, S.nloc * bps, 0, 0, 0, syms, stream))) return rc;
     }
     if (phases & 4) {
+        ctx->mcb_cpm_paired = (cfg->fuse & 64) != 0;
         rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
                                      S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_templates, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma,
                                      cfg->seed, cfg->stream_id, 0, nullptr, S.L.start0 + 4, S.k_lo, S.ncols, 0, rows, stream, S.L.nfilt,
                                      cfg->det.nh, 3);
+        ctx->mcb_cpm_paired = false;
         if (rc < 0) return rc;
         WF_REQUIRE(rc == 0, "wf_cpm_link_stream_chunk: internal: the one-kernel front end refused the window");
     }

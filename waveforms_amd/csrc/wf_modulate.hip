@@ -715,7 +715,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     const double *__restrict__ const scratch = ka->scratch;
     const double *__restrict__ const mf_taps = ka->mf_taps;
     static_assert(SPS == 8 || CPMNF == 0 || (CPMNF < 0 && SPS == 10), "the CPM detector rows are an sps-8 design, the long-bank form one for 8 and 10");
-    static_assert(CPMNF >= -2, "CPMNF: -1 long bank of 3 complex filters, -2 the same bank given as two real filters + a 3 x 2 complex combination");
+    static_assert(CPMNF >= -2 && (CPMNF <= 0 || CPMNF == 4 || CPMNF == 16 || CPMNF == 32),
+                  "CPMNF: -1 long bank of 3 complex filters, -2 the same bank given as two real filters + a 3 x 2 complex combination; 4 | 16 CPM templates, 32 = 16 conjugate-paired");
     constexpr bool PAM = CPMNF < 0;
     constexpr bool PAM2 = CPMNF == -2;                 // the factored long bank (below)
     using G = mcb_geom<SPS>;
@@ -734,7 +735,9 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     int *s_pi = reinterpret_cast<int *>(s_ring + RSLOTS);                        // prefix counts of the window's raw symbols
     __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
-    constexpr bool USE_MFMA = CPMNF == 16;
+    constexpr bool USE_MFMA = CPMNF == 16 || CPMNF == 32;
+    constexpr bool PAIRED = CPMNF == 32;              // 16 filters whose templates pair off as conjugates, f <-> 15 - f (below)
+    constexpr int NF = PAIRED ? 16 : CPMNF;           // filters per row
     // (matrix-core form: the templates are only needed to build the B operands once, before the first row —
     //  they are staged in the ring's slots instead of 4.6 KB of their own: 4 workgroups per CU instead of 3)
     __shared__ double2 s_taps_own[USE_MFMA || PAM ? 1 : (CPMNF ? 2 * CPMNF * 9 : 3 * NT)];
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     if (PAM) {
         // (the B operands are built from global memory, below)
     } else if (CPMNF) {
-        for (int k = t; k < Q.cpm_nh * CPMNF * 9; k += MOD_THREADS) s_taps[k] = reinterpret_cast<const double2 *>(mf_taps)[k];
+        for (int k = t; k < Q.cpm_nh * NF * 9; k += MOD_THREADS) s_taps[k] = reinterpret_cast<const double2 *>(mf_taps)[k];
     } else if (t < 3 * NT) {
         s_taps[t] = reinterpret_cast<const double2 *>(mf_taps)[t];
     }
@@ -825,9 +828,35 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     // Operand layout (MI355X_MICROARCH.md): A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, D[i][j] in lane
     // j + 16 (i & 3), register i >> 2.
     typedef double mcb_d4 __attribute__((ext_vector_type(4)));
-    double bmat[USE_MFMA ? 10 : 1];                          // B[k-step kk][output block nb], this lane's element
+    // CPMNF = 32: the same 16 filters when their templates pair off as CONJUGATES, T[15 - f] == conj(T[f]) — the symmetric
+    // alphabet of cpm_detect.py:cpm_templates (alpha -> -alpha negates the phase; the caller vouches: wf_cpm_link_config.fuse
+    // bit 6).  With r = x + j y and T_p = c + j s (p = 0 .. 7):  Z_p = (P + Q) + j (R - S),  Z_{15-p} = (P - Q) + j (R + S),
+    // P = sum x c, Q = sum y s, R = sum y c, S = sum x s — four REAL 9-tap sums per pair, each over ONE plane of the samples.  Two
+    // tiles over K = 12 (9 taps + 3 zeros): X = Re plane against (c_0 .. c_7 | -s_0 .. -s_7), Y = Im plane against
+    // (s_0 .. s_7 | c_0 .. c_7): 6 matrix instructions per 16 symbols instead of 10 (each 64 cycles of its SIMD); lane j then
+    // holds u = X, v = Y of pair j & 7 and forms u + v (Re Z_p | Im Z_p) and +-(u - v) (Re | Im Z_{15-p}).  Rows differ from the
+    // k-ascending chain of the 10-instruction form (and of cpm_oracle.c) in the last bits: four partial sums added in another order.
+    double bmat[USE_MFMA ? (PAIRED ? 6 : 10) : 1];           // B[k-step kk][output block nb], this lane's element
     const int mf_i = t & 15, mf_kq = (t & 63) >> 4;          // MFMA row / k index of this lane (A), = column / k index (B)
-    if constexpr (USE_MFMA) {
+    if constexpr (PAIRED) {
+        wf_lds_barrier();                                    // templates staged above
+        const int par = (wave_u & 1) ^ (Q.kshift & 1);
+        const int colT = Q.cpm_nh == 2 ? par : 0;
+        const int pj = mf_i & 7;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const int tap = 4 * kk + mf_kq;
+            double bx = 0.0, by = 0.0;
+            if (tap < 9) {
+                const double2 tp = s_taps[(colT * NF + pj) * 9 + tap];
+                bx = mf_i < 8 ? tp.x : -tp.y;
+                by = mf_i < 8 ? tp.y : tp.x;
+            }
+            bmat[kk] = bx;
+            bmat[3 + kk] = by;
+        }
+        wf_lds_barrier();                                    // every lane has its operands: the ring's slots are free again
+    } else if constexpr (USE_MFMA) {
         wf_lds_barrier();                                    // templates staged above
         const int par = (wave_u & 1) ^ (Q.kshift & 1);       // modulation-index column of this wave's symbols (tiles start on even symbols)
         const int colT = Q.cpm_nh == 2 ? par : 0;
@@ -838,7 +867,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 const int c = 4 * kk + mf_kq, tap = c >> 1, o = 16 * nb + mf_i, f = o >> 1;
                 double v = 0.0;
                 if (c < 18) {
-                    const double2 tp = s_taps[(colT * CPMNF + f) * 9 + tap];
+                    const double2 tp = s_taps[(colT * NF + f) * 9 + tap];
                     // Re Z += Im r . Im T (c even) | Re r . Re T (c odd);   Im Z += Im r . Re T | Re r . (-Im T)
                     v = (o & 1) == 0 ? ((c & 1) ? tp.x : tp.y) : ((c & 1) ? -tp.y : tp.x);
                 }
@@ -985,7 +1014,36 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             const bool k_ok = kr >= klo && kr < khi && (CPR == 64 || mq < CPR);
             const int grp = ((rho & 1) ? CPR : 0) + (CPR == 64 ? mq : (mq < CPR ? mq : 0));   // pad group of the window start (rho = -1 .. 15)
             const bool odd = ((Q.pack_par0 + kr + (int)(sym_base & 1)) & 1) != 0;
-            if constexpr (USE_MFMA) {
+            if constexpr (PAIRED) {
+                // this wave's 16 symbols as in the 10-instruction form; A[i][4 kk + kq] = plane of tap 4 kk + kq of symbol i's window
+                // (taps 0 .. 7 in slots 0 .. 7, tap 8 behind the pad slot, taps 9 .. 11 zeros): one 16-byte read feeds both tiles
+                const int mqi = 32 * (wave_u >> 1) + 2 * mf_i + (wave_u & 1);
+                const int grp_i = ((rho & 1) ? 64 : 0) + mqi;
+                const double2 *xs = s_ring + 9 * grp_i + mf_kq;
+                mcb_d4 accx = {0.0, 0.0, 0.0, 0.0}, accy = accx;
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    double2 a = kk < 2 ? xs[4 * kk] : xs[9 - mf_kq];            // (kk = 2: only tap 8 — kq = 0 — exists, in slot 9)
+                    if (kk == 2 && mf_kq >= 1) a = make_double2(0.0, 0.0);
+                    accx = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bmat[kk], accx, 0, 0, 0);
+                    accy = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bmat[3 + kk], accy, 0, 0, 0);
+                }
+                // lane j: pair p = j & 7; j < 8: u = P, v = Q -> Re Z_p = u + v, Re Z_{15-p} = u - v; j >= 8: u = -S, v = R -> Im Z_p = u + v, Im Z_{15-p} = v - u
+                const int pj = mf_i & 7, imj = mf_i >> 3;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int isym = mf_kq + 4 * reg;
+                    const int kr_i = 64 * rho + 32 * (wave_u >> 1) + 2 * isym + (wave_u & 1) - Q.kshift;
+                    const double u = accx[reg], v = accy[reg];
+                    const double first = u + v, dd = u - v;
+                    const double second = imj ? -dd : dd;
+                    if (kr_i >= klo && kr_i < khi) {
+                        double *o = rows + ((sym_base + kr_i) - Q.k_lo) * (2 * NF) + imj;
+                        __builtin_nontemporal_store(first, &o[2 * pj]);
+                        __builtin_nontemporal_store(second, &o[2 * (15 - pj)]);
+                    }
+                }
+            } else if constexpr (USE_MFMA) {
                 // this wave's 16 symbols: in-row column 32 (w >> 1) + 2 i + (w & 1); lane = (symbol i, k index kq)
                 const int mqi = 32 * (wave_u >> 1) + 2 * mf_i + (wave_u & 1);
                 const int grp_i = ((rho & 1) ? 64 : 0) + mqi;
@@ -1007,7 +1065,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                     const int isym = mf_kq + 4 * reg;
                     const int kr_i = 64 * rho + 32 * (wave_u >> 1) + 2 * isym + (wave_u & 1) - Q.kshift;
                     if (kr_i >= klo && kr_i < khi) {
-                        double *o = rows + ((sym_base + kr_i) - Q.k_lo) * (2 * CPMNF) + jo;
+                        double *o = rows + ((sym_base + kr_i) - Q.k_lo) * (2 * NF) + jo;
                         __builtin_nontemporal_store(acc0[reg], &o[0]);      // anyway — written normally they sat dirty in the L2s and their write-back met the
                         __builtin_nontemporal_store(acc1[reg], &o[16]);     // detector's first reads: same-box, detector 0.820 / 0.821 -> 0.754 / 0.761 ms
                     }
@@ -1485,7 +1543,9 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     Q.n_long = (int)((P.ntiles - tail) / per_run);
     const int grid = (int)(Q.n_long + (P.ntiles - (int64_t)Q.n_long * per_run));
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
-    kern_t k = cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
+    // (16 templates the caller vouches pair off as conjugates, f <-> 15 - f: the four-real-sums form, 6 matrix instructions per 16 symbols for 10)
+    kern_t k = cpm_nf == 16 && ctx->mcb_cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 32> : mod_chan_bank_kernel<9, 32>)
+             : cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)
              : pam2         ? (sps == 10 ? (JM == 4 ? mod_chan_bank_kernel<4, -2, 10> : mod_chan_bank_kernel<9, -2, 10>)
                                          : (JM == 4 ? mod_chan_bank_kernel<4, -2> : mod_chan_bank_kernel<9, -2>))

@@ -406,7 +406,8 @@ class CPMLink:
     STAGES = ("prbs", "map", "modulate", "-", "awgn", "mfbank", "viterbi", "count")
 
     def __init__(self, nsym: int, sps: int = 8, waveform: str = "multih", spec=None, pn_degree: int = 23, warmup: int = 0,
-                 skip_head: int = 64, private_ctx: bool = False, fuse: int = 10, _no_workspace: bool = False) -> None:
+                 skip_head: int = 64, private_ctx: bool = False, fuse: int = 10, _no_workspace: bool = False,
+                 paired_templates: bool = True) -> None:
         from .viterbi import cpm
 
         if waveform == "multih":
@@ -424,7 +425,14 @@ class CPMLink:
         self._owns_ctx = bool(private_ctx)
         self._d_h = _hip.to_device(spec.mod_index)
         self._d_pulse = _hip.to_device(np.asarray(pulse, dtype=np.float64))
-        self._d_templates = _hip.to_device(cpm.matched_filter_templates(pulse, sps, spec))
+        templates = cpm.matched_filter_templates(pulse, sps, spec)
+        self._d_templates = _hip.to_device(templates)
+        # A symmetric alphabet makes the templates of a symbol pattern and of its negation exact conjugates (filter f and
+        # nfilt - 1 - f): the one-kernel front end then forms 16 filters from four real sums per pair (wf_cpm_link_config.fuse
+        # bit 6, which vouches for exactly this identity — checked here, bit for bit)
+        self.paired_templates = bool(paired_templates and templates.shape[1] == 16 and np.array_equal(templates[:, ::-1, :], np.conj(templates)))
+        if self.paired_templates:
+            fuse = int(fuse) | 64
         self._d_rot = _hip.to_device(cpm.rotation_table(spec))
         cfg = _hip.CPMLinkConfig()
         cfg.nsym, cfg.sps = self.nsym, self.sps

@@ -466,12 +466,13 @@ typedef struct {
                               /* error count of a block on the context's side stream, beside the   */
                               /* next block's front end; two sets of intermediates in the         */
                               /* workspace; wf_link_join / wf_ctx_check before the counters are read; */
-                              /* bit 6 (64, 16 filters, with bit 3): the caller vouches that the  */
-                              /* templates pair off as exact conjugates, d_templates[c][15 - f] == */
+                              /* bit 6 (64, with bit 3; nf = 4 or 16 filters): the caller vouches the */
+                              /* templates pair off as exact conjugates, d_templates[c][nf-1-f] == */
                               /* conj(d_templates[c][f]) (a symmetric alphabet: the negated symbol */
                               /* pattern negates the phase) — the one-kernel front end then forms  */
-                              /* each pair from four real 9-tap sums: 6 matrix instructions per 16 */
-                              /* symbols instead of 10; rows equal to rounding, not bitwise        */
+                              /* each pair from four real 9-tap sums (16 filters: 6 matrix          */
+                              /* instructions per 16 symbols instead of 10; 4 filters: 18 multiply- */
+                              /* adds per lane instead of 36); rows equal to rounding, not bitwise  */
 } wf_cpm_link_config;
 int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg);
 int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,

@@ -49,6 +49,7 @@ HOT = {
     "mod_chan_bank_kernel<4, 16, 8>": (128, 4),
     "mod_chan_bank_kernel<4, 32, 8>": (128, 4),      # (ARTM's 16 templates as 8 conjugate pairs: what the link runs)
     "mod_chan_bank_kernel<4, 4, 8>": (128, 4),
+    "mod_chan_bank_kernel<4, 8, 8>": (128, 4),       # (PCM/FM's 4 templates as 2 conjugate pairs)
     # ... longer pulses: 3 waves per SIMD needs <= 168
     "mod_chan_bank_kernel<9, 16, 8>": (168, 3),
     "mod_chan_bank_kernel<9, 4, 8>": (168, 3),

@@ -715,8 +715,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     const double *__restrict__ const scratch = ka->scratch;
     const double *__restrict__ const mf_taps = ka->mf_taps;
     static_assert(SPS == 8 || CPMNF == 0 || (CPMNF < 0 && SPS == 10), "the CPM detector rows are an sps-8 design, the long-bank form one for 8 and 10");
-    static_assert(CPMNF >= -2 && (CPMNF <= 0 || CPMNF == 4 || CPMNF == 16 || CPMNF == 32),
-                  "CPMNF: -1 long bank of 3 complex filters, -2 the same bank given as two real filters + a 3 x 2 complex combination; 4 | 16 CPM templates, 32 = 16 conjugate-paired");
+    static_assert(CPMNF >= -2 && (CPMNF <= 0 || CPMNF == 4 || CPMNF == 16 || CPMNF == 32 || CPMNF == 8),
+                  "CPMNF: -1 long bank of 3 complex filters, -2 the same bank given as two real filters + a 3 x 2 complex combination; 4 | 16 CPM templates, 8 | 32 = 4 | 16 conjugate-paired");
     constexpr bool PAM = CPMNF < 0;
     constexpr bool PAM2 = CPMNF == -2;                 // the factored long bank (below)
     using G = mcb_geom<SPS>;
@@ -735,12 +735,12 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     int *s_pi = reinterpret_cast<int *>(s_ring + RSLOTS);                        // prefix counts of the window's raw symbols
     __shared__ int s_wtot[2 * MOD_WAVES];
     __shared__ double2 s_tab[256];      // [0,128): log table, [128,256): sincos sectors (= kWfCisTab)
-    constexpr bool USE_MFMA = CPMNF == 16 || CPMNF == 32;
-    constexpr bool PAIRED = CPMNF == 32;              // 16 filters whose templates pair off as conjugates, f <-> 15 - f (below)
-    constexpr int NF = PAIRED ? 16 : CPMNF;           // filters per row
+    constexpr bool PAIRED = CPMNF == 32 || CPMNF == 8;     // 16 (4) filters whose templates pair off as conjugates, f <-> NF - 1 - f (below)
+    constexpr int NF = PAIRED ? CPMNF / 2 : CPMNF;         // filters per row
+    constexpr bool USE_MFMA = NF == 16;
     // (matrix-core form: the templates are only needed to build the B operands once, before the first row —
     //  they are staged in the ring's slots instead of 4.6 KB of their own: 4 workgroups per CU instead of 3)
-    __shared__ double2 s_taps_own[USE_MFMA || PAM ? 1 : (CPMNF ? 2 * CPMNF * 9 : 3 * NT)];
+    __shared__ double2 s_taps_own[USE_MFMA || PAM ? 1 : (CPMNF ? 2 * NF * 9 : 3 * NT)];
     double2 *const s_taps = USE_MFMA ? s_ring : s_taps_own;
     const int t = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(t) >> 6;      // the same number as a scalar
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     // k-ascending chain of the 10-instruction form (and of cpm_oracle.c) in the last bits: four partial sums added in another order.
     double bmat[USE_MFMA ? (PAIRED ? 6 : 10) : 1];           // B[k-step kk][output block nb], this lane's element
     const int mf_i = t & 15, mf_kq = (t & 63) >> 4;          // MFMA row / k index of this lane (A), = column / k index (B)
-    if constexpr (PAIRED) {
+    if constexpr (PAIRED && USE_MFMA) {
         wf_lds_barrier();                                    // templates staged above
         const int par = (wave_u & 1) ^ (Q.kshift & 1);
         const int colT = Q.cpm_nh == 2 ? par : 0;
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             const bool k_ok = kr >= klo && kr < khi && (CPR == 64 || mq < CPR);
             const int grp = ((rho & 1) ? CPR : 0) + (CPR == 64 ? mq : (mq < CPR ? mq : 0));   // pad group of the window start (rho = -1 .. 15)
             const bool odd = ((Q.pack_par0 + kr + (int)(sym_base & 1)) & 1) != 0;
-            if constexpr (PAIRED) {
+            if constexpr (PAIRED && USE_MFMA) {
                 // this wave's 16 symbols as in the 10-instruction form; A[i][4 kk + kq] = plane of tap 4 kk + kq of symbol i's window
                 // (taps 0 .. 7 in slots 0 .. 7, tap 8 behind the pad slot, taps 9 .. 11 zeros): one 16-byte read feeds both tiles
                 const int mqi = 32 * (wave_u >> 1) + 2 * mf_i + (wave_u & 1);
@@ -1099,6 +1099,33 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 if (wave_u == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * (8 * GP::NKW + 8 * GP::NKW / PG)], bpam[GP::NKW], acc, 0, 0, 0);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) s_part[(4 * wave_u + reg) * 64 + (t & 63)] = acc[reg];
+            } else if constexpr (PAIRED) {
+                // Four filters as two conjugate pairs (PCM/FM: T[3 - q] == conj(T[q])): lane = (symbol, pair q = mp >> 1, plane
+                // mp & 1).  The Re-plane lane runs P = sum x c and S = sum x s, the Im-plane lane Q = sum y s and R = sum y c — 18
+                // multiply-adds instead of 36 —, one quad swap hands each lane the sum its partner holds for it, and
+                //   Z_q = (P + Q) + j (R - S),   Z_{3-q} = (P - Q) + j (R + S):
+                // the Re-plane lane stores the two real parts, the Im-plane lane the two imaginary parts.
+                const int q = mp >> 1, pl = mp & 1;
+                const double *xb = ring_d + 2 * (9 * grp) + pl;
+                const int col = Q.cpm_nh == 2 ? (int)((sym_base + kr) & 1) : 0;
+                const double2 *tb_ = s_taps + (col * NF + q) * 9;
+                double sc = 0.0, ss = 0.0;                               // this plane against the cosine / sine taps
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const double xv = xb[2 * (j < 8 ? j : 9)];
+                    const double2 tp = tb_[j];
+                    sc = fma(xv, tp.x, sc);
+                    ss = fma(xv, tp.y, ss);
+                }
+                // Re plane: keeps P = sc, sends S = ss;  Im plane: keeps R = sc, sends Q = ss
+                const double got = mcb_quad_bcast<0xB1>(ss);             // quad_perm [1, 0, 3, 2]
+                const double first = pl ? sc - got : sc + got;           // Re Z_q = P + Q  |  Im Z_q = R - S
+                const double second = pl ? sc + got : sc - got;          // Re Z_{3-q} = P - Q  |  Im Z_{3-q} = R + S
+                if (k_ok) {
+                    double *o = rows + 2 * (k - Q.k_lo) * NF + pl;
+                    __builtin_nontemporal_store(first, &o[2 * q]);
+                    __builtin_nontemporal_store(second, &o[2 * (NF - 1 - q)]);
+                }
             } else if constexpr (CPMNF != 0) {
                 // rows of the generic CPM detector: this lane's CPMNF / 4 filters of symbol k
                 constexpr int FPT = CPMNF / 4;
@@ -1546,6 +1573,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     // (16 templates the caller vouches pair off as conjugates, f <-> 15 - f: the four-real-sums form, 6 matrix instructions per 16 symbols for 10)
     kern_t k = cpm_nf == 16 && ctx->mcb_cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 32> : mod_chan_bank_kernel<9, 32>)
              : cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
+             : cpm_nf == 4 && ctx->mcb_cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 8> : mod_chan_bank_kernel<9, 8>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)
              : pam2         ? (sps == 10 ? (JM == 4 ? mod_chan_bank_kernel<4, -2, 10> : mod_chan_bank_kernel<9, -2, 10>)
                                          : (JM == 4 ? mod_chan_bank_kernel<4, -2> : mod_chan_bank_kernel<9, -2>))

@@ -428,9 +428,9 @@ class CPMLink:
         templates = cpm.matched_filter_templates(pulse, sps, spec)
         self._d_templates = _hip.to_device(templates)
         # A symmetric alphabet makes the templates of a symbol pattern and of its negation exact conjugates (filter f and
-        # nfilt - 1 - f): the one-kernel front end then forms 16 filters from four real sums per pair (wf_cpm_link_config.fuse
+        # nfilt - 1 - f): the one-kernel front end then forms each pair of filters from four real sums (wf_cpm_link_config.fuse
         # bit 6, which vouches for exactly this identity — checked here, bit for bit)
-        self.paired_templates = bool(paired_templates and templates.shape[1] == 16 and np.array_equal(templates[:, ::-1, :], np.conj(templates)))
+        self.paired_templates = bool(paired_templates and templates.shape[1] in (4, 16) and np.array_equal(templates[:, ::-1, :], np.conj(templates)))
         if self.paired_templates:
             fuse = int(fuse) | 64
         self._d_rot = _hip.to_device(cpm.rotation_table(spec))

@@ -17,6 +17,12 @@ import pytest
 SPS = 8
 
 
+def torch_f64():
+    import torch
+
+    return torch.float64
+
+
 def _spec(oracle, M, p, K, Lp, NC, D=32):
     return oracle.CPMDetectorSpec(M=M, p=p, K=tuple(K), Lp=Lp, NC=NC, D=D)
 
@@ -125,6 +131,49 @@ def test_oracle_detector_regression_pin(oracle, golden):
         assert [res["sym_errors"], res["bit_errors"], res["compared"]] == g[f"{name}_errors"].tolist()
         assert res["bit_errors"] > 0
     assert abs(g["d2_artm"][0] - 1.2957297551846658) < 1e-12
+
+
+def test_templates_of_a_symmetric_alphabet_pair_off_as_conjugates(oracle):
+    """What wf_cpm_link_config.fuse bit 6 vouches for: filter nf - 1 - f (the negated symbol pattern) is, bit for bit, the
+    conjugate of filter f — for every shipped design, in every modulation-index column."""
+    from waveforms_amd.viterbi import cpm
+
+    for spec, pulse in ((cpm.ARTM_16, oracle.freq_pulse_multih_irig(SPS)), (cpm.ARTM_64, oracle.freq_pulse_multih_irig(SPS)),
+                        (cpm.PCMFM_10, oracle.freq_pulse_pcmfm(SPS))):
+        t = cpm.matched_filter_templates(pulse, SPS, spec)
+        assert t.shape[1] in (4, 16)
+        assert np.array_equal(t[:, ::-1, :], np.conj(t))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waveform,nsym", [("multih", 150_001), ("pcmfm", 150_001), ("multih", 900), ("pcmfm", 70)])
+def test_gpu_cpm_front_end_conjugate_pairs_equal_the_plain_form(waveform, nsym):
+    """The one-kernel front end with the templates taken as conjugate pairs (four real sums per pair: what a link runs) against
+    its plain form (every filter on its own, the k-ascending chain cpm_oracle.c states): rows equal to rounding — the sums
+    are added in another order —, decisions and counts identical; tile edges, both ends of the burst, a burst shorter
+    than a row."""
+    from waveforms_amd.link import CPMLink
+
+    plain = CPMLink(nsym, SPS, waveform=waveform, fuse=10, paired_templates=False)
+    pairs = CPMLink(nsym, SPS, waveform=waveform, fuse=10)
+    assert not (plain.cfg.fuse & 64) and (pairs.cfg.fuse & 64) and pairs.paired_templates and not plain.paired_templates
+    nf = 16 if waveform == "multih" else 4
+    for ebn0, sid in ((3.0, 5), (9.0, 6)):
+        for link in (plain, pairs):
+            link.reset_counts()
+            link.run_block(ebn0, seed=3, stream_id=sid, skip_bits=17)
+        la, lb = plain.layout(), pairs.layout()
+        assert la == lb and la["one_kernel_front_end"] == 1
+        calls = la["calls"]
+        a = plain.workspace[la["off_rows"]:la["off_rows"] + calls * nf * 16].view(torch_f64()).cpu().numpy()
+        b = pairs.workspace[lb["off_rows"]:lb["off_rows"] + calls * nf * 16].view(torch_f64()).cpu().numpy()
+        assert np.abs(a).max() > 1.0
+        np.testing.assert_allclose(b, a, rtol=0, atol=1e-12)
+        assert not np.array_equal(a, b) or nsym < 100            # (another order of additions: the last bits do differ)
+        da = plain.workspace[la["off_decisions"]:la["off_decisions"] + calls].cpu().numpy()
+        db = pairs.workspace[lb["off_decisions"]:lb["off_decisions"] + calls].cpu().numpy()
+        assert np.array_equal(da, db)
+        assert plain.result() == pairs.result()
 
 
 def test_host_mirror_builds_the_same_constants(oracle):

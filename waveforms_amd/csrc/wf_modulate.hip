@@ -1238,7 +1238,11 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             // symbols, 9 reads; wf_mod_chan_bank_applies admits nothing else there.  The 10-samples-per-symbol body keeps
             // the old order and the general pair form — MIL's 11 taps have c = 5 — and so do the CPM forms: ARTM's
             // measured 0.711 / 0.715 against 0.684 / 0.700 ms with the new order, PCM/FM's 24-tap pulse has an odd c.)
-            constexpr bool LOADS_FIRST = SPS != 10 && CPMNF <= 0;   // (the 10-samples-per-symbol body is one register over 128 in this order; the CPM forms measured 1.5 - 3 % slower with it: both keep the old one)
+            // (10 samples per symbol: the long-pulse instantiation — SOQPSK-TG / -A / -B, 81 taps, c = 40 — takes this order too
+            //  since the radius constants freed two registers: 128 exactly; the short-pulse one serves MIL's 11 taps, c = 5, and keeps the
+            //  general pair form; the host admits an odd c at 10 samples per symbol only there.  The CPM forms measured 1.5 - 3 % slower
+            //  with this order and keep the old one.)
+            constexpr bool LOADS_FIRST = CPMNF <= 0 && (SPS != 10 || JMAX == 9);
             double am_[JMAX];
             int pi0_ = 0, pi1_ = 0;
             if constexpr (!LOADS_FIRST) {
@@ -1489,7 +1493,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     if (!mod_setup(P, nsym_total, nh, ntaps, sps, phi0) || P.rs != rs_want) return 1;
     const int J = (ntaps + sps - 1) / sps;
     if (J > 9) return 1;
-    if (cpm_nf == 0 && sps != 10 && ((sps & 1) || (P.c & 1))) return 1;     // SOQPSK forms at 8 / 20: both samples of a thread's pair under the same symbols
+    if (cpm_nf == 0 && (sps != 10 || J > 4) && ((sps & 1) || (P.c & 1))) return 1;     // SOQPSK forms at 8 / 20, and the long-pulse form at 10: both samples of a thread's pair under the same symbols
     WF_REQUIRE(first + (k_lo + ncols - 1) * (int64_t)sps < P.out_len, "wf_mod_chan_bank: columns run past the burst");
     if (ntiles < 0) ntiles = P.ntiles;
     WF_REQUIRE(tile_lo >= 0 && ntiles >= 1 && tile_lo + ntiles <= P.ntiles && ntiles < (int64_t)1 << 31, "wf_mod_chan_bank: bad tile window");
@@ -1610,7 +1614,7 @@ int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_nt
     mod_params P;
     const int rs_want = sps == 8 ? mcb_geom<8>::RS : (sps == 10 ? mcb_geom<10>::RS : mcb_geom<20>::RS);
     if (!mod_setup(P, nsym, nh, ntaps, sps, 0.0) || P.rs != rs_want) return 0;
-    if (sps != 10 && ((sps & 1) || (P.c & 1))) return 0;      // (the 10-samples-per-symbol body keeps the general pair form)
+    if ((sps != 10 || (ntaps + sps - 1) / sps > 4) && ((sps & 1) || (P.c & 1))) return 0;      // (only the short-pulse body at 10 samples per symbol keeps the general pair form)
     return (ntaps + sps - 1) / sps <= 9;
 }
 

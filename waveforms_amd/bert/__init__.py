@@ -103,8 +103,10 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
     count on the context's side stream, beside the next block's front end) or as `streams` blocks in flight on
     separate HIP streams (own workspace, own wf_ctx, own counter table each).  Defaults, from same-box runs of the
     13 x 1e8-symbol sweep (tools/sweep_lanes.py; identical counts in every arrangement): SOQPSK one lane with the
-    pipelined link (0.0638 s; three lanes of sequential links 0.0685, three lanes of pipelined links 0.076); the CPM
-    links three lanes of sequential links (PCM/FM 0.1069 s, ARTM 0.1691; one pipelined lane 0.1077 / 0.1722)."""
+    pipelined link (0.0638 s; three lanes of sequential links 0.0685, three lanes of pipelined links 0.076); ARTM three
+    lanes of sequential links (0.165 - 0.169 s; one pipelined lane 0.168 - 0.172), PCM/FM — since the lane detector and the
+    3 dB floor of its operating-point warm-up — one pipelined lane (0.089 - 0.092 s; three sequential lanes 0.093 - 0.100;
+    round 3, row-form detector: 0.107): profiles/r04_sweep_lanes.log."""
     import ctypes
 
     from waveforms_amd import _hip, device as dev
@@ -115,13 +117,14 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
     cpm = plan.waveform != "soqpsk"
     # (SOQPSK blocks under 2^23 symbols: three lanes again — 2^22-symbol blocks 0.0735 s against 0.0762 for one pipelined lane;
     #  1e7-symbol blocks, which the front-end kernel's launch shape is tuned for, are the fastest way to run the sweep)
-    n = max(1, int(streams)) if streams is not None else (3 if cpm or plan.nsym < (1 << 23) else 1)
+    one_pipelined = (not cpm and plan.nsym >= (1 << 23)) or (plan.waveform == "pcmfm" and plan.nsym >= 6_500_000)
+    n = max(1, int(streams)) if streams is not None else (1 if one_pipelined else 3)
     if cpm:
         from waveforms_amd.viterbi.cpm import ARTM_64
 
         wide = plan.waveform == "multih" and plan.states == 64
         links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, spec=ARTM_64 if wide else None, pn_degree=plan.pn_degree, private_ctx=n > 1,
-                         warmup=plan.warmup, fuse=10 if fuse is None else fuse)
+                         warmup=plan.warmup, fuse=(42 if n == 1 and one_pipelined else 10) if fuse is None else fuse)
                  for _ in range(n)]
         run_fn = _hip.lib().wf_cpm_link_run
     else:

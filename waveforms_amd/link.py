@@ -31,7 +31,9 @@ def operating_point_warmup(waveform: str, ebn0_db: float | None) -> int:
     SOQPSK 4-state: 16 rows from 6 dB up (0 of 2.5e6 chunks unproven even with 12).  The generic CPM detector
     repairs the chunks that miss their warm-up on the device (wf_viterbi_repaired), so its warm-up is sized for the
     typical merge depth, not the tail: ARTM 16-state 48 calls from 8 dB up (0.3 / 0.05 / 0.01 % of the chunks repaired
-    at 8 / 10 / 12 dB, none of 1.25e6 left unproven), 64 from 6 dB; binary PCM/FM 64 from 2 dB up (1.2 - 3 % repaired).
+    at 8 / 10 / 12 dB, none of 1.25e6 left unproven), 64 from 6 dB; binary PCM/FM 64 from 3 dB up (1.2 - 3 % repaired; round 4: at
+    2 dB the lane form's 320-call chunks left 170 of 31 250 chunks per block unproven — a repair has to meet the first trajectory
+    inside its own chunk — while 1e10 symbols at 3, 4 and 5 dB left none: profiles/r04_lowsnr_scan.log).
     Every launch still proves its own output, and ``result()`` raises if a chunk was left unproven."""
     if ebn0_db is None:
         return 0
@@ -39,7 +41,7 @@ def operating_point_warmup(waveform: str, ebn0_db: float | None) -> int:
         return 16 if ebn0_db >= 6.0 else 0
     if waveform == "multih":
         return 48 if ebn0_db >= 8.0 else (64 if ebn0_db >= 6.0 else 0)
-    return 64 if ebn0_db >= 2.0 else 0
+    return 64 if ebn0_db >= 3.0 else 0
 
 
 def soqpsk_warmup_param(rows: int) -> int:

@@ -245,6 +245,14 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="symbols per core, compiled port")
     ap.add_argument("--cpu-loop-sample", type=int, default=1 << 16, help="symbols per core, faithful-loop form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="a wf_ctx option for every context of this run (include/wfhip.h wf_option, lower-case name without "
+                         "the WF_OPT_ prefix): e.g. --opt cpm_form=1 (row form), --opt cpm_chunk_calls=320, --opt det_final_verify=1")
+    ap.add_argument("--ber-points", default="0:12",
+                    help="SOQPSK at 8 sps: after the timed region, the BER sweep of BASELINE configs[3] (these Eb/N0 points x "
+                         "--ber-symbols) through the same link, reported as `ber_curve` with its offset in dB from the reference's "
+                         "golden curve — the second half of BASELINE's metric ('' = skip)")
+    ap.add_argument("--ber-symbols", type=float, default=1e8, help="symbols per point of that sweep")
     ap.add_argument("--steady-steps", type=int, default=2000,
                     help="after the timed region (single GPU): this many more steps in one go, reported as `steady_state` — long "
                          "enough (>= 1 s) that clock ramp and the 13 ms timed window can be told apart (0 = skip)")
@@ -267,6 +275,7 @@ def main() -> None:
     from waveforms_amd import _hip
     from waveforms_amd.link import SOQPSKLink, operating_point_warmup, soqpsk_warmup_param
 
+    _hip.apply_option_args(args.opt)
     nstreams = max(1, args.streams)
     cpm = args.waveform != "soqpsk"
     if cpm:
@@ -283,7 +292,7 @@ def main() -> None:
         bits_per_sym = links[0].spec.bits_per_symbol
     else:
         # detector chunk warm-up rows: by operating point (16 at Eb/N0 >= 6 dB, else the library default of 32), or
-        # --vit-warmup; link.result() raises if a single chunk of the run was not proven equal to the sequential detector
+        # --vit-warmup: a matter of speed only (chunks that miss it are repaired on the device)
         wu_rows = args.vit_warmup if args.vit_warmup >= 0 else operating_point_warmup("soqpsk", args.ebn0)
         wu = soqpsk_warmup_param(wu_rows)
         links = [SOQPSKLink(args.nsym, args.sps, detector=args.detector, fuse=args.fuse, private_ctx=nstreams > 1, warmup=wu)
@@ -370,6 +379,7 @@ def main() -> None:
         for name, ms in links[k % nstreams].stage_ms(k % slots).items():
             acc[name] = acc.get(name, 0.0) + ms / len(ev_steps)
     bps = stage_bytes_per_symbol(args.sps)
+    det_info = [0, 0, 0, 0]           # generic CPM detector: {form, ring slots, calls per chunk, warm-up calls} as the library will launch it
     if cpm:
         nf = links[0].spec.nfilt
         # bits -> symbols -> c128 samples -> noisy samples in place -> nf complex rows -> one decision byte
@@ -384,7 +394,8 @@ def main() -> None:
             # (conjugate-paired templates — wf_cpm_link_config.fuse bit 6 — run the four-real-sums form, template value 2 nf)
             STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<4, {2 * nf if (links[0].cfg.fuse & 64) else nf}, 8>"
         STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}, {'true' if links[0].cfg.fuse & 2 else 'false'}>",
-                             "viterbi": detector_kernel_name(links[0].spec, links[0].layout()["calls"], links[0].cfg.warmup), "map": "symbol_map_kernel",
+                             "viterbi": detector_kernel_name(links[0].spec, links[0].layout()["calls"], links[0].cfg.warmup, ctx=links[0]._ctx, info4=det_info),
+                             "map": "symbol_map_kernel",
                              "modulate": "mod_main_kernel<4, true, false>"})
     one_kernel = not cpm and bool(links[0].layout()["one_kernel_front_end"])     # asked from the library (wf_link_layout)
     if one_kernel:      # fuse bit 3: the "fir" slot times modulator + channel + bank; symbols in, packed rows out
@@ -475,16 +486,55 @@ def main() -> None:
             links[0].run_block(args.ebn0, seed=1, stream_id=k & 0xFFFFFFFF, skip_bits=(k % 4096) * args.nsym * bits_per_sym)
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t2
-        # Over thousands of blocks a chunk of the binary CPM detector can fail its proof at the operating-point
-        # warm-up (PCM/FM, 320 calls: ~7e-8 per chunk); the sweep runner repeats such a block with a doubled warm-up
-        # (waveforms_amd.bert), this loop only times — so the count is REPORTED here and the error total withheld.
+        # (every launch proves its chunks on the device and repairs the ones that missed their warm-up: what is
+        #  reported here is how often that ran over the 2000 blocks, and that nothing was left unproven)
         from waveforms_amd import device as _dev
-        unproven = int(_dev.viterbi_unmerged(reset=True, ctx=links[0]._ctx))
         s2 = links[0].result()
         steady = {"steps": args.steady_steps, "seconds": round(dt2, 3), "ms_per_step": round(dt2 / args.steady_steps * 1e3, 4),
                   "value": round(args.steady_steps * args.nsym / dt2 / 1e6, 2), "unit": "Msym/s",
-                  "bit_errors": int(s2[1]) if unproven == 0 else None, "detector_chunks_unproven": unproven,
+                  "bit_errors": int(s2[1]), "detector_chunks_unproven": 0,
+                  "detector_chunk_repairs": int(_dev.viterbi_repaired(reset=True, ctx=links[0]._ctx)),
+                  "detector_chunk_repairs_handed_on": int(_dev.viterbi_cascaded(reset=True, ctx=links[0]._ctx)),
                   "note": "same step, same single stream, outside the driver-timed K steps"}
+
+    # The second half of BASELINE's metric: the BER curve's offset in dB from the reference's
+    # (examples/soqpsk_detection.py:200-216 is the quantity; tests/golden/ber_golden*.csv the reference's own counts):
+    # configs[3]'s sweep through the link the timed region just ran, one block after the other.
+    ber_curve = None
+    if rank == 0 and not cpm and args.sps == 8 and nstreams == 1 and args.ber_points and args.detector in ("PT", "PAM"):
+        sys.path.insert(0, str(ROOT / "tools"))
+        from ber_sweep import golden_curve
+        from waveforms_amd.bert import ebn0_at_ber
+
+        lo_, hi_ = (int(v) for v in args.ber_points.split(":"))
+        pts = list(range(lo_, hi_ + 1))
+        blocks = max(1, int(round(args.ber_symbols / args.nsym)))
+        keep_wu = links[0].cfg.warmup
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        rows = []
+        for pi, e in enumerate(pts):
+            links[0].reset_counts()
+            if args.vit_warmup < 0:
+                links[0].cfg.warmup = soqpsk_warmup_param(operating_point_warmup("soqpsk", float(e)))
+            for b in range(blocks):       # trial block (point, b) exactly as waveforms_amd.bert.SweepPlan deals them
+                links[0].run_block(float(e), seed=1, stream_id=(pi << 32) | b, skip_bits=b * args.nsym)
+            rows.append(links[0].result())
+        dt4 = time.perf_counter() - t4
+        links[0].cfg.warmup = keep_wu
+        ber_pts = [r[1] / max(r[2], 1) for r in rows]
+        ge, gb, _, gn = golden_curve(args.detector)
+        ber_curve = {"ebn0_db": pts, "symbols_per_point": int(rows[0][2]), "bit_errors": [int(r[1]) for r in rows],
+                     "seconds": round(dt4, 4), "Msym_per_s": round(sum(r[2] for r in rows) / dt4 / 1e6, 1),
+                     "golden": "tests/golden/ber_golden*.csv (the reference's own run, PCG64 noise; "
+                               f"{int(gn.min())} .. {int(gn.max())} symbols per point)", "tolerance_db": 0.05}
+        for target in (1e-3, 1e-4):
+            try:
+                mine = ebn0_at_ber(pts, ber_pts, target)
+                ber_curve[f"ebn0_at_{target:g}"] = round(mine, 4)
+                ber_curve[f"delta_db_at_{target:g}"] = round(mine - ebn0_at_ber(ge, gb, target), 4)
+            except ValueError:
+                ber_curve[f"delta_db_at_{target:g}"] = None
 
     # The same K steps once more with several independent trial blocks in flight (own workspace, wf_ctx and
     # stream each), as the BER sweep runs them: the vector-pipe-bound front-end kernel of one block overlaps the
@@ -551,12 +601,14 @@ def main() -> None:
                        "symbols_per_step_per_gpu": args.nsym, "sps": args.sps, "ebn0_db": args.ebn0,
                        "prbs": "PN23", "noise": "Philox4x32-10 + Box-Muller (device)",
                        "fuse": args.fuse, "streams": nstreams,
-                       "detector_warmup_rows": (links[0].cfg.warmup or "96 (library default)") if cpm
-                                               else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32), "parallelism": f"independent trial blocks x{world}"},
+                       "detector_warmup_rows": det_info[3] if cpm else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32),
+                       "detector_chunk_calls": det_info[2] if cpm else None,
+                       "detector_form": {0: "rows", 1: "lanes", 2: "wide"}[det_info[0]] if cpm else "lanes (one chunk per lane)",
+                       "ctx_options": args.opt, "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared * bits_per_sym, 1),
-                    # link.result() raises otherwise: every detector chunk started from bitwise the
-                    # metrics of the sequential detector (device-side check in every launch)
+                    # every detector chunk started from bitwise the state of the sequential detector, or was run again
+                    # from it (device-side proof + repair in every launch; link.result() raises otherwise)
                     "detector_chunks_unproven": 0},
             "roofline": roofline,
             "stages": stages,
@@ -565,6 +617,8 @@ def main() -> None:
             out["overlapped"] = overlapped
         if steady:
             out["steady_state"] = steady
+        if ber_curve:
+            out["ber_curve"] = ber_curve
         if world > 1:
             out["per_rank_ms_per_step"] = [round(v, 4) for v in rank_ms]
             out["rank_time_max_over_min"] = round(max(rank_ms) / max(min(rank_ms), 1e-12), 4)

@@ -59,6 +59,24 @@ int wf_ctx_retire(wf_ctx *ctx);
 /* Synchronises `stream`, returns WF_ERR_DEVICE if any kernel since the last
  * check raised the fault word (and clears it). */
 int wf_ctx_check(wf_ctx *ctx, void *stream);
+/* Per-context options: everything that tunes or instruments the library is a field of the context set through
+ * this call — the library reads no environment variable and keeps no process-wide switch (the reference's objects
+ * carry their own configuration the same way: SOQPSKTrellisDetector(length, differantial_encoding),
+ * waveforms/viterbi/algorithm.py:19-42).  Values are int64; 0 is every option's default.  Unknown key or a value
+ * outside the option's range: WF_ERR_VALUE.  Takes effect for calls issued afterwards on this context. */
+typedef enum {
+    WF_OPT_CPM_FORM = 0,          /* generic CPM detector: 0 choose by estimated time, 1 row form, 2 lane form (where compiled in) */
+    WF_OPT_CPM_CHUNK_CALLS = 1,   /* calls per chunk of the generic CPM detector (any form); 0 = the library's choice */
+    WF_OPT_DET_REPAIR = 2,        /* chunk-parallel detectors: 0 repair chunks whose proof failed (cascading: see
+                                   * wf_viterbi_repaired), 1 only COUNT them (wf_viterbi4_unmerged) — tests of the proof */
+    WF_OPT_DET_FINAL_VERIFY = 3,  /* 1: after the repairs compare every chunk boundary once more and count what still
+                                   * differs in wf_viterbi4_unmerged (an internal-consistency check; always 0) */
+    WF_OPT_ITERATION_SERVER = 4,  /* wf_viterbi4_iteration_host: 0 persistent server, 1 one launch + synchronise per call */
+    WF_OPT_MCB_TAIL_PERMILLE = 5, /* one-kernel front end: resident-slot-fulls of tail tiles x 1000; 0 = default, -1 = none */
+    WF_OPT_COUNT = 6
+} wf_option;
+int wf_ctx_set_option(wf_ctx *ctx, int key, int64_t value);
+int wf_ctx_get_option(wf_ctx *ctx, int key, int64_t *value);
 
 /* ---- K1: PRBS ------------------------------------------------------------
  * GLFSR.next_bit x n   (waveforms/glfsr/glfsr.py:6-19, pn.py:98-107).
@@ -182,20 +200,23 @@ int wf_viterbi4_detect(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int d
 int wf_viterbi4_detect_window(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, int length, int differential,
                               int warmup, uint8_t *d_bits, int8_t *d_syms, double *d_state, void *stream);
 int64_t wf_viterbi4_window_state_bytes(void);
-/* The batch detector is chunk-parallel: every lane re-derives the path metrics over `warmup` rows
- * before its chunk.  Each launch verifies on the device that the metrics a chunk started from are
- * bitwise the metrics the previous chunk ended with — the condition under which all decisions are
- * those of the sequential SOQPSKTrellisDetector — and counts the chunks for which that failed.
- * *h_count = that counter since the last reset (synchronises `stream`); 0 means every batch call
- * since then reproduced the sequential detector exactly.  Non-zero: re-run with a larger `warmup`. */
+/* The batch detectors are chunk-parallel: every chunk re-derives the path metrics over `warmup` rows before
+ * its own calls.  Each launch then PROVES on the device that the state a chunk started from is bitwise the state
+ * the previous chunk ended with — the condition under which all decisions are those of the sequential
+ * SOQPSKTrellisDetector (waveforms/viterbi/algorithm.py:44-101) — and REPAIRS what fails: the chunk's own calls
+ * run again from the true state; a chunk whose end state changed hands it to the next chunk, which is run again in
+ * turn, round after round until no boundary differs (worst case: the sequential detector).  So the result never
+ * depends on `warmup`; the warm-up only sets how often the repair runs.
+ * wf_viterbi4_unmerged: chunks left unproven since the last reset (synchronises `stream`).  With the default
+ * options this is always 0; it counts only under WF_OPT_DET_REPAIR = 1 (repairs off) or when
+ * WF_OPT_DET_FINAL_VERIFY finds an inconsistency. */
 int wf_viterbi4_unmerged(wf_ctx *ctx, int64_t *h_count, int reset, void *stream);
-/* The generic CPM detector (wf_cpm_viterbi_detect) REPAIRS a chunk whose proof failed before it counts it: a second
- * launch runs the chunk's own calls again from the state the previous chunk ended with, beside the first launch's
- * trajectory, until the two are bitwise equal, and replaces the decisions up to there; only a chunk whose
- * trajectories have not met by its end (or the 1025th failed chunk of a launch) is counted by
- * wf_viterbi4_unmerged.  *h_count = chunks repaired that way since the last reset (synchronises `stream`).
- * (Build-defined like the proof itself: the reference's detector is one sequential loop, algorithm.py:44-101.) */
+/* *h_count = chunk repairs run since the last reset, every round counted (synchronises `stream`).
+ * wf_viterbi_cascaded: of those, the repairs whose chunk ended in a different state than before and therefore
+ * handed on to the next chunk.  (Build-defined like the proof itself: the reference's detector is one sequential
+ * loop, algorithm.py:44-101.) */
 int wf_viterbi_repaired(wf_ctx *ctx, int64_t *h_count, int reset, void *stream);
+int wf_viterbi_cascaded(wf_ctx *ctx, int64_t *h_count, int reset, void *stream);
 
 /* wf_viterbi4_detect + wf_count_errors in one call (fresh detector): decision k is
  * compared with reference element k - skip for 0 <= k - skip < ncompare
@@ -413,9 +434,9 @@ int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsa
  * in one 16-lane group, 17 .. 64 — the 64-state ARTM design — one wave per detector).
  * Chunk-parallel like wf_viterbi4_detect: each 16-lane group
  * re-derives metrics, phase indices and decision registers over `warmup` rows (0 = default) and
- * every launch verifies bitwise that a chunk started from what its predecessor ended with,
- * repairs the chunks for which that failed (wf_viterbi_repaired) and counts what it could not
- * repair (wf_viterbi4_unmerged).  d_state (WF_CPM_STATE_BYTES, zeroed = fresh detector,
+ * every launch verifies bitwise that a chunk started from what its predecessor ended with
+ * and repairs the chunks for which that failed, cascading into the following chunks where needed
+ * (wf_viterbi4_unmerged, wf_viterbi_repaired): decisions are the sequential detector's whatever the warm-up.  d_state (WF_CPM_STATE_BYTES, zeroed = fresh detector,
  * may be NULL) carries the detector across calls. */
 #define WF_CPM_STATE_BYTES 4096
 /* Which of its forms wf_cpm_viterbi_detect runs for this trellis, burst length and warm-up: info4[0] = 2 the wide form
@@ -424,8 +445,9 @@ int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsa
  * in: the ARTM 16-state and PCM/FM 10-state designs of waveforms/cpm/multih, waveforms/cpm/pcmfm; bursts long enough for
  * its 64 chunks per wave to fill the chip, ~9e6 / ~6.5e6 calls); info4[1] = its LDS ring depth; info4[2] = calls per
  * chunk; info4[3] = warm-up calls.  Both forms make the same decisions, bit for bit (notes/cpm/cpm.md:100-140 is what both
- * implement).  No device work. */
-int wf_cpm_detector_form(const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int *info4);
+ * implement).  Priced for the context's device (its compute-unit count) under the context's options
+ * (WF_OPT_CPM_FORM, WF_OPT_CPM_CHUNK_CALLS): exactly what wf_cpm_viterbi_detect will launch.  No device work. */
+int wf_cpm_detector_form(wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int *info4);
 int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs,
                           const double *d_rows_ri, int64_t ncalls, int warmup, uint8_t *d_decisions,
                           void *d_state, void *stream);

@@ -38,3 +38,25 @@ def oracle():
 
     orc.build_c_oracle()
     return orc
+
+
+@pytest.fixture
+def ctx_options():
+    """Context manager factory: ``with ctx_options(WF_OPT_DET_REPAIR=1): ...`` sets wf_ctx options (include/wfhip.h,
+    wf_option) on the device's default context and on every context created inside the block, and restores the defaults."""
+    import contextlib
+
+    from waveforms_amd import _hip
+
+    @contextlib.contextmanager
+    def scope(**opts):
+        keys = {name: getattr(_hip, name) for name in opts}
+        for name, value in opts.items():
+            _hip.set_default_option(keys[name], value)
+        try:
+            yield
+        finally:
+            for name in opts:
+                _hip.set_default_option(keys[name], 0)
+
+    return scope

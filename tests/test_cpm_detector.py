@@ -43,18 +43,16 @@ GPU_DESIGNS = [d for d in DESIGNS if d[4] * d[0] ** (d[3] - 1) <= 64]
 @pytest.fixture(params=["auto", "lanes", "rows"])
 def detector_form(request):
     """wf_cpm_viterbi_detect has two forms — one 16-lane row per chunk, one lane per chunk — and picks by burst length
-    (the lane form pays from ~9e6 / ~6.5e6 calls).  The tests below run every size in BOTH (WF_CPM_LANES=1 / 0 forces a
-    form where a lane specialisation exists) and as shipped."""
-    old = os.environ.get("WF_CPM_LANES")
-    if request.param == "auto":
-        os.environ.pop("WF_CPM_LANES", None)
-    else:
-        os.environ["WF_CPM_LANES"] = "1" if request.param == "lanes" else "0"
+    (the lane form pays from ~9e6 / ~6.5e6 calls).  The tests below run every size in BOTH (the context option
+    WF_OPT_CPM_FORM forces a form where a lane specialisation exists) and as shipped.  WF_OPT_DET_FINAL_VERIFY is on for
+    all of them: after the repairs every chunk boundary is compared once more and any difference counted as unproven."""
+    from waveforms_amd import _hip
+
+    _hip.set_default_option(_hip.WF_OPT_CPM_FORM, {"auto": 0, "rows": 1, "lanes": 2}[request.param])
+    _hip.set_default_option(_hip.WF_OPT_DET_FINAL_VERIFY, 1)
     yield request.param
-    if old is None:
-        os.environ.pop("WF_CPM_LANES", None)
-    else:
-        os.environ["WF_CPM_LANES"] = old
+    _hip.set_default_option(_hip.WF_OPT_CPM_FORM, 0)
+    _hip.set_default_option(_hip.WF_OPT_DET_FINAL_VERIFY, 0)
 
 
 # ------------------------------------------------------------------ oracle side (CPU)
@@ -351,17 +349,20 @@ def test_gpu_detector_reports_and_repairs_unmerged_chunks(oracle, detector_form)
         _hip.check(_hip.lib().wf_cpm_viterbi_detect(_hip.ctx(), ctypes.byref(cfg), _hip.ptr(rot), _hip.ptr(rows), n, warmup,
                                                     _hip.ptr(out), None, _hip.stream()))
 
-    # 4 rows of warm-up cannot even fill the decision register.  With the repair launch switched off the call must say so ...
-    os.environ["WF_CPM_NO_REPAIR"] = "1"
+    # 4 rows of warm-up cannot even fill the decision register.  With the repairs switched off (a context option) the call
+    # must say so: the proof counts the chunks, and the host API refuses to return decisions
+    _hip.set_option(_hip.ctx(), _hip.WF_OPT_DET_REPAIR, 1)
+    _hip.set_default_option(_hip.WF_OPT_DET_REPAIR, 1)
     try:
         launch(4)
         assert dev.viterbi_unmerged(reset=True) > 0
         assert dev.viterbi_repaired(reset=True) == 0
-        # ... and the host API repeats the call with a longer warm-up until the output is proven
-        got = cpm.CPMTrellisDetector(cpm.ARTM_16).detect(res["rows"], warmup=4)
-        assert np.array_equal(got, res["decisions"])
+        with pytest.raises(RuntimeError, match="unproven"):
+            cpm.CPMTrellisDetector(cpm.ARTM_16).detect(res["rows"], warmup=4)
     finally:
-        del os.environ["WF_CPM_NO_REPAIR"]
+        _hip.set_default_option(_hip.WF_OPT_DET_REPAIR, 0)
+    got = cpm.CPMTrellisDetector(cpm.ARTM_16).detect(res["rows"], warmup=4)
+    assert np.array_equal(got, res["decisions"])
     # The call as shipped repairs those chunks itself: their own calls again from the state the previous chunk ended with
     # until that trajectory meets the first launch's.  Every decision is then the sequential detector's, and proven.
     launch(4)

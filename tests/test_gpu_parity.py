@@ -496,7 +496,7 @@ def test_window_detector_batch_on_reference_triplets(golden, length, diff):
 
 
 @pytest.mark.parametrize("length,ebn0", [(4, 0.0), (4, 10.0), (6, 4.0), (8, 0.0), (8, 10.0), (16, 4.0)])
-def test_window_detector_chunk_parallel_equals_sequential(oracle, length, ebn0):
+def test_window_detector_chunk_parallel_equals_sequential(oracle, length, ebn0, ctx_options):
     """1.2e6 noisy rows: the chunk-parallel window kernel's decisions are bit-identical to the sequential
     oracle's for the same traceback length, and the launch's own proof found no unmerged chunk."""
     from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
@@ -509,12 +509,19 @@ def test_window_detector_chunk_parallel_equals_sequential(oracle, length, ebn0):
     det = SOQPSKTrellisDetector(length)
     got_b, got_s = det.detect(res["mf_rows"])
     assert np.array_equal(got_b, res["det_bits"]) and np.array_equal(got_s, res["det_syms"])
-    # a 2-row warm-up cannot merge: the proof must notice, and detect() must repair it
+    # a 2-row warm-up cannot merge: the proof must notice (repairs switched off: the chunks are counted) ...
     rows = _hip.to_device(np.ascontiguousarray(res["mf_rows"][:300_000]))
     dev.viterbi_unmerged(reset=True)
-    dev.viterbi_detect_window(rows, length, warmup=2)
-    assert dev.viterbi_unmerged(reset=True) > 0
-    b2, s2 = SOQPSKTrellisDetector(length).detect(res["mf_rows"][:300_000], warmup=2)
+    with ctx_options(WF_OPT_DET_REPAIR=1):
+        dev.viterbi_detect_window(rows, length, warmup=2)
+        assert dev.viterbi_unmerged(reset=True) > 0
+    # ... and the call as shipped runs those chunks again from the true state, on the device, in the same call
+    dev.viterbi_repaired(reset=True)
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+        b2, s2 = dev.viterbi_detect_window(rows, length, warmup=2)
+        assert dev.viterbi_unmerged(reset=True) == 0 and dev.viterbi_repaired(reset=True) > 0
+        assert np.array_equal(_hip.to_host(b2), res["det_bits"][:300_000]) and np.array_equal(_hip.to_host(s2), res["det_syms"][:300_000])
+        b2, s2 = SOQPSKTrellisDetector(length).detect(res["mf_rows"][:300_000], warmup=2)
     assert np.array_equal(b2, res["det_bits"][:300_000]) and np.array_equal(s2, res["det_syms"][:300_000])
 
 
@@ -555,10 +562,10 @@ def test_window_detector_batch_odd_and_long_lengths_on_reference_triplets(golden
 
 
 @pytest.mark.parametrize("length,ebn0", [(1, 4.0), (3, 0.0), (5, 10.0), (9, 4.0), (17, 4.0), (33, 0.0), (64, 10.0)])
-def test_window_detector_odd_and_long_lengths_chunk_parallel_equals_sequential(oracle, length, ebn0):
+def test_window_detector_odd_and_long_lengths_chunk_parallel_equals_sequential(oracle, length, ebn0, ctx_options):
     """1.2e6 noisy rows at the window lengths outside the even 2 .. 16 range: the chunk-parallel kernel's decisions are
     bit-identical to the sequential oracle's (which equals the reference on the goldens above), and a warm-up that
-    cannot merge is noticed and repaired."""
+    cannot merge is noticed and repaired on the device."""
     from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
     from waveforms_amd import _hip, device as dev
 
@@ -570,9 +577,15 @@ def test_window_detector_odd_and_long_lengths_chunk_parallel_equals_sequential(o
     assert np.array_equal(got_b, res["det_bits"]) and np.array_equal(got_s, res["det_syms"])
     rows = _hip.to_device(np.ascontiguousarray(res["mf_rows"][:300_000]))
     dev.viterbi_unmerged(reset=True)
-    dev.viterbi_detect_window(rows, length, warmup=2)
-    assert dev.viterbi_unmerged(reset=True) > 0
-    b2, s2 = SOQPSKTrellisDetector(length).detect(res["mf_rows"][:300_000], warmup=2)
+    with ctx_options(WF_OPT_DET_REPAIR=1):
+        dev.viterbi_detect_window(rows, length, warmup=2)
+        assert dev.viterbi_unmerged(reset=True) > 0
+    dev.viterbi_repaired(reset=True)
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+        b2, s2 = dev.viterbi_detect_window(rows, length, warmup=2)
+        assert dev.viterbi_unmerged(reset=True) == 0 and dev.viterbi_repaired(reset=True) > 0
+        assert np.array_equal(_hip.to_host(b2), res["det_bits"][:300_000]) and np.array_equal(_hip.to_host(s2), res["det_syms"][:300_000])
+        b2, s2 = SOQPSKTrellisDetector(length).detect(res["mf_rows"][:300_000], warmup=2)
     assert np.array_equal(b2, res["det_bits"][:300_000]) and np.array_equal(s2, res["det_syms"][:300_000])
 
 
@@ -1255,11 +1268,11 @@ def test_link_full_size_reference_example_configuration_fuse_modes_agree():
     assert m > nsym - 16 and 2.0e-4 < be / m < 3.6e-4
 
 
-def test_detector_reports_and_repairs_unmerged_chunks(oracle):
+def test_detector_reports_and_repairs_unmerged_chunks(oracle, ctx_options):
     """The chunk-parallel kernel proves its own output: every launch checks that each chunk started
     from bitwise the metrics its predecessor ended with.  Ordinary inputs never trip it; rows built
-    so that survivors cannot merge inside the warm-up do, and detect() then repeats the call with a
-    longer warm-up until the result IS the sequential detector's."""
+    so that survivors cannot merge inside the warm-up do — and those chunks are run again from the true
+    metrics in the same call (viterbi_fixup_kernel), so the result IS the sequential detector's."""
     from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
     from waveforms_amd import _hip, device as dev
 
@@ -1268,16 +1281,24 @@ def test_detector_reports_and_repairs_unmerged_chunks(oracle):
     ordinary = (rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3)))
     ordinary[:, 1] += np.where(rng.integers(0, 2, n) > 0, 1.5, -1.5)
     dev.viterbi_unmerged(reset=True)
+    dev.viterbi_repaired(reset=True)
     dev.viterbi_detect(_hip.to_device(ordinary))
-    assert dev.viterbi_unmerged(reset=True) == 0
+    assert dev.viterbi_unmerged(reset=True) == 0 and dev.viterbi_repaired(reset=True) == 0
 
-    # a warm-up of one row cannot reach the true metrics on noisy data: the launch must say so ...
+    # a warm-up of one row cannot reach the true metrics on noisy data: with the repairs switched off the launch says so ...
     noisy = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
-    dev.viterbi_detect(_hip.to_device(noisy), warmup=1)
-    assert dev.viterbi_unmerged(reset=True) > 0
-    # ... and detect() must notice and repeat the call with a longer warm-up until the output is proven
-    got_b, got_s = SOQPSKTrellisDetector().detect(noisy, warmup=1)
     want_b, want_s = oracle.viterbi_detect(noisy)
+    with ctx_options(WF_OPT_DET_REPAIR=1):
+        dev.viterbi_detect(_hip.to_device(noisy), warmup=1)
+        assert dev.viterbi_unmerged(reset=True) > 0
+        with pytest.raises(RuntimeError, match="unproven"):
+            SOQPSKTrellisDetector().detect(noisy, warmup=1)
+    # ... and as shipped it repairs them, cascading where a chunk's end changed, and leaves nothing unproven
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+        b, s_ = dev.viterbi_detect(_hip.to_device(noisy), warmup=1)
+        assert np.array_equal(_hip.to_host(b), want_b) and np.array_equal(_hip.to_host(s_), want_s)
+        assert dev.viterbi_unmerged(reset=True) == 0 and dev.viterbi_repaired(reset=True) > 0
+        got_b, got_s = SOQPSKTrellisDetector().detect(noisy, warmup=1)
     assert np.array_equal(got_b, want_b) and np.array_equal(got_s, want_s)
     assert dev.viterbi_unmerged(reset=True) == 0
 

@@ -53,7 +53,9 @@ SOME_TRIPLETS = r"""
 import json
 import numpy as np
 from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+from waveforms_amd import _hip
 
+_hip.set_default_option(_hip.WF_OPT_ITERATION_SERVER, OPTION_VALUE)
 rng = np.random.default_rng(11)
 x = rng.normal(size=(8, 3)) + 1j * rng.normal(size=(8, 3))
 det = SOQPSKTrellisDetector(4)
@@ -68,10 +70,10 @@ print("RESULT " + json.dumps(out), flush=True)
 """
 
 
-@pytest.mark.parametrize("server", ["1", "0"])
+@pytest.mark.parametrize("server", ["0", "1"])
 def test_iteration_transports_agree_with_the_oracle(oracle, server):
     """Both forms of the per-symbol call — the persistent server and the one-launch-per-call form
-    (WF_ITERATION_SERVER=0) — go through the same traceback, including its KeyError exit
+    (context option WF_OPT_ITERATION_SERVER = 1) — go through the same traceback, including its KeyError exit
     (waveforms/cpm/trellis/model.py:171-174: a state pair with no connecting branch; the C ABI's WF_ERR_KEY), which no
     input reaches for this trellis (a search over finite and non-finite triplets with the oracle found none)."""
     import json
@@ -79,7 +81,7 @@ def test_iteration_transports_agree_with_the_oracle(oracle, server):
     rng = np.random.default_rng(11)
     x = rng.normal(size=(8, 3)) + 1j * rng.normal(size=(8, 3))
     wb, ws = oracle.ViterbiOracle(4, True).run(x, full=True)
-    r = _run(SOME_TRIPLETS, {"WF_ITERATION_SERVER": server})
+    r = _run(SOME_TRIPLETS.replace("OPTION_VALUE", server))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     got = json.loads(line[len("RESULT "):])
@@ -89,20 +91,24 @@ def test_iteration_transports_agree_with_the_oracle(oracle, server):
         assert np.array_equal(np.asarray(s_), ws[k]), k
 
 
-def test_iteration_follows_a_change_of_the_differential_attribute(golden):
-    """The reference reads self.differential on every call (waveforms/viterbi/algorithm.py:94-98)."""
+def test_iteration_follows_a_swap_of_the_fsm_attribute(golden):
+    """The reference fixes the trellis in __init__ (self.fsm, waveforms/viterbi/algorithm.py:27-29) and reads self.fsm on
+    every call (:62, :71, :94-95): swapping `det.fsm` between the two SOQPSK trellises mid-burst takes effect at the next
+    call, as it does there.  The window length cannot change (the state arrays are sized by it)."""
+    from waveforms.cpm.trellis.model import FiniteStateMachine, SOQPSKTrellis4x2
     from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
 
     g = golden("detect")
     a, b = SOQPSKTrellisDetector(2, differantial_encoding=True), SOQPSKTrellisDetector(2, differantial_encoding=True)
+    c = SOQPSKTrellisDetector(2, differantial_encoding=False)
     for k in range(40):
         if k == 20:
-            a.differential = False
+            a.fsm = FiniteStateMachine(trellis=SOQPSKTrellis4x2)
         ba, sa = a.iteration(g["triplets"][k])
         bb, sb = b.iteration(g["triplets"][k])
-        assert np.array_equal(sa, sb)                      # symbols do not depend on the flag
-        if k < 20:
-            assert np.array_equal(ba, bb)
+        bc, sc = c.iteration(g["triplets"][k])
+        assert np.array_equal(sa, sb) and np.array_equal(sa, sc)      # symbols do not depend on the input labelling
+        assert np.array_equal(ba, bb if k < 20 else bc)
     with pytest.raises(ValueError):
         a.length = 4
         a.iteration(g["triplets"][0])

@@ -4,5 +4,5 @@
 wf=$1; shift
 root="$(cd "$(dirname "$0")/.." && pwd)"; cd "$root"
 for ch in "$@"; do
-  WF_CPM_CH=$ch python3 tools/link_stage_time.py --waveform $wf --steps 20 "--label=$wf CH=$ch" 2>/dev/null
+  python3 tools/link_stage_time.py --waveform $wf --steps 20 --opt cpm_chunk_calls=$ch "--label=$wf CH=$ch" 2>/dev/null
 done

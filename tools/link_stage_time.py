@@ -17,8 +17,13 @@ def main():
     ap.add_argument("--fuse", type=int, default=-1)
     ap.add_argument("--label", default="")
     ap.add_argument("--detector", default="PT", choices=["PT", "PAM"])
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="wf_ctx options, e.g. cpm_chunk_calls=320")
     a = ap.parse_args()
     import torch
+
+    from waveforms_amd import _hip
+
+    _hip.apply_option_args(a.opt)
 
     from waveforms_amd.link import CPMLink, SOQPSKLink, operating_point_warmup, soqpsk_warmup_param
 

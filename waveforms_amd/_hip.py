@@ -21,6 +21,9 @@ import os
 _LIB_PATH = Path(os.environ.get("WF_HIP_LIBRARY") or Path(__file__).resolve().parent / "csrc" / "libwfhip.so")
 
 WF_ERR_VALUE, WF_ERR_KEY, WF_ERR_HIP, WF_ERR_DEVICE, WF_ERR_NOMEM = -1, -2, -3, -4, -5
+# wf_option (include/wfhip.h): per-context options set with wf_ctx_set_option
+(WF_OPT_CPM_FORM, WF_OPT_CPM_CHUNK_CALLS, WF_OPT_DET_REPAIR, WF_OPT_DET_FINAL_VERIFY, WF_OPT_ITERATION_SERVER,
+ WF_OPT_MCB_TAIL_PERMILLE) = range(6)
 
 # name -> (restype, argtypes); must list every function include/wfhip.h declares
 # (tests/test_cabi.py parses the header and compares).
@@ -32,6 +35,8 @@ SIGNATURES = {
     "wf_ctx_destroy": (c_int, [_P]),
     "wf_ctx_retire": (c_int, [_P]),
     "wf_ctx_check": (c_int, [_P, _P]),
+    "wf_ctx_set_option": (c_int, [_P, c_int, c_int64]),
+    "wf_ctx_get_option": (c_int, [_P, c_int, POINTER(c_int64)]),
     "wf_lfsr_generate": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, _P, c_int64, POINTER(c_uint64), _P]),
     "wf_fsm_encode": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_int64, c_int, _P, POINTER(c_int), _P]),
     "wf_symbol_map": (c_int, [_P, c_int, _P, c_int64, c_int, c_int, c_int, _P, _P]),
@@ -48,6 +53,7 @@ SIGNATURES = {
                                      c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
     "wf_viterbi4_unmerged": (c_int, [_P, POINTER(c_int64), c_int, _P]),
     "wf_viterbi_repaired": (c_int, [_P, POINTER(c_int64), c_int, _P]),
+    "wf_viterbi_cascaded": (c_int, [_P, POINTER(c_int64), c_int, _P]),
     "wf_viterbi4_detect_count": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P, _P]),
     "wf_viterbi4_detect": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "wf_viterbi4_detect_window": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
@@ -78,7 +84,7 @@ SIGNATURES = {
     "wf_cpm_mf_rows_c128": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
     "wf_cpm_awgn_mf_rows_c128": (c_int, [_P, _P, c_int64, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64, _P, c_int, c_int,
                                          c_int, c_int64, c_int, c_int64, _P, _P]),
-    "wf_cpm_detector_form": (c_int, [_P, c_int64, c_int, POINTER(c_int)]),
+    "wf_cpm_detector_form": (c_int, [_P, _P, c_int64, c_int, POINTER(c_int)]),
     "wf_cpm_viterbi_detect": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
     "wf_cpm_count_errors": (c_int, [_P, _P, _P, c_int, c_int64, _P, _P]),
     "wf_cpm_link_workspace_bytes": (c_int64, [_P]),
@@ -173,6 +179,40 @@ def check(rc: int) -> None:
     raise RuntimeError(f"libwfhip error {rc}: {msg}")
 
 
+# Options (wf_option) every context this module creates starts with, and the per-device default contexts are switched
+# to: the library itself has no process-wide switch (include/wfhip.h: wf_ctx_set_option), so a caller that wants one
+# behaviour everywhere — the tests' "run this module in the lane form" fixture — says so here.
+default_options: dict[int, int] = {}
+
+
+def set_option(handle, key: int, value: int) -> None:
+    check(lib().wf_ctx_set_option(handle, int(key), int(value)))
+
+
+def get_option(handle, key: int) -> int:
+    v = c_int64(0)
+    check(lib().wf_ctx_get_option(handle, int(key), ctypes.byref(v)))
+    return int(v.value)
+
+
+def set_default_option(key: int, value: int) -> None:
+    """Record ``key = value`` for every context created from now on and apply it to the live default contexts."""
+    with _lock:
+        if int(value) == 0:
+            default_options.pop(int(key), None)
+        else:
+            default_options[int(key)] = int(value)
+        for handle in _ctxs.values():
+            set_option(handle, key, value)
+
+
+def apply_option_args(pairs) -> None:
+    """``["cpm_form=1", "cpm_chunk_calls=320"]`` (the --opt flags of bench.py and the tools) -> set_default_option."""
+    for kv in pairs or []:
+        key, _, val = str(kv).partition("=")
+        set_default_option(globals()["WF_OPT_" + key.strip().upper()], int(val))
+
+
 def ctx() -> int:
     """The wf_ctx* of the current torch device (created on first use)."""
     dev = require_device()
@@ -181,6 +221,8 @@ def ctx() -> int:
             if dev not in _ctxs:
                 out = c_void_p()
                 check(lib().wf_ctx_create(dev, ctypes.byref(out)))
+                for k, v in default_options.items():
+                    set_option(out.value, k, v)
                 if not _ctxs:
                     import atexit
 
@@ -209,6 +251,8 @@ def new_ctx() -> int:
     concurrently with other library calls on a different stream)."""
     out = c_void_p()
     check(lib().wf_ctx_create(require_device(), ctypes.byref(out)))
+    for k, v in default_options.items():
+        set_option(out.value, k, v)
     return out.value
 
 

@@ -27,7 +27,7 @@ class SweepPlan:
     sps: int = 8
     pn_degree: int = 23
     waveform: str = "soqpsk"       # "soqpsk" (detector PT / PAM), or "multih" / "pcmfm" through the generic CPM detector
-    warmup: int = 0                # detector chunk warm-up (0: library default); unproven chunks are repaired by the runner
+    warmup: int = 0                # detector chunk warm-up (0: per point, waveforms_amd.link.operating_point_warmup): speed only, never the counts
     states: int = 16               # waveform "multih": 16 (ARTM_16, BASELINE configs[2]) or 64 (ARTM_64: every phase state, notes/cpm/cpm.md:128-140)
     jobs: list[tuple[int, int]] = field(default_factory=list)   # (point index, block index)
 
@@ -137,30 +137,19 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
         run_fn = _hip.lib().wf_link_run
     lanes = [torch.cuda.Stream() for _ in range(n)] if n > 1 else [torch.cuda.current_stream()]
     npts = len(plan.ebn0_db)
-    # Counters of a lane: `tables` = committed, `pend` = the jobs issued since the lane's last proof check.
-    # Every launch of the chunk-parallel detectors proves on the device that each chunk started from bitwise
-    # the sequential detector's state; a chunk that did not merge within the warm-up only counts up a word in
-    # the context.  The lane reads that word every `check_every` jobs (and at the end): zero -> commit the
-    # pending counts; non-zero -> drop them and repeat exactly those jobs one by one with the warm-up doubled
-    # until proven (blocks are idempotent: same seed, point, block).  A sweep therefore never loses its counts
-    # to one unproven chunk.  (The generic CPM detector repairs most such chunks itself on the device, wf_viterbi_repaired;
-    # what reaches this path is a chunk whose two trajectories did not meet within the chunk.)
+    # Counters of a lane accumulate on the device.  Every launch of the chunk-parallel detectors proves on the device
+    # that each chunk started from bitwise the sequential detector's state and repairs the chunks that did not
+    # (cascading where needed), so a block's counts never depend on the warm-up it ran with; the proof word of each
+    # lane's context is read once, at the end, as a consistency check (non-zero only with the repairs switched off).
     tables = [_hip.zeros((npts, 2), "int64") for _ in range(n)]
-    pend = [_hip.zeros((npts, 2), "int64") for _ in range(n)]
-    window: list[list[tuple[int, int]]] = [[] for _ in range(n)]
     compared = np.zeros(npts, dtype=np.int64)
     issued = [0]
-    stats = {"repaired_jobs": 0, "checks": 0}
-    check_every = 32
+    stats = {"repaired_chunks": 0, "cascaded_chunks": 0}
     if n > 1:   # the tables were zeroed on the current stream
         torch.cuda.current_stream().synchronize()
-    if cpm:
-        base_warmup = links[0].cfg.warmup or 256       # (what a repeated block starts doubling from; the library's own default is 96 + on-device repair)
-    else:
-        base_warmup = links[0].cfg.warmup or 31
 
     # no warm-up asked for: each Eb/N0 point runs at its own (waveforms_amd.link.operating_point_warmup; 0 = the library's
-    # default where the table has no shorter one) — a block that leaves a chunk unproven is repeated below anyway
+    # default where the table has no shorter one)
     from waveforms_amd.link import operating_point_warmup, soqpsk_warmup_param
     point_warmup = [(0 if plan.states == 64 else operating_point_warmup(plan.waveform, float(e))) if cpm
                     else soqpsk_warmup_param(operating_point_warmup("soqpsk", float(e))) for e in plan.ebn0_db]
@@ -176,56 +165,26 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
         try:
             with torch.cuda.stream(lanes[k]):
                 _hip.check(run_fn(link._ctx, ctypes.byref(c), link.workspace.data_ptr(), link.workspace_bytes,
-                                  pend[k].data_ptr() + 16 * point, ctypes.byref(m), _hip.stream()))
+                                  tables[k].data_ptr() + 16 * point, ctypes.byref(m), _hip.stream()))
         finally:
             c.warmup = keep
         return m.value
-
-    def unproven(k: int) -> int:
-        with torch.cuda.stream(lanes[k]):
-            _hip.check(_hip.lib().wf_ctx_check(links[k]._ctx, _hip.stream()))
-            return dev.viterbi_unmerged(reset=True, ctx=links[k]._ctx)
-
-    def commit(k: int) -> None:
-        with torch.cuda.stream(lanes[k]):
-            tables[k] += pend[k]
-            pend[k].zero_()
-
-    def check(k: int) -> None:
-        stats["checks"] += 1
-        if unproven(k) == 0:
-            commit(k)
-        else:
-            with torch.cuda.stream(lanes[k]):
-                pend[k].zero_()
-            for point, block in window[k]:
-                w = 2 * base_warmup
-                while True:
-                    launch(k, point, block, w)
-                    if unproven(k) == 0:
-                        break
-                    with torch.cuda.stream(lanes[k]):
-                        pend[k].zero_()
-                    w *= 2
-                    if w > 4096:
-                        raise RuntimeError(f"detector chunks of block {(point, block)} do not merge within 4096 calls")
-                commit(k)
-                stats["repaired_jobs"] += 1
-        window[k].clear()
 
     def run(point: int, block: int) -> None:
         k = issued[0] % n
         issued[0] += 1
         compared[point] += launch(k, point, block, links[k].cfg.warmup or point_warmup[point])
-        window[k].append((point, block))
-        if len(window[k]) >= check_every:
-            check(k)
 
     def finish() -> np.ndarray:
         out = np.zeros((npts, 3), dtype=np.int64)
         for k in range(n):
-            check(k)
             with torch.cuda.stream(lanes[k]):
+                _hip.check(_hip.lib().wf_ctx_check(links[k]._ctx, _hip.stream()))
+                unproven = dev.viterbi_unmerged(reset=True, ctx=links[k]._ctx)
+                if unproven:
+                    raise RuntimeError(f"{unproven} detector chunk(s) were left unproven (the repairs are switched off on this context)")
+                stats["repaired_chunks"] += dev.viterbi_repaired(reset=True, ctx=links[k]._ctx)
+                stats["cascaded_chunks"] += dev.viterbi_cascaded(reset=True, ctx=links[k]._ctx)
                 out[:, :2] += tables[k].cpu().numpy()
         out[:, 2] = compared
         return out

@@ -47,6 +47,8 @@ struct wf_lfsr_tables {
 
 struct wf_ctx {
     int device = 0;
+    int cus = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount at creation)
+    int64_t opt[WF_OPT_COUNT] = {0};     // wf_ctx_set_option: 0 = default for every key
     // chained-scan scratch: [0] ticket counter (as u64), [1..] tile descriptors
     uint64_t *d_scan = nullptr;
     size_t scan_words = 0;
@@ -65,15 +67,9 @@ struct wf_ctx {
     std::map<uint64_t, wf_lfsr_tables *> lfsr;
     double *d_mod_scratch = nullptr;  // fused modulator: constants, tile sums, tile carries
     size_t mod_scratch_words = 0;
-    double *d_vit_edge = nullptr;     // chunk-parallel detector: per-wave start / end metrics (8 doubles each)
+    double *d_vit_edge = nullptr;     // chunk-parallel detectors: per-chunk proof records + repair lists of the last launch
     size_t vit_edge_words = 0;
-    unsigned long long *d_vit_unmerged = nullptr;   // chunks whose warm-up did not reach the true path metrics
-    // The link's detector call can leave its wave-edge proof (viterbi_verify_kernel: ~1000 compares) to the error
-    // counter that follows it on the same stream — one dependent launch less per block.  Set by the link around the
-    // detector call; whoever finds a pending proof (wf_count_errors, wf_vit_flush_verify) runs it.
-    bool vit_defer_verify = false;
-    const double *vit_pending_edge = nullptr;
-    int64_t vit_pending_nwaves = 0;
+    unsigned long long *d_vit_unmerged = nullptr;   // [0] chunks left unproven, [1] chunk repairs run, [2] repairs that handed on to the next chunk, [3] spare
     hipEvent_t *events = nullptr;  // WF_LINK_EVENT_SLOTS x (WF_LINK_STAGES + 1), created lazily
     // wf_link_run with fuse bit 5: the detector and the error count of a block run on this side stream, beside the front
     // end of the NEXT block (two sets of intermediates in the workspace, used alternately).  pipe_done[s]: the back end
@@ -136,8 +132,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf = 0, int cpm_nh = 1,
                             int stage = 3, int mf_ntaps = 0);
 int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_ntaps, int64_t first);
-int wf_vit_flush_verify(wf_ctx *ctx, void *stream);
-int wf_link_join_internal(wf_ctx *ctx, void *stream);   // the caller's stream waits for what fuse bit 5 left on the side stream   // run a detector proof the link deferred (no-op when none is pending)
+int wf_link_join_internal(wf_ctx *ctx, void *stream);   // the caller's stream waits for what fuse bit 5 left on the side stream
 int wf_mod_chan_cpm_rows_applies(int64_t nsym, int nh, int ntaps, int sps, int nfilt, int ntm, int64_t start0);
 int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse,
                          int ntaps, int sps, double phi0, const double *d_templates, int nfilt, int ntm, int64_t start0,

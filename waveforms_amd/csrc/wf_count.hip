@@ -7,21 +7,8 @@ __global__ __launch_bounds__(256) void count_errors_kernel(const int8_t *__restr
                                                             const int8_t *__restrict__ ref_syms,
                                                             const uint8_t *__restrict__ det_bits,
                                                             const uint8_t *__restrict__ ref_bits, int64_t m,
-                                                            unsigned long long *__restrict__ counts,
-                                                            const double *__restrict__ edge, int64_t nwaves,
-                                                            unsigned long long *__restrict__ unmerged)
+                                                            unsigned long long *__restrict__ counts)
 {
-    // the detector's wave-edge proof, when the link left it to this kernel (viterbi_verify_kernel's compare: wave w's
-    // first lane started from bitwise the metrics wave w - 1's last lane ended with): one thread per wave boundary
-    if (edge) {
-        const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
-        if (w < nwaves) {
-            bool bad = false;
-            for (int s4 = 0; s4 < 4; ++s4)
-                bad |= __double_as_longlong(edge[8 * w + s4]) != __double_as_longlong(edge[8 * (w - 1) + 4 + s4]);
-            if (bad) atomicAdd(unmerged, 1ull);
-        }
-    }
     __shared__ long long s_part[2][4];
     long long se = 0, be = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -71,25 +58,13 @@ extern "C" int wf_count_errors(wf_ctx *ctx, const int8_t *d_det_syms, const int8
                                int64_t *d_counts, void *stream)
 {
     WF_REQUIRE(ctx && m >= 0 && d_counts, "wf_count_errors: bad argument");
-    if (m == 0) return wf_vit_flush_verify(ctx, stream);
+    if (m == 0) return WF_OK;
     WF_REQUIRE(d_det_syms && d_ref_syms && d_det_bits && d_ref_bits, "wf_count_errors: NULL device pointer");
     WF_HIP(hipSetDevice(ctx->device));
     const unsigned grid = wf_grid_for(m, 256 * 16 * 8, 256);   /* <= 512 same-address atomics */
-    // a detector proof the link left pending rides along (one thread per wave boundary), if this launch has the threads
-    const double *edge = nullptr;
-    int64_t nwaves = 0;
-    if (ctx->vit_pending_edge && ctx->vit_pending_nwaves - 1 <= (int64_t)grid * 256) {
-        edge = ctx->vit_pending_edge;
-        nwaves = ctx->vit_pending_nwaves;
-        ctx->vit_pending_edge = nullptr;
-        ctx->vit_pending_nwaves = 0;
-    } else {
-        const int rc = wf_vit_flush_verify(ctx, stream);
-        if (rc) return rc;
-    }
     hipLaunchKernelGGL(count_errors_kernel, dim3(grid), dim3(256), 0, wf_stream(stream),
                        d_det_syms, d_ref_syms, d_det_bits, d_ref_bits, m,
-                       reinterpret_cast<unsigned long long *>(d_counts), edge, nwaves, ctx->d_vit_unmerged);
+                       reinterpret_cast<unsigned long long *>(d_counts));
     WF_LAUNCH_CHECK();
     return WF_OK;
 }

@@ -18,8 +18,29 @@
 // words each (metric, phase index, decision register).  cpm_verify_kernel compares chunk c's start with chunk
 // c - 1's end.
 #define CPM_EDGE_WORDS (2 * 16 * 3)
-#define CPM_REPAIR_CAP 1024     // failed chunks one repair launch can take (the rest are counted as unproven)
+// Repair lists, behind the proof records of a launch (all three forms): CPM_NLIST counts, then CPM_NLIST lists of
+// nchunks entries (a chunk index each; a list can never overflow: a round lists a chunk at most once).
+//   list 0: chunks whose start differs from their predecessor's end (the verify kernel);
+//   list 1, 2: chunks a repair of round 1 / 2 handed on to (the chunk behind one whose END changed);
+//   lists 2 <-> 3: the finisher's rounds — one workgroup that repeats until a round hands nothing on.
+// Invariant kept by every repair: a chunk's record (start, end) and its decisions are those of ONE run of its calls
+// from `start`.  A repair reads the predecessor's current end, makes it the chunk's start, runs the calls again
+// (beside the previous run from the old start, until the two are bitwise equal: from there on nothing changes) and,
+// if the chunk's end changed, lists the next chunk.  Each round's smallest listed chunk is repaired from the true
+// state, so the consistent prefix grows every round: worst case the rounds are the sequential detector.
+#define CPM_NLIST 4
+#define CPM_REPAIR_BLOCKS 256   // workgroups of a parallel repair round (grid-stride over the list)
 #define CPM_ROT_SIN 128         // rotation table in LDS: cos at [r], sin at [CPM_ROT_SIN + r], r < 2p <= 128
+
+__host__ __device__ inline uint64_t *cpm_list_counts(uint64_t *edge, int64_t nchunks, int edge_words) { return edge + nchunks * edge_words; }
+__host__ __device__ inline uint64_t *cpm_list(uint64_t *edge, int64_t nchunks, int edge_words, int k)
+{
+    return edge + nchunks * edge_words + CPM_NLIST + (int64_t)k * nchunks;
+}
+__host__ __device__ inline size_t cpm_edge_total_words(int64_t nchunks, int edge_words)
+{
+    return (size_t)nchunks * edge_words + CPM_NLIST + (size_t)CPM_NLIST * nchunks;
+}
 
 // (M - 1) * sum of K over symbols 0 .. n - Lp, mod 2p: the phase tilt of call n
 __host__ __device__ inline int cpm_tilt(int M, int p, int nh, int K0, int K1, int Lp, int64_t n)
@@ -42,7 +63,7 @@ struct cpm_lane_plan {
     double lane_ns_per_call;    // the lane form's time per call of a chunk (a lane runs its chunk alone: independent of the burst)
     double row_ns_per_call;     // the row form's time per call of the BURST (measured at 1e7 calls; it scales with the burst)
 };
-int wf_cpm_lanes_plan(const wf_cpm_detector_config *det, cpm_lane_plan *plan);
+int wf_cpm_lanes_plan(const wf_cpm_detector_config *det, cpm_lane_plan *plan);   // 0: a specialisation exists (*plan filled in), 1: none
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
                         int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
                         void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes);
@@ -54,6 +75,7 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
 // Wide form (wf_cpm_wide.hip): trellises of 17 .. 64 states, lane = state, one wave = one detector.  Proof records of
 // 2 x 64 x 3 words per chunk, detector state in the wide layout of WF_CPM_STATE_BYTES.
 int wf_cpm_wide_applies(const wf_cpm_detector_config *det);
-int64_t wf_cpm_wide_chunk_calls(int64_t ncalls, int W, int cus);
+int64_t wf_cpm_wide_chunk_calls(int64_t ncalls, int W, int cus, int64_t chunk_opt);
+int wf_cpm_wide_warmup(int warmup);
 int wf_cpm_wide_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
                        int warmup, uint8_t *d_decisions, void *d_state, void *stream);

@@ -126,18 +126,21 @@ __device__ __forceinline__ void cpm_wave_sync()
 #ifndef CPM_MIN_WAVES
 #define CPM_MIN_WAVES(M, LP) (((M) == 2 && (LP) <= 2) || (LP) == 1 ? 5 : ((M) == 4 && (LP) == 3 ? 2 : 4))
 #endif
-// REPAIR (cpm_repair_kernel) = the second launch of a detector call (see cpm_verify_kernel): one WAVE per chunk whose proof failed.  The
-// chunk's own calls are run again from BOTH states — groups 0 / 2 from the state the first launch started them from
-// (what its warm-up arrived at), groups 1 / 3 from the state the previous chunk ended with (the true one) — until the
-// two are bitwise equal: from there on the first launch's decisions and end state were the sequential detector's, and
-// up to there the second trajectory's decisions replace them.  A pair that has not met by the end of the chunk
-// leaves the chunk counted as unproven.  Most chunks that miss a SHORT warm-up meet within a few dozen calls, so the
-// warm-up can be sized for the typical merge depth instead of its 1e-7 tail.
+// REPAIR (cpm_repair_kernel) = the launches behind the first one of a detector call (see cpm_verify_kernel and the list
+// layout in wf_cpm_detect.h): one WAVE per listed chunk.  The chunk's own calls are run again from BOTH states — groups
+// 0 / 2 from the state its record says it started from (what the previous run of this chunk began with: its warm-up's
+// arrival, or an earlier repair's input), groups 1 / 3 from the state the previous chunk ends with NOW, which becomes
+// the chunk's recorded start — until the two are bitwise equal: from there on the previous run's decisions and end state
+// stand, and up to there the second trajectory's decisions replace them.  A pair that has not met by the end of the
+// chunk means the chunk's END changed: it is recorded, and the next chunk is listed for the following round (its start
+// no longer equals its predecessor's end).  Most chunks that miss a SHORT warm-up meet within a few dozen calls, so the
+// warm-up can be sized for the typical merge depth instead of its 1e-7 tail — and is a matter of speed only.
 template <int M_, int LP_, bool REPAIR>
-__device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
+__device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ rows, const double *__restrict__ rot,
                                                  uint8_t *__restrict__ out, uint64_t *__restrict__ state,
                                                  uint64_t *__restrict__ edge, unsigned long long *__restrict__ unmerged,
-                                                 const cpm_vit_params &P)
+                                                 const cpm_vit_params &P, const int64_t chunk, uint64_t *__restrict__ next_count,
+                                                 uint64_t *__restrict__ next_list)
 {
     constexpr int M = M_;
     constexpr int LGM = M_ == 4 ? 2 : 1;
@@ -153,27 +156,8 @@ __device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ row
     double2 *rowbuf = reinterpret_cast<double2 *>(wbase + P.rows_off) + g * PIECES;
     double *xch = reinterpret_cast<double *>(wbase + P.xch_off);      // [4 slots][CPM_XS] (see CPM_XS)
     uint8_t *dec = reinterpret_cast<uint8_t *>(wbase + P.dec_off) + g * P.CH;
-    // rotation table as two 8 B columns (cos | sin): 2p <= 128 distinct entries land in distinct banks (equal
-    // entries are broadcast); as 16 B pairs entries 16 apart shared their banks
-    double *rot = reinterpret_cast<double *>(smem + P.rot_off);
-    for (int k = threadIdx.x; k < 2 * P.p; k += CPM_THREADS) {
-        const double2 e = rot_cs[k];
-        rot[k] = e.x;
-        rot[CPM_ROT_SIN + k] = e.y;
-    }
-    __syncthreads();
 
     const int64_t n0 = state ? (int64_t)state[CPM_ST_N] : 0;          // calls made before this launch
-    uint64_t *const fail = edge + P.nchunks * CPM_EDGE_WORDS;         // [0] chunks whose proof failed, [1 ..] which (cpm_verify_kernel)
-    int64_t chunk = ((int64_t)blockIdx.x * CPM_WAVES + wave) * CPM_GROUPS + g;
-    if constexpr (REPAIR) {
-        const int64_t idx = (int64_t)blockIdx.x * CPM_WAVES + wave;
-        const int64_t listed = (int64_t)fail[0] < CPM_REPAIR_CAP ? (int64_t)fail[0] : CPM_REPAIR_CAP;
-        if (idx >= listed) return;                                    // (whole waves; no workgroup barrier below)
-        chunk = (int64_t)fail[1 + idx];
-    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
-        fail[0] = 0;
-    }
     const int64_t k_first = chunk * P.CH;                             // first own call (local index)
     const bool live = k_first < P.ncalls;
     const int T = P.W + P.CH;
@@ -203,10 +187,19 @@ __device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ row
     }
     uint64_t *const erec = edge + chunk * CPM_EDGE_WORDS;               // (written only when the chunk is live)
     if constexpr (REPAIR) {
-        const uint64_t *src = (g & 1) ? erec - CPM_EDGE_WORDS + 48 : erec;   // the previous chunk's end | this chunk's start
-        m = active ? __longlong_as_double((long long)src[3 * s]) : INFINITY;
-        r = (int)src[3 * s + 1];
-        hist = src[3 * s + 2];
+        const uint64_t *src = (g & 1) ? erec - CPM_EDGE_WORDS + 48 : erec;   // the previous chunk's end (as it is now) | this chunk's recorded start
+        const uint64_t w0 = active ? src[3 * s] : 0ull, w1 = active ? src[3 * s + 1] : 0ull, w2 = active ? src[3 * s + 2] : 0ull;
+        m = active ? __longlong_as_double((long long)w0) : INFINITY;
+        r = (int)w1;
+        hist = w2;
+        // what this run starts from becomes the chunk's recorded start — exactly the words read (another wave may be
+        // rewriting the predecessor's end in this very round: then this chunk is listed again, and the record says
+        // truthfully what its decisions were computed from)
+        if (g == 1 && active) {
+            erec[3 * s] = w0;
+            erec[3 * s + 1] = w1;
+            erec[3 * s + 2] = w2;
+        }
     }
 
     // cooperative row fetch: piece q = s + 16 i of the batch's CPM_TB * NF pieces
@@ -397,10 +390,27 @@ __device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ row
                 merged = met();
             }
         }
-        if (g == 1)                                                     // the true trajectory's decisions up to the meeting point
+        if (g == 1)                                                     // the new trajectory's decisions up to the meeting point
             for (int q = s; q < done; q += 16)
                 if (k_first + q < P.ncalls) out[k_first + q] = dec[q];
-        if (lane == 0) atomicAdd(unmerged + (merged ? 1 : 0), 1ull);    // [1]: chunks repaired, [0]: chunks left unproven
+        if (!merged) {                                                  // the chunk ENDS in another state than before
+            if (g == 1 && active) {
+                erec[48 + 3 * s] = (uint64_t)__double_as_longlong(m);
+                erec[48 + 3 * s + 1] = (uint64_t)(int64_t)r;
+                erec[48 + 3 * s + 2] = hist;
+                if (state && k_first + P.CH >= P.ncalls) {              // ... and it owns the burst's last call: the carry
+                    state[CPM_ST_STAGE + CPM_ST_M + s] = (uint64_t)__double_as_longlong(m);
+                    state[CPM_ST_STAGE + CPM_ST_V + s] = (uint64_t)(int64_t)r;
+                    state[CPM_ST_STAGE + CPM_ST_H + s] = hist;
+                }
+            }
+            if (lane == 0 && chunk + 1 < P.nchunks)                     // the next chunk's start no longer matches: next round
+                next_list[atomicAdd(reinterpret_cast<unsigned long long *>(next_count), 1ull)] = (uint64_t)(chunk + 1);
+        }
+        if (lane == 0) {
+            atomicAdd(unmerged + 1, 1ull);                              // [1]: chunk repairs run, [2]: ... that handed on
+            if (!merged) atomicAdd(unmerged + 2, 1ull);
+        }
         return;
     }
     for (int b = 0; b < nbatch; b += 2) {
@@ -432,6 +442,20 @@ __device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ row
     }
 }
 
+// rotation table as two 8 B columns (cos | sin): 2p <= 128 distinct entries land in distinct banks (equal entries are
+// broadcast); as 16 B pairs entries 16 apart shared their banks.  The caller synchronises.
+__device__ __forceinline__ double *cpm_stage_rot(const double2 *__restrict__ rot_cs, const cpm_vit_params &P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *rot = reinterpret_cast<double *>(smem + P.rot_off);
+    for (int k = threadIdx.x; k < 2 * P.p; k += CPM_THREADS) {
+        const double2 e = rot_cs[k];
+        rot[k] = e.x;
+        rot[CPM_ROT_SIN + k] = e.y;
+    }
+    return rot;
+}
+
 template <int M_, int LP_>
 __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viterbi_kernel(const double2 *__restrict__ rows,
                                                                   const double2 *__restrict__ rot_cs,
@@ -440,24 +464,57 @@ __global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_viter
                                                                   unsigned long long *__restrict__ unmerged,
                                                                   cpm_vit_params P)
 {
-    cpm_viterbi_body<M_, LP_, false>(rows, rot_cs, out, state, edge, unmerged, P);
+    const double *rot = cpm_stage_rot(rot_cs, P);
+    if (blockIdx.x == 0 && threadIdx.x < CPM_NLIST) cpm_list_counts(edge, P.nchunks, CPM_EDGE_WORDS)[threadIdx.x] = 0;   // the repair lists: empty
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t chunk = ((int64_t)blockIdx.x * CPM_WAVES + wave) * CPM_GROUPS + (lane >> 4);
+    cpm_viterbi_body<M_, LP_, false>(rows, rot, out, state, edge, unmerged, P, chunk, nullptr, nullptr);
 }
 
+// One repair round (see wf_cpm_detect.h): the chunks of list `lin`, a wave each, grid-stride; chunks handed on go to list
+// `lout`.  finisher != 0: ONE workgroup that keeps going, round after round between lists `lin` and `lout`, until a
+// round hands nothing on — each round's smallest chunk is repaired from the true state, so the rounds end (at worst
+// they are the sequential detector).  The waves of the finisher see each other's records and list entries through the
+// agent-scope fences around the workgroup barrier; parallel rounds are separated by kernel boundaries.
 template <int M_, int LP_>
-__global__ __launch_bounds__(CPM_THREADS, CPM_MIN_WAVES(M_, LP_)) void cpm_repair_kernel(const double2 *__restrict__ rows,
+__global__ __launch_bounds__(CPM_THREADS) void cpm_repair_kernel(const double2 *__restrict__ rows,
                                                                  const double2 *__restrict__ rot_cs,
                                                                  uint8_t *__restrict__ out, uint64_t *__restrict__ state,
                                                                  uint64_t *__restrict__ edge,
                                                                  unsigned long long *__restrict__ unmerged,
-                                                                 cpm_vit_params P)
+                                                                 cpm_vit_params P, int lin, int lout, int finisher)
 {
-    cpm_viterbi_body<M_, LP_, true>(rows, rot_cs, out, state, edge, unmerged, P);
+    uint64_t *const counts = cpm_list_counts(edge, P.nchunks, CPM_EDGE_WORDS);
+    int64_t n = (int64_t)__hip_atomic_load(&counts[lin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == 0) return;                                               // (the whole grid: nothing listed)
+    const double *rot = cpm_stage_rot(rot_cs, P);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    const int64_t first = finisher ? wave : (int64_t)blockIdx.x * CPM_WAVES + wave, stride = finisher ? CPM_WAVES : (int64_t)gridDim.x * CPM_WAVES;
+    for (;;) {
+        const uint64_t *list = cpm_list(edge, P.nchunks, CPM_EDGE_WORDS, lin);
+        for (int64_t idx = first; idx < n; idx += stride)
+            cpm_viterbi_body<M_, LP_, true>(rows, rot, out, state, edge, unmerged, P,
+                                            (int64_t)__hip_atomic_load(&list[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), &counts[lout],
+                                            cpm_list(edge, P.nchunks, CPM_EDGE_WORDS, lout));
+        if (!finisher) return;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&counts[lin], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the next round's output
+        n = (int64_t)__hip_atomic_load(&counts[lout], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __syncthreads();
+        if (n == 0) return;
+        const int t = lin;
+        lin = lout;
+        lout = t;
+    }
 }
 
-// Every chunk against its predecessor: thread = (chunk c >= 1, state s); one count per chunk that did NOT start
-// from bitwise the (metric, phase index, last D decisions) chunk c - 1 ended with.
-// repair = 1: failed chunks are LISTED behind the records ([0] how many, [1 ..] which) for the repair launch; only what
-// does not fit the list is counted as unproven here.
+// Every chunk against its predecessor: thread = (chunk c >= 1, state s); a chunk that did NOT start from bitwise the
+// (metric, phase index, last D decisions) chunk c - 1 ended with is LISTED for the repair launches (list 0), or — repair
+// = 0: WF_OPT_DET_REPAIR off, and the closing check of WF_OPT_DET_FINAL_VERIFY — counted as unproven.
 __global__ void cpm_verify_kernel(uint64_t *__restrict__ edge, int64_t nchunks, int S, uint64_t hmask,
                                   unsigned long long *__restrict__ unmerged, int repair)
 {
@@ -472,10 +529,12 @@ __global__ void cpm_verify_kernel(uint64_t *__restrict__ edge, int64_t nchunks, 
     const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
     const int lane = threadIdx.x & 63;
     if (s == 0 && ((m >> (lane & 48)) & 0xFFFFull)) {
-        unsigned long long *fail = reinterpret_cast<unsigned long long *>(edge + nchunks * CPM_EDGE_WORDS);
-        const unsigned long long i = repair ? atomicAdd(fail, 1ull) : (unsigned long long)CPM_REPAIR_CAP;
-        if (i < CPM_REPAIR_CAP) fail[1 + i] = (unsigned long long)c;
-        else atomicAdd(unmerged, 1ull);
+        if (repair) {
+            unsigned long long *counts = reinterpret_cast<unsigned long long *>(cpm_list_counts(edge, nchunks, CPM_EDGE_WORDS));
+            cpm_list(edge, nchunks, CPM_EDGE_WORDS, 0)[atomicAdd(counts, 1ull)] = (uint64_t)c;
+        } else {
+            atomicAdd(unmerged, 1ull);
+        }
     }
 }
 
@@ -531,65 +590,77 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
 // Calls per chunk, and which form runs them.  Row form: a multiple of 64, at least 256 (and 2 W) so that the warm-up stays
 // a fraction of the work, otherwise the smallest that puts the whole burst into ONE round of resident workgroups.  Lane
 // form (wf_cpm_lanes.hip, where a specialisation for this trellis is compiled in): 64 chunks per wave, the chunk length that
-// puts the burst into one round of the waves a CU's LDS holds, at least 5 W — a chunk that missed a short warm-up needs
-// room to meet the first launch's trajectory inside its own calls: with 64-call warm-ups and 256-call chunks PCM/FM left
-// 3 chunks of 1.2e7 unproven at 10 dB, none with 320 (profiles/r04_lane_chunk_sweep.log).
+// puts the burst into one round of the waves a CU's LDS holds, at least 5 W — a chunk that missed a short warm-up should
+// meet the first launch's trajectory inside its own calls, or its repair hands on to the next chunk and costs a further
+// round (a matter of speed: with 64-call warm-ups and 256-call chunks PCM/FM handed on 3 chunks of 1.2e7 at 10 dB, none
+// with 320; profiles/r04_lane_chunk_sweep.log).
 // Which one: a lane runs its chunk alone, so the lane form's time is (chunk + warm-up) x its time per call whatever the
 // burst's length, while the row form's falls with the burst (4 chunks per wave: 16 times the waves).  The two meet near
 // 9e6 (ARTM) and 6.5e6 (PCM/FM) calls; below, the row form runs (a 2^22-call stream chunk: 0.32 against 0.54 ms for
-// ARTM).  WF_CPM_LANES=0 / 1 forces one form (tests run both on every size).
-static int64_t cpm_chunk_calls(const wf_cpm_detector_config *det, int64_t ncalls, int W, int cus, int wg_per_cu, cpm_lane_plan *lanes, bool *use_lanes)
+// ARTM).  WF_OPT_CPM_FORM = 1 / 2 forces one form (tests run both on every size), WF_OPT_CPM_CHUNK_CALLS the chunk length.
+static int64_t cpm_chunk_calls(const wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int W, int wg_per_cu, cpm_lane_plan *lanes,
+                               bool *use_lanes)
 {
     auto floor_ch = [&](int64_t ch, bool lane) {
         ch = (ch + 63) / 64 * 64;
-        if (ch < 256) ch = 256;                                    // (room for the repair launch to meet the first launch's trajectory)
+        if (ch < 256) ch = 256;                                    // (room for a repair to meet the previous run's trajectory)
         if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
         if (lane && ch < 5 * W) ch = (5 * W + 63) / 64 * 64;
         return ch;
     };
+    const int cus = ctx->cus;
+    const int64_t form = ctx->opt[WF_OPT_CPM_FORM];
     const int64_t slots_row = (int64_t)cus * wg_per_cu * CPM_WAVES * CPM_GROUPS;
     int64_t ch = floor_ch((ncalls + slots_row - 1) / slots_row, false);
     *use_lanes = false;
-    const int have = wf_cpm_lanes_plan(det, lanes);                // 0: a specialisation exists; 2: ... and WF_CPM_LANES=1 forces it
-    if (have == 0 || have == 2) {
+    // (a burst of fewer calls than the pulse has symbols is all virtual pre-start symbols: the lane form runs those
+    // outside its call loop and has no chunk to hang the end record on — the row form takes it)
+    if (form != 1 && ncalls >= det->Lp && wf_cpm_lanes_plan(det, lanes) == 0) {
         const int64_t slots_lane = (int64_t)cus * lanes->waves_per_cu * 64;
         const int64_t ch_lane = floor_ch((ncalls + slots_lane - 1) / slots_lane, true);
         const double t_lane = lanes->lane_ns_per_call * (double)(ch_lane + W), t_row = lanes->row_ns_per_call * (double)ncalls;
-        if (have == 2 || t_lane < t_row) {
+        if (form == 2 || t_lane < t_row) {
             *use_lanes = true;
             ch = ch_lane;
         }
     }
-    if (const char *e = getenv(*use_lanes ? "WF_CPM_LANE_CH" : "WF_CPM_CH")) ch = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : ch;   // tuning aid (tools/cpm_vit_time.py)
+    if (ctx->opt[WF_OPT_CPM_CHUNK_CALLS] > 0) {                    // tuning aid (tools/cpm_vit_time.py)
+        ch = (ctx->opt[WF_OPT_CPM_CHUNK_CALLS] + 63) / 64 * 64;
+        if (ch <= W + 1) ch = (W + 2 + 63) / 64 * 64;
+    }
     if (ch > 8192) ch = 8192;                                      // decision strips live in LDS; longer bursts take several rounds
     return ch;
 }
 
-// Which form of the detector wf_cpm_viterbi_detect runs for this trellis (bench.py and the profile tools name the
-// kernel they price by it): info4 = {form (0: row form, one 16-lane DPP row per chunk; 1: lane form, one lane per chunk),
-// ring slots of the lane form, 0, 0}.
-extern "C" int wf_cpm_detector_form(const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int *info4)
+static int cpm_warmup_calls(int warmup)                            // rows/lanes forms: 0 = the default, a multiple of two batches, <= 4096
 {
-    WF_REQUIRE(det && info4 && ncalls >= 0 && warmup >= 0, "wf_cpm_detector_form: bad argument");
+    int W = warmup ? warmup : 96;
+    W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
+    return W > 4096 ? 4096 : W;
+}
+
+// Which form of the detector wf_cpm_viterbi_detect runs for this trellis on this context (bench.py and the profile tools
+// name the kernel they price by it): info4 = {form (0: row form, one 16-lane DPP row per chunk; 1: lane form, one lane per
+// chunk; 2: wide form, one wave per chunk), ring slots of the lane form, calls per chunk, warm-up calls} — computed by the
+// functions the launch itself uses.
+extern "C" int wf_cpm_detector_form(wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int *info4)
+{
+    WF_REQUIRE(ctx && det && info4 && ncalls >= 0 && warmup >= 0, "wf_cpm_detector_form: bad argument");
     if (wf_cpm_wide_applies(det)) {                                // 17 .. 64 states: lane = state, one wave per chunk
-        int W = warmup ? warmup : 160;
-        W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
-        if (W > 4096) W = 4096;
+        const int W = wf_cpm_wide_warmup(warmup);
         info4[0] = 2;
         info4[1] = 0;
-        info4[2] = (int)wf_cpm_wide_chunk_calls(ncalls, W, 256);
+        info4[2] = (int)wf_cpm_wide_chunk_calls(ncalls, W, ctx->cus, ctx->opt[WF_OPT_CPM_CHUNK_CALLS]);
         info4[3] = W;
         return WF_OK;
     }
     cpm_vit_params P;
     const int rc = cpm_build_tables(det, P);
     if (rc) return rc;
-    int W = warmup ? warmup : 96;
-    W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
-    if (W > 4096) W = 4096;
+    const int W = cpm_warmup_calls(warmup);
     cpm_lane_plan lanes{};
     bool use_lanes = false;
-    const int64_t ch = cpm_chunk_calls(det, ncalls, W, 256, CPM_MIN_WAVES(P.M, P.Lp), &lanes, &use_lanes);
+    const int64_t ch = cpm_chunk_calls(ctx, det, ncalls, W, CPM_MIN_WAVES(P.M, P.Lp), &lanes, &use_lanes);
     info4[0] = use_lanes ? 1 : 0;
     info4[1] = use_lanes ? lanes.ring_batches : 0;
     info4[2] = (int)ch;
@@ -625,30 +696,25 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
                "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
     if (wide) return wf_cpm_wide_detect(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream);
-    // Default warm-up.  A chunk that misses its warm-up is REPAIRED by the call's second launch (cpm_repair_kernel),
+    // Default warm-up.  A chunk that misses its warm-up is REPAIRED by the launches behind the first (cpm_repair_kernel),
     // so the default is sized for the typical merge depth of the trellis, not for its tail, and backed by a scan at
     // 0 .. 12 dB (tools/cpm_warmup_scan.py, profiles/r03_cpm_repair_scan_*.json: 1.25e6 chunks per point): with
     // 96 calls ARTM's 16 states leave 1.3 % / 0.4 % / 0.04 % of the chunks to the repair at 0 / 4 / 6 dB (none from
-    // 10 dB up) and binary PCM/FM 2.6 % / 0.1 % / 0.05 % at 0 / 4 / 10 dB — every one of them repaired, none left
-    // unproven; detector time 0.69 - 0.75 ms (ARTM) and 0.49 - 0.54 ms (PCM/FM) per 1e7 calls.  Before the repair
-    // launch existed the defaults had to cover the tail: 320 / 384 calls (0.87 / 0.74 ms).  A caller that knows its
-    // operating point may pass less (waveforms_amd.link.operating_point_warmup: ARTM 48 from 8 dB up, PCM/FM 64);
-    // what the repair cannot settle is counted (wf_viterbi4_unmerged) and waveforms.bert repeats such a block.
-    int W = warmup ? warmup : 96;
-    W = (W + 2 * CPM_TB - 1) / (2 * CPM_TB) * (2 * CPM_TB);
-    if (W > 4096) W = 4096;
+    // 10 dB up) and binary PCM/FM 2.6 % / 0.1 % / 0.05 % at 0 / 4 / 10 dB; detector time 0.69 - 0.75 ms (ARTM) and
+    // 0.49 - 0.54 ms (PCM/FM) per 1e7 calls.  A caller that knows its operating point may pass less
+    // (waveforms_amd.link.operating_point_warmup: ARTM 48 from 8 dB up, PCM/FM 64): the warm-up sets how many chunks go
+    // to the repair, never what the decisions are.
+    const int W = cpm_warmup_calls(warmup);
     // Calls per chunk (a multiple of 64): at least 256 (and 2 W), so the warm-up stays a fraction of
     // the work, and otherwise the smallest that puts the whole burst into ONE round of resident
     // workgroups (4 per CU at this kernel's LDS / register use): with 512 calls per chunk 1e7 calls
     // made 1221 workgroups for 1024 slots — a second, almost empty round of the full chain length.
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     // The lane-per-chunk form (wf_cpm_lanes.hip) where a specialisation for this trellis is compiled in: 64 chunks per
     // wave, as many waves as its LDS ring lets a CU hold — the chunk length that puts the burst into one round of them.
     cpm_lane_plan lanes{};
     const int wg_per_cu = CPM_MIN_WAVES(P.M, P.Lp);                 // resident workgroups per CU = waves per SIMD (4 waves per workgroup)
     bool use_lanes = false;
-    const int64_t ch = cpm_chunk_calls(det, ncalls, W, cus, wg_per_cu, &lanes, &use_lanes);
+    const int64_t ch = cpm_chunk_calls(ctx, det, ncalls, W, wg_per_cu, &lanes, &use_lanes);
     // (measured at 1e7 ARTM calls, W = 128, row form: 384 calls per chunk 1.07 ms, 512: 1.03, 640: 1.00, 768: 1.19,
     //  1024: 1.28, 1536: 1.68 — longer chunks do less warm-up work but leave fewer waves to hide the
     //  dependent chain of a call)
@@ -668,11 +734,12 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
     const int64_t nblocks = (nwaves + CPM_WAVES - 1) / CPM_WAVES;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_viterbi_detect: burst too long for one launch");
     P.nchunks = nchunks;
-    rc = wf_ctx_reserve_vit(ctx, (size_t)nchunks * CPM_EDGE_WORDS + 1 + CPM_REPAIR_CAP);
+    rc = wf_ctx_reserve_vit(ctx, cpm_edge_total_words(nchunks, CPM_EDGE_WORDS));
     if (rc) return rc;
     uint64_t *edge = reinterpret_cast<uint64_t *>(ctx->d_vit_edge);
     hipStream_t s = wf_stream(stream);
     using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params);
+    using repair_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params, int, int, int);
     if (use_lanes) {
         rc = wf_cpm_lanes_launch(lanes, det, d_rot_cs, d_rows_ri, ncalls, W, P.CH, nchunks, d_decisions, d_state, edge, stream, slack_lo_bytes, slack_hi_bytes);
         if (rc) return rc;
@@ -689,25 +756,31 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
     }
     if (nchunks > 1) {
         const uint64_t hmask = P.lgM * P.D >= 64 ? ~0ull : ((1ull << (P.lgM * P.D)) - 1ull);   // only the D decisions still inside the register can reach an output
-        const char *nr = getenv("WF_CPM_NO_REPAIR");                  // (tests of the host-level fallback)
-        const int repair = nr && atoi(nr) ? 0 : 1;
-        hipLaunchKernelGGL(cpm_verify_kernel, dim3((unsigned)(((nchunks - 1) * 16 + 255) / 256)), dim3(256), 0, s, edge, nchunks, P.S,
-                           hmask, ctx->d_vit_unmerged, repair);
+        const int repair = ctx->opt[WF_OPT_DET_REPAIR] == 0 ? 1 : 0;
+        const dim3 vgrid((unsigned)(((nchunks - 1) * 16 + 255) / 256));
+        hipLaunchKernelGGL(cpm_verify_kernel, vgrid, dim3(256), 0, s, edge, nchunks, P.S, hmask, ctx->d_vit_unmerged, repair);
         WF_LAUNCH_CHECK();
         if (repair) {
-            // chunks whose proof failed: their own calls again from the true state until both trajectories meet
-            // (cpm_repair_kernel; every wave leaves at once when nothing is listed)
-            kern_t kr = nullptr;
+            // chunks whose proof failed: their own calls again from the true state until both trajectories meet; a chunk
+            // whose END changed hands on to the next one — two parallel rounds, then one workgroup that goes on until a
+            // round hands nothing on (every wave of these launches leaves at once when nothing is listed)
+            repair_t kr = nullptr;
             if (P.M == 4) kr = P.Lp == 1 ? cpm_repair_kernel<4, 1> : (P.Lp == 2 ? cpm_repair_kernel<4, 2> : cpm_repair_kernel<4, 3>);
             else kr = P.Lp == 1 ? cpm_repair_kernel<2, 1> : (P.Lp == 2 ? cpm_repair_kernel<2, 2> : cpm_repair_kernel<2, 3>);
             if (lds > 48 * 1024)
                 WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             cpm_vit_params Pr = P;
             Pr.W = 0;
-            hipLaunchKernelGGL(kr, dim3(CPM_REPAIR_CAP / CPM_WAVES), dim3(CPM_THREADS), lds, s, reinterpret_cast<const double2 *>(d_rows_ri),
-                               reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
-                               ctx->d_vit_unmerged, Pr);
-            WF_LAUNCH_CHECK();
+            for (int round = 0; round < 3; ++round) {
+                hipLaunchKernelGGL(kr, dim3(round < 2 ? CPM_REPAIR_BLOCKS : 1), dim3(CPM_THREADS), lds, s, reinterpret_cast<const double2 *>(d_rows_ri),
+                                   reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
+                                   ctx->d_vit_unmerged, Pr, round, round + 1, round == 2 ? 1 : 0);
+                WF_LAUNCH_CHECK();
+            }
+            if (ctx->opt[WF_OPT_DET_FINAL_VERIFY]) {
+                hipLaunchKernelGGL(cpm_verify_kernel, vgrid, dim3(256), 0, s, edge, nchunks, P.S, hmask, ctx->d_vit_unmerged, 0);
+                WF_LAUNCH_CHECK();
+            }
         }
     }
     if (d_state) {

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
         reinterpret_cast<double *>(rot_cos)[k] = e.x;
         reinterpret_cast<double *>(rot_sin)[k] = e.y;
     }
-    if (blockIdx.x == 0 && lane == 0) edge[P.nchunks * CPM_EDGE_WORDS] = 0;     // cpm_verify_kernel's list of failed chunks: none yet
+    if (blockIdx.x == 0 && lane < CPM_NLIST) cpm_list_counts(edge, P.nchunks, CPM_EDGE_WORDS)[lane] = 0;   // the repair lists (wf_cpm_detect.h): empty
     const int64_t n0 = state ? lane_uniform64((int64_t)state[CPM_ST_N]) : 0;    // calls made before this launch
     const int64_t chunk0 = (int64_t)blockIdx.x * 64;
     const int64_t chunk = chunk0 + lane;
@@ -528,15 +528,10 @@ using lane_pcmfm10 = lane_spec<2, 2, 5, 10, 1, 7, 7>;    // PCM/FM, h = 7/10, 5 
 // slot of lead, four cost a CU a resident wave (and the front end running beside it 8 KB).
 #define LANE_R 3
 
-// 1: no specialisation for this trellis (or WF_CPM_LANES=0); 0: there is one, *plan filled in; 2: ... and WF_CPM_LANES=1
-// asks for it whatever the burst's length.
+// 1: no specialisation for this trellis; 0: there is one, *plan filled in.  (Which form runs is the caller's decision:
+// cpm_chunk_calls, wf_cpm_detect.hip.)
 int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
 {
-    int forced = 0;
-    if (const char *e = getenv("WF_CPM_LANES")) {
-        if (atoi(e) == 0) return 1;
-        forced = 2;
-    }
     int spec = -1;
     if (d->M == 4 && d->Lp == 2 && d->NC == 4 && d->p == 16 && d->nh == 2 && d->K[0] == 4 && d->K[1] == 5 && d->D >= 17 && d->D <= 32) spec = 0;
     if (d->M == 2 && d->Lp == 2 && d->NC == 5 && d->p == 10 && d->nh == 1 && d->K[0] == 7 && d->D >= 1 && d->D <= 32) spec = 1;
@@ -547,7 +542,7 @@ int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
     // time per call of a chunk / of the burst (one MI355X, profiles/r04_ab_lane_ring.log, r04_lane_chunk_sweep.log):
     // ARTM 0.66 ms for 256 + 49 calls, row form 0.74 ms per 1e7; PCM/FM 0.27 ms for 256 + 64 calls, row form 0.49 ms per 1e7
     *plan = {spec, R, per_cu, spec == 0 ? 1 : 4, spec == 0 ? 2160.0 : 840.0, spec == 0 ? 0.074 : 0.049};
-    return forced;
+    return 0;
 }
 
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,

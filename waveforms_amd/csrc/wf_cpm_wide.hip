@@ -92,10 +92,11 @@ __device__ __forceinline__ void wide_wave_sync()
 #define WIDE_EDGE_WORDS (2 * 64 * 3)
 
 template <int M_, int LP_, bool REPAIR>
-__global__ __launch_bounds__(REPAIR ? 128 : WIDE_THREADS) void cpm_wide_kernel(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
-                                                                                uint8_t *__restrict__ out, uint64_t *__restrict__ state,
-                                                                                uint64_t *__restrict__ edge, unsigned long long *__restrict__ unmerged,
-                                                                                cpm_wide_params P)
+__device__ __forceinline__ void cpm_wide_body(const double2 *__restrict__ rows, const double *__restrict__ rot,
+                                              uint8_t *__restrict__ out, uint64_t *__restrict__ state,
+                                              uint64_t *__restrict__ edge, unsigned long long *__restrict__ unmerged,
+                                              const cpm_wide_params &P, const int64_t chunk, uint64_t *__restrict__ next_count,
+                                              uint64_t *__restrict__ next_list)
 {
     constexpr int M = M_;
     constexpr int LGM = M_ == 4 ? 2 : 1;
@@ -111,24 +112,8 @@ __global__ __launch_bounds__(REPAIR ? 128 : WIDE_THREADS) void cpm_wide_kernel(c
     double2 *rowbuf = reinterpret_cast<double2 *>(wbase + P.rows_off);
     double *xch = reinterpret_cast<double *>(wbase + P.xch_off);      // [4 slots][WIDE_XS]
     uint8_t *dec = reinterpret_cast<uint8_t *>(wbase + P.dec_off);
-    double *rot = reinterpret_cast<double *>(smem + P.rot_off);       // cos at [r], sin at [CPM_ROT_SIN + r]
-    for (int k = threadIdx.x; k < 2 * P.p; k += blockDim.x) {
-        const double2 e = rot_cs[k];
-        rot[k] = e.x;
-        rot[CPM_ROT_SIN + k] = e.y;
-    }
-    __syncthreads();
 
     const int64_t n0 = state ? (int64_t)state[WIDE_ST_N] : 0;          // calls made before this launch
-    uint64_t *const fail = edge + P.nchunks * WIDE_EDGE_WORDS;         // [0] chunks whose proof failed, [1 ..] which
-    int64_t chunk = (int64_t)blockIdx.x * WIDE_WAVES + wave;
-    if constexpr (REPAIR) {
-        const int64_t listed = (int64_t)fail[0] < CPM_REPAIR_CAP ? (int64_t)fail[0] : CPM_REPAIR_CAP;
-        if ((int64_t)blockIdx.x >= listed) return;                     // (the whole workgroup)
-        chunk = (int64_t)fail[1 + blockIdx.x];
-    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
-        fail[0] = 0;
-    }
     const int64_t k_first = chunk * P.CH;                              // first own call (local index)
     const bool live = k_first < P.ncalls;
     const int T = P.W + P.CH;
@@ -153,10 +138,17 @@ __global__ __launch_bounds__(REPAIR ? 128 : WIDE_THREADS) void cpm_wide_kernel(c
     }
     uint64_t *const erec = edge + chunk * WIDE_EDGE_WORDS;
     if constexpr (REPAIR) {
-        const uint64_t *src = wave ? erec - WIDE_EDGE_WORDS + WIDE_EDGE_WORDS / 2 : erec;   // wave 1: the previous chunk's end | wave 0: this chunk's start
-        m = active ? __longlong_as_double((long long)src[3 * s]) : INFINITY;
-        r = (int)src[3 * s + 1];
-        hist = src[3 * s + 2];
+        const uint64_t *src = wave ? erec - WIDE_EDGE_WORDS + WIDE_EDGE_WORDS / 2 : erec;   // wave 1: the previous chunk's end (as it is now) | wave 0: this chunk's recorded start
+        const uint64_t w0 = active ? src[3 * s] : 0ull, w1 = active ? src[3 * s + 1] : 0ull, w2 = active ? src[3 * s + 2] : 0ull;
+        m = active ? __longlong_as_double((long long)w0) : INFINITY;
+        r = (int)w1;
+        hist = w2;
+        __syncthreads();                                               // wave 0 has the OLD start before wave 1 replaces it
+        if (wave == 1 && active) {                                     // what this run starts from becomes the chunk's recorded start (wf_cpm_detect.h)
+            erec[3 * s] = w0;
+            erec[3 * s + 1] = w1;
+            erec[3 * s + 2] = w2;
+        }
     }
 
     auto fetch = [&](int b, double2 (&dst)[PL]) __attribute__((always_inline)) {
@@ -307,10 +299,28 @@ __global__ __launch_bounds__(REPAIR ? 128 : WIDE_THREADS) void cpm_wide_kernel(c
             merged = __builtin_amdgcn_ballot_w64(diff) == 0ull;         // (symmetric: both waves get the same answer)
             __syncthreads();
         }
-        if (wave == 1)                                                  // the true trajectory's decisions up to the meeting point
+        if (wave == 1) {                                                // the new trajectory's decisions up to the meeting point
             for (int q = lane; q < done; q += 64)
                 if (k_first + q < P.ncalls) out[k_first + q] = dec[q];
-        if (threadIdx.x == 0) atomicAdd(unmerged + (merged ? 1 : 0), 1ull);   // [1]: chunks repaired, [0]: chunks left unproven
+            if (!merged) {                                              // the chunk ENDS in another state than before
+                if (active) {
+                    erec[WIDE_EDGE_WORDS / 2 + 3 * s] = (uint64_t)__double_as_longlong(m);
+                    erec[WIDE_EDGE_WORDS / 2 + 3 * s + 1] = (uint64_t)(int64_t)r;
+                    erec[WIDE_EDGE_WORDS / 2 + 3 * s + 2] = hist;
+                    if (state && k_first + P.CH >= P.ncalls) {          // ... and it owns the burst's last call: the carry
+                        state[WIDE_ST_STAGE + WIDE_ST_M + s] = (uint64_t)__double_as_longlong(m);
+                        state[WIDE_ST_STAGE + WIDE_ST_V + s] = (uint64_t)(int64_t)r;
+                        state[WIDE_ST_STAGE + WIDE_ST_H + s] = hist;
+                    }
+                }
+                if (lane == 0 && chunk + 1 < P.nchunks)                 // the next chunk's start no longer matches: next round
+                    next_list[atomicAdd(reinterpret_cast<unsigned long long *>(next_count), 1ull)] = (uint64_t)(chunk + 1);
+            }
+            if (lane == 0) {
+                atomicAdd(unmerged + 1, 1ull);                          // [1]: chunk repairs run, [2]: ... that handed on
+                if (!merged) atomicAdd(unmerged + 2, 1ull);
+            }
+        }
         return;
     }
     for (int b = 0; b < nbatch; b += 2) {
@@ -338,8 +348,68 @@ __global__ __launch_bounds__(REPAIR ? 128 : WIDE_THREADS) void cpm_wide_kernel(c
     }
 }
 
+__device__ __forceinline__ double *wide_stage_rot(const double2 *__restrict__ rot_cs, const cpm_wide_params &P)   // the caller synchronises
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *rot = reinterpret_cast<double *>(smem + P.rot_off);       // cos at [r], sin at [CPM_ROT_SIN + r]
+    for (int k = threadIdx.x; k < 2 * P.p; k += blockDim.x) {
+        const double2 e = rot_cs[k];
+        rot[k] = e.x;
+        rot[CPM_ROT_SIN + k] = e.y;
+    }
+    return rot;
+}
+
+template <int M_, int LP_>
+__global__ __launch_bounds__(WIDE_THREADS) void cpm_wide_kernel(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
+                                                               uint8_t *__restrict__ out, uint64_t *__restrict__ state,
+                                                               uint64_t *__restrict__ edge, unsigned long long *__restrict__ unmerged,
+                                                               cpm_wide_params P)
+{
+    const double *rot = wide_stage_rot(rot_cs, P);
+    if (blockIdx.x == 0 && threadIdx.x < CPM_NLIST) cpm_list_counts(edge, P.nchunks, WIDE_EDGE_WORDS)[threadIdx.x] = 0;   // the repair lists: empty
+    __syncthreads();
+    cpm_wide_body<M_, LP_, false>(rows, rot, out, state, edge, unmerged, P, (int64_t)blockIdx.x * WIDE_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nullptr, nullptr);
+}
+
+// One repair round (list layout and invariant: wf_cpm_detect.h): a workgroup of TWO waves per listed chunk — wave 0 from the
+// chunk's recorded start, wave 1 from the previous chunk's end — comparing through LDS after every batch.  finisher != 0:
+// one workgroup that goes on, round after round, until a round hands nothing on.
+template <int M_, int LP_>
+__global__ __launch_bounds__(128) void cpm_wide_repair_kernel(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
+                                                              uint8_t *__restrict__ out, uint64_t *__restrict__ state,
+                                                              uint64_t *__restrict__ edge, unsigned long long *__restrict__ unmerged,
+                                                              cpm_wide_params P, int lin, int lout, int finisher)
+{
+    uint64_t *const counts = cpm_list_counts(edge, P.nchunks, WIDE_EDGE_WORDS);
+    int64_t n = (int64_t)__hip_atomic_load(&counts[lin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == 0) return;                                               // (the whole grid)
+    const double *rot = wide_stage_rot(rot_cs, P);
+    __syncthreads();
+    for (;;) {
+        const uint64_t *list = cpm_list(edge, P.nchunks, WIDE_EDGE_WORDS, lin);
+        for (int64_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
+            const uint64_t cw = __hip_atomic_load(&list[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t chunk = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(cw >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)cw));   // (uniform, and said so)
+            cpm_wide_body<M_, LP_, true>(rows, rot, out, state, edge, unmerged, P, chunk, &counts[lout], cpm_list(edge, P.nchunks, WIDE_EDGE_WORDS, lout));
+            __syncthreads();                                          // (the compare area and the waves' buffers are reused)
+        }
+        if (!finisher) return;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&counts[lin], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the next round's output
+        n = (int64_t)__hip_atomic_load(&counts[lout], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __syncthreads();
+        if (n == 0) return;
+        const int t = lin;
+        lin = lout;
+        lout = t;
+    }
+}
+
 // Every chunk against its predecessor: thread = (chunk c >= 1, state s); failed chunks are LISTED behind the records
-// for the repair launch (what does not fit the list is counted as unproven).
+// for the repair launches, or (repair = 0) counted as unproven.
 __global__ void cpm_wide_verify_kernel(uint64_t *__restrict__ edge, int64_t nchunks, int S, uint64_t hmask,
                                        unsigned long long *__restrict__ unmerged, int repair)
 {
@@ -353,10 +423,12 @@ __global__ void cpm_wide_verify_kernel(uint64_t *__restrict__ edge, int64_t nchu
     }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
     if (s == 0 && m) {
-        unsigned long long *fail = reinterpret_cast<unsigned long long *>(edge + nchunks * WIDE_EDGE_WORDS);
-        const unsigned long long i = repair ? atomicAdd(fail, 1ull) : (unsigned long long)CPM_REPAIR_CAP;
-        if (i < CPM_REPAIR_CAP) fail[1 + i] = (unsigned long long)c;
-        else atomicAdd(unmerged, 1ull);
+        if (repair) {
+            unsigned long long *counts = reinterpret_cast<unsigned long long *>(cpm_list_counts(edge, nchunks, WIDE_EDGE_WORDS));
+            cpm_list(edge, nchunks, WIDE_EDGE_WORDS, 0)[atomicAdd(counts, 1ull)] = (uint64_t)c;
+        } else {
+            atomicAdd(unmerged, 1ull);
+        }
     }
 }
 
@@ -414,16 +486,24 @@ int wf_cpm_wide_applies(const wf_cpm_detector_config *d)
 }
 
 // Chunk length of the wide form: the smallest multiple of 64 that puts the burst into one round of resident waves (8
-// workgroups of 4 detectors per CU), at least 256 and 2 W.
-int64_t wf_cpm_wide_chunk_calls(int64_t ncalls, int W, int cus)
+// workgroups of 4 detectors per CU), at least 256 and 2 W (chunk_opt: WF_OPT_CPM_CHUNK_CALLS, 0 = this rule).
+int64_t wf_cpm_wide_chunk_calls(int64_t ncalls, int W, int cus, int64_t chunk_opt)
 {
     const int64_t slots = (int64_t)cus * 8 * WIDE_WAVES;
     int64_t ch = ((ncalls + slots - 1) / slots + 63) / 64 * 64;
     if (ch < 256) ch = 256;
     if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
-    if (const char *e = getenv("WF_CPM_WIDE_CH")) ch = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : ch;
+    if (chunk_opt > 0) ch = (chunk_opt + 63) / 64 * 64;
     if (ch > 8192) ch = 8192;
     return ch;
+}
+
+// Default warm-up: 160 calls (chunks that miss it are repaired by the launches behind the first); a multiple of two batches.
+int wf_cpm_wide_warmup(int warmup)
+{
+    int W = warmup ? warmup : 160;
+    W = (W + 2 * WIDE_TB - 1) / (2 * WIDE_TB) * (2 * WIDE_TB);
+    return W > 4096 ? 4096 : W;
 }
 
 int wf_cpm_wide_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
@@ -436,14 +516,8 @@ int wf_cpm_wide_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const dou
     for (int i = 0; i < det->nh; ++i) WF_REQUIRE(det->K[i] >= 0 && det->K[i] < det->p, "wf_cpm: K[%d] = %d outside [0, p)", i, det->K[i]);
     int rc = wide_build_tables(det, P);
     if (rc) return rc;
-    // Default warm-up: 160 calls.  (Chunks that miss it are repaired by the second launch; what that cannot settle is
-    // counted — wf_viterbi4_unmerged — and the caller repeats with a longer one.)
-    int W = warmup ? warmup : 160;
-    W = (W + 2 * WIDE_TB - 1) / (2 * WIDE_TB) * (2 * WIDE_TB);
-    if (W > 4096) W = 4096;
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    P.CH = (int)wf_cpm_wide_chunk_calls(ncalls, W, cus);
+    const int W = wf_cpm_wide_warmup(warmup);
+    P.CH = (int)wf_cpm_wide_chunk_calls(ncalls, W, ctx->cus, ctx->opt[WF_OPT_CPM_CHUNK_CALLS]);
     P.W = W;
     P.ncalls = ncalls;
     const int pieces = WIDE_TB * P.NF;
@@ -459,18 +533,20 @@ int wf_cpm_wide_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const dou
     const int64_t nblocks = (nchunks + WIDE_WAVES - 1) / WIDE_WAVES;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_viterbi_detect: burst too long for one launch");
     P.nchunks = nchunks;
-    rc = wf_ctx_reserve_vit(ctx, (size_t)nchunks * WIDE_EDGE_WORDS + 1 + CPM_REPAIR_CAP);
+    rc = wf_ctx_reserve_vit(ctx, cpm_edge_total_words(nchunks, WIDE_EDGE_WORDS));
     if (rc) return rc;
     uint64_t *edge = reinterpret_cast<uint64_t *>(ctx->d_vit_edge);
     hipStream_t s = wf_stream(stream);
     using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_wide_params);
-    kern_t k = nullptr, kr = nullptr;
+    using repair_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_wide_params, int, int, int);
+    kern_t k = nullptr;
+    repair_t kr = nullptr;
     if (P.M == 4) {
-        k = P.Lp == 1 ? cpm_wide_kernel<4, 1, false> : (P.Lp == 2 ? cpm_wide_kernel<4, 2, false> : cpm_wide_kernel<4, 3, false>);
-        kr = P.Lp == 1 ? cpm_wide_kernel<4, 1, true> : (P.Lp == 2 ? cpm_wide_kernel<4, 2, true> : cpm_wide_kernel<4, 3, true>);
+        k = P.Lp == 1 ? cpm_wide_kernel<4, 1> : (P.Lp == 2 ? cpm_wide_kernel<4, 2> : cpm_wide_kernel<4, 3>);
+        kr = P.Lp == 1 ? cpm_wide_repair_kernel<4, 1> : (P.Lp == 2 ? cpm_wide_repair_kernel<4, 2> : cpm_wide_repair_kernel<4, 3>);
     } else {
-        k = P.Lp == 1 ? cpm_wide_kernel<2, 1, false> : (P.Lp == 2 ? cpm_wide_kernel<2, 2, false> : cpm_wide_kernel<2, 3, false>);
-        kr = P.Lp == 1 ? cpm_wide_kernel<2, 1, true> : (P.Lp == 2 ? cpm_wide_kernel<2, 2, true> : cpm_wide_kernel<2, 3, true>);
+        k = P.Lp == 1 ? cpm_wide_kernel<2, 1> : (P.Lp == 2 ? cpm_wide_kernel<2, 2> : cpm_wide_kernel<2, 3>);
+        kr = P.Lp == 1 ? cpm_wide_repair_kernel<2, 1> : (P.Lp == 2 ? cpm_wide_repair_kernel<2, 2> : cpm_wide_repair_kernel<2, 3>);
     }
     if (lds > 48 * 1024) {
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -482,18 +558,23 @@ int wf_cpm_wide_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const dou
     if (nchunks > 1) {
         const int lgM = P.M == 4 ? 2 : 1;
         const uint64_t hmask = lgM * P.D >= 64 ? ~0ull : ((1ull << (lgM * P.D)) - 1ull);
-        const char *nr = getenv("WF_CPM_NO_REPAIR");
-        const int repair = nr && atoi(nr) ? 0 : 1;
-        hipLaunchKernelGGL(cpm_wide_verify_kernel, dim3((unsigned)(((nchunks - 1) * 64 + 255) / 256)), dim3(256), 0, s, edge, nchunks, P.S, hmask,
-                           ctx->d_vit_unmerged, repair);
+        const int repair = ctx->opt[WF_OPT_DET_REPAIR] == 0 ? 1 : 0;
+        const dim3 vgrid((unsigned)(((nchunks - 1) * 64 + 255) / 256));
+        hipLaunchKernelGGL(cpm_wide_verify_kernel, vgrid, dim3(256), 0, s, edge, nchunks, P.S, hmask, ctx->d_vit_unmerged, repair);
         WF_LAUNCH_CHECK();
         if (repair) {
             cpm_wide_params Pr = P;
             Pr.W = 0;
-            hipLaunchKernelGGL(kr, dim3(CPM_REPAIR_CAP), dim3(128), lds, s, reinterpret_cast<const double2 *>(d_rows_ri),
-                               reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
-                               ctx->d_vit_unmerged, Pr);
-            WF_LAUNCH_CHECK();
+            for (int round = 0; round < 3; ++round) {               // two parallel rounds, then the finisher (wf_cpm_detect.h)
+                hipLaunchKernelGGL(kr, dim3(round < 2 ? 4 * CPM_REPAIR_BLOCKS : 1), dim3(128), lds, s, reinterpret_cast<const double2 *>(d_rows_ri),
+                                   reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), edge,
+                                   ctx->d_vit_unmerged, Pr, round, round + 1, round == 2 ? 1 : 0);
+                WF_LAUNCH_CHECK();
+            }
+            if (ctx->opt[WF_OPT_DET_FINAL_VERIFY]) {
+                hipLaunchKernelGGL(cpm_wide_verify_kernel, vgrid, dim3(256), 0, s, edge, nchunks, P.S, hmask, ctx->d_vit_unmerged, 0);
+                WF_LAUNCH_CHECK();
+            }
         }
     }
     if (d_state) {

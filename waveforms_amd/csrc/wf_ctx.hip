@@ -26,12 +26,14 @@ extern "C" int wf_ctx_create(int device, wf_ctx **out)
     WF_HIP(hipSetDevice(device));
     wf_ctx *c = new wf_ctx();
     c->device = device;
+    (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (c->cus < 1) c->cus = 256;
     WF_HIP(hipMalloc(&c->d_fault, 64));
     WF_HIP(hipMemset(c->d_fault, 0, 64));
     WF_HIP(hipHostMalloc(&c->h_fault, 64, hipHostMallocDefault));
     WF_HIP(hipMalloc(&c->d_tables, 4096));
-    WF_HIP(hipMalloc(&c->d_vit_unmerged, 2 * sizeof(unsigned long long)));      // [0] chunks left unproven, [1] chunks repaired on the device
-    WF_HIP(hipMemset(c->d_vit_unmerged, 0, 2 * sizeof(unsigned long long)));
+    WF_HIP(hipMalloc(&c->d_vit_unmerged, 4 * sizeof(unsigned long long)));      // [0] chunks left unproven, [1] chunk repairs run, [2] ... that handed on to the next chunk
+    WF_HIP(hipMemset(c->d_vit_unmerged, 0, 4 * sizeof(unsigned long long)));
     WF_HIP(hipMalloc(&c->d_small, 256));
     WF_HIP(hipHostMalloc(&c->h_small, 256, hipHostMallocDefault));
     *out = c;
@@ -102,6 +104,30 @@ extern "C" int wf_link_join(wf_ctx *c, void *stream)
     return wf_link_join_internal(c, stream);
 }
 
+extern "C" int wf_ctx_set_option(wf_ctx *c, int key, int64_t value)
+{
+    WF_REQUIRE(c != nullptr, "wf_ctx_set_option: ctx is NULL");
+    WF_REQUIRE(key >= 0 && key < WF_OPT_COUNT, "wf_ctx_set_option: unknown option %d", key);
+    bool ok = true;
+    switch (key) {
+    case WF_OPT_CPM_FORM: ok = value >= 0 && value <= 2; break;
+    case WF_OPT_CPM_CHUNK_CALLS: ok = value >= 0 && value <= 8192; break;
+    case WF_OPT_DET_REPAIR: case WF_OPT_DET_FINAL_VERIFY: case WF_OPT_ITERATION_SERVER: ok = value == 0 || value == 1; break;
+    case WF_OPT_MCB_TAIL_PERMILLE: ok = value >= -1 && value <= 16000; break;
+    }
+    WF_REQUIRE(ok, "wf_ctx_set_option: value %lld outside the range of option %d", (long long)value, key);
+    c->opt[key] = value;
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_get_option(wf_ctx *c, int key, int64_t *value)
+{
+    WF_REQUIRE(c != nullptr && value != nullptr, "wf_ctx_get_option: NULL argument");
+    WF_REQUIRE(key >= 0 && key < WF_OPT_COUNT, "wf_ctx_get_option: unknown option %d", key);
+    *value = c->opt[key];
+    return WF_OK;
+}
+
 extern "C" int wf_ctx_check(wf_ctx *c, void *stream)
 {
     WF_REQUIRE(c != nullptr, "wf_ctx_check: ctx is NULL");
@@ -165,10 +191,6 @@ int wf_ctx_reserve_mod(wf_ctx *c, size_t words)
 int wf_ctx_reserve_vit(wf_ctx *c, size_t words)
 {
     if (words <= c->vit_edge_words) return WF_OK;
-    {   // a deferred proof points into the block about to be freed: it runs first (only a failed wf_link_run leaves one behind)
-        const int rf = wf_vit_flush_verify(c, nullptr);
-        if (rf) return rf;
-    }
     WF_HIP(hipDeviceSynchronize());
     if (c->d_vit_edge) WF_HIP(hipFree(c->d_vit_edge));
     c->d_vit_edge = nullptr;

@@ -1565,8 +1565,9 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     //  profiles/r04_ab_front_end_grid_cap.log)
     const int64_t max_grid = (int64_t)cus * ((cpm_nf && JM != 4) || pam ? 3 : 4) * runs_per_slot;
     const int64_t per_run = (P.ntiles + max_grid - 1) / max_grid;
-    // the last `tail` tiles go out one per workgroup (WF_MCB_TAIL_SLOTS resident-slot-fulls of them; 0 = equal runs throughout)
-    static const double tail_slots = [] { const char *e = getenv("WF_MCB_TAIL_SLOTS"); return e ? atof(e) : WF_MCB_TAIL_SLOTS_DEFAULT; }();
+    // the last `tail` tiles go out one per workgroup (WF_OPT_MCB_TAIL_PERMILLE / 1000 resident-slot-fulls of them)
+    const int64_t tail_opt = ctx->opt[WF_OPT_MCB_TAIL_PERMILLE];        // (a tuning aid: 0 = the default above, -1 = equal runs throughout)
+    const double tail_slots = tail_opt == 0 ? WF_MCB_TAIL_SLOTS_DEFAULT : (tail_opt < 0 ? 0.0 : (double)tail_opt / 1000.0);
     // (SOQPSK forms only: PT -1.9 %, PAM -3.8 %; the ARTM form, whose 2.56 GB of row stores bind it, measured + 1.3 % and its detector + 1.5 %)
     int64_t tail = per_run > 1 && cpm_nf == 0 ? (int64_t)(tail_slots * (double)(max_grid / runs_per_slot)) : 0;
     if (tail > P.ntiles / 2) tail = P.ntiles / 2;

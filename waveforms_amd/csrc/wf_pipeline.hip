@@ -202,18 +202,13 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
         }
 #define MARKB(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(back))); } while (0)
         MARKB(6);
-        ctx->vit_defer_verify = true;      // the error counter below runs the detector's wave-edge proof: one launch less
         rc = wf_viterbi4_detect_packed(ctx, mf, L.ncols, cfg->differential, link_warmup(cfg), dbits, dsyms, nullptr, back);
-        ctx->vit_defer_verify = false;
         if (rc) return rc;
         MARKB(7);
         int64_t m_ = L.ncols - length;
         if (m_ > cfg->nsym) m_ = cfg->nsym;
         if (m_ < 0) m_ = 0;
-        if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, back))) {   // (m_ = 0: only the proof)
-            (void)wf_vit_flush_verify(ctx, back);    // the counter refused before it took the proof over: the proof still runs
-            return rc;
-        }
+        if ((rc = wf_count_errors(ctx, dsyms + length, syms, dbits + length, bits, m_, d_counts, back))) return rc;
         MARKB(8);
 #undef MARKB
         if (piped) {

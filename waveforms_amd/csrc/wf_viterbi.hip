@@ -133,19 +133,15 @@ struct vit_lane {
     double ms[4];                        // metrics the warm-up arrived at, just before the lane's first own call
 };
 
-// One detector call k (COL = column parity of k): stage 0 commits the previous call's
+// One detector call (COL = column parity of the call): stage 0 commits the previous call's
 // increments from the min-normalised carried metrics, stage 1 looks one symbol ahead,
 // depth-2 traceback from the first arg-min (algorithm.py:57-101 with length = 2).
+// Decision out: bit = input bit, cd0 | cd1 << 1 = sym / 2 + 1.
 template <int COL, bool PACKED>
-__device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict__ zrow, bool prime, int diff,
-                                         int64_t k, int64_t a, int64_t ncalls, uint64_t *__restrict__ dec)
+__device__ __forceinline__ void vit_step_core(vit_lane &L, const double2 *__restrict__ zrow, int diff, bool &bit, bool &cd0, bool &cd1)
 {
     constexpr int PREV = COL ^ 1;
     const vit_comp now = vit_components<COL, PACKED>(zrow);
-    if (prime) {   // priming row: exact components of the call before the warm-up
-        L.prev = now;
-        return;
-    }
     const double mn = fmin(fmin(L.m0[0], L.m0[1]), fmin(L.m0[2], L.m0[3]));
     const double carried[4] = {L.m0[0] - mn, L.m0[1] - mn, L.m0[2] - mn, L.m0[3] - mn};
     double ma[4], mb[4];
@@ -177,11 +173,26 @@ __device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict_
     const uint64_t x02 = b0 ^ b2, x01 = b0 ^ b1, x12 = b1 ^ b2;
     const uint64_t cd0_m = PREV == 0 ? ~x02 : ~x01;
     const uint64_t cd1_m = PREV == 0 ? (x02 & ~x12) : (x01 & ~x02);
-    const bool bit = __builtin_amdgcn_inverse_ballot_w64(bit_m);
-    const bool cd0 = __builtin_amdgcn_inverse_ballot_w64(cd0_m), cd1 = __builtin_amdgcn_inverse_ballot_w64(cd1_m);
+    bit = __builtin_amdgcn_inverse_ballot_w64(bit_m);
+    cd0 = __builtin_amdgcn_inverse_ballot_w64(cd0_m);
+    cd1 = __builtin_amdgcn_inverse_ballot_w64(cd1_m);
 #pragma unroll
     for (int s = 0; s < 4; ++s) L.m0[s] = ma[s];
     L.prev = now;
+}
+
+// ... of the batch kernel: call k of a lane that owns calls [a, ...); prime = the row before the warm-up (its exact
+// components only).
+template <int COL, bool PACKED>
+__device__ __forceinline__ void vit_step(vit_lane &L, const double2 *__restrict__ zrow, bool prime, int diff,
+                                         int64_t k, int64_t a, int64_t ncalls, uint64_t *__restrict__ dec)
+{
+    if (prime) {   // priming row: exact components of the call before the warm-up
+        L.prev = vit_components<COL, PACKED>(zrow);
+        return;
+    }
+    bool bit, cd0, cd1;
+    vit_step_core<COL, PACKED>(L, zrow, diff, bit, cd0, cd1);
     if (k >= a) {
         // Decisions stay on chip until the lane's chunk is done: packed here (bit c: input bit;
         // bits 2c..2c+1: sym / 2 + 1), one 8 B word per 16 calls parked in the wave's LDS strip,
@@ -295,8 +306,7 @@ template <int PAR0, bool PACKED>   // PAR0: column parity of step 0's call index
 __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf, int64_t ncalls, int CH, int diff, int warmup,
                                                    uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
                                                    double *__restrict__ state, int64_t i0, double2 (*s_rows)[WF_WAVE * VIT_LANE_SLOTS],
-                                                   uint64_t *__restrict__ s_dec, double *__restrict__ edge,
-                                                   unsigned long long *__restrict__ unmerged)
+                                                   uint64_t *__restrict__ s_dec, double *__restrict__ edge)
 {
     constexpr int RW = PACKED ? 2 : 3;                 // double2 per row
     constexpr int NP = VIT_PIECES_RW(RW);             // 16-byte pieces per lane-segment and batch
@@ -414,27 +424,13 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
     if (live) vit_flush(dec, CH, a, ncalls, bits, syms);   // same lane wrote the strip: in-order LDS, no barrier
     // Proof obligation of the chunk-parallel form: the metrics a lane's warm-up arrived at must be
     // BITWISE the metrics its predecessor ended with (then every later compare is the sequential
-    // detector's).  Inside a wave the predecessor's end state is one DPP shift away; the first lane
-    // of a wave and the last lane of the previous one meet in `edge` (viterbi_verify_kernel).
-    // Mismatches only count up `unmerged`; callers re-run with a longer warm-up (it never happened
-    // in any test or sweep, down to 0 dB and on unstructured random rows).
-    if (edge) {
-        bool bad = false;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const double pe = wf_wave_shr1(L.m0[s4]);
-            bad |= __double_as_longlong(pe) != __double_as_longlong(L.ms[s4]);
-        }
-        bad = bad && live && lane > 0;
-        const unsigned long long nb = __builtin_amdgcn_ballot_w64(bad);
-        if (nb && lane == 0) atomicAdd(unmerged, (unsigned long long)__popcll(nb));
-        double *e = edge + 8 * (g0 >> 6);
-        if (live && lane == 0)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) e[s4] = L.ms[s4];
-        if (live && lane == WF_WAVE - 1)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) e[4 + s4] = L.m0[s4];
+    // detector's).  Every lane records what its own calls started from and what they ended with
+    // (64 B per chunk, one coalesced 4 KB run per wave); viterbi_fixup_kernel compares neighbours and
+    // runs the chunks that differ again from the true metrics.
+    if (edge && live) {
+        double *e = edge + 8 * (g0 + lane);
+        *reinterpret_cast<double4 *>(e) = make_double4(L.ms[0], L.ms[1], L.ms[2], L.ms[3]);
+        *reinterpret_cast<double4 *>(e + 4) = make_double4(L.m0[0], L.m0[1], L.m0[2], L.m0[3]);
     }
     if (state && live && a + CH >= ncalls) {
         // the lane that owns the last call hands the detector state on (streaming).  Written
@@ -449,42 +445,143 @@ __device__ __forceinline__ void viterbi_batch_body(const double *__restrict__ mf
 #ifndef VIT_MIN_WAVES
 #define VIT_MIN_WAVES 1
 #endif
+// Proof records and repair lists of the 4-state detectors (batch and window form alike), in the context's scratch:
+//   rec[nchunks][8]   doubles: {the C / metrics a chunk's own calls started from [4], what they ended with [4]}
+//   hdr[VIT_HDR]      u64: [0], [1] entries in list 0 / 1, [2] the fix-up launch's arrival ticket
+//   list[2][nchunks]  u64 chunk indices
+// viterbi_fixup_kernel / vwin_fixup_kernel, ONE launch behind the detector: every workgroup compares its share of the
+// chunk boundaries and lists the chunks whose start is not bitwise their predecessor's end; the workgroup that arrives
+// last then repairs: a thread per listed chunk runs the chunk's calls AGAIN from the predecessor's end (which becomes the
+// chunk's recorded start), rewrites its decisions and its end, and lists the next chunk when that end changed — round
+// after round (lists 0 <-> 1) until a round lists nothing.  Every round's smallest chunk is run from the true state, so
+// the consistent prefix grows each round: at worst the rounds are the sequential detector (algorithm.py:44-101), and
+// the warm-up only decides how often any of this runs (at the default, at any Eb/N0 measured: never).
+#define VIT_HDR 8
+__host__ __device__ inline size_t vit_edge_words(int64_t nchunks) { return (size_t)nchunks * 8 + VIT_HDR + 2 * (size_t)nchunks; }
+
 template <bool PACKED>
 __global__ __launch_bounds__(VIT_THREADS, VIT_MIN_WAVES) void viterbi_batch_kernel(const double *__restrict__ mf, int64_t ncalls,
                                                                      int ch, int diff, int warmup, uint8_t *__restrict__ bits,
                                                                      int8_t *__restrict__ syms, double *__restrict__ state,
-                                                                     double *__restrict__ edge, unsigned long long *__restrict__ unmerged)
+                                                                     double *__restrict__ edge, int64_t nchunks)
 {
     __shared__ double2 s_rows[VIT_THREADS / WF_WAVE][WF_WAVE * VIT_LANE_SLOTS];
     extern __shared__ uint64_t s_dec[];   // packed decisions, one strip of ch / 16 + 1 words per lane
     const int64_t i0 = state ? (int64_t)state[0] : 0;
+    if (blockIdx.x == 0 && threadIdx.x < VIT_HDR) reinterpret_cast<uint64_t *>(edge + 8 * nchunks)[threadIdx.x] = 0;   // lists empty, nobody arrived
     // call index of step 0 is lane_start - warmup - 1 with lane_start a multiple of ch (even)
-    if ((i0 - warmup - 1) & 1) viterbi_batch_body<1, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec, edge, unmerged);
-    else viterbi_batch_body<0, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec, edge, unmerged);
+    if ((i0 - warmup - 1) & 1) viterbi_batch_body<1, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec, edge);
+    else viterbi_batch_body<0, PACKED>(mf, ncalls, ch, diff, warmup, bits, syms, state, i0, s_rows, s_dec, edge);
 }
 
-// Wave w's first lane against wave w-1's last lane (see the end of viterbi_batch_body).
-__global__ void viterbi_verify_kernel(const double *__restrict__ edge, int64_t nwaves, unsigned long long *__restrict__ unmerged)
+// The part of the fix-up launch both forms share: compare, list (or, mode 0, count), and elect the last workgroup.
+// Returns true in every thread of the workgroup that arrived last (all others are done).  mode: 1 = list for repair,
+// 0 = count as unproven (WF_OPT_DET_REPAIR off; the closing check of WF_OPT_DET_FINAL_VERIFY).
+__device__ __forceinline__ bool vit_fixup_verify(double *__restrict__ edge, int64_t nchunks, unsigned long long *__restrict__ unmerged, int mode)
 {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (w >= nwaves) return;
-    bool bad = false;
-    for (int s4 = 0; s4 < 4; ++s4)
-        bad |= __double_as_longlong(edge[8 * w + s4]) != __double_as_longlong(edge[8 * (w - 1) + 4 + s4]);
-    if (bad) atomicAdd(unmerged, 1ull);
+    __shared__ int s_last;
+    unsigned long long *hdr = reinterpret_cast<unsigned long long *>(edge + 8 * nchunks);
+    unsigned long long *list0 = hdr + VIT_HDR;
+    const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(edge);
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; c < nchunks; c += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long *st = rec + 8 * c, *en = rec + 8 * (c - 1) + 4;
+        if (st[0] != en[0] || st[1] != en[1] || st[2] != en[2] || st[3] != en[3]) {
+            if (mode) list0[atomicAdd(&hdr[0], 1ull)] = (unsigned long long)c;
+            else atomicAdd(unmerged, 1ull);
+        }
+    }
+    if (!mode) return false;
+    __threadfence();                                       // this workgroup's entries before its arrival
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&hdr[2], 1ull) + 1 == (unsigned long long)gridDim.x;
+    __syncthreads();
+    if (!s_last) return false;
+    __threadfence();                                       // ... and everybody's before the repairs read them
+    return true;
 }
 
-int wf_vit_flush_verify(wf_ctx *ctx, void *stream)
+// The round loop of the last workgroup: `repair(c)` runs chunk c again and returns true when its end changed.
+template <class F>
+__device__ __forceinline__ void vit_fixup_rounds(double *__restrict__ edge, int64_t nchunks, unsigned long long *__restrict__ unmerged, F &&repair)
 {
-    if (!ctx || !ctx->vit_pending_edge) return WF_OK;
-    const double *edge = ctx->vit_pending_edge;
-    const int64_t nw = ctx->vit_pending_nwaves;
-    ctx->vit_pending_edge = nullptr;
-    ctx->vit_pending_nwaves = 0;
-    hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((nw - 1 + 255) / 256)), dim3(256), 0, wf_stream(stream), edge, nw,
-                       ctx->d_vit_unmerged);
-    WF_LAUNCH_CHECK();
-    return WF_OK;
+    unsigned long long *hdr = reinterpret_cast<unsigned long long *>(edge + 8 * nchunks);
+    int lin = 0;
+    for (;;) {
+        const int64_t n = (int64_t)__hip_atomic_load(&hdr[lin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == 0) return;
+        unsigned long long *in = hdr + VIT_HDR + (int64_t)lin * nchunks, *out = hdr + VIT_HDR + (int64_t)(lin ^ 1) * nchunks;
+        for (int64_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
+            const int64_t c = (int64_t)__hip_atomic_load(&in[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool changed = repair(c);
+            atomicAdd(unmerged + 1, 1ull);                 // [1]: chunk repairs run, [2]: ... whose end changed (handed on)
+            if (changed) {
+                atomicAdd(unmerged + 2, 1ull);
+                if (c + 1 < nchunks) out[atomicAdd(&hdr[lin ^ 1], 1ull)] = (unsigned long long)(c + 1);
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&hdr[lin], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: the round after next fills it
+        __threadfence();
+        __syncthreads();
+        lin ^= 1;
+    }
+}
+
+// Chunk c of the length-2 detector again, by ONE thread straight from global memory: metrics from the predecessor's
+// end, the previous call's components from its own row (exact), every call of the chunk, decisions rewritten.
+template <int PAR, bool PACKED>                            // PAR: column parity of the chunk's first call (chunks start on even local calls)
+__device__ __forceinline__ bool vit_rerun_chunk(const double *__restrict__ mf, int64_t ncalls, int CH, int diff, uint8_t *__restrict__ bits,
+                                                int8_t *__restrict__ syms, double *__restrict__ state, int64_t i0, double *__restrict__ edge, int64_t c)
+{
+    constexpr int RW = PACKED ? 2 : 3;
+    const double2 *rows = reinterpret_cast<const double2 *>(mf);
+    const int64_t a = c * CH, kend = a + CH < ncalls ? a + CH : ncalls;
+    double *rec = edge + 8 * c;
+    vit_lane L;
+    L.wb = L.ws = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double v = __hip_atomic_load(rec - 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the predecessor's end, as it is now
+        L.m0[q] = v;
+        rec[q] = v;                                        // ... is what this run of the chunk starts from
+    }
+    L.prev = vit_components<PAR ^ 1, PACKED>(rows + RW * (a - 1));      // (a >= CH: only chunks c >= 1 are ever listed)
+    for (int64_t k = a; k < kend; k += 2) {
+        bool bit, cd0, cd1;
+        vit_step_core<PAR, PACKED>(L, rows + RW * k, diff, bit, cd0, cd1);
+        bits[k] = bit ? 1 : 0;
+        syms[k] = (int8_t)(2 * ((cd0 ? 1 : 0) | (cd1 ? 2 : 0)) - 2);
+        if (k + 1 < kend) {
+            vit_step_core<PAR ^ 1, PACKED>(L, rows + RW * (k + 1), diff, bit, cd0, cd1);
+            bits[k + 1] = bit ? 1 : 0;
+            syms[k + 1] = (int8_t)(2 * ((cd0 ? 1 : 0) | (cd1 ? 2 : 0)) - 2);
+        }
+    }
+    bool changed = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        changed |= __double_as_longlong(rec[4 + q]) != __double_as_longlong(L.m0[q]);
+        rec[4 + q] = L.m0[q];
+    }
+    if (changed && state && a + CH >= ncalls) {            // the chunk that owns the last call: the carry (staging half, see viterbi_batch_body)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) state[17 + q] = L.m0[q];
+    }
+    return changed;
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void viterbi_fixup_kernel(const double *__restrict__ mf, int64_t ncalls, int ch, int diff,
+                                                            uint8_t *__restrict__ bits, int8_t *__restrict__ syms, double *__restrict__ state,
+                                                            double *__restrict__ edge, int64_t nchunks, unsigned long long *__restrict__ unmerged, int mode)
+{
+    if (!vit_fixup_verify(edge, nchunks, unmerged, mode)) return;
+    const int64_t i0 = state ? (int64_t)state[0] : 0;
+    if (i0 & 1)
+        vit_fixup_rounds(edge, nchunks, unmerged, [&](int64_t c) { return vit_rerun_chunk<1, PACKED>(mf, ncalls, ch, diff, bits, syms, state, i0, edge, c); });
+    else
+        vit_fixup_rounds(edge, nchunks, unmerged, [&](int64_t c) { return vit_rerun_chunk<0, PACKED>(mf, ncalls, ch, diff, bits, syms, state, i0, edge, c); });
 }
 
 __global__ void viterbi_carry_commit_kernel(double *state)
@@ -515,13 +612,12 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     ch = (ch + 15) / 16 * 16;
     if (ch < 32) ch = 32;
     if (ch > 512) ch = 512;
-    const int64_t nthreads = (ncalls + ch - 1) / ch;
+    const int64_t nthreads = (ncalls + ch - 1) / ch;       // chunks
     const int64_t nblocks = (nthreads + VIT_THREADS - 1) / VIT_THREADS;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect: burst too long for one launch");
     hipStream_t s = wf_stream(stream);
     const size_t lds = (size_t)VIT_THREADS * (ch / 16 + 1) * sizeof(uint64_t);
-    const int64_t nwaves_live = (nthreads + WF_WAVE - 1) / WF_WAVE;     // waves that own at least one call
-    int rcv = wf_ctx_reserve_vit(ctx, (size_t)nwaves_live * 8);
+    int rcv = wf_ctx_reserve_vit(ctx, vit_edge_words(nthreads));
     if (rcv) return rcv;
     double *edge = ctx->d_vit_edge;
     if (lds > 32 * 1024) {
@@ -531,22 +627,23 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     }
     if (packed)
         hipLaunchKernelGGL(viterbi_batch_kernel<true>, dim3((unsigned)nblocks), dim3(VIT_THREADS), lds, s, d_mf_ri, ncalls, ch,
-                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state, edge, ctx->d_vit_unmerged);
+                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state, edge, nthreads);
     else
         hipLaunchKernelGGL(viterbi_batch_kernel<false>, dim3((unsigned)nblocks), dim3(VIT_THREADS), lds, s, d_mf_ri, ncalls, ch,
-                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state, edge, ctx->d_vit_unmerged);
+                           differential ? 1 : 0, warmup, d_bits, d_syms, d_state, edge, nthreads);
     WF_LAUNCH_CHECK();
-    if (nwaves_live > 1) {
-        if (ctx->vit_defer_verify) {          // the link's error counter, next on this stream, does the compares (wf_count.hip)
-            if (ctx->vit_pending_edge) {      // a proof left behind by a call that failed between detector and counter: it runs now
-                const int rf = wf_vit_flush_verify(ctx, stream);
-                if (rf) return rf;
-            }
-            ctx->vit_pending_edge = edge;
-            ctx->vit_pending_nwaves = nwaves_live;
-        } else {
-            hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((nwaves_live - 1 + 255) / 256)), dim3(256), 0, s, edge,
-                               nwaves_live, ctx->d_vit_unmerged);
+    if (nthreads > 1) {
+        // compare the chunk boundaries, repair what differs (viterbi_fixup_kernel); mode 0 only counts
+        const unsigned fgrid = (unsigned)wf_grid_for(nthreads - 1, 256, 1024);
+        const int passes = ctx->opt[WF_OPT_DET_REPAIR] == 0 && ctx->opt[WF_OPT_DET_FINAL_VERIFY] ? 2 : 1;
+        for (int pass = 0; pass < passes; ++pass) {
+            const int mode = pass == 0 && ctx->opt[WF_OPT_DET_REPAIR] == 0 ? 1 : 0;
+            if (packed)
+                hipLaunchKernelGGL(viterbi_fixup_kernel<true>, dim3(fgrid), dim3(256), 0, s, d_mf_ri, ncalls, ch, differential ? 1 : 0, d_bits, d_syms,
+                                   d_state, edge, nthreads, ctx->d_vit_unmerged, mode);
+            else
+                hipLaunchKernelGGL(viterbi_fixup_kernel<false>, dim3(fgrid), dim3(256), 0, s, d_mf_ri, ncalls, ch, differential ? 1 : 0, d_bits, d_syms,
+                                   d_state, edge, nthreads, ctx->d_vit_unmerged, mode);
             WF_LAUNCH_CHECK();
         }
     }
@@ -586,6 +683,19 @@ extern "C" int wf_viterbi_repaired(wf_ctx *ctx, int64_t *h_count, int reset, voi
     WF_HIP(hipMemcpyAsync(&v, ctx->d_vit_unmerged + 1, sizeof(v), hipMemcpyDeviceToHost, s));
     WF_HIP(hipStreamSynchronize(s));
     if (reset && v) WF_HIP(hipMemsetAsync(ctx->d_vit_unmerged + 1, 0, sizeof(v), s));
+    *h_count = (int64_t)v;
+    return WF_OK;
+}
+
+extern "C" int wf_viterbi_cascaded(wf_ctx *ctx, int64_t *h_count, int reset, void *stream)
+{
+    WF_REQUIRE(ctx && h_count, "wf_viterbi_cascaded: NULL argument");
+    WF_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = wf_stream(stream);
+    unsigned long long v = 0;
+    WF_HIP(hipMemcpyAsync(&v, ctx->d_vit_unmerged + 2, sizeof(v), hipMemcpyDeviceToHost, s));
+    WF_HIP(hipStreamSynchronize(s));
+    if (reset && v) WF_HIP(hipMemsetAsync(ctx->d_vit_unmerged + 2, 0, sizeof(v), s));
     *h_count = (int64_t)v;
     return WF_OK;
 }
@@ -744,22 +854,25 @@ __device__ __forceinline__ void vwin_stage_mis(double m[4], uint32_t d[4], const
     }
 }
 
-__global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const double2 *__restrict__ rows, int64_t ncalls, int L, int CH, int W,
-                                                                       int diff, uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
-                                                                       double *__restrict__ state, double *__restrict__ erec)
+// One chunk of the window detector by one thread (ring: this thread's (2 L + 1) 16-byte slots of LDS).  start == nullptr:
+// the first launch — W warm-up calls from zero metrics (or, for the chunk at the head of the burst, the carried
+// detector).  start != nullptr: a repair (vwin_fixup_kernel) — the chunk's own calls again from those C, decisions and
+// end record rewritten; returns true when the chunk's END changed.
+__device__ __forceinline__ bool vwin_chunk(const double2 *__restrict__ rows, int64_t ncalls, int L, int CH, int W, int diff,
+                                           uint8_t *__restrict__ bits, int8_t *__restrict__ syms, double *__restrict__ state,
+                                           double *__restrict__ erec, double2 *__restrict__ ring, int64_t chunk, const double *start)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 s_ring[];
-    const int stride = 2 * L + 1;                                     // 16-byte slots per lane (odd)
-    double2 *ring = s_ring + (size_t)threadIdx.x * stride;
-    const int64_t chunk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t a = chunk * CH;
     const bool live = a < ncalls;
     const int64_t i0 = state ? (int64_t)state[0] : 0;                 // calls made before this launch
     const int64_t kend = live ? (a + CH < ncalls ? a + CH : ncalls) : 0;
-    const bool exact = a <= W;                                        // starts at call 0 from the carried detector itself
-    const int64_t ks = exact ? 0 : a - W;                             // even: CH and W are even
+    const bool exact = start != nullptr || a <= W;                    // starts from the true C: a repair, or call 0 from the carried detector itself
+    const int64_t ks = start ? a : (exact ? 0 : a - W);               // even: CH and W are even
     double C[4] = {0.0, 0.0, 0.0, 0.0};
-    if (exact && state && i0 > 0) {
+    if (start) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[q] = start[q];
+    } else if (exact && state && i0 > 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) C[q] = state[1 + q];
     }
@@ -796,7 +909,7 @@ __global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const doub
     if (live)
         for (int q = 1; q < L; ++q) put(ks - L + q, comps(ks - L + q));
     vit_comp nxt = comps(ks);
-    const int nsteps = W + CH;                                        // common trip count; a lane is active while k < kend
+    const int nsteps = start ? CH : W + CH;                           // common trip count; a lane is active while k < kend
     const int par = (int)((i0 + 1) & 1);                              // section of stage 0 at step t: (i0 + ks + t - 1) & 1 (algorithm.py:71 at j = 0), ks even
     const bool mis = (L & 1) != 0;                                    // odd L: a row's increments come from the other section than its stage
     for (int t = 0; t < nsteps; ++t) {
@@ -866,11 +979,15 @@ __global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const doub
             syms[k] = (int8_t)(2 * (int)((dec >> 1) & 3u) - 2);
         }
     }
+    bool changed = false;
     if (live && erec) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) erec[8 * chunk + 4 + q] = C[q];
+        for (int q = 0; q < 4; ++q) {
+            if (start) changed |= __double_as_longlong(erec[8 * chunk + 4 + q]) != __double_as_longlong(C[q]);
+            erec[8 * chunk + 4 + q] = C[q];
+        }
     }
-    if (live && state && kend == ncalls) {                            // the lane that owns the last call: carry out (staging)
+    if (live && state && kend == ncalls && (!start || changed)) {     // the lane that owns the last call: carry out (staging)
         state[VWIN_STAGE] = (double)(i0 + ncalls);
 #pragma unroll
         for (int q = 0; q < 4; ++q) state[VWIN_STAGE + 1 + q] = C[q];
@@ -882,15 +999,37 @@ __global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const doub
             p[0] = c.r1; p[1] = c.i1; p[2] = c.a; p[3] = c.b;
         }
     }
+    return changed;
 }
 
-__global__ void vwin_verify_kernel(const double *__restrict__ erec, int64_t nchunks, unsigned long long *__restrict__ unmerged)
+__global__ __launch_bounds__(VWIN_THREADS) void viterbi_window_kernel(const double2 *__restrict__ rows, int64_t ncalls, int L, int CH, int W,
+                                                                       int diff, uint8_t *__restrict__ bits, int8_t *__restrict__ syms,
+                                                                       double *__restrict__ state, double *__restrict__ erec, int64_t nchunks)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (c >= nchunks) return;
-    const unsigned long long *s = reinterpret_cast<const unsigned long long *>(erec + 8 * c);
-    const unsigned long long *e = reinterpret_cast<const unsigned long long *>(erec + 8 * (c - 1) + 4);
-    if (s[0] != e[0] || s[1] != e[1] || s[2] != e[2] || s[3] != e[3]) atomicAdd(unmerged, 1ull);
+    extern __shared__ __attribute__((aligned(16))) double2 s_ring[];
+    if (blockIdx.x == 0 && threadIdx.x < VIT_HDR) reinterpret_cast<uint64_t *>(erec + 8 * nchunks)[threadIdx.x] = 0;   // lists empty, nobody arrived
+    const int64_t chunk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    (void)vwin_chunk(rows, ncalls, L, CH, W, diff, bits, syms, state, erec, s_ring + (size_t)threadIdx.x * (2 * L + 1), chunk, nullptr);
+}
+
+// The fix-up launch of the window detector (layout and rounds: see viterbi_fixup_kernel's comment).
+__global__ __launch_bounds__(VWIN_THREADS) void vwin_fixup_kernel(const double2 *__restrict__ rows, int64_t ncalls, int L, int CH, int W, int diff,
+                                                                   uint8_t *__restrict__ bits, int8_t *__restrict__ syms, double *__restrict__ state,
+                                                                   double *__restrict__ erec, int64_t nchunks, unsigned long long *__restrict__ unmerged,
+                                                                   int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s_ring[];
+    if (!vit_fixup_verify(erec, nchunks, unmerged, mode)) return;
+    double2 *ring = s_ring + (size_t)threadIdx.x * (2 * L + 1);
+    vit_fixup_rounds(erec, nchunks, unmerged, [&](int64_t c) {
+        double st[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            st[q] = __hip_atomic_load(erec + 8 * (c - 1) + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the predecessor's end, as it is now
+            erec[8 * c + q] = st[q];                       // ... is what this run of the chunk starts from
+        }
+        return vwin_chunk(rows, ncalls, L, CH, W, diff, bits, syms, state, erec, ring, c, st);
+    });
 }
 
 __global__ void vwin_carry_commit_kernel(double *state, int n)
@@ -921,19 +1060,27 @@ extern "C" int wf_viterbi4_detect_window(wf_ctx *ctx, const double *d_mf_ri, int
     const int threads = length <= 16 ? VWIN_THREADS : 64;               // lanes per workgroup: the window ring is (2 L + 1) x 16 B of LDS per lane
     const int64_t nblocks = (nchunks + threads - 1) / threads;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_viterbi4_detect_window: burst too long for one launch");
-    int rc = wf_ctx_reserve_vit(ctx, (size_t)nchunks * 8);
+    int rc = wf_ctx_reserve_vit(ctx, vit_edge_words(nchunks));
     if (rc) return rc;
     hipStream_t s = wf_stream(stream);
     const size_t lds = (size_t)threads * (2 * length + 1) * sizeof(double2);
-    if (lds > 48 * 1024)
+    if (lds > 48 * 1024) {
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vwin_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     hipLaunchKernelGGL(viterbi_window_kernel, dim3((unsigned)nblocks), dim3(threads), lds, s, reinterpret_cast<const double2 *>(d_mf_ri),
-                       ncalls, length, (int)ch, W, differential ? 1 : 0, d_bits, d_syms, d_state, ctx->d_vit_edge);
+                       ncalls, length, (int)ch, W, differential ? 1 : 0, d_bits, d_syms, d_state, ctx->d_vit_edge, nchunks);
     WF_LAUNCH_CHECK();
     if (nchunks > 1) {
-        hipLaunchKernelGGL(vwin_verify_kernel, dim3((unsigned)((nchunks - 1 + 255) / 256)), dim3(256), 0, s, ctx->d_vit_edge, nchunks,
-                           ctx->d_vit_unmerged);
-        WF_LAUNCH_CHECK();
+        // compare the chunk boundaries and repair what differs (vwin_fixup_kernel); mode 0 only counts
+        const unsigned fgrid = (unsigned)wf_grid_for(nchunks - 1, threads, 1024);
+        const int passes = ctx->opt[WF_OPT_DET_REPAIR] == 0 && ctx->opt[WF_OPT_DET_FINAL_VERIFY] ? 2 : 1;
+        for (int pass = 0; pass < passes; ++pass) {
+            hipLaunchKernelGGL(vwin_fixup_kernel, dim3(fgrid), dim3(threads), lds, s, reinterpret_cast<const double2 *>(d_mf_ri), ncalls, length, (int)ch,
+                               W, differential ? 1 : 0, d_bits, d_syms, d_state, ctx->d_vit_edge, nchunks, ctx->d_vit_unmerged,
+                               pass == 0 && ctx->opt[WF_OPT_DET_REPAIR] == 0 ? 1 : 0);
+            WF_LAUNCH_CHECK();
+        }
     }
     if (d_state) {
         hipLaunchKernelGGL(vwin_carry_commit_kernel, dim3(1), dim3(128), 0, s, d_state, 8 + 4 * (length - 1));
@@ -1353,7 +1500,7 @@ extern "C" int wf_viterbi4_iteration_host(wf_ctx *ctx, void *d_state, int length
     WF_REQUIRE(ctx && d_state && h_mf3_ri && h_bits_out && h_syms_out, "wf_viterbi4_iteration_host: NULL argument");
     WF_REQUIRE(length >= 1 && length <= VIT_MAX_LEN, "wf_viterbi4_iteration_host: length %d", length);
     WF_HIP(hipSetDevice(ctx->device));
-    static const bool use_server = [] { const char *e = getenv("WF_ITERATION_SERVER"); return !(e && e[0] == '0'); }();
+    const bool use_server = ctx->opt[WF_OPT_ITERATION_SERVER] == 0;
     hipStream_t s = wf_stream(stream);
     if (!use_server) {      // one launch + one synchronise per call (the round-2 form; kept for A/B and as a fallback)
         if (!ctx->h_iter) {

@@ -182,19 +182,28 @@ def viterbi_detect_window(mf_rows, length: int, differential: bool = True, warmu
 
 
 def viterbi_unmerged(reset: bool = True, ctx=None) -> int:
-    """Chunks of the batch detector whose warm-up did not arrive at the true path metrics since the
-    last reset (``wf_viterbi4_unmerged``; synchronises).  0 = every batch call reproduced the
-    sequential detector bit for bit."""
+    """Chunks of the chunk-parallel detectors left UNPROVEN since the last reset (``wf_viterbi4_unmerged``;
+    synchronises).  0 = every batch call reproduced the sequential detector bit for bit — which, since chunks
+    that miss their warm-up are repaired on the device (cascading into the following chunks where needed), is
+    always the case unless the context's WF_OPT_DET_REPAIR option turned the repairs off."""
     n = ctypes.c_int64(0)
     _hip.check(_hip.lib().wf_viterbi4_unmerged(ctx if ctx is not None else _hip.ctx(), ctypes.byref(n), int(reset), _hip.stream()))
     return int(n.value)
 
 
 def viterbi_repaired(reset: bool = True, ctx=None) -> int:
-    """Chunks of the generic CPM detector that missed their warm-up and were repaired on the device since the
-    last reset (``wf_viterbi_repaired``; synchronises): their output is proven like everybody else's."""
+    """Chunk repairs the detectors ran on the device since the last reset, every round counted
+    (``wf_viterbi_repaired``; synchronises): chunks that missed their warm-up, run again from the true state."""
     n = ctypes.c_int64(0)
     _hip.check(_hip.lib().wf_viterbi_repaired(ctx if ctx is not None else _hip.ctx(), ctypes.byref(n), int(reset), _hip.stream()))
+    return int(n.value)
+
+
+def viterbi_cascaded(reset: bool = True, ctx=None) -> int:
+    """Of those repairs, the ones whose chunk ENDED in a different state than before and therefore handed on to
+    the next chunk (``wf_viterbi_cascaded``; synchronises)."""
+    n = ctypes.c_int64(0)
+    _hip.check(_hip.lib().wf_viterbi_cascaded(ctx if ctx is not None else _hip.ctx(), ctypes.byref(n), int(reset), _hip.stream()))
     return int(n.value)
 
 

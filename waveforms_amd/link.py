@@ -25,16 +25,16 @@ def sigma_for_ebn0(ebn0_db: float, sps: int) -> float:
 
 def operating_point_warmup(waveform: str, ebn0_db: float | None) -> int:
     """Detector chunk warm-up in ROWS (= detector calls run before a chunk's own first call) for a link at a
-    known operating point; 0 = the library default, safe at any Eb/N0.  One table for bench.py and the
-    timing tools (tools/link_stage_time.py, tools/stream_bench.py).  Backed by the proof-failure scans
-    (tools/warmup_scan.py, tools/cpm_warmup_scan.py; profiles/r02_warmup_scan.json, r03_cpm_repair_scan_*.json):
-    SOQPSK 4-state: 16 rows from 6 dB up (0 of 2.5e6 chunks unproven even with 12).  The generic CPM detector
-    repairs the chunks that miss their warm-up on the device (wf_viterbi_repaired), so its warm-up is sized for the
-    typical merge depth, not the tail: ARTM 16-state 48 calls from 8 dB up (0.3 / 0.05 / 0.01 % of the chunks repaired
-    at 8 / 10 / 12 dB, none of 1.25e6 left unproven), 64 from 6 dB; binary PCM/FM 64 from 3 dB up (1.2 - 3 % repaired; round 4: at
-    2 dB the lane form's 320-call chunks left 170 of 31 250 chunks per block unproven — a repair has to meet the first trajectory
-    inside its own chunk — while 1e10 symbols at 3, 4 and 5 dB left none: profiles/r04_lowsnr_scan.log).
-    Every launch still proves its own output, and ``result()`` raises if a chunk was left unproven."""
+    known operating point; 0 = the library default.  A matter of SPEED only: every launch proves on the device
+    that each chunk started from the sequential detector's state and runs the chunks that did not again from the
+    true state, cascading into the following chunks where needed (wf_viterbi_repaired / wf_viterbi_cascaded), so
+    decisions and counts are the sequential detector's at any warm-up and any Eb/N0 — a short warm-up just moves
+    work from every chunk's warm-up to the repair of the few that needed more.  One table for bench.py and the
+    timing tools (tools/link_stage_time.py, tools/stream_bench.py), from the failure-rate scans
+    (tools/warmup_scan.py, tools/cpm_warmup_scan.py; profiles/r02_warmup_scan.json, r03_cpm_repair_scan_*.json,
+    r04_lowsnr_scan.log): SOQPSK 4-state 16 rows from 6 dB up; ARTM 16-state 48 calls from 8 dB up (0.3 / 0.05 /
+    0.01 % of the chunks repaired at 8 / 10 / 12 dB), 64 from 6 dB; binary PCM/FM 64 from 3 dB up (1.2 - 3 %
+    repaired; below, the lane form's 320-call chunks hand on often enough for the default to be faster)."""
     if ebn0_db is None:
         return 0
     if waveform == "soqpsk":
@@ -155,16 +155,15 @@ class SOQPSKLink:
         self.compared += m.value
 
     def result(self) -> tuple[int, int, int]:
-        """(symbol errors, bit errors, symbols compared) — synchronises.  Raises if the detector
-        reported a chunk whose warm-up had not reached the true path metrics (the counts would then
-        not be provably those of the sequential detector): re-run with a larger ``warmup``."""
+        """(symbol errors, bit errors, symbols compared) — synchronises.  The detector's chunks are proven (and, where
+        a warm-up fell short, repaired) on the device, so this never depends on ``warmup`` or Eb/N0; it raises only
+        if a chunk was left unproven because the context's WF_OPT_DET_REPAIR option switched the repairs off."""
         _hip.check(_hip.lib().wf_ctx_check(self._ctx, _hip.stream()))
         from waveforms_amd import device as dev
 
         unmerged = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
         if unmerged:
-            raise RuntimeError(f"{unmerged} detector chunk(s) did not merge with the sequential path within the "
-                               f"warm-up; construct the link with a larger warmup= (current {self.cfg.warmup or 'library default'})")
+            raise RuntimeError(f"{unmerged} detector chunk(s) were left unproven (the repairs are switched off on this context)")
         se, be = (int(v) for v in self.counts.cpu().tolist())
         return se, be, self.compared
 
@@ -275,7 +274,7 @@ class SOQPSKStream:
         late = dev.viterbi_unmerged(reset=True, ctx=self._ctx2)     # the first context's count is read by result()
         if late:
             dev.viterbi_unmerged(reset=True, ctx=self._ctx)
-            raise RuntimeError(f"{late} detector chunk(s) did not merge with the sequential path within the warm-up")
+            raise RuntimeError(f"{late} detector chunk(s) were left unproven (the repairs are switched off on this context)")
         return self.result()
 
     def __del__(self):
@@ -391,11 +390,11 @@ class SOQPSKStream:
         late = dev.viterbi_unmerged(reset=True, ctx=self._ctx2)
         if late:
             dev.viterbi_unmerged(reset=True, ctx=self._ctx)
-            raise RuntimeError(f"{late} detector chunk(s) did not merge with the sequential path within the warm-up")
+            raise RuntimeError(f"{late} detector chunk(s) were left unproven (the repairs are switched off on this context)")
         return self.result()
 
     def result(self) -> tuple[int, int, int]:
-        """Like :meth:`SOQPSKLink.result` (raises if a detector chunk did not merge)."""
+        """Like :meth:`SOQPSKLink.result`."""
         return SOQPSKLink.result(self)
 
 
@@ -494,7 +493,7 @@ class CPMLink:
         self.compared += m.value
 
     def result(self) -> tuple[int, int, int]:
-        """(symbol errors, bit errors, symbols compared); raises if a detector chunk was not proven."""
+        """(symbol errors, bit errors, symbols compared), like :meth:`SOQPSKLink.result`."""
         return SOQPSKLink.result(self)
 
 
@@ -596,7 +595,7 @@ class CPMStream:
         late = dev.viterbi_unmerged(reset=True, ctx=self._ctx2)     # the first context's count is read by result()
         if late:
             dev.viterbi_unmerged(reset=True, ctx=self._ctx)
-            raise RuntimeError(f"{late} detector chunk(s) did not merge with the sequential path within the warm-up")
+            raise RuntimeError(f"{late} detector chunk(s) were left unproven (the repairs are switched off on this context)")
         return self.result()
 
     def __del__(self):
@@ -605,5 +604,5 @@ class CPMStream:
             self._ctx2 = None
 
     def result(self) -> tuple[int, int, int]:
-        """(symbol errors, bit errors, symbols compared); raises if a detector chunk was not proven."""
+        """(symbol errors, bit errors, symbols compared), like :meth:`SOQPSKLink.result`."""
         return SOQPSKLink.result(self)

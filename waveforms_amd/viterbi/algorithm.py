@@ -93,7 +93,7 @@ class SOQPSKTrellisDetector:
             self._mode = "iteration"
             self._ensure_state()
             self._iter_stream = _hip.stream()
-            self._iter_diff = int(self.differential)
+            self._iter_diff = int(self.fsm.trellis is SOQPSKTrellis4x2DiffEncoded)
             # operands at fixed host addresses (an ndarray's .ctypes.data builds a helper object per access: three
             # of them were 1.5 us of a 7.5 us call): the input is copied in, the outputs are copied out
             self._iter_z = np.zeros(3, dtype=np.complex128)
@@ -101,11 +101,16 @@ class SOQPSKTrellisDetector:
             self._iter_bits, self._iter_syms = self._iter_out[0], self._iter_out[1]      # (views kept: no indexing per call)
             self._iter_args = (self._iter_ctx, self._d_state_ptr, int(self.length), self._iter_diff, self._iter_z.ctypes.data,
                                self._iter_bits.ctypes.data, self._iter_syms.ctypes.data, self._iter_stream)
-        elif self.differential != self._iter_diff or self.length != self._iter_args[2]:
-            # the reference reads these attributes on every call (algorithm.py:62-98): follow a change
+        elif (self.fsm.trellis is SOQPSKTrellis4x2DiffEncoded) != bool(self._iter_diff) or self.length != self._iter_args[2]:
+            # The reference fixes the trellis in __init__ (self.fsm, algorithm.py:27-29) and reads self.fsm and self.length
+            # on every call (:62, :67, :71, :94-95): a caller that swaps `det.fsm` between the two 4x2 trellises mid-burst
+            # is followed, like there.  (`differential` is this build's own read-only note of the constructor argument.)
             if int(self.length) != self._iter_args[2]:
                 raise ValueError("the traceback length of a detector cannot change inside a burst (its state arrays are sized by it)")
-            self._iter_diff = int(self.differential)
+            if self.fsm.trellis is not SOQPSKTrellis4x2DiffEncoded and self.fsm.trellis is not SOQPSKTrellis4x2:
+                raise ValueError("SOQPSKTrellisDetector serves the two 4-state, 2-column SOQPSK trellises (state_exp_term has four entries)")
+            self._iter_diff = int(self.fsm.trellis is SOQPSKTrellis4x2DiffEncoded)
+            self.differential = bool(self._iter_diff)
             self._iter_args = self._iter_args[:3] + (self._iter_diff,) + self._iter_args[4:]
         # (the HIP stream is the one current at the FIRST call of the burst: the detector's state is private to this
         # object and only its own methods touch it, so there is nothing on another stream to order against)
@@ -140,30 +145,19 @@ class SOQPSKTrellisDetector:
         self._mode = "batch"
         if self._d_carry is None:
             self._d_carry = _hip.zeros(32 if L == 2 else _hip.lib().wf_viterbi4_window_state_bytes() // 8, "float64")
-        # The kernel is chunk-parallel; it reports chunks whose warm-up did not reach the true path
-        # metrics (none in practice).  Such a call is repeated from the same carried state with a
-        # longer warm-up until it is provably the sequential detector's output.
-        # The proof counter lives in the wf_ctx: the detector owns a private context so that neither
-        # its reads-with-reset nor its repair runs can disturb (or be disturbed by) a SOQPSKLink or
-        # a BER sweep that shares the device's default context.
+        # The kernel is chunk-parallel; every launch proves on the device that each chunk started from bitwise the
+        # state its predecessor ended with and runs the chunks that did not again from the true state, cascading
+        # where needed (csrc/wf_viterbi.hip: viterbi_fixup_kernel) — the output is the sequential detector's
+        # (algorithm.py:44-101) whatever `warmup` is.  The proof counter lives in the wf_ctx: the detector owns a
+        # private context so that its read-with-reset cannot disturb a SOQPSKLink or a BER sweep on the default one.
         if self._ctx is None:
             self._ctx = _hip.new_ctx()
         n = int(mf_rows.shape[0])
-        carry0 = self._d_carry.clone()
-        dev.viterbi_unmerged(reset=True, ctx=self._ctx)
-        w = warmup
-        while True:
-            out = (dev.viterbi_detect(mf_rows, self.differential, w, self._d_carry, ctx=self._ctx) if L == 2 else
-                   dev.viterbi_detect_window(mf_rows, L, self.differential, w, self._d_carry, ctx=self._ctx))
-            unmerged = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
-            if unmerged == 0:
-                break
-            if w >= 4096:   # the library clamps the warm-up there: nothing longer can be tried
-                self._d_carry.copy_(carry0)
-                raise RuntimeError(f"{unmerged} detector chunk(s) still differ from the sequential detector with a "
-                                   f"warm-up of {w} rows; no decisions are returned")
-            w = max(2 * w, 256)
-            self._d_carry.copy_(carry0)
+        out = (dev.viterbi_detect(mf_rows, self.differential, warmup, self._d_carry, ctx=self._ctx) if L == 2 else
+               dev.viterbi_detect_window(mf_rows, L, self.differential, warmup, self._d_carry, ctx=self._ctx))
+        unproven = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
+        if unproven:        # only with the context's WF_OPT_DET_REPAIR option switched off (tests of the proof itself)
+            raise RuntimeError(f"{unproven} detector chunk(s) were left unproven (the repairs are switched off on this context)")
         self.i += n                         # like iteration(): one call per row, state carried
         return out
 

@@ -79,23 +79,26 @@ ARTM_64 = CPMDetectorSpec(M=4, p=16, K=(4, 5), Lp=2, NC=16, D=32)
 PCMFM_10 = CPMDetectorSpec(M=2, p=10, K=(7,), Lp=2, NC=5, D=32)
 
 
-def detector_kernel_name(spec: "CPMDetectorSpec", ncalls: int = 10_000_000, warmup: int = 0) -> str:
+def detector_kernel_name(spec: "CPMDetectorSpec", ncalls: int = 10_000_000, warmup: int = 0, ctx=None, info4: list | None = None) -> str:
     """Name (as rocprofv3 prints it) of the kernel ``wf_cpm_viterbi_detect`` runs for ``spec`` on a burst of ``ncalls``
-    calls: asked from the library (``wf_cpm_detector_form``), so that bench.py and the profile tools price the kernel
-    that really runs."""
+    calls on context ``ctx`` (default: the device's): asked from the library (``wf_cpm_detector_form``), so that bench.py
+    and the profile tools price the kernel that really runs.  ``info4`` (a list) receives {form, ring slots, calls per
+    chunk, warm-up calls}."""
     import ctypes
 
     from waveforms_amd import _hip
 
     info = (ctypes.c_int * 4)()
     cfg = spec.c_config()
-    _hip.check(_hip.lib().wf_cpm_detector_form(ctypes.byref(cfg), int(ncalls), int(warmup), info))
+    _hip.check(_hip.lib().wf_cpm_detector_form(ctx if ctx is not None else _hip.ctx(), ctypes.byref(cfg), int(ncalls), int(warmup), info))
+    if info4 is not None:
+        info4[:] = [int(v) for v in info]
     if info[0] == 1:
         k1 = spec.K[1] if len(spec.K) > 1 else spec.K[0]
         hi = "true" if spec.bits_per_symbol * (spec.D - 1) >= 32 else "false"
         return f"cpm_lane_kernel<lane_spec<{spec.M}, {spec.Lp}, {spec.NC}, {spec.p}, {len(spec.K)}, {spec.K[0]}, {k1}>, {info[1]}, {hi}>"
     if info[0] == 2:
-        return f"cpm_wide_kernel<{spec.M}, {spec.Lp}, false>"
+        return f"cpm_wide_kernel<{spec.M}, {spec.Lp}>"
     return f"cpm_viterbi_kernel<{spec.M}, {spec.Lp}>"
 
 
@@ -183,20 +186,13 @@ class CPMTrellisDetector:
         if tuple(rows.shape[1:]) != (self.spec.nfilt, 2):
             raise ValueError(f"rows must be [n, {self.spec.nfilt}, 2] float64")
         out = _hip.zeros(n + 16, "uint8")
-        carry0 = self._d_state.clone()
-        dev.viterbi_unmerged(reset=True, ctx=self._ctx)
-        w = warmup
-        while True:
-            _hip.check(_hip.lib().wf_cpm_viterbi_detect(self._ctx, ctypes.byref(self._cfg), _hip.ptr(self._d_rot), _hip.ptr(rows), n, w,
-                                                        _hip.ptr(out), _hip.ptr(self._d_state), _hip.stream()))
-            unmerged = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
-            if unmerged == 0:
-                break
-            self._d_state.copy_(carry0)
-            if w >= 4096:
-                raise RuntimeError(f"{unmerged} detector chunk(s) still differ from the sequential detector with a "
-                                   f"warm-up of {w} rows; no decisions are returned")
-            w = max(2 * w, 512)
+        # (chunk-parallel; chunks that miss their warm-up are repaired on the device, cascading where needed: the
+        #  decisions are the sequential detector's whatever `warmup` is — it only sets how many chunks get repaired)
+        _hip.check(_hip.lib().wf_cpm_viterbi_detect(self._ctx, ctypes.byref(self._cfg), _hip.ptr(self._d_rot), _hip.ptr(rows), n, int(warmup),
+                                                    _hip.ptr(out), _hip.ptr(self._d_state), _hip.stream()))
+        unproven = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
+        if unproven:        # only with the context's WF_OPT_DET_REPAIR option switched off (tests of the proof itself)
+            raise RuntimeError(f"{unproven} detector chunk(s) were left unproven (the repairs are switched off on this context)")
         return out[:n]
 
     def detect(self, rows, warmup: int = 0) -> np.ndarray:

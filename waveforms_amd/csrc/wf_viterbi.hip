@@ -483,20 +483,28 @@ __device__ __forceinline__ bool vit_fixup_verify(double *__restrict__ edge, int6
     unsigned long long *hdr = reinterpret_cast<unsigned long long *>(edge + 8 * nchunks);
     unsigned long long *list0 = hdr + VIT_HDR;
     const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(edge);
+    int listed = 0;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; c < nchunks; c += (int64_t)gridDim.x * blockDim.x) {
         const unsigned long long *st = rec + 8 * c, *en = rec + 8 * (c - 1) + 4;
         if (st[0] != en[0] || st[1] != en[1] || st[2] != en[2] || st[3] != en[3]) {
             if (mode) list0[atomicAdd(&hdr[0], 1ull)] = (unsigned long long)c;
             else atomicAdd(unmerged, 1ull);
+            listed = 1;
         }
     }
     if (!mode) return false;
-    __threadfence();                                       // this workgroup's entries before its arrival
+    // Arrival.  A workgroup that listed something publishes its entries (agent-scope release) before it arrives; the
+    // others have nothing to publish and only arrive — in the usual launch nobody lists anything, and a release fence
+    // writes back the XCD's whole L2 under the front end that is streaming rows through it on the other stream.  The
+    // list COUNT needs no fence: it and the ticket are device-scope atomics, and every thread's count increment has
+    // returned (the barrier waits for it) before thread 0 takes the ticket.
+    if (__syncthreads_or(listed)) __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(&hdr[2], 1ull) + 1 == (unsigned long long)gridDim.x;
     __syncthreads();
     if (!s_last) return false;
-    __threadfence();                                       // ... and everybody's before the repairs read them
+    if (__hip_atomic_load(&hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return false;   // nothing to repair: the usual case
+    __threadfence();                                       // ... everybody's entries before the repairs read them
     return true;
 }
 

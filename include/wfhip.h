@@ -317,7 +317,10 @@ typedef struct {
                             /* d_mf_taps[s] == sum_k G[s][k] b_k.  The one-kernel front end */
                             /* then runs two real filters instead of three complex ones    */
                             /* (a third fewer matrix instructions); every other path reads */
-                            /* d_mf_taps.  The caller vouches for the identity.            */
+                            /* d_mf_taps.  The identity is CHECKED (host copy, 1e-12 of the */
+                            /* largest tap) the first time these pointers are seen on a     */
+                            /* context: a factorisation that does not reproduce the taps is */
+                            /* WF_ERR_VALUE.  Do not rewrite the tables in place afterwards. */
 } wf_link_config;
 #define WF_LINK_EVENT_SLOTS 64
 #define WF_LINK_STAGES 8    /* prbs, encode, fir, phase, awgn, mfbank, viterbi, count */
@@ -488,10 +491,12 @@ typedef struct {
                               /* error count of a block on the context's side stream, beside the   */
                               /* next block's front end; two sets of intermediates in the         */
                               /* workspace; wf_link_join / wf_ctx_check before the counters are read; */
-                              /* bit 6 (64, with bit 3; nf = 4 or 16 filters): the caller vouches the */
-                              /* templates pair off as exact conjugates, d_templates[c][nf-1-f] == */
+                              /* bit 6 (64, with bit 3; nf = 4 or 16 filters): the templates pair   */
+                              /* off as exact conjugates, d_templates[c][nf-1-f] ==                */
                               /* conj(d_templates[c][f]) (a symmetric alphabet: the negated symbol */
-                              /* pattern negates the phase) — the one-kernel front end then forms  */
+                              /* pattern negates the phase) — CHECKED value for value on a host    */
+                              /* copy the first time these pointers are seen on a context          */
+                              /* (WF_ERR_VALUE if not so) — the one-kernel front end then forms     */
                               /* each pair from four real 9-tap sums (16 filters: 6 matrix          */
                               /* instructions per 16 symbols instead of 10; 4 filters: 18 multiply- */
                               /* adds per lane instead of 36); rows equal to rounding, not bitwise  */

@@ -1,0 +1,71 @@
+"""Caller promises the C ABI used to trust are checked in C (round-4 verdict, weak #6): `wf_cpm_link_config.fuse` bit 6
+(templates f and nfilt - 1 - f are conjugates) and `wf_link_config.d_mf_factor` (the long bank equals two real filters x a
+3 x 2 combination).  A false promise is WF_ERR_VALUE (ValueError through ctypes), not silently wrong rows."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("waveform", ["multih", "pcmfm"])
+def test_cpm_link_refuses_a_false_conjugate_pair_promise(waveform):
+    from waveforms_amd import _hip
+    from waveforms_amd.link import CPMLink
+
+    nsym = 200_000
+    plain = CPMLink(nsym, 8, waveform=waveform, paired_templates=False, private_ctx=True)
+    assert not (plain.cfg.fuse & 64)
+    plain.run_block(8.0, seed=1, stream_id=3)
+    want = plain.result()
+
+    link = CPMLink(nsym, 8, waveform=waveform, private_ctx=True)
+    assert link.cfg.fuse & 64, "the reference's alphabets are symmetric: the link was expected to pair the templates"
+    link.run_block(8.0, seed=1, stream_id=3)
+    assert link.result() == want                       # (the paired form reorders sums: decisions and counts still equal)
+
+    # the same promise over templates that do NOT pair off (one tap of one filter nudged): refused, in C, before any launch
+    t = _hip.to_host(link._d_templates, complex_pairs=True).copy()
+    t[0, 1, 4] += 1e-9
+    bad = _hip.to_device(t)
+    good_ptr = link.cfg.d_templates
+    link.cfg.d_templates = bad.data_ptr()
+    with pytest.raises(ValueError, match="bit 6"):
+        link.run_block(8.0, seed=1, stream_id=3)
+    # ... and without the promise the same templates are simply a different bank (no error)
+    link.cfg.fuse &= ~64
+    link.run_block(8.0, seed=1, stream_id=3)
+    link.result()
+    # the true templates with the promise again: as before
+    link.cfg.fuse |= 64
+    link.cfg.d_templates = good_ptr
+    link.reset_counts()
+    link.run_block(8.0, seed=1, stream_id=3)
+    assert link.result() == want
+
+
+@pytest.mark.parametrize("sps", [8, 10])
+def test_soqpsk_link_refuses_a_factorisation_that_does_not_reproduce_the_bank(sps):
+    from waveforms_amd import _hip
+    from waveforms_amd.link import SOQPSKLink
+
+    nsym = 200_000
+    link = SOQPSKLink(nsym, sps, detector="PAM", private_ctx=True)
+    assert link.cfg.d_mf_factor, "the PAM bank was expected to be handed over factored"
+    link.run_block(8.0, seed=1, stream_id=5)
+    want = link.result()
+    f = _hip.to_host(link._d_factor).copy()
+    f[int(np.argmax(np.abs(f[:link.cfg.mf_ntaps])))] *= 1.0 + 1e-6       # the largest tap of the first real filter
+    bad = _hip.to_device(f)
+    good_ptr = link.cfg.d_mf_factor
+    link.cfg.d_mf_factor = bad.data_ptr()
+    with pytest.raises(ValueError, match="d_mf_factor"):
+        link.run_block(8.0, seed=1, stream_id=5)
+    link.cfg.d_mf_factor = good_ptr
+    link.reset_counts()
+    link.run_block(8.0, seed=1, stream_id=5)
+    assert link.result() == want
+    # no factorisation at all: the three complex filters (same counts)
+    plain = SOQPSKLink(nsym, sps, detector="PAM", private_ctx=True, factor_bank=False)
+    assert not plain.cfg.d_mf_factor
+    plain.run_block(8.0, seed=1, stream_id=5)
+    assert plain.result() == want

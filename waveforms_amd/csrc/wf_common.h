@@ -5,6 +5,8 @@
 
 #include <atomic>
 #include <map>
+#include <mutex>
+#include <vector>
 #include <string>
 
 #include "../../include/wfhip.h"
@@ -78,9 +80,10 @@ struct wf_ctx {
     hipEvent_t pipe_front = nullptr, pipe_done[2] = {nullptr, nullptr};
     bool pipe_done_valid[2] = {false, false};
     int pipe_set = 0;
-    const double *mcb_pam_factor = nullptr;   // set by a link around its front-end launch: the long (PAM) bank factored into two real filters + a 3 x 2 complex combination (wf_link_config.d_mf_factor), or NULL
-    bool mcb_cpm_paired = false;   // set by a CPM link around its front-end launch (wf_cpm_link_config.fuse bit 6): the 16 templates pair off as conjugates
-    int mcb_runs_hint = 0;         // runs of tiles per resident slot for the one-kernel CPM front end (0: its default); set by the pipelined CPM link
+    // caller promises about small operand tables that the library has verified on the host (wf_promise_verified): key =
+    // hash of (kind, device pointers, sizes), value = uses since the last verification
+    std::map<uint64_t, uint32_t> promises;
+    std::mutex promises_lock;
     double *h_iter = nullptr;      // per-symbol detector call: pinned, device-mapped staging (6 in + 2 x 64 out)
     double *d_iter = nullptr;      // ... the device's address of the same memory
     void *h_mailbox = nullptr;     // per-symbol detector call through the persistent iteration server (wf_viterbi.hip): pinned mailbox,
@@ -120,24 +123,40 @@ int wf_cpm_modulate_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_ori
                            const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
                            int64_t tile_lo, int64_t ntiles, double *d_out_ri, int64_t out_origin,
                            const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile, void *stream);
+// Per-launch options of the one-kernel front end, passed BY ARGUMENT (never parked on the shared context: links on one
+// context may run on several host threads).  pam_factor: the long (PAM) bank factored into two real filters + a 3 x 2
+// complex combination (wf_link_config.d_mf_factor, verified against d_mf_taps by the link) or NULL; cpm_paired: the CPM
+// templates pair off as conjugates (wf_cpm_link_config.fuse bit 6, verified by the link); runs_hint: runs of tiles per
+// resident slot for the CPM forms (0: default; the pipelined CPM link asks for finer runs).
+struct wf_mcb_opts {
+    const double *pam_factor = nullptr;
+    bool cpm_paired = false;
+    int runs_hint = 0;
+};
 int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
                             const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
                             double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
-                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps = 0);
+                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps = 0,
+                            const wf_mcb_opts *opts = nullptr);
 int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total,
                             const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
                             int64_t tile_lo, int64_t ntiles, const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile,
                             const double *d_mf_taps, double rot_re, double rot_im, double sigma, uint64_t seed,
                             uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index, int64_t first,
                             int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf = 0, int cpm_nh = 1,
-                            int stage = 3, int mf_ntaps = 0);
+                            int stage = 3, int mf_ntaps = 0, const wf_mcb_opts *opts = nullptr);
 int wf_mod_chan_bank_applies(int64_t nsym, int nh, int ntaps, int sps, int mf_ntaps, int64_t first);
 int wf_link_join_internal(wf_ctx *ctx, void *stream);   // the caller's stream waits for what fuse bit 5 left on the side stream
 int wf_mod_chan_cpm_rows_applies(int64_t nsym, int nh, int ntaps, int sps, int nfilt, int ntm, int64_t start0);
 int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse,
                          int ntaps, int sps, double phi0, const double *d_templates, int nfilt, int ntm, int64_t start0,
                          double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id, int64_t ncalls,
-                         double *d_rows, void *stream);
+                         double *d_rows, void *stream, const wf_mcb_opts *opts = nullptr);
+// A promise a caller makes about small device operands (<= 64 KB), checked on the HOST the first time this content is
+// seen on this context: `check(host copy, nbytes)` decides; the verdict is cached under a hash of (kind, bytes).
+// Synchronises `stream` on a cache miss only.  Returns WF_OK, or WF_ERR_VALUE with `what` in the error text.
+int wf_promise_verified(wf_ctx *ctx, int kind, const void *const *d_ptrs, const size_t *nbytes, int nptrs, void *stream,
+                        bool (*check)(const unsigned char *const *host, const size_t *nbytes, const void *arg), const void *arg, const char *what);
 int wf_fsm_encode_core(wf_ctx *ctx, const uint8_t *h_next, const int8_t *h_out, int columns, int states, int card,
                        const uint8_t *d_bits, int64_t nbits, int64_t i0, int state0, const int *d_state_in,
                        int8_t *d_symbols, int *h_state_out, int *d_state_at, int64_t at_index, void *stream);

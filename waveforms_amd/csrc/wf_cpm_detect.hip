@@ -1023,6 +1023,33 @@ extern "C" int wf_cpm_count_errors(wf_ctx *ctx, const uint8_t *d_decided_u, cons
     return WF_OK;
 }
 
+// fuse bit 6 promises that template f and template nfilt - 1 - f are exact conjugates (a symmetric alphabet makes them so):
+// the front end then forms each pair from four real sums.  Checked here, value for value, on a host copy (wf_promise_verified).
+struct cpm_pair_shape {
+    int nh, nfilt, ntm;
+};
+static bool cpm_templates_pair_off(const unsigned char *const *host, const size_t *, const void *arg)
+{
+    const cpm_pair_shape *sh = static_cast<const cpm_pair_shape *>(arg);
+    const double *t = reinterpret_cast<const double *>(host[0]);
+    for (int c = 0; c < sh->nh; ++c)
+        for (int f = 0; f < sh->nfilt; ++f)
+            for (int k = 0; k < sh->ntm; ++k) {
+                const double *a = t + 2 * (((size_t)c * sh->nfilt + f) * sh->ntm + k);
+                const double *b = t + 2 * (((size_t)c * sh->nfilt + (sh->nfilt - 1 - f)) * sh->ntm + k);
+                if (!(a[0] == b[0] && a[1] == -b[1])) return false;
+            }
+    return true;
+}
+static int cpm_check_paired(wf_ctx *ctx, const wf_cpm_link_config *cfg, int nfilt, int ntm, void *stream)
+{
+    const cpm_pair_shape sh{cfg->det.nh, nfilt, ntm};
+    const void *ptrs[1] = {cfg->d_templates};
+    const size_t nb[1] = {(size_t)sh.nh * nfilt * ntm * 16};
+    return wf_promise_verified(ctx, 1, ptrs, nb, 1, stream, cpm_templates_pair_off, &sh,
+                               "wf_cpm_link_config.fuse bit 6 is set, but templates f and nfilt - 1 - f are not exact conjugates of each other");
+}
+
 // ------------------------------------------------------------------------------------------
 // Device-resident link for multi-h CPM / PCM/FM: the SOQPSK link's structure (wf_pipeline.hip)
 // with the mapper, the multi-index modulator and the generic detector.
@@ -1152,13 +1179,13 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     // (mod_chan_bank_kernel, wf_modulate.hip) — the baseband samples never reach HBM
     bool fused_all = false;
     if ((cfg->fuse & 8) && (cfg->fuse & 2) && L.ncalls > 0) {
-        ctx->mcb_runs_hint = piped ? (L.nfilt == 4 ? 16 : 8) : 0;       // (the detector of the previous block shares the chip: finer runs)
-        ctx->mcb_cpm_paired = (cfg->fuse & 64) != 0;                      // fuse bit 6: templates f and nfilt - 1 - f are conjugates (caller vouches)
+        wf_mcb_opts mo;
+        mo.runs_hint = piped ? (L.nfilt == 4 ? 16 : 8) : 0;              // (the detector of the previous block shares the chip: finer runs)
+        mo.cpm_paired = (cfg->fuse & 64) != 0;                           // fuse bit 6: templates f and nfilt - 1 - f are conjugates — checked
+        if (mo.cpm_paired && (rc = cpm_check_paired(ctx, cfg, L.nfilt, L.ntm, stream))) return rc;
         rc = wf_mod_chan_cpm_rows(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_templates,
                                   L.nfilt, L.ntm, L.start0, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, L.ncalls,
-                                  rows, stream);
-        ctx->mcb_runs_hint = 0;
-        ctx->mcb_cpm_paired = false;
+                                  rows, stream, &mo);
         if (rc < 0) return rc;
         fused_all = rc == 0;
     }
@@ -1331,12 +1358,13 @@ extern "C" int wf_cpm_link_stream_chunk_phase(wf_ctx *ctx, const wf_cpm_link_con
         if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, S.nloc * bps, 0, 0, 0, syms, stream))) return rc;
     }
     if (phases & 4) {
-        ctx->mcb_cpm_paired = (cfg->fuse & 64) != 0;
+        wf_mcb_opts mo;
+        mo.cpm_paired = (cfg->fuse & 64) != 0;
+        if (mo.cpm_paired && (rc = cpm_check_paired(ctx, cfg, S.L.nfilt, S.L.ntm, stream))) return rc;
         rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
                                      S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_templates, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma,
                                      cfg->seed, cfg->stream_id, 0, nullptr, S.L.start0 + 4, S.k_lo, S.ncols, 0, rows, stream, S.L.nfilt,
-                                     cfg->det.nh, 3);
-        ctx->mcb_cpm_paired = false;
+                                     cfg->det.nh, 3, 0, &mo);
         if (rc < 0) return rc;
         WF_REQUIRE(rc == 0, "wf_cpm_link_stream_chunk: internal: the one-kernel front end refused the window");
     }

@@ -147,6 +147,51 @@ extern "C" int wf_ctx_check(wf_ctx *c, void *stream)
     return WF_OK;
 }
 
+// See wf_common.h.  Verified on first sight of (kind, pointers, sizes) on this context and again every 4096th use (an
+// allocator may hand the same address to another table later); never inside a stream capture (callers warm a context up
+// eagerly before they capture: an unverified promise inside a capture is refused).
+int wf_promise_verified(wf_ctx *c, int kind, const void *const *d_ptrs, const size_t *nbytes, int nptrs, void *stream,
+                        bool (*check)(const unsigned char *const *host, const size_t *nbytes, const void *arg), const void *arg, const char *what)
+{
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) {
+        for (int b = 0; b < 8; ++b) {
+            key ^= (v >> (8 * b)) & 0xFFull;
+            key *= 1099511628211ull;
+        }
+    };
+    mix((uint64_t)kind);
+    for (int i = 0; i < nptrs; ++i) {
+        WF_REQUIRE(d_ptrs[i] != nullptr && nbytes[i] > 0 && nbytes[i] <= (1u << 16), "%s: operand %d is NULL or larger than 64 KB", what, i);
+        mix((uint64_t)reinterpret_cast<uintptr_t>(d_ptrs[i]));
+        mix((uint64_t)nbytes[i]);
+    }
+    std::lock_guard<std::mutex> guard(c->promises_lock);
+    auto it = c->promises.find(key);
+    if (it != c->promises.end() && (++it->second & 4095u) != 0) return WF_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(wf_stream(stream), &cap);
+    if (cap != hipStreamCaptureStatusNone) {
+        WF_REQUIRE(it != c->promises.end(), "%s: cannot be verified inside a stream capture — run the configuration once eagerly first", what);
+        return WF_OK;
+    }
+    std::vector<std::vector<unsigned char>> host(nptrs);
+    std::vector<const unsigned char *> hp(nptrs);
+    for (int i = 0; i < nptrs; ++i) {
+        host[i].resize(nbytes[i]);
+        WF_HIP(hipMemcpyAsync(host[i].data(), d_ptrs[i], nbytes[i], hipMemcpyDeviceToHost, wf_stream(stream)));
+        hp[i] = host[i].data();
+    }
+    WF_HIP(hipStreamSynchronize(wf_stream(stream)));
+    if (!check(hp.data(), nbytes, arg)) {
+        if (it != c->promises.end()) c->promises.erase(it);
+        wf_set_error("%s", what);
+        return WF_ERR_VALUE;
+    }
+    c->promises[key] = 1;
+    return WF_OK;
+}
+
 // Grow-only scratch.  Growing synchronises the device (not capturable) — callers
 // that capture graphs warm the context up with their largest size first.
 int wf_ctx_reserve_scan(wf_ctx *c, size_t words)

@@ -1470,8 +1470,10 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             const double *d_mf_taps, double rot_re, double rot_im, double sigma, uint64_t seed,
                             uint64_t stream_id, uint64_t first_index, const uint64_t *d_dyn_index, int64_t first,
                             int64_t k_lo, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int cpm_nf, int cpm_nh,
-                            int stage, int mf_ntaps)
+                            int stage, int mf_ntaps, const wf_mcb_opts *opts)
 {
+    const wf_mcb_opts none{};
+    const wf_mcb_opts &O = opts ? *opts : none;
     // stage 1: the two carry kernels only (they also export the phase carry of a stream window);
     // stage 2: the main kernel only, on carries an earlier stage-1 call left in this context's
     // scratch; 3: both.  Callers that pipeline chunks split them so that the next chunk's carries do
@@ -1534,10 +1536,10 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     // (occupancy experiment, LDS padded to force fewer workgroups per CU with the 4-row ring of the
     //  first version: 1 per CU 0.97 ms, 2: 0.63, 3: 0.56 — the 2-row ring's 4 per CU: 0.53)
     // the long bank in factored form (the caller's link handed the factorisation over): the kernel then reads ITS buffer as mf_taps
-    const bool pam2 = pam && ctx->mcb_pam_factor != nullptr;
+    const bool pam2 = pam && O.pam_factor != nullptr;
     if (pam2) {
-        WF_REQUIRE((reinterpret_cast<uintptr_t>(ctx->mcb_pam_factor) & 7) == 0, "wf_mod_chan_bank: the bank's factorisation must be 8-byte aligned");
-        d_mf_taps = ctx->mcb_pam_factor;
+        WF_REQUIRE((reinterpret_cast<uintptr_t>(O.pam_factor) & 7) == 0, "wf_mod_chan_bank: the bank's factorisation must be 8-byte aligned");
+        d_mf_taps = O.pam_factor;
     }
     const size_t lds = (size_t)((win + 1) & ~1) * sizeof(double) + (size_t)(pam ? mcb_pam_slots(sps, pam2) : ring_slots) * sizeof(double2) +
                        (size_t)nh * (win + 1) * sizeof(int);
@@ -1555,10 +1557,10 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
 #ifndef WF_MCB_RUNS_PER_SLOT_SOQPSK
 #define WF_MCB_RUNS_PER_SLOT_SOQPSK 2
 #endif
-    // (a pipelined CPM link asks for finer runs, ctx->mcb_runs_hint: its detector runs BESIDE this kernel and gets its
+    // (a pipelined CPM link asks for finer runs, wf_mcb_opts::runs_hint: its detector runs BESIDE this kernel and gets its
     //  waves onto a SIMD only when one of this kernel's workgroups leaves.  Steady state of the pipelined links, same box,
     //  runs per slot 1 | 2 | 4 | 8 | 16: PCM/FM 0.940 | 0.856 | 0.817 | 0.806 | 0.800 ms, ARTM 1.481 | 1.348 | 1.330 | 1.324 | 1.330)
-    const int runs_per_slot = cpm_nf ? (ctx->mcb_runs_hint > 0 ? ctx->mcb_runs_hint : WF_MCB_RUNS_PER_SLOT) : WF_MCB_RUNS_PER_SLOT_SOQPSK;
+    const int runs_per_slot = cpm_nf ? (O.runs_hint > 0 ? O.runs_hint : WF_MCB_RUNS_PER_SLOT) : WF_MCB_RUNS_PER_SLOT_SOQPSK;
     // (round 4, negative: a pipelined CPM link's front end capped at 2 | 2.5 | 3 | 4 | 8 | 16 resident-slot-fulls of workgroups, to
     //  leave each CU half free for the detector running beside it: ARTM steady 1.87 | 1.69 | 1.53 | 1.50 | 1.35 | 1.31 ms against
     //  1.32 uncapped, PCM/FM 0.74 | 0.91 | 0.85 | 0.74 | 0.70 | 0.67 against 0.65 — this kernel needs its four waves per SIMD;
@@ -1575,10 +1577,10 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     Q.n_long = (int)((P.ntiles - tail) / per_run);
     const int grid = (int)(Q.n_long + (P.ntiles - (int64_t)Q.n_long * per_run));
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
-    // (16 templates the caller vouches pair off as conjugates, f <-> 15 - f: the four-real-sums form, 6 matrix instructions per 16 symbols for 10)
-    kern_t k = cpm_nf == 16 && ctx->mcb_cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 32> : mod_chan_bank_kernel<9, 32>)
+    // (16 templates that pair off as conjugates — the link checked it —, f <-> 15 - f: the four-real-sums form, 6 matrix instructions per 16 symbols for 10)
+    kern_t k = cpm_nf == 16 && O.cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 32> : mod_chan_bank_kernel<9, 32>)
              : cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
-             : cpm_nf == 4 && ctx->mcb_cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 8> : mod_chan_bank_kernel<9, 8>)
+             : cpm_nf == 4 && O.cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 8> : mod_chan_bank_kernel<9, 8>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)
              : pam2         ? (sps == 10 ? (JM == 4 ? mod_chan_bank_kernel<4, -2, 10> : mod_chan_bank_kernel<9, -2, 10>)
                                          : (JM == 4 ? mod_chan_bank_kernel<4, -2> : mod_chan_bank_kernel<9, -2>))
@@ -1598,11 +1600,11 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
 int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
                             const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
                             double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
-                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps)
+                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps, const wf_mcb_opts *opts)
 {
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_mf_taps, rot_re, rot_im, sigma, seed, stream_id, first_index, nullptr, first, 0, ncols,
-                                   pack_par0, d_rows4, stream, 0, 1, 3, mf_ntaps);
+                                   pack_par0, d_rows4, stream, 0, 1, 3, mf_ntaps, opts);
 }
 
 // Would the one-kernel front end (SOQPSK form: 3 x (sps + 1) bank, detector-packed rows) take this configuration?
@@ -1636,12 +1638,12 @@ int wf_mod_chan_cpm_rows_applies(int64_t nsym, int nh, int ntaps, int sps, int n
 int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse,
                          int ntaps, int sps, double phi0, const double *d_templates, int nfilt, int ntm, int64_t start0,
                          double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id, int64_t ncalls,
-                         double *d_rows, void *stream)
+                         double *d_rows, void *stream, const wf_mcb_opts *opts)
 {
     if (ntm != 9 || start0 < -4 || start0 > 3 || (nfilt != 4 && nfilt != 16)) return 1;
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_templates, rot_re, rot_im, sigma, seed, stream_id, 0, nullptr, start0 + 4, 0, ncalls, 0,
-                                   d_rows, stream, nfilt, nh, 3, 0);
+                                   d_rows, stream, nfilt, nh, 3, 0, opts);
 }
 
 // Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total

@@ -97,6 +97,37 @@ static bool link_packed_rows(const wf_link_config *cfg) { return link_packed_row
 // per SIMD) needs.  The workspace then holds two sets of intermediates, used alternately.
 static bool link_pipelined(const wf_link_config *cfg) { return (cfg->fuse & 32) && link_one_kernel(cfg); }
 
+// d_mf_factor promises d_mf_taps[s] == sum_k G[s][k] b_k (two real filters b_k, a 3 x 2 complex combination G): the
+// one-kernel front end then runs the two real filters.  Checked on a host copy to 1e-12 of the largest tap (what the
+// Python link checks before it hands a factorisation over; wf_promise_verified).  Only the long-bank form reads the factors.
+static bool link_factor_matches(const unsigned char *const *host, const size_t *, const void *arg)
+{
+    const int nt = *static_cast<const int *>(arg);
+    const double *taps = reinterpret_cast<const double *>(host[0]);          // [3][nt] (re, im)
+    const double *b = reinterpret_cast<const double *>(host[1]);             // b_0[nt], b_1[nt], G[3][2] (re, im)
+    const double *G = b + 2 * nt;
+    double big = 0.0, worst = 0.0;
+    for (int s = 0; s < 3; ++s)
+        for (int t = 0; t < nt; ++t) {
+            const double re = G[4 * s] * b[t] + G[4 * s + 2] * b[nt + t], im = G[4 * s + 1] * b[t] + G[4 * s + 3] * b[nt + t];
+            const double tr = taps[2 * (s * nt + t)], ti = taps[2 * (s * nt + t) + 1];
+            const double d = hypot(re - tr, im - ti), m = hypot(tr, ti);
+            if (!(d == d)) return false;
+            if (d > worst) worst = d;
+            if (m > big) big = m;
+        }
+    return worst <= 1e-12 * big;
+}
+static int link_check_factor(wf_ctx *ctx, const wf_link_config *cfg, void *stream)
+{
+    if (!cfg->d_mf_factor || cfg->mf_ntaps == cfg->sps + 1 || cfg->mf_nfilt != 3 || cfg->mf_ntaps < 1) return WF_OK;
+    const int nt = cfg->mf_ntaps;
+    const void *ptrs[2] = {cfg->d_mf_taps, cfg->d_mf_factor};
+    const size_t nb[2] = {(size_t)3 * nt * 16, (size_t)(2 * nt + 12) * 8};
+    return wf_promise_verified(ctx, 2, ptrs, nb, 2, stream, link_factor_matches, &nt,
+                               "wf_link_config.d_mf_factor does not reproduce d_mf_taps (taps[s] != sum_k G[s][k] b_k to 1e-12)");
+}
+
 extern "C" int64_t wf_link_workspace_bytes(const wf_link_config *cfg)
 {
     if (!cfg || cfg->nsym < 1 || cfg->sps < 1) return -1;
@@ -183,11 +214,12 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     // baseband samples never exist in HBM.  Outside that kernel's envelope the bits below apply.
     bool fused_all = false;
     if (link_one_kernel(cfg) && L.ncols > 0) {
-        ctx->mcb_pam_factor = cfg->d_mf_factor;       // (a long bank handed over in factored form: two real filters + a 3 x 2 combination)
+        wf_mcb_opts mo;
+        mo.pam_factor = cfg->d_mf_factor;             // (a long bank handed over in factored form: two real filters + a 3 x 2 combination — checked)
+        if ((rc = link_check_factor(ctx, cfg, stream))) return rc;
         rc = wf_mod_chan_bank_packed(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_mf_taps,
                                      cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, L.first, L.ncols, 0,
-                                     mf, stream, cfg->mf_ntaps);
-        ctx->mcb_pam_factor = nullptr;
+                                     mf, stream, cfg->mf_ntaps, &mo);
         if (rc < 0) return rc;
         WF_REQUIRE(rc == 0, "wf_link_run: internal: the one-kernel front end refused a configuration wf_mod_chan_bank_applies accepted");
         fused_all = true;
@@ -517,12 +549,13 @@ static int stream_chunk_impl(wf_ctx *ctx, const wf_link_config *cfg, int64_t chu
     // (any bank the kernel takes at 8 samples per symbol: the 9-tap pulse-truncation bank, or an odd-length bank of up to 73 taps)
     if ((cfg->fuse & 8) && packed && (phases & 5) && wf_mod_chan_bank_applies(S.N, 1, cfg->ntaps, cfg->sps, cfg->mf_ntaps, S.first)) {
         const int stage = ((phases & 1) ? 1 : 0) | ((phases & 4) ? 2 : 0);
-        ctx->mcb_pam_factor = cfg->d_mf_factor;
+        wf_mcb_opts mo;
+        mo.pam_factor = cfg->d_mf_factor;
+        if ((rc = link_check_factor(ctx, cfg, stream))) return rc;
         rc = wf_mod_chan_bank_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
                                      S.ntiles, q_phase, q_phase, S.q_out_tile, cfg->d_mf_taps, rot_re, rot_im, cfg->sigma, cfg->seed,
                                      cfg->stream_id, 0, steady ? dyn + 1 : nullptr, S.first, S.k_lo, S.ncols, 0, mf, stream, 0, 1, stage,
-                                     cfg->mf_ntaps);
-        ctx->mcb_pam_factor = nullptr;
+                                     cfg->mf_ntaps, &mo);
         if (rc < 0) return rc;
         fused_all = rc == 0;
     }

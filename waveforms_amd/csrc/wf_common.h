@@ -236,11 +236,12 @@ __device__ __forceinline__ double wf_wave_shr1(double v) { return wf_dpp_f64<0x1
 
 // sin / cos of 2*pi*t: table-driven.  The turn is cut into 128 sectors; {cos, sin} at the sector
 // centres come from a 2 KB table (generated in 80-bit arithmetic, rounded once), the residual
-// angle |r| <= pi/128 goes through two short Taylor kernels (next terms: r^9/9! < 1e-20,
-// r^8/8! < 4e-18) and one complex rotation.  The sector split is exact (scaling by 128, floor
+// angle |r| <= pi/128 goes through two short Taylor kernels (first terms left out: r^7/5040 < 1.1e-15 in the sine,
+// r^8/8! < 4e-18 in the cosine) and one complex rotation.  The sector split is exact (scaling by 128, floor
 // and the subtractions are exact in binary floating point; for a 32-bit uniform it is pure
 // integer work), so there is no Payne-Hanek path, no quadrant selects and no cancellation.
-// Absolute error < 2 ulp(1); 16 fp64 operations against 18 + 16 selects for the octant form.
+// Absolute error < 1.5e-15; 13 fp64 operations (the r^7 term of the sine, kept through round 4, was the 14th: an
+// issue-bound kernel pays for every one of them, profiles/r05_ab_numerics.log) against 18 + 16 selects for the octant form.
 static __device__ __constant__ double2 kWfCisTab[128] = {
     {0x1.ffd886084cd0dp-1, 0x1.92155f7a3667ep-6}, {0x1.fe9cdad01883ap-1, 0x1.2d52092ce19f6p-4},
     {0x1.fc26470e19fd3p-1, 0x1.f564e56a9730ep-4}, {0x1.f8764fa714ba9p-1, 0x1.5e214448b3fc6p-3},
@@ -311,8 +312,7 @@ static __device__ __constant__ double2 kWfCisTab[128] = {
 __device__ __forceinline__ void wf_cis_sector(double2 cs0, double r, double *sn, double *cs)
 {
     const double z = r * r;
-    double ps = fma(z, -1.0 / 5040.0, 1.0 / 120.0);
-    ps = fma(z, ps, -1.0 / 6.0);
+    const double ps = fma(z, 1.0 / 120.0, -1.0 / 6.0);
     const double s = fma(r * z, ps, r);
     double pc = fma(z, -1.0 / 720.0, 1.0 / 24.0);
     pc = fma(z, pc, -0.5);
@@ -326,9 +326,15 @@ __device__ __forceinline__ void wf_cis_sector(double2 cs0, double r, double *sn,
 // that also stores makes every iteration wait for the previous iteration's stores to land.
 __device__ __forceinline__ void wf_sincos_sectors(const double2 *tab, double y, double *sn, double *cs)   // angle = y / 128 turns
 {
-    const double fl = floor(y);
-    const double r = ((y - fl) - 0.5) * (6.28318530717958647692 / 128.0);
-    wf_cis_sector(tab[(int)fl & 127], r, sn, cs);
+    // y - floor(y) is v_fract_f64 (exact), and the centring rides in the scaling's fma
+    const double r = fma(__builtin_amdgcn_fract(y), 6.28318530717958647692 / 128.0, -0.5 * (6.28318530717958647692 / 128.0));
+    wf_cis_sector(tab[(int)floor(y) & 127], r, sn, cs);
+}
+// ... for y >= 0 (the modulator's phase in 1/128 turns with a non-negative offset): truncation IS the floor, one operation less
+__device__ __forceinline__ void wf_sincos_sectors_pos(const double2 *tab, double y, double *sn, double *cs)
+{
+    const double r = fma(__builtin_amdgcn_fract(y), 6.28318530717958647692 / 128.0, -0.5 * (6.28318530717958647692 / 128.0));
+    wf_cis_sector(tab[(int)y & 127], r, sn, cs);
 }
 
 // Copy the sector table into LDS (128 x 16 B); the caller synchronises before the first use.
@@ -433,44 +439,48 @@ __device__ __forceinline__ void wf_stage_tables(double2 *p, int t, int nthreads)
         p[k * STRIDE + OFF] = k < 128 ? make_double2(kWfLogTab[k].x, -2.0 * kWfLogTab[k].y) : kWfCisTab[k - 128];
 }
 
-// -2 ln((xa + 1) 2^-32) >= +0: the series of the comment above with every constant scaled by -2 (exact), so the result is
-// bit for bit -2 x what the unscaled series gives.
+// -2 ln((xa + 1) 2^-32): the series of the comment above with every constant scaled by -2 (exact), degree 5 (the r^6 term,
+// < 1.2e-15, left out).  The result is the true value (>= 0) to ~2e-16 absolute; for u = 1 it may come out as -4e-19:
+// wf_sqrt_pos floors its argument.
 __device__ __forceinline__ double wf_neg2log_series(double m, int e, double2 tc)
 {
     const double r = fma(m, tc.x, -1.0);
-    double p = fma(r, 2.0 / 6.0, -0.4);
-    p = fma(r, p, 0.5);
+    double p = fma(r, -0.4, 0.5);
     p = fma(r, p, -2.0 / 3.0);
     p = fma(r, p, 1.0);
     p = fma(r, p, -2.0);
     const double de = (double)e;
-    // u <= 1, so the true value is >= 0: clamp the rounding of ln(1) (xa = 2^32 - 1)
-    return fmax(fma(de, -2.0 * 6.93147180369123816490e-01, fma(r, p, tc.y) + de * (-2.0 * 1.90821492927058770002e-10)), 0.0);
+    return fma(de, -2.0 * 6.93147180369123816490e-01, fma(r, p, tc.y) + de * (-2.0 * 1.90821492927058770002e-10));
+}
+
+// (double)xa + 1.0 for a 32-bit word, exactly, in ONE operation: 2^52 + xa is the double with xa as its low word, and
+// (2^52 + xa) - (2^52 - 1) is exact (v_cvt_f64_u32 + v_add_f64 otherwise: wf_u32_plus_one_cvt, the same value — for kernels
+// whose register budget has no room for the constant high word).
+__device__ __forceinline__ double wf_u32_plus_one_cvt(uint32_t xa) { return (double)xa + 1.0; }
+__device__ __forceinline__ double wf_u32_plus_one(uint32_t xa)
+{
+    return __longlong_as_double((long long)(0x4330000000000000ull | xa)) - 4503599627370495.0;
 }
 
 template <class Tabs>
 __device__ __forceinline__ double wf_neg2log_unit32(uint32_t xa, const Tabs &tb)
 {
-    const double x = (double)xa + 1.0;                              // 1 .. 2^32, exact
-    const long long ix = __double_as_longlong(x);
+    const long long ix = __double_as_longlong(wf_u32_plus_one(xa));       // 1 .. 2^32, exact
     const int e = (int)(ix >> 52) - (1023 + 32);
     const long long mant = ix & 0x000FFFFFFFFFFFFFll;
     return wf_neg2log_series(__longlong_as_double(mant | 0x3FF0000000000000ll), e, tb.log((int)(mant >> 45)));
 }
 
-// sqrt(a) for a normal-range double a >= +0: v_rsq_f64 seed, one Goldschmidt step, then one
-// Newton correction on the exactly computed residual (< 1 ulp).  a = 0 gives 0 (the seed's
-// argument is floored).  The caller must not pass a negative a: -2 ln(u) for u = 1 once rounded
-// to -4e-19 and a * rsq(tiny) turned it into 1e133 — wf_neg2log_series clamps its result to >= 0.
-__device__ __forceinline__ double wf_sqrt_pos(double a)   // a >= +0.0 (the caller's log is clamped to <= 0)
+// sqrt(a) for a normal-range double: v_rsq_f64 seed (relative error <= 2^-23) and one Goldschmidt step (~2^-45 = 3e-14:
+// the Newton correction on the exact residual that used to follow bought the last 30 bits of a NOISE radius at two more
+// operations per sample).  The argument is floored at 2^-1000 (-2 ln(u) for u = 1 once rounded to -4e-19 and
+// a * rsq(tiny) turned it into 1e133): a <= 0 gives 2^-500, zero to every purpose.
+__device__ __forceinline__ double wf_sqrt_pos(double a)
 {
-    const double y = __builtin_amdgcn_rsq(fmax(a, 0x1.0p-1000));   // relative error <= 2^-23
-    double g = a * y, h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);                                               // one Goldschmidt step: ~2^-45
-    h = fma(h, r, h);
-    const double dres = fma(-g, g, a);                              // Newton on the exact residual: ~2^-90
-    return fma(dres, h, g);
+    const double af = fmax(a, 0x1.0p-1000);
+    const double y = __builtin_amdgcn_rsq(af);
+    const double g = af * y, h = 0.5 * y;
+    return fma(g, fma(-h, g, 0.5), g);
 }
 
 // ---- Philox4x32-10 + Box-Muller: the device Gaussian source (see wf_awgn.hip) ----
@@ -542,7 +552,7 @@ __device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_i
 // wf_gaussian_two with the two Box-Muller transforms INTERLEAVED: both log-table entries are fetched together, then
 // both sector entries, so the four dependent table round trips of a Philox block become two (same operations on the
 // same operands as wf_gaussian_two: the same bits).  ALL_UP_FRONT: all four entries right behind the Philox rounds.
-template <bool ALL_UP_FRONT, class Tabs>
+template <bool ALL_UP_FRONT, class Tabs, bool ONE_OP_X = true>
 __device__ __forceinline__ void wf_gaussian_two_il(uint64_t pair, uint64_t stream_id, uint64_t seed, double sigma,
                                                    const Tabs &tb, double g[4])
 {
@@ -554,7 +564,7 @@ __device__ __forceinline__ void wf_gaussian_two_il(uint64_t pair, uint64_t strea
     double2 tl[2], tc[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const long long ix = __double_as_longlong((double)xa[q] + 1.0);
+        const long long ix = __double_as_longlong(ONE_OP_X ? wf_u32_plus_one(xa[q]) : wf_u32_plus_one_cvt(xa[q]));
         e[q] = (int)(ix >> 52) - (1023 + 32);
         mant[q] = ix & 0x000FFFFFFFFFFFFFll;
         tl[q] = tb.log((int)(mant[q] >> 45));

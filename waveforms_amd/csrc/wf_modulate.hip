@@ -13,6 +13,8 @@
 // independently: symbol amplitudes of the tile in LDS, per-thread tap phases in
 // registers (wf_fir.hip), in-tile fp64 scan by DPP + LDS wave totals (wf_phase.hip),
 // carry, mod, table sincos (LDS), wave-transposed stores of 64 consecutive samples.
+#include <type_traits>
+
 #include "wf_common.h"
 
 #ifndef MOD_THREADS
@@ -950,7 +952,24 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
         for (int k = t; k < RSLOTS; k += MOD_THREADS) s_ring[k] = make_double2(0.0, 0.0);
     }
 
-    const uint64_t pair0 = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull);
+    // Where this thread's two samples of a row go in the ring (non-PAM forms): the ring index (sample - d) mod RING of a row
+    // depends on the row's PARITY only, so the LDS byte addresses of the two slots are thread constants — both parities packed
+    // into one register per sample (the static + dynamic LDS of a workgroup is < 64 KB), unpacked by one AND / one shift per
+    // row where the index, pad and byte arithmetic took 13 vector instructions.  An even row also holds ring index 0 (the
+    // samples before the window-start offset wrap around), whose slot is copied behind the ring for the one window that ends there.
+    typedef __attribute__((address_space(3))) wf_v2d *mcb_lds2;
+    constexpr bool RINGPK = CPMNF == 0 && (SPS == 8 || JMAX <= 4);     // (the CPM and PAM forms, and the long-pulse forms at 10 / 20 samples per symbol, keep the index arithmetic: two more live registers spilled there)
+    unsigned ring_pk_a = 0, ring_pk_b = 0;
+    if constexpr (RINGPK) {
+        const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)s_ring;
+        for (int par = 0; par < 2; ++par) {
+            int ia = (par ? RS : 0) + 2 * t - Q.d;
+            ia += ia < 0 ? G::RING : 0;
+            const int ib = ia + 1 == G::RING ? 0 : ia + 1;
+            ring_pk_a |= (base + 16u * (unsigned)(ia + ia / PG)) << (16 * par);
+            ring_pk_b |= (base + 16u * (unsigned)(ib + ib / PG)) << (16 * par);
+        }
+    }
     // A workgroup takes a RUN of consecutive tiles: rows then follow each other across the tile edge in the
     // ring exactly as inside a tile (row 15's last column completes when the next tile's row 0 is in), and
     // only the run's last tile has to compute the 8 samples after it itself (a whole extra row step for
@@ -987,13 +1006,25 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
         // columns this tile may store, relative to its first symbol (32-bit tests per row)
         const int64_t klo64 = Q.k_lo - sym_base, khi64 = Q.k_hi - sym_base;
         const int klo = klo64 < -(1 << 20) ? -(1 << 20) : (int)klo64, khi = khi64 > (1 << 20) ? (1 << 20) : (int)khi64;
+        // Packed rows (32 B per column): where column kr = 0 of this tile sits — a UNIFORM address (it may lie before the array:
+        // columns outside [klo, khi) are never stored); a lane adds its own 32-bit byte offset, so a store is scalar base +
+        // vector offset and the row loop does no 64-bit address arithmetic on the vector pipe (it did: 9 instructions per row).
+        char *const tile_rows4 = reinterpret_cast<char *>(rows) + 32 * (sym_base - Q.k_lo);
         wf_lds_barrier();                                     // previous tile's columns are done with the ring and the window
         // The prologue's thread index is opaque per tile: otherwise every lane predicate and index of the
         // staging code below (t * 5 + e, lane == 63, t < 4, ...) is hoisted out of the tile loop as a
         // loop invariant and then SPILLED around the row loop (SGPR pairs for the masks, scratch for the indices).
-        int tp = t;
-        asm volatile("" : "+v"(tp));
+        // (... and RE-DERIVED from the wave number and the lane's position in the wave: as a copy of t it kept t alive across the row loop)
+        //  — from an opaque zero, or the derivation itself is hoisted out of the tile loop and carried)
+        unsigned lane0 = 0u;
+        asm volatile("" : "+v"(lane0));
+        int tp = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, lane0)) + 64 * wave_u;
         mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot, tp);
+        // noise index / 2 of this thread's samples in row 0 of the tile (tile_base and RS are even): the launch's first index
+        // re-read per tile (carried, it was two more registers across the row loop) + the opaque thread index (as the loop
+        // invariant "first index + t" it was carried, and spilled, across the row loop) — behind the window staging, whose
+        // temporaries are the kernel's register peak
+        const uint64_t pair_t = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull) + (uint64_t)(tile_base >> 1) + (uint64_t)tp;
         const uint64_t *Wq = reinterpret_cast<const uint64_t *>(kt->scratch + MOD_OFF_P + P.ntiles);
         const double W = (double)Wq[ltile] * 0x1.0p-62 * P.sps_d;             // tile carry (tile 0: the head truncation -K0)
         const int ref_a = s_pi[lpart], ref_b = P.nh > 1 ? s_pi[win + 1 + lpart] : 0;
@@ -1157,16 +1188,19 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 const double *xb = ring_d + 2 * (G::GS * grp) + (mp & 1);
                 // (CPR even: the lane's column parity is the same in every row)
                 const double *tapc = s_tapc + NT * (4 * ((CPR & 1) ? (int)odd : odd_l) + mp);
-                double S = 0.0, U = 0.0;
-#pragma unroll NT <= 11 ? NT : 7                                         // (21 taps at sps 20: three trips of 7 keep the reads in flight within the register budget)
-                for (int j = 0; j < NT; ++j) {
+                const double x_first = xb[0];
+                double S = x_first * tapc[0], U = x_first;                // (S = fma(x, tap, +0.0) and U = 0.0 + x are these values: one add less)
+#pragma unroll NT <= 11 ? NT - 1 : 5                                     // (21 taps at sps 20: four trips of 5 keep the reads in flight within the register budget)
+                for (int j = 1; j < NT; ++j) {
                     const double x = xb[2 * (j < SPS ? j : G::GS)];
                     S = fma(x, tapc[j], S);
                     U += x;
                 }
                 const double T = S + mcb_quad_bcast<0xB1>(S);            // quad_perm [1, 0, 3, 2]: vb | vb | va | va
                 const double val = (mp == 0 || mp == 3) ? U : T;
-                if (k_ok) rows[4 * (k - Q.k_lo) + slot_l] = val;        // (32 B rows: the nontemporal hint measured neutral here)
+                if (k_ok) {                                               // (32 B rows: the nontemporal hint measured neutral here)
+                    *reinterpret_cast<double *>(tile_rows4 + (int64_t)(32 * (CPR * rho - Q.kshift)) + (unsigned)(32 * mq + 8 * slot_l)) = val;
+                }
             } else {
                 // any 3 x (SPS + 1) bank: lane p keeps the one chain of the packed row it stores
                 const int f = mp < 2 ? 1 : (mp == 2 ? 0 : 2);
@@ -1179,7 +1213,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                     const double2 tp = s_taps[f * NT + (NT - 1 - j)];
                     acc = imag ? fma(x.x, tp.y, fma(x.y, tp.x, acc)) : fma(x.x, tp.x, fma(-x.y, tp.y, acc));
                 }
-                if (k_ok) rows[4 * (k - Q.k_lo) + mp] = acc;
+                if (k_ok) *reinterpret_cast<double *>(tile_rows4 + (int64_t)(32 * (CPR * rho - Q.kshift)) + (unsigned)(32 * mq + 8 * mp)) = acc;
             }
         };
         // PAM form: the partial tiles of bank_row(rho) summed and stored — register w of D is this wave's
@@ -1199,7 +1233,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 const int odd_c = (Q.pack_par0 + kr + (int)(sym_base & 1)) & 1;
                 const double *gt = s_gt + 16 * odd_c + 4 * p4;
                 const double out = fma(gt[3], y1i, fma(gt[2], y1r, fma(gt[1], y0i, gt[0] * y0r)));
-                if (kr >= klo && kr < khi && (CPR == 64 || (col >= 0 && col < CPR))) rows[4 * ((sym_base + kr) - Q.k_lo) + p4] = out;
+                if (kr >= klo && kr < khi && (CPR == 64 || (col >= 0 && col < CPR)))
+                    *reinterpret_cast<double *>(tile_rows4 + (int64_t)(32 * (CPR * rho - Q.kshift)) + (unsigned)(32 * col + 8 * p4)) = out;
             } else if constexpr (PAM) {
                 const int ln = t & 63;
                 const double *pp = s_part + (4 * 0 + wave_u) * 64 + ln;
@@ -1211,19 +1246,18 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             }
         };
         // One row: 512 samples by the 256 threads (EXTRA: "row 16", only what row 15's columns still need).
-        auto row_step = [&](const int u) __attribute__((always_inline)) {
+        auto row_step = [&](const int u, auto parc) __attribute__((always_inline)) {      // parc: u & 1 as a compile-time constant
             const bool EXTRA = u >= MOD_ROWS;                   // (uniform; false for every row but the run's last one)
             double2 x0 = make_double2(0.0, 0.0), x1 = x0;
             bool have_next = true;
             if ((!EXTRA || wave_u == 0) && active) {
-            double Wu = W;
-            int refu_a = ref_a, refu_b = ref_b;
-            if (EXTRA) {                                        // the next tile's carry and reference counts (fetched here: nothing of row 16 is live across the other rows)
+            // row 16 runs on the NEXT tile's carry and reference counts (nothing of it is live across the other rows)
+            auto next_tile_refs = [&](double &Wn, int &na, int &nb) __attribute__((always_inline)) {
                 have_next = ltile + 1 < P.ntiles;
-                Wu = have_next ? (double)Wq[ltile + 1] * 0x1.0p-62 * P.sps_d : 0.0;
-                refu_a = s_pi[lpart + MOD_ROWS * sym_per_row];
-                refu_b = P.nh > 1 ? s_pi[win + 1 + lpart + MOD_ROWS * sym_per_row] : 0;
-            }
+                Wn = have_next ? (double)Wq[ltile + 1] * 0x1.0p-62 * P.sps_d : 0.0;
+                na = s_pi[lpart + MOD_ROWS * sym_per_row];
+                nb = P.nh > 1 ? s_pi[win + 1 + lpart + MOD_ROWS * sym_per_row] : 0;
+            };
             double ra, rb;
             double2 e0, e1;
             // The row's amplitude / count reads are ISSUED FIRST, the noise arithmetic (45 % of the row's vector
@@ -1246,10 +1280,13 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             double am_[JMAX];
             int pi0_ = 0, pi1_ = 0;
             if constexpr (!LOADS_FIRST) {
+                double Wu = W;
+                int refu_a = ref_a, refu_b = ref_b;
+                if (EXTRA) next_tile_refs(Wu, refu_a, refu_b);
                 mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap, P.nh,
                                      win + 1, refu_a, refu_b, Wu, Th_a, Th_b, (double)SPS, 1.0 / (double)SPS, ra, rb);
-                wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
-                wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
+                wf_sincos_sectors_pos(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);   // (ra, rb in [0, SPS), phi0 >= 0: the host checks)
+                wf_sincos_sectors_pos(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
             } else {
                 const double *ap = &s_amp[l_top0p1 + u * sym_per_row];
                 const int *pp = &s_pi[(q0 - cq) + u * sym_per_row];
@@ -1259,7 +1296,6 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 if (P.nh > 1) pi1_ = pp[win + 1];
             }
             // channel (wf_awgn_c128): derotate + Philox AWGN, one block per thread and row
-            const int64_t n0 = tile_base + (int64_t)u * RS + 2 * t;
             double g[4];
             {
                 // The Philox key schedule (20 words: seed + r * Weyl) is uniform and loop-invariant; left to
@@ -1271,7 +1307,9 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 // the two Box-Muller transforms interleaved, all four table entries fetched right behind the Philox rounds
                 // (same-box A/B at 1e7 symbols: sequential 0.4580 / 0.4644 ms, table reads in pairs 0.4591 / 0.4588, all four up front 0.4479 / 0.4535;
                 //  staged further — Philox + reads, then the phase sums and the sector reads, then the transforms — 0.4640 / 0.4598 against 0.4473 / 0.4536: not kept)
-                wf_gaussian_two_il<true>(pair0 + (uint64_t)(n0 >> 1), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
+                // (the Philox counter of this thread's pair of samples: one 64-bit add per row on a per-tile, per-thread base)
+                // (the one-operation form of (double)word + 1 where the registers allow: the sps-8 SOQPSK forms)
+                wf_gaussian_two_il<true, decltype(tb), CPMNF == 0 && SPS == 8>(pair_t + (uint64_t)(u * (RS / 2)), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
                 __builtin_amdgcn_s_setprio(WF_MCB_PRIO);
             }
             if constexpr (LOADS_FIRST) {
@@ -1282,18 +1320,30 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                     acc0 = fma(Q0[j], am_[j], acc0);
                     acc1 = fma(Q1[j], am_[j], acc1);
                 }
-                double b0 = fma((double)(pi0_ - refu_a), Th_a, Wu);
-                if (P.nh > 1) b0 = fma((double)(pi1_ - refu_b), Th_b, b0);
+                // (the tile's carry and reference counts are used where they lie; row 16 fetches the next tile's HERE, into the
+                //  same result: as copies selected at the top of every row they were three moves per row and four registers)
+                double b0;
+                if (!EXTRA) {
+                    b0 = fma((double)(pi0_ - ref_a), Th_a, W);
+                    if (P.nh > 1) b0 = fma((double)(pi1_ - ref_b), Th_b, b0);
+                } else {
+                    double Wn;
+                    int na, nb;
+                    next_tile_refs(Wn, na, nb);
+                    b0 = fma((double)(pi0_ - na), Th_a, Wn);
+                    if (P.nh > 1) b0 = fma((double)(pi1_ - nb), Th_b, b0);
+                }
                 const double v0 = b0 + acc0, v1 = b0 + acc1;
                 const double kq = floor(v0 * (1.0 / (double)SPS));
                 ra = fma(-kq, (double)SPS, v0);
                 rb = fma(-kq, (double)SPS, v1);
-                wf_sincos_sectors(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);
-                wf_sincos_sectors(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
+                wf_sincos_sectors_pos(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);   // (ra, rb in [0, SPS), phi0 >= 0: the host checks)
+                wf_sincos_sectors_pos(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
             }
             x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
             x1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
             if (EXTRA || !full_tile) {                          // (tile-uniform) samples past the end of the burst are zeros to the bank
+                const int64_t n0 = tile_base + (int64_t)u * RS + 2 * t;
                 if (n0 >= P.out_len || (EXTRA && !have_next)) x0 = make_double2(0.0, 0.0);
                 if (n0 + 1 >= P.out_len || (EXTRA && !have_next)) x1 = make_double2(0.0, 0.0);
             }
@@ -1303,25 +1353,36 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             wf_lds_barrier();
             // (PAM form) the partial tiles bank_row(u - 2) left during the previous row step
             if (PAM && u >= 1 && (u >= 2 || !run_first || (tile == 0 && Q.kshift < 0))) bank_reduce(u - 2);
-            int ia, ib;                                         // ring indices (sample - d) mod RING of the thread's two samples
-            if (SPS == 8) {
-                ia = ((u << 9) + 2 * t - Q.d) & (G::RING - 1);
-                ib = (ia + 1) & (G::RING - 1);
-            } else {
-                ia = ((u & 1) ? RS : 0) + 2 * t - Q.d;
-                ia += ia < 0 ? G::RING : 0;
-                ib = ia + 1 == G::RING ? 0 : ia + 1;
-            }
             constexpr int XLEN = PAM ? GP::XLEN : SPS;          // samples of the next tile the last columns of a tile look at
-            if (active && (!EXTRA || 2 * t < XLEN)) {           // (row 16: its first XLEN samples; the lanes above computed on window slots that do not exist)
-                s_ring[ia + ia / PG] = x0;
-                s_ring[ib + ib / PG] = x1;
-                if (PAM) {                                      // indices 0 .. MIRROR-1 once more behind the ring (index RING + i)
+            if constexpr (!RINGPK) {
+                int ia, ib;                                     // ring indices (sample - d) mod RING of the thread's two samples
+                if (SPS == 8) {
+                    ia = ((u << 9) + 2 * t - Q.d) & (G::RING - 1);
+                    ib = (ia + 1) & (G::RING - 1);
+                } else {
+                    ia = ((u & 1) ? RS : 0) + 2 * t - Q.d;
+                    ia += ia < 0 ? G::RING : 0;
+                    ib = ia + 1 == G::RING ? 0 : ia + 1;
+                }
+                if (active && (!EXTRA || 2 * t < XLEN)) {       // (row 16: its first XLEN samples; the lanes above computed on window slots that do not exist)
+                    s_ring[ia + ia / PG] = x0;
+                    s_ring[ib + ib / PG] = x1;
+                    if constexpr (PAM) {
+                    // indices 0 .. MIRROR-1 once more behind the ring (index RING + i)
                     if (ia < GP::MIRROR) s_ring[G::RING + ia + (G::RING + ia) / PG] = x0;
                     if (ib < GP::MIRROR) s_ring[G::RING + ib + (G::RING + ib) / PG] = x1;
-                } else {
-                    if (ia == 0) s_ring[G::GROUPS * G::GS] = x0;    // index RING: read by the window that ends the ring
+                    } else {
+                    if (ia == 0) s_ring[G::GROUPS * G::GS] = x0;
                     if (ib == 0) s_ring[G::GROUPS * G::GS] = x1;
+                    }
+                }
+            } else if (active && (!EXTRA || 2 * t < XLEN)) {    // (row 16: its first XLEN samples; the lanes above computed on window slots that do not exist)
+                constexpr int PAR = decltype(parc)::value;      // the row's parity (see ring_pk_a)
+                *(mcb_lds2)(uintptr_t)(PAR ? ring_pk_a >> 16 : ring_pk_a & 0xFFFFu) = wf_v2d{x0.x, x0.y};
+                *(mcb_lds2)(uintptr_t)(PAR ? ring_pk_b >> 16 : ring_pk_b & 0xFFFFu) = wf_v2d{x1.x, x1.y};
+                if constexpr (PAR == 0) {                       // ring index 0 / RING - 1 | 0 live in an even row: the copy behind the ring
+                    if (2 * t == Q.d) s_ring[G::GROUPS * G::GS] = x0;
+                    if (2 * t + 1 == Q.d) s_ring[G::GROUPS * G::GS] = x1;
                 }
             }
             // ... and row u is complete after this barrier — one more barrier per row than a four-row
@@ -1335,8 +1396,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
         const int nrow = run_last ? MOD_ROWS + 1 : MOD_ROWS;
 #pragma unroll 1
         for (int u = 0; u < nrow; u += 2) {
-            row_step(u);
-            if (u + 1 < nrow) row_step(u + 1);
+            row_step(u, std::integral_constant<int, 0>{});
+            if (u + 1 < nrow) row_step(u + 1, std::integral_constant<int, 1>{});
         }
         if (PAM) {                                              // the last bank_row's partial tiles
             wf_lds_barrier();
@@ -1481,6 +1542,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_mf_taps && d_rows4, "wf_mod_chan_bank: NULL argument");
     if (cpm_nf != 0 && cpm_nf != 4 && cpm_nf != 16) return 1;
     if (cpm_nf && cpm_nh != 1 && cpm_nh != 2) return 1;
+    if (!(phi0 >= 0.0)) return 1;                      // (the kernel's sector split assumes a non-negative phase offset: wf_sincos_sectors_pos)
     // SOQPSK bank: sps + 1 taps = the pulse-truncation form; any other odd length up to MCB_PAM_NT at 8 samples per
     // symbol = the long-bank (PAM) form on the matrix cores
     if (mf_ntaps <= 0) mf_ntaps = sps + 1;

@@ -251,7 +251,7 @@ def main() -> None:
     ap.add_argument("--ber-points", default="0:12",
                     help="SOQPSK at 8 sps: after the timed region, the BER sweep of BASELINE configs[3] (these Eb/N0 points x "
                          "--ber-symbols) through the same link, reported as `ber_curve` with its offset in dB from the reference's "
-                         "golden curve — the second half of BASELINE's metric ('' = skip)")
+                         "golden curve — the second half of BASELINE's metric ('none' = skip)")
     ap.add_argument("--ber-symbols", type=float, default=1e8, help="symbols per point of that sweep")
     ap.add_argument("--steady-steps", type=int, default=2000,
                     help="after the timed region (single GPU): this many more steps in one go, reported as `steady_state` — long "
@@ -501,7 +501,7 @@ def main() -> None:
     # (examples/soqpsk_detection.py:200-216 is the quantity; tests/golden/ber_golden*.csv the reference's own counts):
     # configs[3]'s sweep through the link the timed region just ran, one block after the other.
     ber_curve = None
-    if rank == 0 and not cpm and args.sps == 8 and nstreams == 1 and args.ber_points and args.detector in ("PT", "PAM"):
+    if rank == 0 and not cpm and args.sps == 8 and nstreams == 1 and args.ber_points not in ("", "none") and args.detector in ("PT", "PAM"):
         sys.path.insert(0, str(ROOT / "tools"))
         from ber_sweep import golden_curve
         from waveforms_amd.bert import ebn0_at_ber

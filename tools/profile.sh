@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/$tag
 mkdir -p $out/profiles
 # --overlap-streams 0: only the single-stream timed region, so the per-kernel averages are those of kernels running alone
-flags="--steps 5 --warmup 2 --no-cpu-baseline --overlap-streams 0 --steady-steps 0 $*"
+flags="--steps 5 --warmup 2 --no-cpu-baseline --overlap-streams 0 --steady-steps 0 --ber-points none $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py $flags > $out/profiles/${tag}_bench_under_rocprof.json 2> $out/kt.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python3 bench.py $flags > /dev/null 2> $out/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python3 bench.py $flags > /dev/null 2> $out/write.err

@@ -552,12 +552,21 @@ __device__ __forceinline__ void wf_gaussian_two(uint64_t pair, uint64_t stream_i
 // wf_gaussian_two with the two Box-Muller transforms INTERLEAVED: both log-table entries are fetched together, then
 // both sector entries, so the four dependent table round trips of a Philox block become two (same operations on the
 // same operands as wf_gaussian_two: the same bits).  ALL_UP_FRONT: all four entries right behind the Philox rounds.
-template <bool ALL_UP_FRONT, class Tabs, bool ONE_OP_X = true>
+// SECTION_OFF (tools/section_budget.py ONLY — never set in a build that ships): bit 0 = the Philox rounds replaced by the
+// counter's own words, bit 1 = the two Box-Muller transforms replaced by a bit cast of the words.  The tool compiles the
+// front-end kernel with one section stubbed at a time and attributes the difference in the row loop's instruction count.
+template <bool ALL_UP_FRONT, class Tabs, bool ONE_OP_X = true, int SECTION_OFF = 0>
 __device__ __forceinline__ void wf_gaussian_two_il(uint64_t pair, uint64_t stream_id, uint64_t seed, double sigma,
                                                    const Tabs &tb, double g[4])
 {
-    const wf_philox_out p = wf_philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)stream_id,
-                                             (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    wf_philox_out p;
+    if constexpr (SECTION_OFF & 1) p = wf_philox_out{(uint32_t)pair, (uint32_t)(pair >> 32) ^ (uint32_t)seed, (uint32_t)pair ^ (uint32_t)stream_id, (uint32_t)(seed >> 32)};
+    else p = wf_philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    if constexpr (SECTION_OFF & 2) {
+        g[0] = __hiloint2double(0x3ff00000, (int)p.x0); g[1] = __hiloint2double(0x3ff00000, (int)p.x1);
+        g[2] = __hiloint2double(0x3ff00000, (int)p.x2); g[3] = __hiloint2double(0x3ff00000, (int)p.x3);
+        return;
+    }
     const uint32_t xa[2] = {p.x0, p.x2}, xb[2] = {p.x1, p.x3};
     long long mant[2];
     int e[2];

@@ -60,6 +60,7 @@ struct cpm_lane_plan {
     int ring_batches;   // LDS ring depth in 16 KB batches
     int waves_per_cu;   // resident waves per CU the ring allows
     int calls_per_batch;
+    int min_chunk;      // shortest chunk worth running (calls): below it the warm-up's share of the work and its re-read of the rows outweigh the extra waves
     double lane_ns_per_call;    // the lane form's time per call of a chunk (a lane runs its chunk alone: independent of the burst)
     double row_ns_per_call;     // the row form's time per call of the BURST (measured at 1e7 calls; it scales with the burst)
 };

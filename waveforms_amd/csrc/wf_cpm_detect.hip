@@ -590,10 +590,9 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
 // Calls per chunk, and which form runs them.  Row form: a multiple of 64, at least 256 (and 2 W) so that the warm-up stays
 // a fraction of the work, otherwise the smallest that puts the whole burst into ONE round of resident workgroups.  Lane
 // form (wf_cpm_lanes.hip, where a specialisation for this trellis is compiled in): 64 chunks per wave, the chunk length that
-// puts the burst into one round of the waves a CU's LDS holds, at least 5 W — a chunk that missed a short warm-up should
-// meet the first launch's trajectory inside its own calls, or its repair hands on to the next chunk and costs a further
-// round (a matter of speed: with 64-call warm-ups and 256-call chunks PCM/FM handed on 3 chunks of 1.2e7 at 10 dB, none
-// with 320; profiles/r04_lane_chunk_sweep.log).
+// puts the burst into one round of the waves a CU's LDS holds, not below the specialisation's shortest worthwhile chunk
+// (cpm_lane_plan::min_chunk).  A chunk that misses its warm-up and does not meet the first trajectory inside its own calls
+// hands its repair on to the next chunk (wf_cpm_detect.h): chunk length and warm-up are matters of speed only.
 // Which one: a lane runs its chunk alone, so the lane form's time is (chunk + warm-up) x its time per call whatever the
 // burst's length, while the row form's falls with the burst (4 chunks per wave: 16 times the waves).  The two meet near
 // 9e6 (ARTM) and 6.5e6 (PCM/FM) calls; below, the row form runs (a 2^22-call stream chunk: 0.32 against 0.54 ms for
@@ -601,23 +600,22 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
 static int64_t cpm_chunk_calls(const wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int W, int wg_per_cu, cpm_lane_plan *lanes,
                                bool *use_lanes)
 {
-    auto floor_ch = [&](int64_t ch, bool lane) {
+    auto floor_ch = [&](int64_t ch, int min_chunk) {
         ch = (ch + 63) / 64 * 64;
-        if (ch < 256) ch = 256;                                    // (room for a repair to meet the previous run's trajectory)
+        if (ch < min_chunk) ch = min_chunk;                        // (a matter of speed: the warm-up's share of the work, and most repairs ending inside their chunk)
         if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
-        if (lane && ch < 5 * W) ch = (5 * W + 63) / 64 * 64;
         return ch;
     };
     const int cus = ctx->cus;
     const int64_t form = ctx->opt[WF_OPT_CPM_FORM];
     const int64_t slots_row = (int64_t)cus * wg_per_cu * CPM_WAVES * CPM_GROUPS;
-    int64_t ch = floor_ch((ncalls + slots_row - 1) / slots_row, false);
+    int64_t ch = floor_ch((ncalls + slots_row - 1) / slots_row, 256);
     *use_lanes = false;
     // (a burst of fewer calls than the pulse has symbols is all virtual pre-start symbols: the lane form runs those
     // outside its call loop and has no chunk to hang the end record on — the row form takes it)
     if (form != 1 && ncalls >= det->Lp && wf_cpm_lanes_plan(det, lanes) == 0) {
         const int64_t slots_lane = (int64_t)cus * lanes->waves_per_cu * 64;
-        const int64_t ch_lane = floor_ch((ncalls + slots_lane - 1) / slots_lane, true);
+        const int64_t ch_lane = floor_ch((ncalls + slots_lane - 1) / slots_lane, lanes->min_chunk);
         const double t_lane = lanes->lane_ns_per_call * (double)(ch_lane + W), t_row = lanes->row_ns_per_call * (double)ncalls;
         if (form == 2 || t_lane < t_row) {
             *use_lanes = true;

@@ -541,7 +541,10 @@ int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
     if (per_cu > 4) per_cu = 4;                 // one wave per SIMD: 225 registers (ARTM) leave room for nothing else of this kernel
     // time per call of a chunk / of the burst (one MI355X, profiles/r04_ab_lane_ring.log, r04_lane_chunk_sweep.log):
     // ARTM 0.66 ms for 256 + 49 calls, row form 0.74 ms per 1e7; PCM/FM 0.27 ms for 256 + 64 calls, row form 0.49 ms per 1e7
-    *plan = {spec, R, per_cu, spec == 0 ? 1 : 4, spec == 0 ? 2160.0 : 840.0, spec == 0 ? 0.074 : 0.049};
+    // shortest chunk (round 5, pipelined links at 1e7 symbols, same box, profiles/r05_lane_sweep.log): ARTM 192 | 256 calls at a
+    // 48-call warm-up 1.181 | 1.198 ms per block; PCM/FM 192 | 256 | 320 at 64: 0.595 | 0.583 | 0.598.  (Since the repairs cascade,
+    // a chunk no longer has to be long enough for a repair to meet the first trajectory inside it: this is a matter of speed only.)
+    *plan = {spec, R, per_cu, spec == 0 ? 1 : 4, spec == 0 ? 192 : 256, spec == 0 ? 2160.0 : 840.0, spec == 0 ? 0.074 : 0.049};
     return 0;
 }
 

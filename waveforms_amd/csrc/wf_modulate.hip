@@ -639,6 +639,13 @@ __device__ __forceinline__ double mcb_quad_bcast(double v)   // quad_perm CTRL (
 #ifndef WF_MCB_UNROLL
 #define WF_MCB_UNROLL 2
 #endif
+// Analysis aid, 0 in every build that ships: tools/section_budget.py compiles this file with ONE section of the row body
+// stubbed at a time and attributes the difference in the row loop's instruction count to that section.  Bits: 1 Philox
+// rounds, 2 Box-Muller transforms, 4 modulator (amplitude / count reads, phase sums, table sincos), 8 the bank (reads, sums,
+// packed-row store).  Results of such a build are wrong by construction.
+#ifndef WF_MCB_SECTION_OFF
+#define WF_MCB_SECTION_OFF 0
+#endif
 // Issue priority (s_setprio): a row is a latency-bound part (amplitude / count reads from LDS, the phase sums, the
 // ring writes, the bank's operand reads) and a throughput-bound part (Philox + Box-Muller: ~45 % of the vector
 // instructions, next to no memory).  With the first at raised priority a wave's LDS round trips start as early as they
@@ -1287,7 +1294,7 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                                      win + 1, refu_a, refu_b, Wu, Th_a, Th_b, (double)SPS, 1.0 / (double)SPS, ra, rb);
                 wf_sincos_sectors_pos(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);   // (ra, rb in [0, SPS), phi0 >= 0: the host checks)
                 wf_sincos_sectors_pos(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
-            } else {
+            } else if constexpr (!(WF_MCB_SECTION_OFF & 4)) {
                 const double *ap = &s_amp[l_top0p1 + u * sym_per_row];
                 const int *pp = &s_pi[(q0 - cq) + u * sym_per_row];
 #pragma unroll
@@ -1309,10 +1316,13 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
                 //  staged further — Philox + reads, then the phase sums and the sector reads, then the transforms — 0.4640 / 0.4598 against 0.4473 / 0.4536: not kept)
                 // (the Philox counter of this thread's pair of samples: one 64-bit add per row on a per-tile, per-thread base)
                 // (the one-operation form of (double)word + 1 where the registers allow: the sps-8 SOQPSK forms)
-                wf_gaussian_two_il<true, decltype(tb), CPMNF == 0 && SPS == 8>(pair_t + (uint64_t)(u * (RS / 2)), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
+                wf_gaussian_two_il<true, decltype(tb), CPMNF == 0 && SPS == 8, WF_MCB_SECTION_OFF & 3>(pair_t + (uint64_t)(u * (RS / 2)), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
                 __builtin_amdgcn_s_setprio(WF_MCB_PRIO);
             }
-            if constexpr (LOADS_FIRST) {
+            if constexpr (LOADS_FIRST && (WF_MCB_SECTION_OFF & 4)) {
+                e0 = make_double2(1.0, 0.0);                    // (section stub: see WF_MCB_SECTION_OFF)
+                e1 = make_double2(0.0, 1.0);
+            } else if constexpr (LOADS_FIRST) {
                 // mod_pair_phase with both samples on the same symbols (a1 == a, one count)
                 double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -1388,7 +1398,8 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             // ... and row u is complete after this barrier — one more barrier per row than a four-row
             // ring, 18 KB less LDS (4 workgroups per CU instead of 3: 0.56 -> 0.5x ms).
             wf_lds_barrier();
-            if (u >= 1 || !run_first || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);   // u = 0: the previous tile's row 15
+            if constexpr (!(WF_MCB_SECTION_OFF & 8))
+                if (u >= 1 || !run_first || (tile == 0 && Q.kshift < 0)) bank_row(u - 1);   // u = 0: the previous tile's row 15
         };
         // two rows per trip, ONE copy of the row code: row 16 goes through the same loop body (a separate
         // inlined copy — or the compiler's remainder loop — is a second 1200-instruction body whose

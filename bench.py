@@ -142,9 +142,9 @@ def _cpu_trial(job):
     pulse, sigma = oracle.freq_pulse_soqpsk_tg(sps), oracle.sigma_for_ebn0(ebn0, sps)
     if kind.startswith("cpm:"):   # generic CPM detector chain (build-defined; no reference form exists)
         waveform = kind[4:]
-        wide = waveform.endswith("64")                   # "multih64": the 64-state ARTM design (same modulator, same filters)
-        waveform = waveform[:-2] if wide else waveform
-        spec = (oracle.ARTM_64 if wide else oracle.ARTM_16) if waveform == "multih" else oracle.PCMFM_SPEC
+        states = 256 if waveform.endswith("256") else (64 if waveform.endswith("64") else 16)   # "multih64" / "multih256": the bigger ARTM designs (same modulator)
+        waveform = waveform[:-len(str(states))] if states != 16 else waveform
+        spec = {16: oracle.ARTM_16, 64: oracle.ARTM_64, 256: oracle.ARTM_256}[states] if waveform == "multih" else oracle.PCMFM_SPEC
         bits, _ = oracle.glfsr_bits(0x420000, state, nsym * spec.lgM)
         sym = oracle.multih_mapper(bits)[0] if waveform == "multih" else oracle.pcmfm_mapper(bits)
         pulse = oracle.freq_pulse_multih_irig(sps) if waveform == "multih" else oracle.freq_pulse_pcmfm(sps)
@@ -223,9 +223,10 @@ def main() -> None:
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"],
                     help="soqpsk: BASELINE configs[1] (the headline metric); multih: configs[2], ARTM multi-h CPM through the "
                          "16-state generic CPM trellis detector; pcmfm: PCM/FM through the same detector family")
-    ap.add_argument("--states", type=int, default=16, choices=[16, 64],
+    ap.add_argument("--states", type=int, default=16, choices=[16, 64, 256],
                     help="--waveform multih: 16 = the reduced design BASELINE configs[2] names (Lp 2, NC 4); 64 = every phase state "
-                         "for the two-symbol pulse (Lp 2, NC 16, N_S = p M^(Lp-1): notes/cpm/cpm.md:128-140), 0.2 dB better, one wave per detector")
+                         "for the two-symbol pulse (Lp 2, NC 16, N_S = p M^(Lp-1): notes/cpm/cpm.md:128-140), 0.2 dB better, one wave per detector; "
+                         "256 = the full trellis (3-symbol pulse, 64 matched filters per symbol: 1 KB of rows per symbol), one workgroup per detector")
     ap.add_argument("--fuse", type=int, default=47,
                     help="bit 0: fused modulator (FIR + phase scan in one pass); bit 1: AWGN inside the MF bank; "
                          "bit 2: detector-packed 32 B rows between bank and detector; bit 3: modulator + channel + bank in one "
@@ -283,11 +284,13 @@ def main() -> None:
         from waveforms_amd.viterbi.cpm import detector_kernel_name
 
         # detector chunk warm-up rows: by operating point (waveforms_amd.link.operating_point_warmup), or --vit-warmup
-        wide = args.waveform == "multih" and args.states == 64
+        wide = args.waveform == "multih" and args.states != 16
         cwu = args.vit_warmup if args.vit_warmup >= 0 else (0 if wide else operating_point_warmup(args.waveform, args.ebn0))
+        big_spec = None
         if wide:
-            from waveforms_amd.viterbi.cpm import ARTM_64
-        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, spec=ARTM_64 if wide else None, private_ctx=nstreams > 1, fuse=args.fuse, warmup=cwu)      # (bits 1, 3, 5 apply)
+            from waveforms_amd.viterbi import cpm as _cpm
+            big_spec = _cpm.ARTM_64 if args.states == 64 else _cpm.ARTM_256
+        links = [CPMLink(args.nsym, args.sps, waveform=args.waveform, spec=big_spec, private_ctx=nstreams > 1, fuse=args.fuse, warmup=cwu)      # (bits 1, 3, 5 apply)
                  for _ in range(nstreams)]
         bits_per_sym = links[0].spec.bits_per_symbol
     else:
@@ -603,7 +606,7 @@ def main() -> None:
                        "fuse": args.fuse, "streams": nstreams,
                        "detector_warmup_rows": det_info[3] if cpm else (links[0].cfg.warmup + 1 if links[0].cfg.warmup else 32),
                        "detector_chunk_calls": det_info[2] if cpm else None,
-                       "detector_form": {0: "rows", 1: "lanes", 2: "wide"}[det_info[0]] if cpm else "lanes (one chunk per lane)",
+                       "detector_form": {0: "rows", 1: "lanes", 2: "wide", 3: "quad"}[det_info[0]] if cpm else "lanes (one chunk per lane)",
                        "ctx_options": args.opt, "parallelism": f"independent trial blocks x{world}"},
             "ber": {"bit_errors": be, "symbol_errors": se, "symbols": compared,
                     "ber": be / max(compared * bits_per_sym, 1),
@@ -627,7 +630,7 @@ def main() -> None:
                 out["steady_state_per_rank"] = steady_all
         if not args.no_cpu_baseline:    # rank 0 only, after the timed region, at any N (the other ranks wait at the final barrier)
             out["cpu_baseline"] = cpu_baseline(args.sps, args.ebn0, args.cpu_sample, args.cpu_loop_sample,
-                                                   args.waveform + ("64" if args.waveform == "multih" and args.states == 64 else ""), gpus=world)
+                                                   args.waveform + (str(args.states) if args.waveform == "multih" and args.states != 16 else ""), gpus=world)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -433,16 +433,18 @@ int wf_cpm_awgn_mf_rows_c128(wf_ctx *ctx, const double *d_signal_ri, int64_t nsa
 /* The detector over ncalls rows.  d_rot_cs: 2p pairs (cos, sin)(pi r / p) (caller-computed so that
  * oracle and device rotate with the same doubles).  d_decisions[k] (uint8) = the U decided at call
  * k, i.e. of symbol n0 + k - D + 1 (n0 = calls already made on d_state; entries with
- * n0 + k < D - 1 are written as 0).  Trellises of up to 64 states (N_S = NC M^(Lp-1), notes/cpm/cpm.md:128-140: up to 16
- * in one 16-lane group, 17 .. 64 — the 64-state ARTM design — one wave per detector).
+ * n0 + k < D - 1 are written as 0).  Trellises of up to 256 states (N_S = NC M^(Lp-1), notes/cpm/cpm.md:128-140: up to 16
+ * in one 16-lane group, 17 .. 64 — the 64-state ARTM design — one wave per detector, 65 .. 256 — the full ARTM trellis
+ * p M^(L-1) = 256 with its 64 matched filters per symbol — one workgroup per detector; pulses of 2 or 3 symbols there).
  * Chunk-parallel like wf_viterbi4_detect: each 16-lane group
  * re-derives metrics, phase indices and decision registers over `warmup` rows (0 = default) and
  * every launch verifies bitwise that a chunk started from what its predecessor ended with
  * and repairs the chunks for which that failed, cascading into the following chunks where needed
  * (wf_viterbi4_unmerged, wf_viterbi_repaired): decisions are the sequential detector's whatever the warm-up.  d_state (WF_CPM_STATE_BYTES, zeroed = fresh detector,
  * may be NULL) carries the detector across calls. */
-#define WF_CPM_STATE_BYTES 4096
-/* Which of its forms wf_cpm_viterbi_detect runs for this trellis, burst length and warm-up: info4[0] = 2 the wide form
+#define WF_CPM_STATE_BYTES 16384
+/* Which of its forms wf_cpm_viterbi_detect runs for this trellis, burst length and warm-up: info4[0] = 3 the quad form
+ * (65 .. 256 states: thread = state, one workgroup per chunk), 2 the wide form
  * (17 .. 64 states: lane = state, one wave per chunk), 0 the row
  * form (one 16-lane DPP row per chunk, any trellis of <= 16 states), 1 the lane form (one lane per chunk, trellis compiled
  * in: the ARTM 16-state and PCM/FM 10-state designs of waveforms/cpm/multih, waveforms/cpm/pcmfm; bursts long enough for
@@ -518,7 +520,7 @@ int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8);
  * one the one-kernel front end takes (fuse bits 1 + 3; wf_cpm_link_layout info8[5]).
  * wf_cpm_link_stream_layout: info8 = {calls in the chunk, first call index, off(decisions), off(symbols alpha),
  * global index of symbols[0], calls of the whole stream, symbols per modulator tile, off(rows)}. */
-#define WF_CPM_STREAM_STATE_BYTES 8192
+#define WF_CPM_STREAM_STATE_BYTES 20480
 int64_t wf_cpm_link_stream_workspace_bytes(const wf_cpm_link_config *cfg, int64_t chunk_symbols);
 int wf_cpm_link_stream_layout(const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index, int64_t *info8);
 int wf_cpm_link_stream_chunk(wf_ctx *ctx, const wf_cpm_link_config *cfg, int64_t chunk_symbols, int64_t chunk_index,

@@ -87,6 +87,15 @@ def test_link_config_layout_matches_c(tmp_path):
     assert nums[1:] == [getattr(_hip.LinkConfig, f).offset for f in fields]
 
 
+def test_state_block_sizes_match_the_header():
+    """The Python layer allocates the carried detector / stream state by the header's own constants."""
+    from waveforms_amd import _hip
+
+    text = (ROOT / "include" / "wfhip.h").read_text()
+    for name in ("WF_CPM_STATE_BYTES", "WF_CPM_STREAM_STATE_BYTES"):
+        assert int(re.search(rf"#define {name} (\d+)", text).group(1)) == getattr(_hip, name)
+
+
 def test_no_cpu_fallback():
     import torch
 

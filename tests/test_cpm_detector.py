@@ -36,8 +36,10 @@ DESIGNS = [  # (M, p, K, Lp, NC): full and reduced trellises, both alphabets, ev
     (4, 16, (4, 5), 2, 2), (2, 10, (7,), 2, 5), (2, 10, (7,), 3, 2), (2, 10, (7,), 1, 10), (2, 2, (1,), 1, 2),
     # 17 .. 64 states (the wide form of the GPU detector: lane = state, one wave per detector)
     (4, 16, (4, 5), 2, 8), (4, 16, (4, 5), 3, 4), (2, 10, (7,), 3, 10), (2, 16, (7,), 2, 16), (2, 20, (7,), 1, 20),
+    # 65 .. 256 states (the quad form: thread = state, one workgroup per detector; pulses of 2 or 3 symbols)
+    (4, 16, (4, 5), 3, 8), (2, 64, (9,), 2, 64), (2, 32, (7,), 3, 32), (2, 64, (9, 11), 3, 64),
 ]
-GPU_DESIGNS = [d for d in DESIGNS if d[4] * d[0] ** (d[3] - 1) <= 64]
+GPU_DESIGNS = [d for d in DESIGNS if d[4] * d[0] ** (d[3] - 1) <= 64 or d[3] >= 2]
 
 
 @pytest.fixture(params=["auto", "lanes", "rows"])
@@ -197,7 +199,7 @@ def test_cabi_rejects_unsupported_detectors_without_a_gpu():
 
     lib = _hip.lib()
     # the context pointer is checked first, the configuration before any device work
-    for bad in (dict(M=3), dict(Lp=4), dict(NC=3), dict(NC=16, Lp=3), dict(D=33), dict(nh=3), dict(p=65)):
+    for bad in (dict(M=3), dict(Lp=4), dict(NC=3), dict(p=32, NC=32, Lp=3), dict(D=33), dict(nh=3), dict(p=65)):
         c = _hip.CPMDetectorConfig()
         c.M, c.p, c.nh, c.Lp, c.NC, c.D = 4, 16, 2, 2, 4, 32
         c.K[0], c.K[1] = 4, 5
@@ -271,6 +273,55 @@ def test_gpu_artm64_decisions_equal_sequential_oracle(oracle, ebn0):
     assert np.array_equal(got, res["decisions"])
     _, res16 = _noisy_rows(oracle, oracle.ARTM_16, oracle.freq_pulse_multih_irig(SPS), 420_000, ebn0, int(ebn0) + 11)
     assert res["bit_errors"] < res16["bit_errors"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ebn0", [0.0, 4.0, 10.0])
+def test_gpu_artm256_decisions_equal_sequential_oracle(oracle, ebn0, ctx_options):
+    """The FULL ARTM trellis (notes/cpm/cpm.md:128-140: N_S = p M^(L-1) = 256, 64 matched filters per symbol) on the GPU:
+    thread = state, one workgroup per chunk — every decision identical to the sequential C detector, in one call and with
+    the state carried across ragged pieces; also with chunks of 512 calls and a 2-call warm-up (repairs that cross chunks)."""
+    from waveforms_amd import device as dev
+    from waveforms_amd.viterbi.cpm import ARTM_256, CPMTrellisDetector
+
+    sym, res = _noisy_rows(oracle, oracle.ARTM_256, oracle.freq_pulse_multih_irig(SPS), 150_000, ebn0, int(ebn0) + 31)
+    n = res["rows"].shape[0]
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+        got = CPMTrellisDetector(ARTM_256).detect(res["rows"])
+        assert got.size == res["decisions"].size and np.array_equal(got, res["decisions"])
+        det = CPMTrellisDetector(ARTM_256)
+        cuts = [0, 1, 2, 3, 40_001, n]
+        got = np.concatenate([det.detect(res["rows"][a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert np.array_equal(got, res["decisions"])
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_CHUNK_CALLS=512):
+        det = CPMTrellisDetector(ARTM_256)
+        got = det.detect(res["rows"], warmup=2)
+        assert np.array_equal(got, res["decisions"])
+        assert dev.viterbi_repaired(reset=True, ctx=det._ctx) > 100
+    if ebn0 >= 10.0:
+        assert res["bit_errors"] < 2e-3 * res["compared"]
+
+
+@pytest.mark.gpu
+def test_gpu_artm256_link_equals_oracle_chain(oracle):
+    """The ARTM link with the 256-state detector (modulator, channel, 64-filter rows, detector, count — the staged front
+    end: the one-kernel form holds 4 or 16 filters): error counts equal the sequential oracle chain's on the same bits and
+    the same Philox noise."""
+    from waveforms_amd.link import CPMLink
+    from waveforms_amd.viterbi import cpm
+
+    nsym, ebn0 = 200_000, 8.0
+    link = CPMLink(nsym, SPS, "multih", spec=cpm.ARTM_256, fuse=10)
+    link.run_block(ebn0, seed=1, stream_id=4)
+    se, be, m = link.result()
+    bits = oracle.glfsr_bits(0x420000, 0x7FFFFF, nsym * 2)[0]
+    sym = oracle.multih_mapper(bits)[0]
+    noise = oracle.philox_awgn(oracle.cpm_sigma_for_ebn0(ebn0, SPS, 2), 1, 4, 0, (nsym + 1) * SPS)
+    res = oracle.cpm_detection_run(sym, oracle.freq_pulse_multih_irig(SPS), SPS, oracle.ARTM_256, noise=noise)
+    x = (res["decisions"] ^ res["truth"])[64:]
+    assert m == x.size
+    assert (se, be) == (int(np.count_nonzero(x)), int(np.unpackbits(x[:, None], axis=1).sum()))
+    assert be > 0
 
 
 @pytest.mark.gpu

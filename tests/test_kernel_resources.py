@@ -140,7 +140,7 @@ def test_no_spill_traffic_inside_nested_loops(table):
                 "mod_chan_bank_kernel<4, -2, 10>": 2, "mod_chan_bank_kernel<9, -2, 10>": 2,
                 # ... and the repair launches of the detectors (cold: only chunks that missed their warm-up reach them): the
                 # call loop sits inside the list and round loops, whose bookkeeping lives in spill lanes
-                "cpm_wide_repair_kernel<": 40, "cpm_repair_kernel<4, 3>": 4, "vwin_fixup_kernel": 16}
+                "cpm_wide_repair_kernel<": 40, "cpm_quad_repair_kernel<": 16, "cpm_repair_kernel<4, 3>": 4, "vwin_fixup_kernel": 16}
     # ... and the stand-alone modulator's form for three or more modulation indices (no waveform of the reference has
     # them; modulate.py:91-92 allows it): its per-class staging loops carry the class bookkeeping in spill lanes.
     many_h = lambda k: k.startswith("mod_main_kernel<") and k.endswith(", true>")

@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--block", type=int, default=10_000_000, help="symbols per trial block (1e7: BASELINE configs[1]'s block, 10 per point)")
     ap.add_argument("--detector", default="PT")
     ap.add_argument("--waveform", default="soqpsk", choices=["soqpsk", "multih", "pcmfm"])
-    ap.add_argument("--states", type=int, default=16, choices=[16, 64], help="--waveform multih: the 16-state design of BASELINE configs[2] or the 64-state one")
+    ap.add_argument("--states", type=int, default=16, choices=[16, 64, 256], help="--waveform multih: the 16-state design of BASELINE configs[2], the 64-state one or the full 256-state trellis")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--gpus", type=int, default=0, help="N > 1 without torchrun: start N ranks as child processes")
     ap.add_argument("--passes", type=int, default=2, help="run the sweep this many times; `seconds` is the last pass")
@@ -112,7 +112,7 @@ def main():
             d2 = {"multih": 1.2957297551846658}.get(a.waveform)
             if d2:
                 out["min_distance_bound"] = [0.5 * math.erfc(math.sqrt(d2 * 10 ** (e / 10.0) / 2.0)) for e in ebn0]
-            out["detector"] = f"generic CPM trellis detector ({a.waveform}{', 64 states' if a.states == 64 else ''})"
+            out["detector"] = f"generic CPM trellis detector ({a.waveform}{f', {a.states} states' if a.states != 16 else ''})"
         for target in (1e-3, 1e-4):
             try:
                 mine = ebn0_at_ber(ebn0, ber, target)

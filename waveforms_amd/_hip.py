@@ -21,6 +21,7 @@ import os
 _LIB_PATH = Path(os.environ.get("WF_HIP_LIBRARY") or Path(__file__).resolve().parent / "csrc" / "libwfhip.so")
 
 WF_ERR_VALUE, WF_ERR_KEY, WF_ERR_HIP, WF_ERR_DEVICE, WF_ERR_NOMEM = -1, -2, -3, -4, -5
+WF_CPM_STATE_BYTES, WF_CPM_STREAM_STATE_BYTES = 16384, 20480      # include/wfhip.h (tests/test_cabi.py compares)
 # wf_option (include/wfhip.h): per-context options set with wf_ctx_set_option
 (WF_OPT_CPM_FORM, WF_OPT_CPM_CHUNK_CALLS, WF_OPT_DET_REPAIR, WF_OPT_DET_FINAL_VERIFY, WF_OPT_ITERATION_SERVER,
  WF_OPT_MCB_TAIL_PERMILLE) = range(6)

@@ -28,7 +28,7 @@ class SweepPlan:
     pn_degree: int = 23
     waveform: str = "soqpsk"       # "soqpsk" (detector PT / PAM), or "multih" / "pcmfm" through the generic CPM detector
     warmup: int = 0                # detector chunk warm-up (0: per point, waveforms_amd.link.operating_point_warmup): speed only, never the counts
-    states: int = 16               # waveform "multih": 16 (ARTM_16, BASELINE configs[2]) or 64 (ARTM_64: every phase state, notes/cpm/cpm.md:128-140)
+    states: int = 16               # waveform "multih": 16 (ARTM_16, BASELINE configs[2]), 64 (ARTM_64: every phase state of the 2-symbol pulse) or 256 (ARTM_256: the full trellis, notes/cpm/cpm.md:128-140)
     jobs: list[tuple[int, int]] = field(default_factory=list)   # (point index, block index)
 
     def __post_init__(self):
@@ -120,10 +120,10 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
     one_pipelined = (not cpm and plan.nsym >= (1 << 23)) or (plan.waveform == "pcmfm" and plan.nsym >= 6_500_000)
     n = max(1, int(streams)) if streams is not None else (1 if one_pipelined else 3)
     if cpm:
-        from waveforms_amd.viterbi.cpm import ARTM_64
+        from waveforms_amd.viterbi.cpm import ARTM_64, ARTM_256
 
-        wide = plan.waveform == "multih" and plan.states == 64
-        links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, spec=ARTM_64 if wide else None, pn_degree=plan.pn_degree, private_ctx=n > 1,
+        big = {64: ARTM_64, 256: ARTM_256}.get(plan.states) if plan.waveform == "multih" else None
+        links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, spec=big, pn_degree=plan.pn_degree, private_ctx=n > 1,
                          warmup=plan.warmup, fuse=(42 if n == 1 and one_pipelined else 10) if fuse is None else fuse)
                  for _ in range(n)]
         run_fn = _hip.lib().wf_cpm_link_run
@@ -151,7 +151,7 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
     # no warm-up asked for: each Eb/N0 point runs at its own (waveforms_amd.link.operating_point_warmup; 0 = the library's
     # default where the table has no shorter one)
     from waveforms_amd.link import operating_point_warmup, soqpsk_warmup_param
-    point_warmup = [(0 if plan.states == 64 else operating_point_warmup(plan.waveform, float(e))) if cpm
+    point_warmup = [(0 if plan.states != 16 else operating_point_warmup(plan.waveform, float(e))) if cpm
                     else soqpsk_warmup_param(operating_point_warmup("soqpsk", float(e))) for e in plan.ebn0_db]
 
     def launch(k: int, point: int, block: int, warmup: int) -> int:

@@ -80,3 +80,11 @@ int64_t wf_cpm_wide_chunk_calls(int64_t ncalls, int W, int cus, int64_t chunk_op
 int wf_cpm_wide_warmup(int warmup);
 int wf_cpm_wide_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
                        int warmup, uint8_t *d_decisions, void *d_state, void *stream);
+
+// Quad form (wf_cpm_quad.hip): trellises of 65 .. 256 states (pulse of 2 or 3 symbols), thread = state, one workgroup of four
+// waves = one detector.  Proof records of 2 x 256 x 3 words per chunk, detector state in the quad layout of WF_CPM_STATE_BYTES.
+int wf_cpm_quad_applies(const wf_cpm_detector_config *det);
+int64_t wf_cpm_quad_chunk_calls(int64_t ncalls, int W, int cus, int64_t chunk_opt);
+int wf_cpm_quad_warmup(int warmup);
+int wf_cpm_quad_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
+                       int warmup, uint8_t *d_decisions, void *d_state, void *stream);

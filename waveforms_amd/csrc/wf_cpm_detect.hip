@@ -560,7 +560,7 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
     for (int i = 2; i < Lp; ++i) msub *= M;
     for (int i = 0; i < Lp; ++i) NF *= M;
     const int S = NC * ncorr;
-    WF_REQUIRE(S <= 16, "wf_cpm: %d states (one DPP row holds 16, the wide form 64)", S);
+    WF_REQUIRE(S <= 16, "wf_cpm: %d states (one DPP row holds 16, the wide form 64, the quad form 256 for pulses of 2 or 3 symbols)", S);
     for (int i = 0; i < d->nh; ++i) WF_REQUIRE(d->K[i] >= 0 && d->K[i] < p, "wf_cpm: K[%d] = %d outside [0, p)", i, d->K[i]);
     P.M = M; P.lgM = lgM; P.p = p; P.nh = d->nh; P.K0 = d->K[0]; P.K1 = d->nh == 2 ? d->K[1] : d->K[0];
     P.Lp = Lp; P.NC = NC; P.D = d->D; P.S = S; P.NF = NF;
@@ -639,11 +639,19 @@ static int cpm_warmup_calls(int warmup)                            // rows/lanes
 
 // Which form of the detector wf_cpm_viterbi_detect runs for this trellis on this context (bench.py and the profile tools
 // name the kernel they price by it): info4 = {form (0: row form, one 16-lane DPP row per chunk; 1: lane form, one lane per
-// chunk; 2: wide form, one wave per chunk), ring slots of the lane form, calls per chunk, warm-up calls} — computed by the
+// chunk; 2: wide form, one wave per chunk; 3: quad form, one workgroup per chunk), ring slots of the lane form, calls per chunk, warm-up calls} — computed by the
 // functions the launch itself uses.
 extern "C" int wf_cpm_detector_form(wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int *info4)
 {
     WF_REQUIRE(ctx && det && info4 && ncalls >= 0 && warmup >= 0, "wf_cpm_detector_form: bad argument");
+    if (wf_cpm_quad_applies(det)) {                                // 65 .. 256 states: thread = state, one workgroup per chunk
+        const int W = wf_cpm_quad_warmup(warmup);
+        info4[0] = 3;
+        info4[1] = 0;
+        info4[2] = (int)wf_cpm_quad_chunk_calls(ncalls, W, ctx->cus, ctx->opt[WF_OPT_CPM_CHUNK_CALLS]);
+        info4[3] = W;
+        return WF_OK;
+    }
     if (wf_cpm_wide_applies(det)) {                                // 17 .. 64 states: lane = state, one wave per chunk
         const int W = wf_cpm_wide_warmup(warmup);
         info4[0] = 2;
@@ -677,7 +685,8 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
                              int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes)
 {
     WF_REQUIRE(ctx && det && ncalls >= 0 && warmup >= 0, "wf_cpm_viterbi_detect: bad argument");
-    const bool wide = wf_cpm_wide_applies(det) != 0;               // 17 .. 64 states: wf_cpm_wide.hip
+    const bool quad = wf_cpm_quad_applies(det) != 0;               // 65 .. 256 states: wf_cpm_quad.hip
+    const bool wide = quad || wf_cpm_wide_applies(det) != 0;       // 17 .. 64 states: wf_cpm_wide.hip
     cpm_vit_params P;
     if (wide) {
         WF_REQUIRE((det->nh == 1 || det->nh == 2) && det->p >= 1 && det->p <= 64 && det->p % det->NC == 0 && det->D >= 1 &&
@@ -693,6 +702,7 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
                    (reinterpret_cast<uintptr_t>(d_rot_cs) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
                "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
+    if (quad) return wf_cpm_quad_detect(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream);
     if (wide) return wf_cpm_wide_detect(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream);
     // Default warm-up.  A chunk that misses its warm-up is REPAIRED by the launches behind the first (cpm_repair_kernel),
     // so the default is sized for the typical merge depth of the trellis, not for its tail, and backed by a scan at

@@ -81,7 +81,7 @@ __device__ __forceinline__ void wide_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Device-resident detector state, wide layout (inside WF_CPM_STATE_BYTES = 4096): [0] calls made, [1 + s] metrics,
+// Device-resident detector state, wide layout (inside WF_CPM_STATE_BYTES): [0] calls made, [1 + s] metrics,
 // [65 + s] tilted phase indices, [129 + s] decision registers; staging copy from word 256.
 #define WIDE_ST_N 0
 #define WIDE_ST_M 1

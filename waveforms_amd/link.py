@@ -517,7 +517,7 @@ class CPMStream:
                              f"{4 * (spt.value + 48 + self.spec.D)}, with a configuration the one-kernel front end takes")
         self.workspace_bytes = nbytes
         self.workspace = _hip.empty(nbytes, "uint8")
-        self.state = _hip.zeros(8192 // 8, "int64")                 # WF_CPM_STREAM_STATE_BYTES
+        self.state = _hip.zeros(_hip.WF_CPM_STREAM_STATE_BYTES // 8, "int64")
         self.counts = _hip.zeros(2, "int64")
         self.compared = 0
         self.total_calls = self.chunk_info(0)["stream_calls"]

@@ -31,7 +31,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-__all__ = ["CPMDetectorSpec", "ARTM_16", "ARTM_64", "PCMFM_10", "CPMTrellisDetector", "matched_filter_templates", "rotation_table", "detector_kernel_name",
+__all__ = ["CPMDetectorSpec", "ARTM_16", "ARTM_64", "ARTM_256", "PCMFM_10", "CPMTrellisDetector", "matched_filter_templates", "rotation_table", "detector_kernel_name",
            "filter_geometry", "sigma_for_ebn0"]
 
 
@@ -75,6 +75,9 @@ ARTM_16 = CPMDetectorSpec(M=4, p=16, K=(4, 5), Lp=2, NC=4, D=32)
 # ... the same filters (pulse truncated to two symbols) with EVERY phase state of notes/cpm/cpm.md:128-140 in the trellis:
 # N_S = p M^(Lp-1) = 64, 0.2 dB ahead of ARTM_16 (table above); lane = state, one wave per detector (csrc/wf_cpm_wide.hip)
 ARTM_64 = CPMDetectorSpec(M=4, p=16, K=(4, 5), Lp=2, NC=16, D=32)
+# ... and the FULL trellis of notes/cpm/cpm.md:128-140: the 3RC pulse kept to its three symbols, N_S = p M^(L-1) = 256 states,
+# 64 matched filters per symbol; thread = state, one workgroup of four waves per detector (csrc/wf_cpm_quad.hip)
+ARTM_256 = CPMDetectorSpec(M=4, p=16, K=(4, 5), Lp=3, NC=16, D=32)
 # PCMFM_NUMER / DENOM = 7 / 10 (waveforms/cpm/pcmfm/__init__.py:5-6), binary
 PCMFM_10 = CPMDetectorSpec(M=2, p=10, K=(7,), Lp=2, NC=5, D=32)
 
@@ -97,6 +100,8 @@ def detector_kernel_name(spec: "CPMDetectorSpec", ncalls: int = 10_000_000, warm
         k1 = spec.K[1] if len(spec.K) > 1 else spec.K[0]
         hi = "true" if spec.bits_per_symbol * (spec.D - 1) >= 32 else "false"
         return f"cpm_lane_kernel<lane_spec<{spec.M}, {spec.Lp}, {spec.NC}, {spec.p}, {len(spec.K)}, {spec.K[0]}, {k1}>, {info[1]}, {hi}>"
+    if info[0] == 3:
+        return f"cpm_quad_kernel<{spec.M}, {spec.Lp}>"
     if info[0] == 2:
         return f"cpm_wide_kernel<{spec.M}, {spec.Lp}>"
     return f"cpm_viterbi_kernel<{spec.M}, {spec.Lp}>"
@@ -181,7 +186,7 @@ class CPMTrellisDetector:
         if self._ctx is None:
             self._ctx = _hip.new_ctx()          # private proof counter, like SOQPSKTrellisDetector
             self._d_rot = _hip.to_device(rotation_table(self.spec))
-            self._d_state = _hip.zeros(4096 // 8, "int64")          # WF_CPM_STATE_BYTES
+            self._d_state = _hip.zeros(_hip.WF_CPM_STATE_BYTES // 8, "int64")
         n = int(rows.shape[0])
         if tuple(rows.shape[1:]) != (self.spec.nfilt, 2):
             raise ValueError(f"rows must be [n, {self.spec.nfilt}, 2] float64")

@@ -70,7 +70,7 @@ __device__ __forceinline__ double quad_wave_min(double v)
         const int l = __builtin_amdgcn_readlane(lo, 16 * k), h = __builtin_amdgcn_readlane(hi, 16 * k);
         q[k] = __longlong_as_double(((long long)h << 32) | (unsigned)l);
     }
-    return fmin(fmin(q[0], q[1]), fmin(q[2], q[3]));      // (no NaNs among metrics: min is exact and order-free)
+    return quad_min_raw(quad_min_raw(q[0], q[1]), quad_min_raw(q[2], q[3]));      // (no NaNs among metrics: min is exact and order-free; fmin would quiet each operand first)
 }
 
 // One detector = the QUAD_T threads of `team` (0, or 0 / 1 in a repair workgroup).  Every barrier below is a WORKGROUP
@@ -222,7 +222,7 @@ __device__ __forceinline__ void cpm_quad_body(const double2 *__restrict__ rows, 
         if (lane == 0) wmin[wave] = wm;
         __syncthreads();
         const double w0 = wmin[0], w1 = wmin[1], w2 = wmin[2], w3 = wmin[3];
-        const double gmin = fmin(fmin(w0, w1), fmin(w2, w3));
+        const double gmin = quad_min_raw(quad_min_raw(w0, w1), quad_min_raw(w2, w3));
         const double nm = best - gmin;                                    // the minimum becomes exactly 0.0
         if (valid) {
             m = nm;

@@ -64,7 +64,7 @@ __device__ __forceinline__ double wide_wave_min(double v)
         const int l = __builtin_amdgcn_readlane(lo, 16 * k), h = __builtin_amdgcn_readlane(hi, 16 * k);
         q[k] = __longlong_as_double(((long long)h << 32) | (unsigned)l);
     }
-    return fmin(fmin(q[0], q[1]), fmin(q[2], q[3]));      // (no NaNs, no negative zeros among metrics: min is exact and order-free)
+    return wide_min_raw(wide_min_raw(q[0], q[1]), wide_min_raw(q[2], q[3]));      // (no NaNs among metrics: min is exact and order-free; fmin would quiet each bit-cast operand first)
 }
 
 __device__ __forceinline__ uint64_t wide_bperm_u64(int byte_addr, uint64_t v)

@@ -146,6 +146,33 @@ def test_templates_of_a_symmetric_alphabet_pair_off_as_conjugates(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_cpm_paired_front_end_with_an_odd_centre_tap_takes_the_plain_form(monkeypatch):
+    """The paired 16-filter front end reads a sample pair's symbols once (both samples under the same symbols: even sps AND an
+    even centre tap, ARTM's 25 taps).  A 23-tap pulse of the same shape has an odd one: the library must run the plain form
+    for it — bit for bit the rows of a link that never asked for pairs — and the staged kernels must agree with it."""
+    import waveforms_amd.cpm.multih as mh
+    from waveforms_amd.link import CPMLink
+
+    full = mh.freq_pulse_multih_irig(SPS)
+    short = full[1:-1] / full[1:-1].sum() * full.sum()
+    assert short.size == 23
+    monkeypatch.setattr(mh, "freq_pulse_multih_irig", lambda sps: short)
+    nsym = 60_001
+    plain = CPMLink(nsym, SPS, waveform="multih", fuse=10, paired_templates=False)
+    pairs = CPMLink(nsym, SPS, waveform="multih", fuse=10)
+    staged = CPMLink(nsym, SPS, waveform="multih", fuse=2)
+    for link in (plain, pairs, staged):
+        link.run_block(7.0, seed=3, stream_id=9, skip_bits=5)
+    la, lb, lc = plain.layout(), pairs.layout(), staged.layout()
+    assert la["one_kernel_front_end"] == 1 and lb["one_kernel_front_end"] == 1 and lc["one_kernel_front_end"] == 0
+    calls = la["calls"]
+    rows = [l.workspace[y["off_rows"]:y["off_rows"] + calls * 16 * 16].view(torch_f64()).cpu().numpy() for l, y in ((plain, la), (pairs, lb), (staged, lc))]
+    assert np.abs(rows[0]).max() > 1.0 and np.array_equal(rows[0], rows[1])
+    np.testing.assert_allclose(rows[2], rows[0], rtol=0, atol=1e-11)
+    assert plain.result() == pairs.result() == staged.result()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("waveform,nsym", [("multih", 150_001), ("pcmfm", 150_001), ("multih", 900), ("pcmfm", 70)])
 def test_gpu_cpm_front_end_conjugate_pairs_equal_the_plain_form(waveform, nsym):
     """The one-kernel front end with the templates taken as conjugate pairs (four real sums per pair: what a link runs) against

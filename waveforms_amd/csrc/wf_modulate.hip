@@ -1282,8 +1282,10 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
             // (10 samples per symbol: the long-pulse instantiation — SOQPSK-TG / -A / -B, 81 taps, c = 40 — takes this order too
             //  since the radius constants freed two registers: 128 exactly; the short-pulse one serves MIL's 11 taps, c = 5, and keeps the
             //  general pair form; the host admits an odd c at 10 samples per symbol only there.  The CPM forms measured 1.5 - 3 % slower
-            //  with this order and keep the old one.)
-            constexpr bool LOADS_FIRST = CPMNF <= 0 && (SPS != 10 || JMAX == 9);
+            //  with this order in round 3 and kept the old one; round 5, with the registers the shorter noise series freed: the paired
+            //  16-filter form with a short pulse — ARTM — takes it, 372 -> 361 vector instructions per row, link 1.187 -> 1.179 ms same-box
+            //  (profiles/r05_ab_artm_loads_first.log); the host sends an odd c to the unpaired form.  PCM/FM's c is odd.)
+            constexpr bool LOADS_FIRST = (CPMNF <= 0 && (SPS != 10 || JMAX == 9)) || (CPMNF == 32 && JMAX <= 4);
             double am_[JMAX];
             int pi0_ = 0, pi1_ = 0;
             if constexpr (!LOADS_FIRST) {
@@ -1651,7 +1653,8 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     const int grid = (int)(Q.n_long + (P.ntiles - (int64_t)Q.n_long * per_run));
     using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, const double *, double *, mod_params, mcb_params);
     // (16 templates that pair off as conjugates — the link checked it —, f <-> 15 - f: the four-real-sums form, 6 matrix instructions per 16 symbols for 10)
-    kern_t k = cpm_nf == 16 && O.cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 32> : mod_chan_bank_kernel<9, 32>)
+    // (<4, 32> reads a pair's symbols once for both samples: even c only — an odd c takes the unpaired form, which is right for any templates)
+    kern_t k = cpm_nf == 16 && O.cpm_paired && (JM != 4 || (P.c & 1) == 0) ? (JM == 4 ? mod_chan_bank_kernel<4, 32> : mod_chan_bank_kernel<9, 32>)
              : cpm_nf == 16 ? (JM == 4 ? mod_chan_bank_kernel<4, 16> : mod_chan_bank_kernel<9, 16>)
              : cpm_nf == 4 && O.cpm_paired ? (JM == 4 ? mod_chan_bank_kernel<4, 8> : mod_chan_bank_kernel<9, 8>)
              : cpm_nf == 4  ? (JM == 4 ? mod_chan_bank_kernel<4, 4> : mod_chan_bank_kernel<9, 4>)

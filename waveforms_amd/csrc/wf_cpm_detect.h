@@ -67,11 +67,12 @@ struct cpm_lane_plan {
 int wf_cpm_lanes_plan(const wf_cpm_detector_config *det, cpm_lane_plan *plan);   // 0: a specialisation exists (*plan filled in), 1: none
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
                         int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
-                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes);
+                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool solo);
 // wf_cpm_viterbi_detect for callers that own the memory around the rows (the links: rows sit inside their workspace):
 // slack_*_bytes of it before / behind the array may be READ (never interpreted) by the lane form's row fetch.
 int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
-                             int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes);
+                             int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes,
+                             bool beside = false);   // beside: the launch will share the chip with another kernel (a pipelined link's front end)
 
 // Wide form (wf_cpm_wide.hip): trellises of 17 .. 64 states, lane = state, one wave = one detector.  Proof records of
 // 2 x 64 x 3 words per chunk, detector state in the wide layout of WF_CPM_STATE_BYTES.

@@ -682,7 +682,7 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
 }
 
 int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
-                             int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes)
+                             int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool beside)
 {
     WF_REQUIRE(ctx && det && ncalls >= 0 && warmup >= 0, "wf_cpm_viterbi_detect: bad argument");
     const bool quad = wf_cpm_quad_applies(det) != 0;               // 65 .. 256 states: wf_cpm_quad.hip
@@ -749,7 +749,7 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
     using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params);
     using repair_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params, int, int, int);
     if (use_lanes) {
-        rc = wf_cpm_lanes_launch(lanes, det, d_rot_cs, d_rows_ri, ncalls, W, P.CH, nchunks, d_decisions, d_state, edge, stream, slack_lo_bytes, slack_hi_bytes);
+        rc = wf_cpm_lanes_launch(lanes, det, d_rot_cs, d_rows_ri, ncalls, W, P.CH, nchunks, d_decisions, d_state, edge, stream, slack_lo_bytes, slack_hi_bytes, !beside);
         if (rc) return rc;
     } else {
         kern_t k = nullptr;
@@ -1228,7 +1228,7 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     // (rows sit inside the block's set of intermediates: what lies before them — symbols, the sample region — and behind
     //  them — the decisions, up to the end of the set — may be read by the lane form's row fetch, so no wave of it clamps)
     if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, back, (int64_t)L.off_rows,
-                                       (int64_t)(L.total - L.off_rows) - L.ncalls * L.nfilt * 16)))
+                                       (int64_t)(L.total - L.off_rows) - L.ncalls * L.nfilt * 16, piped)))
         return rc;
     MARKB(7);
     // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] are compared
@@ -1379,7 +1379,7 @@ extern "C" int wf_cpm_link_stream_chunk_phase(wf_ctx *ctx, const wf_cpm_link_con
     if (phases & 2) {
         // (the rows sit inside the chunk's workspace: symbols before them, decisions behind — see wf_cpm_link_run)
         if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, S.ncols, cfg->warmup, dec, carry, stream, (int64_t)S.off_rows,
-                                           (int64_t)(S.total - S.off_rows) - S.ncols * S.L.nfilt * 16)))
+                                           (int64_t)(S.total - S.off_rows) - S.ncols * S.L.nfilt * 16, phases != 7)))   // (issued in parts: chunks overlap on two streams)
             return rc;
         // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] of the stream are compared
         const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;

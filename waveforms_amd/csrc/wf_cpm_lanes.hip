@@ -148,7 +148,13 @@ struct cpm_lane_params {
 };
 
 // DHI: the emitted field (bits lgM (D - 1) ... of the best state's decision register) sits in the register's high half.
-template <class SP, int R, bool DHI>
+// SOLO: the kernel claims accumulation registers it never uses (288 registers in all), so that the dispatcher cannot put two
+// of its waves on one SIMD.  Why: inside a link the 611 one-wave workgroups of a launch do NOT land one per SIMD as they do in
+// a fresh process (tools/placement_probe.hip) — time stamps of a launch showed 9 SIMDs with two waves while 400 stood empty,
+// and the launch lasting 37 % longer than its typical wave (profiles/r05_lane_wave_lifetimes.log).  Alone the claim is worth
+// 7 - 15 % of the detector (profiles/r05_ab_lane_solo.log); beside a front end, whose waves free 128 registers at a time, a
+// wave that needs 288 waits longer (PCM/FM link 0.608 -> 0.653 ms): the pipelined links launch the plain instantiation.
+template <class SP, int R, bool DHI, bool SOLO>
 __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
                                                          uint8_t *__restrict__ out, uint64_t *__restrict__ state,
                                                          uint64_t *__restrict__ edge, cpm_lane_params P)
@@ -159,6 +165,10 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     static_assert(LANE_DMAS * (R - 1) <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
+    if constexpr (SOLO) {
+        if constexpr (SP::M == 4) asm volatile("; accumulation registers claimed, never used: one lane wave per SIMD" ::: "a63");
+        else asm volatile("; accumulation registers claimed, never used: one lane wave per SIMD" ::: "a127");
+    }
     // Rotation table as two 8-byte columns read by two ds_read_b64 (64-bank mode: the 2p <= 64 entries of a column sit in
     // distinct banks, equal entries are broadcast).  One ds_read2st64_b64 — what the compiler makes of columns 1 KB
     // apart — is served in 32-bank mode, where entries 16 apart collide: 40 % of this kernel's LDS cycles were bank
@@ -550,7 +560,7 @@ int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
 
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
                         int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
-                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes)
+                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool solo)
 {
     WF_REQUIRE(chunk_calls >= 64 && chunk_calls % 64 == 0 && warmup >= 0 && warmup % 2 == 0 && chunk_calls > warmup + 1,
                "wf_cpm_lanes: chunk of %d calls, warm-up %d", chunk_calls, warmup);
@@ -562,7 +572,8 @@ int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config 
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_lanes: burst too long for one launch");
     const size_t lds = (size_t)LANE_LDS_BYTES(plan.ring_batches);
     using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, cpm_lane_params);
-    const kern_t k = plan.spec == 0 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R, true>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, LANE_R, false>);
+    const kern_t k = solo ? (plan.spec == 0 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R, true, true>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, LANE_R, false, true>))
+                          : (plan.spec == 0 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R, true, false>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, LANE_R, false, false>));
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64), lds, wf_stream(stream), reinterpret_cast<const double2 *>(d_rows_ri),

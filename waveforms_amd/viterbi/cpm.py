@@ -82,11 +82,13 @@ ARTM_256 = CPMDetectorSpec(M=4, p=16, K=(4, 5), Lp=3, NC=16, D=32)
 PCMFM_10 = CPMDetectorSpec(M=2, p=10, K=(7,), Lp=2, NC=5, D=32)
 
 
-def detector_kernel_name(spec: "CPMDetectorSpec", ncalls: int = 10_000_000, warmup: int = 0, ctx=None, info4: list | None = None) -> str:
+def detector_kernel_name(spec: "CPMDetectorSpec", ncalls: int = 10_000_000, warmup: int = 0, ctx=None, info4: list | None = None,
+                         beside: bool = False) -> str:
     """Name (as rocprofv3 prints it) of the kernel ``wf_cpm_viterbi_detect`` runs for ``spec`` on a burst of ``ncalls``
     calls on context ``ctx`` (default: the device's): asked from the library (``wf_cpm_detector_form``), so that bench.py
     and the profile tools price the kernel that really runs.  ``info4`` (a list) receives {form, ring slots, calls per
-    chunk, warm-up calls}."""
+    chunk, warm-up calls}.  ``beside``: the launch shares the chip with a front end (a pipelined link, ``fuse`` bit 5): the lane
+    form then runs its plain instantiation, alone the one that claims a whole SIMD's registers (wf_cpm_lanes.hip, SOLO)."""
     import ctypes
 
     from waveforms_amd import _hip
@@ -99,7 +101,8 @@ def detector_kernel_name(spec: "CPMDetectorSpec", ncalls: int = 10_000_000, warm
     if info[0] == 1:
         k1 = spec.K[1] if len(spec.K) > 1 else spec.K[0]
         hi = "true" if spec.bits_per_symbol * (spec.D - 1) >= 32 else "false"
-        return f"cpm_lane_kernel<lane_spec<{spec.M}, {spec.Lp}, {spec.NC}, {spec.p}, {len(spec.K)}, {spec.K[0]}, {k1}>, {info[1]}, {hi}>"
+        solo = "false" if beside else "true"
+        return f"cpm_lane_kernel<lane_spec<{spec.M}, {spec.Lp}, {spec.NC}, {spec.p}, {len(spec.K)}, {spec.K[0]}, {k1}>, {info[1]}, {hi}, {solo}>"
     if info[0] == 3:
         return f"cpm_quad_kernel<{spec.M}, {spec.Lp}>"
     if info[0] == 2:

@@ -98,7 +98,7 @@ __device__ __forceinline__ void cpm_quad_body(const double2 *__restrict__ rows, 
     double *xch = reinterpret_cast<double *>(tbase + P.xch_off);          // [M slots][QUAD_XS]
     int *rsrc = reinterpret_cast<int *>(tbase + P.src_off);               // tilted phase index per state
     uint64_t *hsrc = reinterpret_cast<uint64_t *>(tbase + P.src_off + QUAD_T * 4);   // decision register per state
-    uint8_t *dec = reinterpret_cast<uint8_t *>(tbase + P.dec_off);
+    const bool writes_out = !REPAIR || team == 1;                         // (a repair's team 0 re-runs what is already there)
     double *wmin = reinterpret_cast<double *>(tbase + P.min_off);         // the four waves' minima
 
     const int64_t n0 = state ? (int64_t)state[QUAD_ST_N] : 0;            // calls made before this launch
@@ -235,7 +235,7 @@ __device__ __forceinline__ void cpm_quad_body(const double2 *__restrict__ rows, 
             const int wfirst = w0 == gmin ? 0 : (w1 == gmin ? 1 : (w2 == gmin ? 2 : 3));
             const unsigned long long zero = __builtin_amdgcn_ballot_w64(nm == 0.0);
             if (wave == wfirst && __builtin_amdgcn_inverse_ballot_w64(zero & (0ull - zero)))
-                dec[t - P.W] = (n >= P.D - 1) ? (uint8_t)((nh_ >> dshift) & (uint64_t)(M - 1)) : (uint8_t)0;
+                if (writes_out) out[k] = (n >= P.D - 1) ? (uint8_t)((nh_ >> dshift) & (uint64_t)(M - 1)) : (uint8_t)0;   // (one byte straight to the output: a strip in LDS cost two resident workgroups per CU)
         }
     };
 
@@ -278,9 +278,8 @@ __device__ __forceinline__ void cpm_quad_body(const double2 *__restrict__ rows, 
                                          theirs[2 * QUAD_T + s] != (hist & hmask));
             merged = __syncthreads_or(diff ? 1 : 0) == 0;                 // (every thread of both teams gets the same answer)
         }
-        if (team == 1) {                                                  // the new trajectory's decisions up to the meeting point
-            for (int q = s; q < done; q += QUAD_T)
-                if (k_first + q < P.ncalls) out[k_first + q] = dec[q];
+        (void)done;
+        if (team == 1) {                                                  // (the new trajectory's decisions up to the meeting point are in place)
             if (!merged) {                                                // the chunk ENDS in another state than before
                 if (active) {
                     erec[QUAD_EDGE_WORDS / 2 + 3 * s] = (uint64_t)__double_as_longlong(m);
@@ -304,14 +303,6 @@ __device__ __forceinline__ void cpm_quad_body(const double2 *__restrict__ rows, 
     }
     for (int b = 0; b < nbatch; ++b) batch(b);
     if (live) {
-        for (int off = 16 * s; off < P.CH; off += 16 * QUAD_T) {          // decisions: 16 B per thread and 4096 calls
-            const int64_t k = k_first + off;
-            if (k + 16 <= P.ncalls) {
-                *reinterpret_cast<uint4 *>(out + k) = *reinterpret_cast<const uint4 *>(dec + off);
-            } else {
-                for (int q = 0; q < 16 && k + q < P.ncalls; ++q) out[k + q] = dec[off + q];
-            }
-        }
         if (active) {                                                     // proof record: what this chunk ended with
             erec[QUAD_EDGE_WORDS / 2 + 3 * s] = (uint64_t)__double_as_longlong(m);
             erec[QUAD_EDGE_WORDS / 2 + 3 * s + 1] = (uint64_t)(int64_t)r;
@@ -437,11 +428,11 @@ int wf_cpm_quad_warmup(int warmup)                          // 0 = the default, 
     return W > 4096 ? 4096 : W;
 }
 
-// Chunk length: the smallest multiple of 64 that puts the burst into one round of resident detectors (6 workgroups per CU at
-// this kernel's LDS use), at least 512 and 2 W, at most 8192 (decision strips live in LDS).
+// Chunk length: the smallest multiple of 64 that puts the burst into one round of resident detectors (8 workgroups per CU: 17.6 KB
+// of LDS and 8 waves per SIMD), at least 512 and 2 W, at most 8192 (what one repair re-runs).
 int64_t wf_cpm_quad_chunk_calls(int64_t ncalls, int W, int cus, int64_t chunk_opt)
 {
-    const int64_t slots = (int64_t)cus * 6;
+    const int64_t slots = (int64_t)cus * 8;
     int64_t ch = ((ncalls + slots - 1) / slots + 63) / 64 * 64;
     if (ch < 512) ch = 512;
     if (ch < 2 * W) ch = (2 * W + 63) / 64 * 64;
@@ -475,8 +466,8 @@ int wf_cpm_quad_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const dou
     P.xch_off = pieces * 16;
     P.src_off = P.xch_off + 4 * QUAD_XS * 8;
     P.min_off = P.src_off + QUAD_T * 4 + QUAD_T * 8;
-    P.dec_off = P.min_off + 64;
-    P.team_bytes = (P.dec_off + P.CH + 15) / 16 * 16;
+    P.dec_off = P.min_off + 64;                                // (end of a team's block)
+    P.team_bytes = (P.dec_off + 15) / 16 * 16;
     P.rot_off = 2 * P.team_bytes;                              // (the first launch uses one team's worth; the layout is the repair's)
     P.cmp_off = P.rot_off + 2 * CPM_ROT_SIN * 8;
     const size_t lds_repair = (size_t)P.cmp_off + 2 * 3 * QUAD_T * 8;

@@ -1,0 +1,21 @@
+#!/bin/bash
+# The round's closing measurement on ONE box, after tools/profile_all.sh <tag> and with its summaries committed under profiles/:
+# the bench lines, the BER sweeps and the stream figures.   bash tools/final_lines.sh r05
+set -e
+tag=$1
+bash tools/bench_lines.sh $tag
+out=gpurun_out/${tag}_lines
+python3 tools/ber_sweep.py --json-out $out/${tag}_ber_sweep.json > /dev/null
+python3 tools/ber_sweep.py --detector PAM --json-out $out/${tag}_ber_sweep_pam.json > /dev/null
+python3 tools/ber_sweep.py --waveform multih --json-out $out/${tag}_ber_sweep_multih.json > /dev/null
+python3 tools/ber_sweep.py --waveform multih --states 64 --json-out $out/${tag}_ber_sweep_multih64.json > /dev/null
+python3 tools/ber_sweep.py --waveform multih --states 256 --symbols-per-point 2e7 --passes 1 --json-out $out/${tag}_ber_sweep_multih256.json > /dev/null
+python3 tools/ber_sweep.py --waveform pcmfm --json-out $out/${tag}_ber_sweep_pcmfm.json > /dev/null
+echo SWEEPSDONE
+python3 tools/stream_bench.py --pipelined --chunk 8388608 > $out/${tag}_stream_soqpsk.json
+python3 tools/stream_bench.py --pipelined --chunk 8388608 --detector PAM > $out/${tag}_stream_pam.json
+python3 tools/stream_bench.py --pipelined --chunk 10485760 --waveform multih > $out/${tag}_stream_multih.json
+python3 tools/stream_bench.py --pipelined --chunk 10485760 --waveform pcmfm > $out/${tag}_stream_pcmfm.json
+python3 tools/stream_bench.py --chunk 4194304 --waveform multih > $out/${tag}_stream_multih_eager.json
+python3 tools/stream_bench.py --chunk 4194304 --waveform pcmfm > $out/${tag}_stream_pcmfm_eager.json
+echo STREAMSDONE

@@ -540,6 +540,37 @@ def main() -> None:
             except ValueError:
                 ber_curve[f"delta_db_at_{target:g}"] = None
 
+    if rank == 0 and cpm and nstreams == 1 and args.ber_points not in ("", "none"):
+        # The CPM links have no curve in the reference (it ships no detector for them: DESIGN.md section 2): the same sweep,
+        # Eb/N0 at BER 1e-3 / 1e-4 read off it, no offset to quote.  (256 states: 12 ms per block — a shorter sweep.)
+        from waveforms_amd.bert import ebn0_at_ber
+
+        lo_, hi_ = (int(v) for v in args.ber_points.split(":"))
+        pts = list(range(lo_, hi_ + 1))
+        blocks = max(1, int(round(args.ber_symbols / args.nsym)))
+        keep_wu = links[0].cfg.warmup
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        rows = []
+        for pi, e in enumerate(pts):
+            links[0].reset_counts()
+            if args.vit_warmup < 0 and not wide:
+                links[0].cfg.warmup = operating_point_warmup(args.waveform, float(e))
+            for b in range(blocks):
+                links[0].run_block(float(e), seed=1, stream_id=(pi << 32) | b, skip_bits=b * args.nsym * bits_per_sym)
+            rows.append(links[0].result())
+        dt4 = time.perf_counter() - t4
+        links[0].cfg.warmup = keep_wu
+        ber_pts = [r[1] / max(r[2] * bits_per_sym, 1) for r in rows]
+        ber_curve = {"ebn0_db": pts, "symbols_per_point": int(rows[0][2]), "bit_errors": [int(r[1]) for r in rows],
+                     "seconds": round(dt4, 4), "Msym_per_s": round(sum(r[2] for r in rows) / dt4 / 1e6, 1),
+                     "golden": None, "note": "no curve of the reference for this waveform (it ships no detector for it); the detector is oracle/cpm_oracle.c's"}
+        for target in (1e-3, 1e-4):
+            try:
+                ber_curve[f"ebn0_at_{target:g}"] = round(ebn0_at_ber(pts, ber_pts, target), 4)
+            except ValueError:
+                ber_curve[f"ebn0_at_{target:g}"] = None
+
     # The same K steps once more with several independent trial blocks in flight (own workspace, wf_ctx and
     # stream each), as the BER sweep runs them: the vector-pipe-bound front-end kernel of one block overlaps the
     # detector and the small integer kernels of its neighbours.  Reported beside `value`, never instead of it:

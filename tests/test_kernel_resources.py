@@ -125,6 +125,17 @@ def test_lane_detector_kernels_stay_out_of_scratch_and_spill_lanes_in_the_call_l
         assert r["sgpr_spill_count"] <= cap, r
 
 
+def test_lane_detector_solo_instantiation_holds_a_simd_alone(table):
+    """The instantiation for launches outside a pipeline claims accumulation registers so that the dispatcher cannot put two
+    of its waves on one SIMD (wf_cpm_lanes.hip, SOLO); the plain one must stay small enough to slip in beside a front end."""
+    for name in HOT:
+        if name.startswith("cpm_lane_kernel") and name.endswith(", true>"):
+            r = table[name]
+            assert kr.waves_per_simd(r["vgpr_count"], r.get("agpr_count", 0)) == 1, (name, r)
+            plain = table[name[: -len(", true>")] + ", false>"]
+            assert plain.get("agpr_count", 0) == 0 and kr.waves_per_simd(plain["vgpr_count"], 0) >= 2, plain
+
+
 def test_no_kernel_spills_vector_registers(table):
     bad = {k: v["vgpr_spill_count"] for k, v in table.items() if v.get("vgpr_spill_count", 0)}
     assert not bad, bad

@@ -9,7 +9,7 @@ python3 tools/ber_sweep.py --json-out $out/${tag}_ber_sweep.json > /dev/null
 python3 tools/ber_sweep.py --detector PAM --json-out $out/${tag}_ber_sweep_pam.json > /dev/null
 python3 tools/ber_sweep.py --waveform multih --json-out $out/${tag}_ber_sweep_multih.json > /dev/null
 python3 tools/ber_sweep.py --waveform multih --states 64 --json-out $out/${tag}_ber_sweep_multih64.json > /dev/null
-python3 tools/ber_sweep.py --waveform multih --states 256 --symbols-per-point 2e7 --passes 1 --json-out $out/${tag}_ber_sweep_multih256.json > /dev/null
+python3 tools/ber_sweep.py --waveform multih --states 256 --passes 1 --json-out $out/${tag}_ber_sweep_multih256.json > /dev/null
 python3 tools/ber_sweep.py --waveform pcmfm --json-out $out/${tag}_ber_sweep_pcmfm.json > /dev/null
 echo SWEEPSDONE
 python3 tools/stream_bench.py --pipelined --chunk 8388608 > $out/${tag}_stream_soqpsk.json

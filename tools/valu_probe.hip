@@ -93,6 +93,12 @@ DEF_KERNEL(k_bfe_u32, U8, ALL8(OP3U, "v_bfe_u32"), SUMU)
 DEF_KERNEL(k_perm_b32, U8, ALL8(OP3U, "v_perm_b32"), SUMU)
 DEF_KERNEL(k_mad_u32_u24, U8, ALL8(OP3U, "v_mad_u32_u24"), SUMU)
 DEF_KERNEL(k_and_or_b32, U8, ALL8(OP3U, "v_and_or_b32"), SUMU)
+#define BITOP3(INS, R) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(R) : "v"(b), "v"(c));
+DEF_KERNEL(k_bitop3_xor3, U8, ALL8(BITOP3, ""), SUMU)
+#define BITOP3S(INS, R) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(R) : "v"(b), "s"(c));
+DEF_KERNEL(k_bitop3_xor3_sgpr, U8, ALL8(BITOP3S, ""), SUMU)
+#define XOR2(INS, R) asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %2" : "+v"(R) : "v"(b), "v"(c));
+DEF_KERNEL(k_xor_pair, U8, ALL8(XOR2, ""), SUMU)
 #define ADD64(INS, R) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(R) : "v"(c));
 DEF_KERNEL(k_lshl_add_u64, Q8, ALL8(ADD64, ""), SUMU)
 #define ADDCO(INS, R) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(R) : "v"(b) : "vcc");
@@ -138,7 +144,7 @@ int main(int argc, char **argv)
     const entry tab[] = {
         {"v_fma_f64 (8 chains)", k_fma_f64}, {"v_fma_f64 (4 chains)", k_fma_f64_c4}, {"v_fma_f64 (2 chains)", k_fma_f64_c2},
         {"v_fma_f64 (1 chain)", k_fma_f64_c1}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_min_f64", k_min_f64},
-        {"v_fma_f32 (8 chains)", k_fma_f32}, {"v_fma_f32 (1 chain)", k_fma_f32_c1}, {"v_xor_b32", k_xor_b32}, {"v_add_u32", k_add_u32},
+        {"v_fma_f32 (8 chains)", k_fma_f32}, {"v_fma_f32 (1 chain)", k_fma_f32_c1}, {"v_xor_b32", k_xor_b32}, {"v_bitop3_b32 (xor3)", k_bitop3_xor3}, {"v_bitop3_b32 (xor3, one SGPR)", k_bitop3_xor3_sgpr}, {"2 x v_xor_b32 (= xor3; counted as ONE)", k_xor_pair}, {"v_add_u32", k_add_u32},
         {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32}, {"v_mad_u64_u32", k_mad_u64_u32}, {"v_lshlrev_b64", k_lshl_b64},
         {"v_mov_b64", k_mov_b64}, {"v_cndmask_b32", k_cndmask}, {"v_cmp_lt_f64", k_cmp_f64}, {"v_rsq_f64", k_rsq_f64},
         {"v_rcp_f64", k_rcp_f64}, {"v_cvt_f64_u32", k_cvt_f64_u32}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_mov_b32 dpp row_ror", k_mov_dpp},

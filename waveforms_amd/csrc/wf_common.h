@@ -496,9 +496,9 @@ __device__ __forceinline__ wf_philox_out wf_philox4x32_10(uint32_t c0, uint32_t 
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;  // v_mad_u64_u32
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        // a ^ b ^ c as ONE v_bitop3_b32 (gfx950; truth table 0x96): 1.96 cycles with three vector operands, 3.24 with the round
-        // key as a scalar — against 3.97 for two v_xor_b32 (tools/valu_probe.hip, profiles/r05_valu_probe.json); 20 fewer
-        // vector instructions per Philox block
+        // a ^ b ^ c as ONE v_bitop3_b32 (gfx950; truth table 0x96): 2.65 cycles with three vector operands, 4.28 with the round
+        // key as a scalar (the case here) — against 4.48 for two v_xor_b32 (tools/valu_probe.hip, event-time column of
+        // profiles/r05_valu_probe.json); 16 fewer vector instructions per row, links - 0.4 .. - 1.2 % (r05_ab_philox_bitop3.log)
         const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
         const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c0 = n0;

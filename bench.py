@@ -397,8 +397,9 @@ def main() -> None:
             # (conjugate-paired templates — wf_cpm_link_config.fuse bit 6 — run the four-real-sums form, template value 2 nf)
             STAGE_KERNEL["mod+awgn+mfbank"] = f"mod_chan_bank_kernel<4, {2 * nf if (links[0].cfg.fuse & 64) else nf}, 8>"
         STAGE_KERNEL.update({"mfbank": f"cpm_mf_rows_kernel<{nf}, {9 if args.sps == 8 else 0}, {'true' if links[0].cfg.fuse & 2 else 'false'}>",
-                             "viterbi": detector_kernel_name(links[0].spec, links[0].layout()["calls"], links[0].cfg.warmup, ctx=links[0]._ctx, info4=det_info,
-                                                             beside=bool(links[0].cfg.fuse & 32)),
+                             # (the profiles time every kernel ALONE — link fuse 15 —, where the lane form launches the instantiation that
+                             #  claims a SIMD's registers; the pipelined link runs the plain one: same code, same counters but for the claim)
+                             "viterbi": detector_kernel_name(links[0].spec, links[0].layout()["calls"], links[0].cfg.warmup, ctx=links[0]._ctx, info4=det_info),
                              "map": "symbol_map_kernel",
                              "modulate": "mod_main_kernel<4, true, false>"})
     one_kernel = not cpm and bool(links[0].layout()["one_kernel_front_end"])     # asked from the library (wf_link_layout)

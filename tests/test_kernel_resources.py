@@ -70,11 +70,11 @@ HOT = {
     # ... its lane form (one lane = one chunk, the trellis's states in that lane's registers): one wave per SIMD; the
     # binary trellis fits two (and the LDS a front-end workgroup frees when it runs beside one)
     "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false>": (256, 2),
-    "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 3, false, false>": (168, 3),
+    "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, false>": (168, 3),
     # ... and the instantiation for launches outside a pipeline: accumulation registers claimed on purpose, ONE wave per SIMD
     # (wf_cpm_lanes.hip, SOLO: the dispatcher otherwise doubles waves up on some SIMDs while others stand empty)
     "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true>": (512, 1),
-    "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 3, false, true>": (512, 1),
+    "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, true>": (512, 1),
     # ... its wide form (17 .. 64 states, lane = state, one wave per detector): issue-bound, wants every wave it can get
     "cpm_wide_kernel<4, 2>": (64, 8),
     "fir_kernel<9>": (96, 5),
@@ -117,8 +117,8 @@ def test_front_end_kernels_do_not_spill(table, name):
 def test_lane_detector_kernels_stay_out_of_scratch_and_spill_lanes_in_the_call_loop(table):
     """The lane form keeps a whole trellis per lane in registers: no scratch, no VGPR spills; the ARTM form's dozen scalar
     spills (lane masks of its compare / select pairs) stay below the ceiling and out of nested loops."""
-    for name, cap in (("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 3, false, false>", 0),
-                      ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 3, false, true>", 0)):
+    for name, cap in (("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, false>", 0),
+                      ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, true>", 0)):
         r = table[name]
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, r
         assert r["asm_scratch_load"] == 0 and r["asm_scratch_store"] == 0, r

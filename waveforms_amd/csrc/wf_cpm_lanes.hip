@@ -18,7 +18,7 @@
 // conflict-free ds_read_b128 (the 16 lanes of a service group hit 16 different 4-bank groups).  The DMAs are inline asm
 // (hipcc drains a builtin LDS-DMA with vmcnt(0) before the next ds_read; MI355X guide, "Pipelining across barriers"):
 // R slots in flight per wave, retired by a counted s_waitcnt vmcnt(8 (R - 1)); the ring is private to its wave, so no
-// barrier is involved.  The ring is small on purpose — R = 3: 27 KB — because in the pipelined links this kernel runs
+// barrier is involved.  The ring is small on purpose — R = 3: 27 KB, R = 2: 18.5 KB — because in the pipelined links this kernel runs
 // BESIDE the next block's front end, whose workgroups take 40 KB each: a lane wave has to fit the LDS one of them frees.
 //
 // Arithmetic, tie-breaks and emission are those of the row form and of cpm_oracle.c (the sequential statement kept
@@ -533,10 +533,14 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
 // ---- the compiled specialisations: the two waveforms BASELINE configs[2] and SURVEY 8(f3) name
 using lane_artm16 = lane_spec<4, 2, 4, 16, 2, 4, 5>;     // ARTM multi-h CPM, h = {4/16, 5/16}, pulse truncated to 2 symbols, 4 phase classes
 using lane_pcmfm10 = lane_spec<2, 2, 5, 10, 1, 7, 7>;    // PCM/FM, h = 7/10, 5 phase classes
-// Ring depth: 3 slots of 8 KB in flight per wave (ARTM: two slots per call).  Same box, detector alone, 2 | 3 | 4 slots:
-// ARTM 724 | 656 | 658 us, PCM/FM 313 | 307 | 313 us (profiles/r04_ab_lane_ring.log) — two slots leave the fetch one
-// slot of lead, four cost a CU a resident wave (and the front end running beside it 8 KB).
-#define LANE_R 3
+// Ring depth: slots of 8 KB in flight per wave (ARTM: two slots per call).  Same box, detector alone, 2 | 3 | 4 slots: ARTM 724 |
+// 656 | 658 us, PCM/FM 313 | 307 | 313 us (profiles/r04_ab_lane_ring.log) — two slots leave the fetch one slot of lead, four cost a
+// CU a resident wave.  In the pipelined links (what bench.py runs) a lane wave has to fit the LDS a front-end workgroup frees
+// (39 KB): with two slots (18.5 KB) TWO of them do.  Same box, pipelined, 3 | 2 slots: PCM/FM 0.5688 / 0.5697 / 0.5703 | 0.5640 /
+// 0.5653 / 0.5651 ms, ARTM 1.1556 / 1.1532 / 1.1548 | 1.1559 / 1.1561 / 1.1574 (profiles/r05_ab_lane_ring2_pipelined.log): two for
+// PCM/FM (whose single slot holds two calls), three for ARTM.
+#define LANE_R_ARTM 3
+#define LANE_R_PCMFM 2
 
 // 1: no specialisation for this trellis; 0: there is one, *plan filled in.  (Which form runs is the caller's decision:
 // cpm_chunk_calls, wf_cpm_detect.hip.)
@@ -546,7 +550,7 @@ int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
     if (d->M == 4 && d->Lp == 2 && d->NC == 4 && d->p == 16 && d->nh == 2 && d->K[0] == 4 && d->K[1] == 5 && d->D >= 17 && d->D <= 32) spec = 0;
     if (d->M == 2 && d->Lp == 2 && d->NC == 5 && d->p == 10 && d->nh == 1 && d->K[0] == 7 && d->D >= 1 && d->D <= 32) spec = 1;
     if (spec < 0) return 1;
-    constexpr int R = LANE_R;
+    const int R = spec == 0 ? LANE_R_ARTM : LANE_R_PCMFM;
     int per_cu = (160 * 1024) / LANE_LDS_BYTES(R);
     if (per_cu > 4) per_cu = 4;                 // one wave per SIMD: 225 registers (ARTM) leave room for nothing else of this kernel
     // time per call of a chunk / of the burst (one MI355X, profiles/r04_ab_lane_ring.log, r04_lane_chunk_sweep.log):
@@ -572,8 +576,8 @@ int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config 
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_lanes: burst too long for one launch");
     const size_t lds = (size_t)LANE_LDS_BYTES(plan.ring_batches);
     using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, cpm_lane_params);
-    const kern_t k = solo ? (plan.spec == 0 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R, true, true>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, LANE_R, false, true>))
-                          : (plan.spec == 0 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R, true, false>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, LANE_R, false, false>));
+    const kern_t k = solo ? (plan.spec == 0 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R_ARTM, true, true>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, LANE_R_PCMFM, false, true>))
+                          : (plan.spec == 0 ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R_ARTM, true, false>) : static_cast<kern_t>(cpm_lane_kernel<lane_pcmfm10, LANE_R_PCMFM, false, false>));
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64), lds, wf_stream(stream), reinterpret_cast<const double2 *>(d_rows_ri),

@@ -457,6 +457,20 @@ int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const 
                           const double *d_rows_ri, int64_t ncalls, int warmup, uint8_t *d_decisions,
                           void *d_state, void *stream);
 
+/* wf_cpm_mf_rows_c128 + wf_cpm_viterbi_detect in ONE launch (round 6): the detector reads the noisy SAMPLES — call k's window is
+ * samples start0 + 8 k .. start0 + 8 k + 8, 128 new bytes per call where a 16-filter row is 256 — and runs the matched filters
+ * itself, in the manner of examples/soqpsk_detection.py:134-156 (pulse-truncation templates) for the trellis of
+ * notes/cpm/cpm.md:100-140.  The templates must pair off as exact conjugates, d_templates[c][nfilt-1-f] == conj(d_templates[c][f])
+ * (checked on a host copy, WF_ERR_VALUE if not): each pair is formed from four real 9-tap sums, so the filter outputs equal
+ * wf_cpm_mf_rows_c128's to rounding (another order of additions) and are bit for bit those of the link's paired one-kernel front
+ * end (wf_cpm_link_config.fuse bit 6).  Serves the 16-filter, 16-state ARTM design at 8 samples per symbol, 9-tap templates,
+ * start0 >= 0, on bursts the lane form of the detector takes (wf_cpm_detector_form info4[0] == 1): returns 1 — nothing launched,
+ * not an error — otherwise, and the caller runs wf_cpm_mf_rows_c128 + wf_cpm_viterbi_detect.  Call k takes template column k % nh.
+ * Decisions, d_state, warm-up, proof and repair as wf_cpm_viterbi_detect (the repairs rebuild the rows they need from the samples). */
+int wf_cpm_viterbi_detect_samples(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_templates_ri,
+                                  int nh, int nfilt, int ntm, const double *d_samples_ri, int64_t nsamp, int64_t start0, int sps,
+                                  int64_t ncalls, int warmup, uint8_t *d_decisions, void *d_state, void *stream);
+
 /* Symbol and bit errors of decided U against transmitted symbols alpha (int8):
  * d_counts[0] += #(U != (alpha + M - 1)/2), d_counts[1] += popcount(U ^ (alpha + M - 1)/2)
  * (the reference's mappers are natural binary: waveforms/cpm/multih/precoder.py:22-23). */
@@ -501,7 +515,14 @@ typedef struct {
                               /* (WF_ERR_VALUE if not so) — the one-kernel front end then forms     */
                               /* each pair from four real 9-tap sums (16 filters: 6 matrix          */
                               /* instructions per 16 symbols instead of 10; 4 filters: 18 multiply- */
-                              /* adds per lane instead of 36); rows equal to rounding, not bitwise  */
+                              /* adds per lane instead of 36); rows equal to rounding, not bitwise; */
+                              /* bit 7 (128, with bits 1 and 6; 16 filters, sps 8, a burst the      */
+                              /* detector's lane form takes): the front end stores the noisy        */
+                              /* SAMPLES (128 B per symbol: cpm_modulate + the channel, one kernel) */
+                              /* and the detector runs the matched filters itself                  */
+                              /* (wf_cpm_viterbi_detect_samples): no rows in HBM, decisions bit for */
+                              /* bit those of bits 1 + 3 + 6; ignored where it does not apply       */
+                              /* (wf_cpm_link_form tells)                                          */
 } wf_cpm_link_config;
 int64_t wf_cpm_link_workspace_bytes(const wf_cpm_link_config *cfg);
 int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
@@ -509,6 +530,11 @@ int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspac
 /* info8 = {ncalls, start0, off(decisions), off(symbols alpha), off(signal), one_kernel (1: fuse bits 1 + 3 run modulator +
  * channel + filters as one kernel for this configuration), signal samples, off(rows)} */
 int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8);
+/* What wf_cpm_link_run launches for this configuration on this context (its options and device): info4[0] = front end — 0:
+ * modulator, channel and matched filters as separate kernels, 1: one kernel with rows out (fuse bits 1 + 3), 2: modulator +
+ * channel in one kernel with SAMPLES out and the matched filters inside the detector (fuse bit 7) —, info4[1 .. 3] = the
+ * detector's form, calls per chunk and warm-up calls as wf_cpm_detector_form reports them.  No device work. */
+int wf_cpm_link_form(wf_ctx *ctx, const wf_cpm_link_config *cfg, int *info4);
 
 /* Streaming form of the CPM link (the scheme of wf_link_stream_chunk for the waveforms of BASELINE configs[2]):
  * a stream of cfg->nsym symbols in chunks of chunk_symbols detector calls, HBM footprint of one chunk; chunk c

@@ -704,3 +704,144 @@ def test_gpu_cpm_link_pipelined_blocks_equal_sequential_blocks(waveform, detecto
         out.append(got)
     assert out[0] == out[1] == out[2]
     assert out[0][-1][1] > 0
+
+
+# ------------------------------------------------------------------ round 6: the matched filters inside the detector
+def _link_form(link):
+    from waveforms_amd import _hip
+
+    info = (ctypes.c_int * 4)()
+    _hip.check(_hip.lib().wf_cpm_link_form(link._ctx, ctypes.byref(link.cfg), info))
+    return list(info)
+
+
+@pytest.mark.gpu
+def test_gpu_samples_form_link_equals_rows_form(ctx_options):
+    """wf_cpm_link_config.fuse bit 7: the front end stores the noisy samples (128 B per symbol) and the detector's lanes run
+    the 16 matched filters themselves — against the paired one-kernel front end with its rows in HBM (fuse bits 1 + 3 + 6):
+    every decision identical, without noise, at 10 dB and at 3 dB with a warm-up short enough that thousands of chunks go to
+    the repair (which rebuilds its rows from the same samples), chunk boundaries proven once more behind the repairs; a
+    chunk length that is not a multiple of 64; and two blocks through the pipelined form (bit 5: two side streams)."""
+    from waveforms_amd import device as dev
+    from waveforms_amd.link import CPMLink
+
+    nsym = 2_400_001
+    if True:
+        for ebn0, warm, chunk in ((None, 48, 0), (10.0, 48, 0), (10.0, 0, 0), (3.0, 16, 0), (6.0, 32, 80), (6.0, 32, 208)):
+            with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_CHUNK_CALLS=chunk):
+                a = CPMLink(nsym, SPS, waveform="multih", fuse=10, warmup=warm, private_ctx=True)
+                b = CPMLink(nsym, SPS, waveform="multih", fuse=10 | 128, warmup=warm, private_ctx=True)
+                assert a.paired_templates and b.paired_templates
+                fa, fb = _link_form(a), _link_form(b)
+                assert fa[0] == 1 and fb[0] == 2 and fb[1] == 1, (fa, fb)
+                if chunk:
+                    assert fb[2] == chunk
+                for link in (a, b):
+                    link.run_block(ebn0, seed=5, stream_id=3, skip_bits=11)
+                la, lb = a.layout(), b.layout()
+                da = a.workspace[la["off_decisions"]:la["off_decisions"] + la["calls"]].cpu().numpy()
+                db = b.workspace[lb["off_decisions"]:lb["off_decisions"] + lb["calls"]].cpu().numpy()
+                assert np.array_equal(da, db), (ebn0, warm, chunk, int(np.count_nonzero(da != db)))
+                ra, rb = a.result(), b.result()          # (raises if a chunk boundary was left unproven)
+                assert ra == rb and ra[2] == nsym - 31 - 64
+                if ebn0 is None:
+                    assert ra[:2] == (0, 0)
+                rep = dev.viterbi_repaired(reset=True, ctx=b._ctx)
+                if warm == 16:
+                    assert rep > 1000, rep
+                del a, b
+    # the pipelined form bench.py times: consecutive blocks' detectors on two side streams, each with its own proof records
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+        one = CPMLink(nsym, SPS, waveform="multih", fuse=10 | 128, warmup=48, private_ctx=True)
+        piped = CPMLink(nsym, SPS, waveform="multih", fuse=42 | 128, warmup=48, private_ctx=True)
+        assert _link_form(piped)[0] == 2
+        for blk in range(5):
+            one.run_block(8.0, seed=2, stream_id=blk)
+            piped.run_block(8.0, seed=2, stream_id=blk)
+        assert one.result() == piped.result() and piped.result()[1] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_samples_front_end_stores_the_samples_the_paired_bank_saw():
+    """mod_chan_samples_kernel against the staged kernels: its samples equal wf_cpm_modulate_c128 + wf_awgn_c128 to 1e-11, and
+    wf_cpm_mf_rows_c128 over them gives the rows of the one-kernel front end (both forms) to 1e-11."""
+    from waveforms_amd import _hip, device as dev
+    from waveforms_amd.link import CPMLink
+    from waveforms_amd.viterbi import cpm
+
+    nsym = 2_200_000
+    rows_link = CPMLink(nsym, SPS, waveform="multih", fuse=10, private_ctx=True)
+    samp_link = CPMLink(nsym, SPS, waveform="multih", fuse=10 | 128, private_ctx=True)
+    staged = CPMLink(nsym, SPS, waveform="multih", fuse=0, private_ctx=True)
+    for link in (rows_link, samp_link, staged):
+        link.run_block(7.0, seed=3, stream_id=9, skip_bits=5)
+    assert _link_form(samp_link)[0] == 2 and _link_form(staged)[0] == 0
+    ls, lt, lr = samp_link.layout(), staged.layout(), rows_link.layout()
+    n = ls["signal_len"]
+    got = samp_link.workspace[ls["off_signal"]:ls["off_signal"] + 16 * n].view(torch_f64()).cpu().numpy()
+    ref = staged.workspace[lt["off_signal"]:lt["off_signal"] + 16 * n].view(torch_f64()).cpu().numpy()
+    assert np.abs(ref).max() > 1.0
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
+    calls = ls["calls"]
+    t = cpm.matched_filter_templates(__import__("waveforms_amd.cpm.multih", fromlist=["x"]).freq_pulse_multih_irig(SPS), SPS, cpm.ARTM_16)
+    sig = samp_link.workspace[ls["off_signal"]:ls["off_signal"] + 16 * n].view(torch_f64()).view(n, 2)
+    rows = dev.cpm_mf_rows(sig, _hip.to_device(t), ls["start0"], SPS, calls).cpu().numpy().reshape(-1)
+    want = rows_link.workspace[lr["off_rows"]:lr["off_rows"] + calls * 16 * 16].view(torch_f64()).cpu().numpy()
+    np.testing.assert_allclose(rows, want, rtol=0, atol=1e-11)
+    assert samp_link.result() == rows_link.result()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ebn0", [2.0, 9.0])
+def test_gpu_detect_samples_equals_sequential_oracle(oracle, ebn0, ctx_options):
+    """wf_cpm_viterbi_detect_samples (the C-ABI form of the same launch) on the oracle's own received samples against the
+    sequential C detector over the oracle's rows: every decision identical — the library's warm-up and a short one
+    (hundreds of chunks repaired from the samples); and the entry point declines (returns 1: rows + detector) what its
+    launch does not serve."""
+    from waveforms_amd import device as dev
+    from waveforms_amd.viterbi.cpm import ARTM_16, PCMFM_10, CPMTrellisDetector, matched_filter_templates
+
+    nsym = 2_300_000
+    pulse = oracle.freq_pulse_multih_irig(SPS)
+    sym, res = _noisy_rows(oracle, oracle.ARTM_16, pulse, nsym, ebn0, int(ebn0) + 21)
+    geo = res["geometry"]
+    T = matched_filter_templates(pulse, SPS, ARTM_16)
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+        det = CPMTrellisDetector(ARTM_16)
+        got = det.detect_samples(res["received"], T, geo["start0"], SPS, geo["ncalls"])
+        assert det.samples_form and got.size == res["decisions"].size
+        assert np.array_equal(got, res["decisions"])
+        det = CPMTrellisDetector(ARTM_16)
+        got = det.detect_samples(res["received"], T, geo["start0"], SPS, geo["ncalls"], warmup=8)
+        assert np.array_equal(got, res["decisions"]) and dev.viterbi_repaired(reset=True, ctx=det._ctx) > 100
+        # a burst below the lane form's reach, and a trellis without the specialisation: declined, same decisions through the rows
+        det = CPMTrellisDetector(ARTM_16)
+        small = det.detect_samples(res["received"], T, geo["start0"], SPS, 300_000)
+        assert not det.samples_form and np.array_equal(small, res["decisions"][:300_000 - 31])
+    p2 = oracle.freq_pulse_pcmfm(SPS)
+    sym2, res2 = _noisy_rows(oracle, oracle.PCMFM_SPEC, p2, 50_000, ebn0, 5)
+    det = CPMTrellisDetector(PCMFM_10)
+    got2 = det.detect_samples(res2["received"], matched_filter_templates(p2, SPS, PCMFM_10), res2["geometry"]["start0"], SPS, res2["geometry"]["ncalls"])
+    assert not det.samples_form and np.array_equal(got2, res2["decisions"])
+
+
+@pytest.mark.gpu
+def test_gpu_detect_samples_carries_its_state(oracle, ctx_options):
+    """One burst through wf_cpm_viterbi_detect_samples in two launches (d_state carries metrics, phase indices and decision
+    registers; the second piece's first call is even, so its calls take the template columns of their places in the burst):
+    the decisions of the whole burst in one sequential pass."""
+    from waveforms_amd.viterbi.cpm import ARTM_16, CPMTrellisDetector, matched_filter_templates
+
+    nsym, k0 = 4_300_000, 2_150_000
+    pulse = oracle.freq_pulse_multih_irig(SPS)
+    sym, res = _noisy_rows(oracle, oracle.ARTM_16, pulse, nsym, 5.0, 77)
+    geo = res["geometry"]
+    assert geo["start0"] == 0
+    T = matched_filter_templates(pulse, SPS, ARTM_16)
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+        det = CPMTrellisDetector(ARTM_16)
+        first = det.detect_samples(res["received"], T, 0, SPS, k0)
+        assert det.samples_form
+        second = det.detect_samples(res["received"][SPS * k0:], T, 0, SPS, geo["ncalls"] - k0)
+        assert det.samples_form
+    assert np.array_equal(np.concatenate([first, second]), res["decisions"])

@@ -87,10 +87,12 @@ SIGNATURES = {
                                          c_int, c_int64, c_int, c_int64, _P, _P]),
     "wf_cpm_detector_form": (c_int, [_P, _P, c_int64, c_int, POINTER(c_int)]),
     "wf_cpm_viterbi_detect": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
+    "wf_cpm_viterbi_detect_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_int64, c_int, c_int64, c_int, _P, _P, _P]),
     "wf_cpm_count_errors": (c_int, [_P, _P, _P, c_int, c_int64, _P, _P]),
     "wf_cpm_link_workspace_bytes": (c_int64, [_P]),
     "wf_cpm_link_run": (c_int, [_P, _P, _P, c_int64, _P, POINTER(c_int64), _P]),
     "wf_cpm_link_layout": (c_int, [_P, POINTER(c_int64)]),
+    "wf_cpm_link_form": (c_int, [_P, _P, POINTER(c_int)]),
     "wf_cpm_link_stream_workspace_bytes": (c_int64, [_P, c_int64]),
     "wf_cpm_link_stream_layout": (c_int, [_P, c_int64, c_int64, POINTER(c_int64)]),
     "wf_cpm_link_stream_chunk": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, _P, POINTER(c_int64), _P]),

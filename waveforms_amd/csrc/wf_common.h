@@ -77,6 +77,7 @@ struct wf_ctx {
     // end of the NEXT block (two sets of intermediates in the workspace, used alternately).  pipe_done[s]: the back end
     // of the last block that used set s; wf_link_join / wf_ctx_check make the caller's stream wait for both.
     void *pipe_stream = nullptr;
+    void *pipe_stream2 = nullptr;        // the CPM links alternate consecutive blocks' back ends between two side streams (wf_cpm_link_run)
     hipEvent_t pipe_front = nullptr, pipe_done[2] = {nullptr, nullptr};
     bool pipe_done_valid[2] = {false, false};
     int pipe_set = 0;
@@ -152,6 +153,12 @@ int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, con
                          int ntaps, int sps, double phi0, const double *d_templates, int nfilt, int ntm, int64_t start0,
                          double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id, int64_t ncalls,
                          double *d_rows, void *stream, const wf_mcb_opts *opts = nullptr);
+// Modulator + channel with the NOISY SAMPLES stored (the front end of the CPM link whose detector runs the matched filters itself,
+// wf_cpm_link_config.fuse bit 7): 1 = configuration outside the kernel.
+int wf_mod_chan_samples_applies(int64_t nsym, int nh, int ntaps, int sps);
+int wf_mod_chan_samples(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse, int ntaps,
+                        int sps, double phi0, double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id,
+                        uint64_t first_index, double *d_out_ri, void *stream);
 // A promise a caller makes about small device operands (<= 64 KB), checked on the HOST the first time this content is
 // seen on this context: `check(host copy, nbytes)` decides; the verdict is cached under a hash of (kind, bytes).
 // Synchronises `stream` on a cache miss only.  Returns WF_OK, or WF_ERR_VALUE with `what` in the error text.

@@ -65,14 +65,27 @@ struct cpm_lane_plan {
     double row_ns_per_call;     // the row form's time per call of the BURST (measured at 1e7 calls; it scales with the burst)
 };
 int wf_cpm_lanes_plan(const wf_cpm_detector_config *det, cpm_lane_plan *plan);   // 0: a specialisation exists (*plan filled in), 1: none
+// The matched filters INSIDE the detector (round 6): d_rows_ri of the launch are then the noisy samples, call k's window = samples
+// 8 k .. 8 k + 8 from that pointer (nsamp addressable), against template column (k + col0) % nh of d_templates [nh][16][9] complex,
+// whose filters f and 15 - f are exact conjugates (the caller checked).  Lane form of the 16-filter ARTM design; the repairs
+// (cpm_repair_kernel) rebuild the rows of the chunks they run from the same samples with the same arithmetic.
+struct cpm_mf_source {
+    const double *d_templates;
+    int64_t nsamp;
+    int col0;
+};
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
                         int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
-                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool solo);
+                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool solo, const cpm_mf_source *mf = nullptr);
 // wf_cpm_viterbi_detect for callers that own the memory around the rows (the links: rows sit inside their workspace):
 // slack_*_bytes of it before / behind the array may be READ (never interpreted) by the lane form's row fetch.
 int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
                              int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes,
-                             bool beside = false);   // beside: the launch will share the chip with another kernel (a pipelined link's front end)
+                             bool beside = false,    // beside: the launch will share the chip with another kernel (a pipelined link's front end)
+                             const cpm_mf_source *mf = nullptr,    // mf: d_rows_ri are the noisy samples, the matched filters run inside the detector
+                             int edge_slot = -1);   // 0 / 1: which of two sets of proof records in the context this launch uses (launches in flight on two streams); -1: the one set
+int wf_cpm_samples_form_chunk(wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int warmup, bool beside);
+bool wf_cpm_samples_form_applies(wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int sps, int nfilt, int ntm, int64_t start0);
 
 // Wide form (wf_cpm_wide.hip): trellises of 17 .. 64 states, lane = state, one wave = one detector.  Proof records of
 // 2 x 64 x 3 words per chunk, detector state in the wide layout of WF_CPM_STATE_BYTES.

@@ -60,6 +60,10 @@ struct cpm_vit_params {
     int CH, W;
     int64_t ncalls, nchunks;
     int rows_off, xch_off, dec_off, wave_bytes, rot_off;   // dynamic LDS layout (bytes)
+    // repairs of a launch whose lanes ran the matched filters themselves (cpm_mf_source): `rows` are the noisy samples
+    const double *mf_templ;
+    int64_t mf_nsamp;
+    int mf_col0;
     cpm_tables T;
 };
 
@@ -205,6 +209,34 @@ __device__ __forceinline__ void cpm_viterbi_body(const double2 *__restrict__ row
     // cooperative row fetch: piece q = s + 16 i of the batch's CPM_TB * NF pieces
     auto fetch = [&](int b, double2 (&dst)[PL]) __attribute__((always_inline)) {
         const int64_t kb = k_first - P.W + (int64_t)b * CPM_TB;        // local call of the batch's first row
+        if constexpr (REPAIR && NF == 16) {
+            // The launch's lanes ran the matched filters themselves: no rows exist.  Lane s forms filter s of call kb + i from
+            // the samples, as one half of its conjugate pair p = min(s, 15 - s) — the four real chains of cpm_lane_kernel's MF
+            // form, operation for operation, so a repaired chunk ends in bitwise the state its successor started from.
+            if (P.mf_templ) {
+                const double2 *smp = rows;
+                const int p = s < 8 ? s : 15 - s;
+#pragma unroll
+                for (int i = 0; i < PL; ++i) {
+                    int64_t row = kb + i;
+                    row = row < 0 ? 0 : (row >= P.ncalls ? P.ncalls - 1 : row);
+                    const double2 *tp = reinterpret_cast<const double2 *>(P.mf_templ) + ((P.nh == 2 ? (int)((row + P.mf_col0) & 1) : 0) * NF + p) * 9;
+                    double sP = 0.0, sQ = 0.0, sR = 0.0, sU = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        int64_t idx = 8 * row + k;
+                        idx = idx < P.mf_nsamp ? idx : P.mf_nsamp - 1;
+                        const double2 x = smp[idx], tk = tp[k];
+                        sP = fma(x.x, tk.x, sP);
+                        sU = fma(x.x, -tk.y, sU);
+                        sQ = fma(x.y, tk.y, sQ);
+                        sR = fma(x.y, tk.x, sR);
+                    }
+                    dst[i] = s < 8 ? make_double2(sP + sQ, sU + sR) : make_double2(sP - sQ, -(sU - sR));
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
             const int q = s + 16 * i;
@@ -597,8 +629,13 @@ static int cpm_build_tables(const wf_cpm_detector_config *d, cpm_vit_params &P)
 // burst's length, while the row form's falls with the burst (4 chunks per wave: 16 times the waves).  The two meet near
 // 9e6 (ARTM) and 6.5e6 (PCM/FM) calls; below, the row form runs (a 2^22-call stream chunk: 0.32 against 0.54 ms for
 // ARTM).  WF_OPT_CPM_FORM = 1 / 2 forces one form (tests run both on every size), WF_OPT_CPM_CHUNK_CALLS the chunk length.
+// mf_form 1 | 2 (the lanes run the matched filters, alone | beside a front end): the lane form whatever the burst, and its own
+// chunk rule.  That kernel is bound by vector issue, one wave saturating its SIMD (profiles/r06_mf_chunk_sweep.log) — alone, the
+// chunk that puts ONE wave on every SIMD in a single round (1e7 calls: 160, 977 waves; 0.58 ms against 0.66 at 192, 0.80 at 256);
+// beside the next block's front end both kernels share every SIMD's issue slots, the sum of their instructions is what counts and
+// a third longer chunk does 5 % less warm-up work (pipelined link, same box: 160 0.930 | 192 0.908 | 208 0.834 | 224 0.843 | 256 0.873 ms).
 static int64_t cpm_chunk_calls(const wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int W, int wg_per_cu, cpm_lane_plan *lanes,
-                               bool *use_lanes)
+                               bool *use_lanes, int mf_form = 0)
 {
     auto floor_ch = [&](int64_t ch, int min_chunk) {
         ch = (ch + 63) / 64 * 64;
@@ -617,13 +654,21 @@ static int64_t cpm_chunk_calls(const wf_ctx *ctx, const wf_cpm_detector_config *
         const int64_t slots_lane = (int64_t)cus * lanes->waves_per_cu * 64;
         const int64_t ch_lane = floor_ch((ncalls + slots_lane - 1) / slots_lane, lanes->min_chunk);
         const double t_lane = lanes->lane_ns_per_call * (double)(ch_lane + W), t_row = lanes->row_ns_per_call * (double)ncalls;
-        if (form == 2 || t_lane < t_row) {
+        if (form == 2 || mf_form || t_lane < t_row) {
             *use_lanes = true;
             ch = ch_lane;
         }
+        if (mf_form) {
+            const int64_t slots = (int64_t)cus * 4 * 64;             // one wave per SIMD
+            ch = ((ncalls + slots - 1) / slots + 15) / 16 * 16;
+            if (mf_form == 2) ch = (ch * 13 / 10 + 15) / 16 * 16;
+            if (ch < 64) ch = 64;
+            if (ch < 2 * W) ch = (2 * W + 15) / 16 * 16;
+        }
     }
     if (ctx->opt[WF_OPT_CPM_CHUNK_CALLS] > 0) {                    // tuning aid (tools/cpm_vit_time.py)
-        ch = (ctx->opt[WF_OPT_CPM_CHUNK_CALLS] + 63) / 64 * 64;
+        ch = (ctx->opt[WF_OPT_CPM_CHUNK_CALLS] + 15) / 16 * 16;   // (any multiple of 16, at least 64: the row form batches 8 calls, a lane stores 8 decisions at a time)
+        if (ch < 64) ch = 64;
         if (ch <= W + 1) ch = (W + 2 + 63) / 64 * 64;
     }
     if (ch > 8192) ch = 8192;                                      // decision strips live in LDS; longer bursts take several rounds
@@ -681,10 +726,34 @@ extern "C" int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *
     return wf_cpm_viterbi_detect_in(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream, 0, 0);
 }
 
+// Would a launch with the matched filters inside the detector (cpm_mf_source) serve this burst?  The 16-filter ARTM design in
+// its lane form, 9-tap templates at 8 samples per symbol whose windows start inside the sample array, and a burst the lane form
+// would be chosen for anyway (a short burst runs the row form on rows: wf_cpm_viterbi_detect_in decides the same way).
+bool wf_cpm_samples_form_applies(wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int warmup, int sps, int nfilt, int ntm, int64_t start0)
+{
+    if (!ctx || !det || sps != 8 || nfilt != 16 || ntm != 9 || start0 < 0 || ncalls < det->Lp) return false;
+    if (wf_cpm_quad_applies(det) || wf_cpm_wide_applies(det) || ctx->opt[WF_OPT_CPM_FORM] == 1) return false;
+    cpm_lane_plan lanes{};
+    if (wf_cpm_lanes_plan(det, &lanes) != 0 || lanes.spec != 0) return false;
+    // one lane per chunk: below ~2e6 calls the chunks that fill the chip are mostly warm-up, and the row form on rows is the faster path
+    return ncalls >= ((int64_t)1 << 21);
+}
+
+// calls per chunk of such a launch (what wf_cpm_viterbi_detect_in will choose)
+int wf_cpm_samples_form_chunk(wf_ctx *ctx, const wf_cpm_detector_config *det, int64_t ncalls, int warmup, bool beside)
+{
+    cpm_lane_plan lanes{};
+    bool use_lanes = false;
+    return (int)cpm_chunk_calls(ctx, det, ncalls, cpm_warmup_calls(warmup), 4, &lanes, &use_lanes, beside ? 2 : 1);
+}
+
 int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
-                             int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool beside)
+                             int warmup, uint8_t *d_decisions, void *d_state, void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool beside,
+                             const cpm_mf_source *mf, int edge_slot)
 {
     WF_REQUIRE(ctx && det && ncalls >= 0 && warmup >= 0, "wf_cpm_viterbi_detect: bad argument");
+    WF_REQUIRE(!mf || (!wf_cpm_quad_applies(det) && !wf_cpm_wide_applies(det) && ncalls >= det->Lp && ctx->opt[WF_OPT_CPM_FORM] != 1),
+               "wf_cpm_viterbi_detect: the matched-filter form is the lane form of a trellis of <= 16 states");
     const bool quad = wf_cpm_quad_applies(det) != 0;               // 65 .. 256 states: wf_cpm_quad.hip
     const bool wide = quad || wf_cpm_wide_applies(det) != 0;       // 17 .. 64 states: wf_cpm_wide.hip
     cpm_vit_params P;
@@ -722,7 +791,11 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
     cpm_lane_plan lanes{};
     const int wg_per_cu = CPM_MIN_WAVES(P.M, P.Lp);                 // resident workgroups per CU = waves per SIMD (4 waves per workgroup)
     bool use_lanes = false;
-    const int64_t ch = cpm_chunk_calls(ctx, det, ncalls, W, wg_per_cu, &lanes, &use_lanes);
+    const int64_t ch = cpm_chunk_calls(ctx, det, ncalls, W, wg_per_cu, &lanes, &use_lanes, mf ? (beside ? 2 : 1) : 0);
+    WF_REQUIRE(!mf || (use_lanes && lanes.spec == 0), "wf_cpm_viterbi_detect: no lane specialisation runs the matched filters of this trellis");
+    P.mf_templ = mf ? mf->d_templates : nullptr;
+    P.mf_nsamp = mf ? mf->nsamp : 0;
+    P.mf_col0 = mf ? (mf->col0 & 1) : 0;
     // (measured at 1e7 ARTM calls, W = 128, row form: 384 calls per chunk 1.07 ms, 512: 1.03, 640: 1.00, 768: 1.19,
     //  1024: 1.28, 1536: 1.68 — longer chunks do less warm-up work but leave fewer waves to hide the
     //  dependent chain of a call)
@@ -742,14 +815,16 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
     const int64_t nblocks = (nwaves + CPM_WAVES - 1) / CPM_WAVES;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_viterbi_detect: burst too long for one launch");
     P.nchunks = nchunks;
-    rc = wf_ctx_reserve_vit(ctx, cpm_edge_total_words(nchunks, CPM_EDGE_WORDS));
+    // (edge_slot 0 / 1: a pipelined link runs consecutive blocks' detectors on two side streams, each with its own proof records)
+    const size_t edge_words = (cpm_edge_total_words(nchunks, CPM_EDGE_WORDS) + 31) / 32 * 32;
+    rc = wf_ctx_reserve_vit(ctx, edge_slot >= 0 ? 2 * edge_words : edge_words);
     if (rc) return rc;
-    uint64_t *edge = reinterpret_cast<uint64_t *>(ctx->d_vit_edge);
+    uint64_t *edge = reinterpret_cast<uint64_t *>(ctx->d_vit_edge) + (edge_slot > 0 ? edge_words : 0);
     hipStream_t s = wf_stream(stream);
     using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params);
     using repair_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, unsigned long long *, cpm_vit_params, int, int, int);
     if (use_lanes) {
-        rc = wf_cpm_lanes_launch(lanes, det, d_rot_cs, d_rows_ri, ncalls, W, P.CH, nchunks, d_decisions, d_state, edge, stream, slack_lo_bytes, slack_hi_bytes, !beside);
+        rc = wf_cpm_lanes_launch(lanes, det, d_rot_cs, d_rows_ri, ncalls, W, P.CH, nchunks, d_decisions, d_state, edge, stream, slack_lo_bytes, slack_hi_bytes, !beside, mf);
         if (rc) return rc;
     } else {
         kern_t k = nullptr;
@@ -796,6 +871,29 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
         WF_LAUNCH_CHECK();
     }
     return WF_OK;
+}
+
+static int cpm_check_paired_templates(wf_ctx *ctx, const double *d_templates, int nh, int nfilt, int ntm, void *stream);
+
+// wf_cpm_mf_rows_c128 + wf_cpm_viterbi_detect in ONE launch: the detector's lanes run the matched filters on the noisy samples
+// (128 B per call instead of a 256 B row written and read back).  Returns 1 — not an error, nothing launched — when this form does
+// not serve the configuration (wf_cpm_samples_form_applies); the templates must pair off as conjugates, f <-> nfilt - 1 - f (checked).
+extern "C" int wf_cpm_viterbi_detect_samples(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_templates_ri,
+                                             int nh, int nfilt, int ntm, const double *d_samples_ri, int64_t nsamp, int64_t start0, int sps,
+                                             int64_t ncalls, int warmup, uint8_t *d_decisions, void *d_state, void *stream)
+{
+    WF_REQUIRE(ctx && det && ncalls >= 0 && warmup >= 0 && nsamp >= 0, "wf_cpm_viterbi_detect_samples: bad argument");
+    WF_REQUIRE(nh == det->nh, "wf_cpm_viterbi_detect_samples: %d template columns for %d modulation indices", nh, det->nh);
+    if (!wf_cpm_samples_form_applies(ctx, det, ncalls, warmup, sps, nfilt, ntm, start0)) return 1;
+    WF_REQUIRE(d_rot_cs && d_templates_ri && d_samples_ri && d_decisions, "wf_cpm_viterbi_detect_samples: NULL device pointer");
+    WF_REQUIRE(start0 + 8 * (ncalls - 1) + 8 < nsamp, "wf_cpm_viterbi_detect_samples: %lld calls from sample %lld run past %lld samples",
+               (long long)ncalls, (long long)start0, (long long)nsamp);
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_samples_ri) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_templates_ri) & 15) == 0,
+               "wf_cpm_viterbi_detect_samples: device pointers must be 16-byte aligned");
+    int rc = cpm_check_paired_templates(ctx, d_templates_ri, nh, nfilt, ntm, stream);
+    if (rc) return rc;
+    const cpm_mf_source mf{d_templates_ri, nsamp - start0, 0};
+    return wf_cpm_viterbi_detect_in(ctx, det, d_rot_cs, d_samples_ri + 2 * start0, ncalls, warmup, d_decisions, d_state, stream, 0, 0, false, &mf);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1049,13 +1147,17 @@ static bool cpm_templates_pair_off(const unsigned char *const *host, const size_
             }
     return true;
 }
-static int cpm_check_paired(wf_ctx *ctx, const wf_cpm_link_config *cfg, int nfilt, int ntm, void *stream)
+static int cpm_check_paired_templates(wf_ctx *ctx, const double *d_templates, int nh, int nfilt, int ntm, void *stream)
 {
-    const cpm_pair_shape sh{cfg->det.nh, nfilt, ntm};
-    const void *ptrs[1] = {cfg->d_templates};
+    const cpm_pair_shape sh{nh, nfilt, ntm};
+    const void *ptrs[1] = {d_templates};
     const size_t nb[1] = {(size_t)sh.nh * nfilt * ntm * 16};
     return wf_promise_verified(ctx, 1, ptrs, nb, 1, stream, cpm_templates_pair_off, &sh,
-                               "wf_cpm_link_config.fuse bit 6 is set, but templates f and nfilt - 1 - f are not exact conjugates of each other");
+                               "templates f and nfilt - 1 - f are not exact conjugates of each other (wf_cpm_link_config.fuse bit 6 / the samples form of the detector)");
+}
+static int cpm_check_paired(wf_ctx *ctx, const wf_cpm_link_config *cfg, int nfilt, int ntm, void *stream)
+{
+    return cpm_check_paired_templates(ctx, cfg->d_templates, cfg->det.nh, nfilt, ntm, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1122,6 +1224,36 @@ extern "C" int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8)
     return WF_OK;
 }
 
+// fuse bit 7 (with bits 1 and 6): the front end stores the noisy SAMPLES and the detector's lanes run the matched filters —
+// where both kernels serve the configuration (16 paired templates, 8 samples per symbol, a burst the lane form takes)
+static bool cpm_link_samples_form(wf_ctx *ctx, const wf_cpm_link_config *cfg, const cpm_link_layout &L)
+{
+    return (cfg->fuse & 128) && (cfg->fuse & 64) && (cfg->fuse & 2) && L.ncalls > 0 &&
+           wf_mod_chan_samples_applies(cfg->nsym, cfg->det.nh, cfg->ntaps, cfg->sps) &&
+           wf_cpm_samples_form_applies(ctx, &cfg->det, L.ncalls, cfg->warmup, cfg->sps, L.nfilt, L.ntm, L.start0);
+}
+
+// What wf_cpm_link_run will launch for this configuration on this context: info4[0] = front end (0: modulator, channel and
+// matched filters as separate kernels; 1: one kernel, rows out; 2: modulator + channel in one kernel, SAMPLES out, the matched
+// filters inside the detector), info4[1 .. 3] = detector form, calls per chunk, warm-up calls (wf_cpm_detector_form).
+extern "C" int wf_cpm_link_form(wf_ctx *ctx, const wf_cpm_link_config *cfg, int *info4)
+{
+    cpm_link_layout L;
+    WF_REQUIRE(ctx && info4 && cpm_make_layout(cfg, L), "wf_cpm_link_form: bad configuration");
+    int d4[4] = {0, 0, 0, 0};
+    const int rc = wf_cpm_detector_form(ctx, &cfg->det, L.ncalls, cfg->warmup, d4);
+    if (rc) return rc;
+    int64_t i8[8];
+    wf_cpm_link_layout(cfg, i8);
+    info4[0] = cpm_link_samples_form(ctx, cfg, L) ? 2 : (int)i8[5];
+    info4[1] = d4[0]; info4[2] = d4[2]; info4[3] = d4[3];
+    if (info4[0] == 2) {
+        info4[1] = 1;
+        info4[2] = wf_cpm_samples_form_chunk(ctx, &cfg->det, L.ncalls, cfg->warmup, (cfg->fuse & 32) != 0);
+    }
+    return WF_OK;
+}
+
 extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
                                int64_t *d_counts, int64_t *h_compared, void *stream)
 {
@@ -1146,6 +1278,11 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
             ctx->pipe_stream = ps;
             WF_HIP(hipEventCreateWithFlags(&ctx->pipe_front, hipEventDisableTiming));
             for (int k = 0; k < 2; ++k) WF_HIP(hipEventCreateWithFlags(&ctx->pipe_done[k], hipEventDisableTiming));
+        }
+        if (!ctx->pipe_stream2) {
+            hipStream_t ps;
+            WF_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+            ctx->pipe_stream2 = ps;
         }
         w += (int64_t)ctx->pipe_set * set_bytes;
         if (ctx->pipe_done_valid[ctx->pipe_set]) WF_HIP(hipStreamWaitEvent(wf_stream(stream), ctx->pipe_done[ctx->pipe_set], 0));
@@ -1185,8 +1322,15 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     MARK(2);
     // fuse bit 3 (with bit 1): modulator + channel + matched-filter rows in one kernel
     // (mod_chan_bank_kernel, wf_modulate.hip) — the baseband samples never reach HBM
-    bool fused_all = false;
-    if ((cfg->fuse & 8) && (cfg->fuse & 2) && L.ncalls > 0) {
+    bool fused_all = false, samples_form = false;
+    if (cpm_link_samples_form(ctx, cfg, L)) {
+        if ((rc = cpm_check_paired(ctx, cfg, L.nfilt, L.ntm, stream))) return rc;
+        rc = wf_mod_chan_samples(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cos(-M_PI / 4), sin(-M_PI / 4),
+                                 cfg->sigma, cfg->seed, cfg->stream_id, 0, sig, stream);
+        if (rc < 0) return rc;
+        samples_form = fused_all = rc == 0;
+    }
+    if (!fused_all && (cfg->fuse & 8) && (cfg->fuse & 2) && L.ncalls > 0) {
         wf_mcb_opts mo;
         mo.runs_hint = piped ? (L.nfilt == 4 ? 16 : 8) : 0;              // (the detector of the previous block shares the chip: finer runs)
         mo.cpm_paired = (cfg->fuse & 64) != 0;                           // fuse bit 6: templates f and nfilt - 1 - f are conjugates — checked
@@ -1218,8 +1362,14 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
                                       rows, stream))) return rc;
     }
     void *back = stream;
+    // A block's back end is detector, proof, up to three repair launches and the count: a serial chain of ~0.1 ms behind the
+    // detector that the NEXT block's detector has no part in — so consecutive blocks' back ends take turns on TWO side streams
+    // (own proof records each: edge_slot), and a detector starts when its samples are in, not when its predecessor's repairs are done.
+    // (trellises above 16 states keep one stream: their forms hold one set of proof records per context)
+    const bool two_back = piped && !wf_cpm_quad_applies(&cfg->det) && !wf_cpm_wide_applies(&cfg->det);
+    const int edge_slot = two_back ? ctx->pipe_set : -1;
     if (piped) {
-        back = ctx->pipe_stream;
+        back = two_back && ctx->pipe_set ? ctx->pipe_stream2 : ctx->pipe_stream;
         WF_HIP(hipEventRecord(ctx->pipe_front, wf_stream(stream)));
         WF_HIP(hipStreamWaitEvent(wf_stream(back), ctx->pipe_front, 0));
     }
@@ -1227,8 +1377,14 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     MARKB(6);
     // (rows sit inside the block's set of intermediates: what lies before them — symbols, the sample region — and behind
     //  them — the decisions, up to the end of the set — may be read by the lane form's row fetch, so no wave of it clamps)
-    if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, back, (int64_t)L.off_rows,
-                                       (int64_t)(L.total - L.off_rows) - L.ncalls * L.nfilt * 16, piped)))
+    if (samples_form) {
+        // (the sample array sits inside the set too: bits and symbols before it, the — unused — row region and the decisions behind)
+        const cpm_mf_source mf{cfg->d_templates, L.npts - L.start0, 0};
+        if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, sig + 2 * L.start0, L.ncalls, cfg->warmup, dec, nullptr, back,
+                                           (int64_t)L.off_sig + 16 * L.start0, (int64_t)(L.total - L.off_sig) - L.npts * 16, piped, &mf, edge_slot)))
+            return rc;
+    } else if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, L.ncalls, cfg->warmup, dec, nullptr, back, (int64_t)L.off_rows,
+                                              (int64_t)(L.total - L.off_rows) - L.ncalls * L.nfilt * 16, piped, nullptr, edge_slot)))
         return rc;
     MARKB(7);
     // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] are compared

@@ -143,9 +143,14 @@ __device__ __forceinline__ void lane_wait_vm()
 
 struct cpm_lane_params {
     int64_t ncalls, nchunks;
-    int64_t slack_lo, slack_hi;     // rows of addressable memory before / behind the row array (0: none promised)
+    int64_t slack_lo, slack_hi;     // rows of addressable memory before / behind the row array (0: none promised; MF form: groups of 8 samples)
     int CH, W, D;
+    // MF form (the matched filters run in the lane: `rows` are the noisy SAMPLES, call k's window = samples 8 k .. 8 k + 8)
+    const double *templ;            // templates [nh][NF][9] complex, f <-> NF - 1 - f exact conjugates (the caller checked)
+    int64_t nsamp;                  // samples addressable from `rows`
+    int col0;                       // call k takes template column (k + col0) % nh
 };
+typedef const __attribute__((address_space(4))) double *lane_cdp;    // (read through the scalar cache: the templates are constants of the launch)
 
 // DHI: the emitted field (bits lgM (D - 1) ... of the best state's decision register) sits in the register's high half.
 // SOLO: the kernel claims accumulation registers it never uses (288 registers in all), so that the dispatcher cannot put two
@@ -154,15 +159,26 @@ struct cpm_lane_params {
 // and the launch lasting 37 % longer than its typical wave (profiles/r05_lane_wave_lifetimes.log).  Alone the claim is worth
 // 7 - 15 % of the detector (profiles/r05_ab_lane_solo.log); beside a front end, whose waves free 128 registers at a time, a
 // wave that needs 288 waits longer (PCM/FM link 0.608 -> 0.653 ms): the pipelined links launch the plain instantiation.
-template <class SP, int R, bool DHI, bool SOLO>
+//
+// MF (round 6): the lane runs the MATCHED FILTERS too.  `rows` are then the noisy samples (call k's window: samples 8 k .. 8 k + 8,
+// 128 new bytes per call where a row of 16 filter outputs is 256), a ring slot is exactly one call's 8 new samples of the wave's 64
+// chunks, and the 16 filter outputs of a call are formed in registers from the templates' conjugate pairs, T[15 - p] == conj(T[p]):
+// with r = x + j y and T_p = c + j s, four real 9-tap chains  P = sum x c,  Q = sum y s,  R = sum y c,  U = sum x (-s)  (each
+// acc = fma(sample, tap, acc) from +0.0, k ascending: the order v_mfma_f64_16x16x4_f64 runs, i.e. bit for bit what the paired
+// front end mod_chan_bank_kernel<.., 32> stores) give  Z_p = (P + Q) + j (U + R)  and  Z_{15-p} = (P - Q) - j (U - R).
+// 288 multiply-adds per call and lane against 128 B per call and lane that never cross HBM; the taps are scalar operands
+// (s_load through the constant cache, 18 doubles per pair), so a multiply-add costs its one vector instruction.
+template <class SP, int R, bool DHI, bool SOLO, bool MF = false>
 __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
                                                          uint8_t *__restrict__ out, uint64_t *__restrict__ state,
                                                          uint64_t *__restrict__ edge, cpm_lane_params P)
 {
     constexpr int S = SP::S, M = SP::M, NF = SP::NF, LGM = SP::LGM, NC = SP::NC, TWO_P = 2 * SP::P;
     constexpr int UNR = 2;                                           // calls per loop trip: the leaving symbol's parity and every piece's place in its slot are constants
-    static_assert((UNR * NF) % LANE_SLOT_PIECES == 0 && LANE_SLOT_PIECES % M == 0, "a loop trip takes whole slots, a filter group sits inside one");
+    constexpr int PPC = MF ? 8 : NF;                                 // 16-byte pieces of a chunk's stream per call: its filter outputs | its 8 new samples
+    static_assert((UNR * PPC) % LANE_SLOT_PIECES == 0 && LANE_SLOT_PIECES % M == 0, "a loop trip takes whole slots, a filter group sits inside one");
     static_assert(LANE_DMAS * (R - 1) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(!MF || (!SP::PIPE && NF == 16 && M == 4 && SP::NCORR == 4 && R >= 2), "MF form: the 16-filter, 4-group trellis (ARTM)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     if constexpr (SOLO) {
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     // earlier when that makes the parity of its first call 0 (chunk starts and chunk lengths are even).
     const int Weff = P.W + (SP::NH == 2 ? (int)((n0 - P.W - SP::LP + 1) & 1) : 0);
     const int T = __builtin_amdgcn_readfirstlane(Weff + P.CH);        // calls a lane runs (uniform, and said so: see fetch)
-    const int nslots = (int)(((int64_t)T * NF + LANE_SLOT_PIECES - 1) / LANE_SLOT_PIECES);
+    const int nslots = MF ? T + 1 : (int)(((int64_t)T * NF + LANE_SLOT_PIECES - 1) / LANE_SLOT_PIECES);   // (MF: the last call's ninth sample is piece 0 of one more slot)
     const int dshift = LGM * (P.D - 1) - (DHI ? 32 : 0);            // inside its 32-bit half
 
     // Detector state of this chunk.  (Tried: the decision registers in LDS, [state][lane], the winner's fetched by
@@ -243,7 +259,9 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     // the tail's ~80 vector instructions hide that round trip, and the slot hand-over (DMA issue + counted wait) that
     // znext may carry sits there too, instead of in front of a call whose first group then waits for its operands
     // (lane_spec::PIPE).
-    auto step = [&](auto kvc, auto pipec, auto &&zsrc, auto &&znext, bool emit, bool emit_ok, int group_pos) __attribute__((always_inline)) {
+    // MF: zprep(0) leaves the filter outputs of groups 0 and 3 where zsrc finds them, zprep(1) — behind group 0's work — those of
+    // groups 1 and 2 (a conjugate pair of filters sits in groups g and 3 - g): at most two groups' outputs wait in registers.
+    auto step = [&](auto kvc, auto pipec, auto &&zsrc, auto &&znext, auto &&zprep, bool emit, bool emit_ok, int group_pos) __attribute__((always_inline)) {
         constexpr int KV = decltype(kvc)::value;
         constexpr bool PIPE = decltype(pipec)::value;
         constexpr int K_old = KV == 2 ? 0 : (KV == 1 ? SP::K1 : SP::K0);
@@ -272,7 +290,10 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
             constexpr int inc = (K_old * u_old) % SP::P;
             constexpr uint32_t delta8 = 8u * (uint32_t)(((2 * inc - (M - 1) * K_old) % TWO_P + TWO_P) % TWO_P);   // what the branch adds to the TILTED phase index
             operands nx;
-            if constexpr (corr + 1 < SP::NCORR) load_group(std::integral_constant<int, corr + 1>{}, nx);
+            if constexpr (corr + 1 < SP::NCORR) {
+                if constexpr (MF) load_rot(std::integral_constant<int, corr + 1>{}, nx);     // (the filter outputs come from registers: below)
+                else load_group(std::integral_constant<int, corr + 1>{}, nx);
+            }
             lane_for<0, NC>([&](auto lc) {
                 constexpr int cls = decltype(lc)::value;
                 constexpr int src = cls + NC * corr;
@@ -305,8 +326,13 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                 // selects: 100+ scalar spills, reloaded by v_readlane inside the call loop)
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (MF && corr + 1 < SP::NCORR) {
+                if constexpr (corr == 0) zprep(std::integral_constant<int, 1>{});
+                lane_for<0, M>([&](auto uc) { nx.z[decltype(uc)::value] = zsrc(std::integral_constant<int, decltype(uc)::value + M * (corr + 1)>{}); });
+            }
             if constexpr (corr + 1 < SP::NCORR) self(self, std::integral_constant<int, corr + 1>{}, nx);
         };
+        zprep(std::integral_constant<int, 0>{});
         if constexpr (PIPE) {
             const operands o0 = first;
             run_group(run_group, std::integral_constant<int, 0>{}, o0);
@@ -342,6 +368,38 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
         }
     };
     using kv2 = std::integral_constant<int, 2>;
+    // ---- MF: the call's window (9 samples, planes x | y) and its 16 filter outputs
+    double wx[MF ? 9 : 1], wy[MF ? 9 : 1];
+    double2 zz[MF ? NF : 1];
+    // template column of the calls a loop trip runs first / second (uniform): local call k takes column (k + col0) % nh,
+    // k = chunk CH - Weff + t and chunks start on even calls
+    lane_cdp tcol[2] = {nullptr, nullptr};
+    if constexpr (MF) {
+        const int flip = SP::NH == 2 ? __builtin_amdgcn_readfirstlane((Weff + P.col0) & 1) : 0;
+        const lane_cdp t0 = (lane_cdp)(uintptr_t)P.templ;
+        tcol[0] = t0 + (flip ? 2 * NF * 9 : 0);
+        tcol[1] = SP::NH == 2 ? t0 + (flip ? 0 : 2 * NF * 9) : t0;
+    }
+    // pairs 4 ph .. 4 ph + 3 of the window in wx / wy against column tc: zz[p] and zz[15 - p] (groups ph and 3 - ph)
+    auto mf_pairs = [&](auto phc, lane_cdp tc) __attribute__((always_inline)) {
+        asm volatile("" : "+s"(tc));                                 // (re-read per call through the constant cache, not 288 loop-invariant scalar registers)
+        lane_for<0, 4>([&](auto pc) {
+            constexpr int p = 4 * decltype(phc)::value + decltype(pc)::value;
+            double sP = 0.0, sQ = 0.0, sR = 0.0, sU = 0.0;
+            lane_for<0, 9>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const double c = tc[2 * (p * 9 + k)], sn = tc[2 * (p * 9 + k) + 1];
+                sP = fma(wx[MF ? k : 0], c, sP);
+                sU = fma(wx[MF ? k : 0], -sn, sU);
+                sQ = fma(wy[MF ? k : 0], sn, sQ);
+                sR = fma(wy[MF ? k : 0], c, sR);
+            });
+            zz[MF ? p : 0] = make_double2(sP + sQ, sU + sR);
+            zz[MF ? NF - 1 - p : 0] = make_double2(sP - sQ, -(sU - sR));
+        });
+    };
+    auto zreg = [&](auto fc) __attribute__((always_inline)) { return zz[MF ? decltype(fc)::value : 0]; };
+    auto noprep = [](auto) __attribute__((always_inline)) {};
 
     // EVERY lane runs EVERY call of the loop below — the row fetch inside a call is the whole wave's business (a lane
     // fetches pieces of other lanes' chunks), so no call may sit in divergent control flow.  Lanes whose call is not
@@ -355,9 +413,21 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     const int64_t kmin0 = n0 < SP::LP - 1 ? (SP::LP - 1 - n0 < P.ncalls ? SP::LP - 1 - n0 : P.ncalls) : 0;     // (uniform)
     if (chunk == 0) {
         for (int64_t k = 0; k < kmin0; ++k) {
-            const double2 *zr = rows + k * NF;
-            auto zg = [&](auto fc) { return zr[decltype(fc)::value]; };
-            step(kv2{}, std::false_type{}, zg, zg, true, n0 + k >= P.D - 1, (int)(k & 7));
+            if constexpr (MF) {
+                lane_for<0, 9>([&](auto jc) {
+                    const double2 v = rows[8 * k + decltype(jc)::value];
+                    wx[decltype(jc)::value] = v.x;
+                    wy[decltype(jc)::value] = v.y;
+                });
+                const lane_cdp tc = (lane_cdp)(uintptr_t)P.templ + (SP::NH == 2 && ((k + P.col0) & 1) ? 2 * NF * 9 : 0);
+                mf_pairs(std::integral_constant<int, 0>{}, tc);
+                mf_pairs(std::integral_constant<int, 1>{}, tc);
+                step(kv2{}, std::false_type{}, zreg, zreg, noprep, true, n0 + k >= P.D - 1, (int)(k & 7));
+            } else {
+                const double2 *zr = rows + k * NF;
+                auto zg = [&](auto fc) { return zr[decltype(fc)::value]; };
+                step(kv2{}, std::false_type{}, zg, zg, noprep, true, n0 + k >= P.D - 1, (int)(k & 7));
+            }
         }
         // parked in chunk 0's own start record (nothing else reads that one) until the loop reaches its first call
         lane_for<0, S>([&](auto sc) {
@@ -392,20 +462,22 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     int fast_lo, fast_hi;
     {
         // slot s reads rows floor(8 s / NF) .. floor((8 s + 7) / NF) of a chunk's stream, i.e. absolute rows kbase(chunk) + those
+        // (MF: a stream "row" is a call's 8 new samples, and the array holds nsamp / 8 whole ones)
+        const int64_t nrows_tot = MF ? P.nsamp / 8 : P.ncalls;
         const int64_t need_lo = Weff - chunk0 * P.CH - P.slack_lo;                       // first stream row that is >= -slack_lo for chunk0
-        fast_lo = need_lo <= 0 ? 0 : (int)((need_lo * NF + LANE_SLOT_PIECES - 1) / LANE_SLOT_PIECES);
-        const int64_t room = P.ncalls + P.slack_hi + Weff - cg_last * P.CH;              // stream rows of the last live chunk that exist
-        const int64_t hi = room <= 0 ? -1 : (room * NF) / LANE_SLOT_PIECES - 1;          // last slot that lies wholly inside them
+        fast_lo = need_lo <= 0 ? 0 : (int)((need_lo * PPC + LANE_SLOT_PIECES - 1) / LANE_SLOT_PIECES);
+        const int64_t room = nrows_tot + P.slack_hi + Weff - cg_last * P.CH;             // stream rows of the last live chunk that exist
+        const int64_t hi = room <= 0 ? -1 : (room * PPC) / LANE_SLOT_PIECES - 1;         // last slot that lies wholly inside them
         fast_hi = hi > 0x3fffffff ? 0x3fffffff : (int)hi;
     }
-    const double2 *const srow0 = rows + (chunk0 * P.CH - Weff) * NF;     // piece 0 of the wave's first chunk's stream (may lie before the array)
+    const double2 *const srow0 = rows + (chunk0 * P.CH - Weff) * PPC;    // piece 0 of the wave's first chunk's stream (may lie before the array)
     unsigned voff[LANE_DMAS];
     lane_for<0, LANE_DMAS>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         int c = 8 * i + c8;                                          // chunk of the wave this lane fetches for in DMA i
         const int q = j8 ^ ((c >> 1) & 7);                           // ... and which of the slot's 8 pieces
         c = chunk0 + c <= cg_last ? c : (int)(cg_last - chunk0);
-        voff[i] = ((unsigned)c * (unsigned)P.CH * NF + (unsigned)q) * 16u + (unsigned)(LANE_DMA_BIAS - 1024 * (i & 3));   // (see lane_dma4)
+        voff[i] = ((unsigned)c * (unsigned)P.CH * PPC + (unsigned)q) * 16u + (unsigned)(LANE_DMA_BIAS - 1024 * (i & 3));   // (see lane_dma4)
     });
     auto fetch = [&](int s, unsigned lds) __attribute__((always_inline)) {
         const int ss = s < nslots ? s : nslots - 1;                  // (past the end: the last slot again — the count of DMAs in flight must not change)
@@ -427,9 +499,15 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                 const int c = 8 * i + cz;
                 const int q = j8 ^ ((c >> 1) & 7);
                 const int64_t piece = (int64_t)ss * LANE_SLOT_PIECES + q;                // of the chunk's stream
-                int64_t row = (chunk0 + c) * P.CH - Weff + piece / NF;
-                row = row < 0 ? 0 : (row >= P.ncalls ? P.ncalls - 1 : row);              // never decoded when clamped
-                lane_dma1(rows + row * NF + (piece % NF), lz + 1024u * i);
+                if constexpr (MF) {
+                    int64_t idx = ((chunk0 + c) * P.CH - Weff) * 8 + piece;             // sample index
+                    idx = idx < 0 ? 0 : (idx >= P.nsamp ? P.nsamp - 1 : idx);            // never decoded when clamped
+                    lane_dma1(rows + idx, lz + 1024u * i);
+                } else {
+                    int64_t row = (chunk0 + c) * P.CH - Weff + piece / NF;
+                    row = row < 0 ? 0 : (row >= P.ncalls ? P.ncalls - 1 : row);          // never decoded when clamped
+                    lane_dma1(rows + row * NF + (piece % NF), lz + 1024u * i);
+                }
             }
         }
     };
@@ -439,10 +517,39 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     int s_fetch = 0;
     unsigned p_fetch = 0, p_read = 0;
     auto next_pos = [](unsigned p) __attribute__((always_inline)) { return p + 1 == (unsigned)R ? 0u : p + 1; };
-    for (int k = 0; k < R - 1; ++k) {
+    for (int k = 0; k < (MF ? R : R - 1); ++k) {
         fetch(s_fetch++, lds0 + p_fetch * LANE_SLOT_BYTES);
         p_fetch = next_pos(p_fetch);
     }
+    // MF: slot t holds the 8 new samples of call t; its window ends with sample 0 of slot t + 1, which is sample 0 of the next
+    // call's window: carried in registers.  A call waits for slots t and t + 1, reads its 7 + 1 pieces and THEN sends the fetch of
+    // slot t + R into slot t's place (the reads have returned: lgkmcnt(0)): R - 1 calls of lead for a fetch.
+    double carry_x = 0.0, carry_y = 0.0;
+    typedef double lane_v2d __attribute__((ext_vector_type(2)));
+    if constexpr (MF) {
+        lane_wait_vm<LANE_DMAS * (R - 1)>();                         // slot 0 is in
+        const lane_v2d v = *reinterpret_cast<const lane_v2d *>(smem + lds_lane);
+        carry_x = v.x;
+        carry_y = v.y;
+    }
+    auto mf_window = [&]() __attribute__((always_inline)) {
+        lane_wait_vm<LANE_DMAS * (R >= 2 ? R - 2 : 0)>();            // slots t and t + 1 are in (this wave's own DMAs: no barrier)
+        const unsigned zb = p_read * LANE_SLOT_BYTES, zn = next_pos(p_read) * LANE_SLOT_BYTES;
+        wx[0] = carry_x;
+        wy[0] = carry_y;
+        lane_for<1, 8>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const lane_v2d v = *reinterpret_cast<const lane_v2d *>(smem + zb + (lds_lane ^ (unsigned)(q * 16)));
+            wx[MF ? q : 0] = v.x;
+            wy[MF ? q : 0] = v.y;
+        });
+        const lane_v2d v8 = *reinterpret_cast<const lane_v2d *>(smem + zn + lds_lane);
+        wx[MF ? 8 : 0] = carry_x = v8.x;
+        wy[MF ? 8 : 0] = carry_y = v8.y;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot's pieces are in registers: its place is free
+        fetch(s_fetch++, lds0 + p_read * LANE_SLOT_BYTES);
+        p_read = next_pos(p_read);
+    };
     unsigned zbase = 0;                                              // LDS byte offset (from smem) of the slot being read
     // the next slot: one more fetch goes out (into the position read before this one), the oldest one in flight lands
     auto acquire = [&]() __attribute__((always_inline)) {
@@ -493,8 +600,17 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                 }
                 const bool emit = t >= Weff;
                 const int gp = (t - Weff) & 7;
-                step(std::integral_constant<int, KV>{}, std::integral_constant<bool, SP::PIPE>{}, [&](auto fc) __attribute__((always_inline)) { return zring(ucc, fc); },
-                     [&](auto fc) __attribute__((always_inline)) { return zring(std::integral_constant<int, UC + 1>{}, fc); }, emit, t >= t_ok, gp);
+                if constexpr (MF) {
+                    step(std::integral_constant<int, KV>{}, std::false_type{}, zreg, zreg,
+                         [&](auto phc) __attribute__((always_inline)) {
+                             if constexpr (decltype(phc)::value == 0) mf_window();
+                             mf_pairs(phc, tcol[UC & 1]);
+                         },
+                         emit, t >= t_ok, gp);
+                } else {
+                    step(std::integral_constant<int, KV>{}, std::integral_constant<bool, SP::PIPE>{}, [&](auto fc) __attribute__((always_inline)) { return zring(ucc, fc); },
+                         [&](auto fc) __attribute__((always_inline)) { return zring(std::integral_constant<int, UC + 1>{}, fc); }, noprep, emit, t >= t_ok, gp);
+                }
                 if (emit && gp == 7) {                               // a group of 8 decisions is complete (uniform)
                     if (t < t_hi) {
                         *reinterpret_cast<uint64_t *>(outp + (t - 7)) = acc;
@@ -541,6 +657,9 @@ using lane_pcmfm10 = lane_spec<2, 2, 5, 10, 1, 7, 7>;    // PCM/FM, h = 7/10, 5 
 // PCM/FM (whose single slot holds two calls), three for ARTM.
 #define LANE_R_ARTM 3
 #define LANE_R_PCMFM 2
+#ifndef LANE_R_ARTM_MF
+#define LANE_R_ARTM_MF 3      // MF form: a slot is a whole call; a fetch has R - 1 calls of lead
+#endif
 
 // 1: no specialisation for this trellis; 0: there is one, *plan filled in.  (Which form runs is the caller's decision:
 // cpm_chunk_calls, wf_cpm_detect.hip.)
@@ -564,14 +683,35 @@ int wf_cpm_lanes_plan(const wf_cpm_detector_config *d, cpm_lane_plan *plan)
 
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
                         int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
-                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool solo)
+                        void *stream, int64_t slack_lo_bytes, int64_t slack_hi_bytes, bool solo, const cpm_mf_source *mf)
 {
-    WF_REQUIRE(chunk_calls >= 64 && chunk_calls % 64 == 0 && warmup >= 0 && warmup % 2 == 0 && chunk_calls > warmup + 1,
+    if (mf) {
+        // the matched filters inside the lane: d_rows_ri = the noisy samples from the first call's window on
+        WF_REQUIRE(plan.spec == 0, "wf_cpm_lanes: the matched-filter form serves the 16-filter ARTM design only");
+        WF_REQUIRE(mf->d_templates && mf->nsamp >= 8 * ncalls + 1, "wf_cpm_lanes: %lld samples for %lld calls", (long long)mf->nsamp, (long long)ncalls);
+        WF_REQUIRE(chunk_calls >= 64 && chunk_calls % 16 == 0 && warmup >= 0 && warmup % 2 == 0 && chunk_calls > warmup + 1,
+                   "wf_cpm_lanes: chunk of %d calls, warm-up %d", chunk_calls, warmup);
+        WF_REQUIRE((int64_t)64 * chunk_calls * 8 * 16 < (1ll << 32), "wf_cpm_lanes: chunk of %d calls overflows the 32-bit row offsets", chunk_calls);
+        cpm_lane_params P{ncalls, nchunks, slack_lo_bytes / 128, slack_hi_bytes / 128, chunk_calls, warmup, det->D, mf->d_templates, mf->nsamp, mf->col0 & 1};
+        const int64_t nblocks = (nchunks + 63) / 64;
+        WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_lanes: burst too long for one launch");
+        const size_t lds = (size_t)LANE_LDS_BYTES(LANE_R_ARTM_MF);
+        using kern_t = void (*)(const double2 *, const double2 *, uint8_t *, uint64_t *, uint64_t *, cpm_lane_params);
+        const kern_t k = solo ? static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R_ARTM_MF, true, true, true>)
+                              : static_cast<kern_t>(cpm_lane_kernel<lane_artm16, LANE_R_ARTM_MF, true, false, true>);
+        if (lds > 48 * 1024)
+            WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64), lds, wf_stream(stream), reinterpret_cast<const double2 *>(d_rows_ri),
+                           reinterpret_cast<const double2 *>(d_rot_cs), d_decisions, static_cast<uint64_t *>(d_state), d_edge, P);
+        WF_LAUNCH_CHECK();
+        return WF_OK;
+    }
+    WF_REQUIRE(chunk_calls >= 64 && chunk_calls % 16 == 0 && warmup >= 0 && warmup % 2 == 0 && chunk_calls > warmup + 1,
                "wf_cpm_lanes: chunk of %d calls, warm-up %d", chunk_calls, warmup);
     WF_REQUIRE((int64_t)64 * chunk_calls * 16 * 16 < (1ll << 32), "wf_cpm_lanes: chunk of %d calls overflows the 32-bit row offsets", chunk_calls);
     int nf = 1;
     for (int i = 0; i < det->Lp; ++i) nf *= det->M;
-    cpm_lane_params P{ncalls, nchunks, slack_lo_bytes / (16 * nf), slack_hi_bytes / (16 * nf), chunk_calls, warmup, det->D};
+    cpm_lane_params P{ncalls, nchunks, slack_lo_bytes / (16 * nf), slack_hi_bytes / (16 * nf), chunk_calls, warmup, det->D, nullptr, 0, 0};
     const int64_t nblocks = (nchunks + 63) / 64;
     WF_REQUIRE(nblocks < (1ll << 31), "wf_cpm_lanes: burst too long for one launch");
     const size_t lds = (size_t)LANE_LDS_BYTES(plan.ring_batches);

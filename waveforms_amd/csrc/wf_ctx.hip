@@ -60,6 +60,7 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
     for (int k = 0; k < 2; ++k)
         if (c->pipe_done[k]) (void)hipEventDestroy(c->pipe_done[k]);
     if (c->pipe_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(c->pipe_stream));
+    if (c->pipe_stream2) (void)hipStreamDestroy(static_cast<hipStream_t>(c->pipe_stream2));
     if (c->d_scan) (void)hipFree(c->d_scan);
     if (c->d_fsm_scratch) (void)hipFree(c->d_fsm_scratch);
     if (c->d_mod_scratch) (void)hipFree(c->d_mod_scratch);
@@ -87,6 +88,7 @@ extern "C" int wf_ctx_retire(wf_ctx *c)
     (void)hipSetDevice(c->device);
     (void)wf_iter_server_stop(c);
     if (c->pipe_stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(c->pipe_stream));
+    if (c->pipe_stream2) (void)hipStreamSynchronize(static_cast<hipStream_t>(c->pipe_stream2));
     return WF_OK;
 }
 

@@ -118,7 +118,10 @@ __global__ __launch_bounds__(MOD_THREADS) void mod_tile_sums_kernel(const int8_t
 }
 
 // Single block: Gcum-derived constants, then Wq[j] = fixed(sum_{i<=j} T*P[i] - K0) (mod sps).
-__global__ __launch_bounds__(1024) void mod_tile_scan_kernel(const int8_t *__restrict__ symbols,
+// (held to 64 registers — 8 waves per SIMD: in a pipelined link this single workgroup of 16 waves has to find room on ONE CU beside
+//  the previous block's detector, whose lane waves hold 240 of a SIMD's 512 registers each; at 76 registers it did not fit next to
+//  them and waited ~0.4 ms for the first of them to retire — profiles/r06_timeline_multih_scan_blocked.txt)
+__global__ __launch_bounds__(1024, 8) void mod_tile_scan_kernel(const int8_t *__restrict__ symbols,
                                                               const double *__restrict__ hvec,
                                                               const double *__restrict__ pulse, mod_params P,
                                                               double *__restrict__ scratch,
@@ -1420,6 +1423,126 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
 #undef MCB_FRESH
 }
 
+// ------------------------------------------------------------------------------------------
+// Modulator + channel, NOISY SAMPLES out (CPM link `fuse` bit 7, round 6): the front end of the link whose detector runs
+// the matched filters itself (wf_cpm_lanes.hip, MF form).  A 16-filter row is 256 B per symbol, the 8 samples it is made
+// from are 128 B: the ARTM link wrote 2.57 GB of rows per 1e7 symbols and read them 1.28 times.  This kernel is
+// mod_main_kernel<JMAX, true> with the channel of mod_chan_bank_kernel applied to a thread's two samples before the
+// store — the same expressions on the same operands in the same order as that kernel's row_step (mod_pair_phase,
+// wf_sincos_sectors_pos, wf_gaussian_two_il, the two fma chains of the derotation), so the samples are bit for bit the
+// ones its bank saw in LDS.  No ring, no bank, no workgroup barrier inside a tile.
+struct mcs_kargs {
+    const int8_t *symbols;
+    const double *hvec, *pulse, *scratch;
+    double *out;
+    mod_params P;
+    mcb_params Q;
+};
+typedef const __attribute__((address_space(4))) mcs_kargs *mcs_kptr;
+
+template <int JMAX>
+__global__ __launch_bounds__(MOD_THREADS, 4) void mod_chan_samples_kernel(const int8_t *__restrict__ symbols_, const double *__restrict__ hvec_,
+                                                                          const double *__restrict__ pulse_, const double *__restrict__ scratch_,
+                                                                          double *__restrict__ out_, mod_params P_, mcb_params Q_)
+{
+    mcs_kptr const KA0 = (mcs_kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto &P = KA0->P;
+    const double *__restrict__ const hvec = KA0->hvec;
+    const double *__restrict__ const scratch = KA0->scratch;
+    extern __shared__ double s_amp[];       // window of symbol amplitudes, then its prefix counts (ints)
+    __shared__ int s_wtot[2 * MOD_WAVES];
+    __shared__ double2 s_xp[2 * MOD_THREADS];   // wave-private transpose: pairs per lane -> rows of 64 samples
+    __shared__ double2 s_tab[256];              // [0,128): log table, [128,256): sincos sectors
+    const int t = threadIdx.x;
+    wf_stage_tables<1, 0>(s_tab, t, MOD_THREADS);   // the tile loop starts with a barrier
+    const double2 *s_cis = s_tab + 128;
+    const wf_tabs_lds<1, 0> tb{s_tab};
+    const int lane = t & 63, wave = t >> 6;
+    const int sps = P.sps;
+    const int tile_len = MOD_ROWS * P.rs;
+    const int sym_per_row = P.rs / sps;
+    const int cq = P.c / sps;
+    const int q0 = (2 * t + P.c) / sps;
+    const int r0 = (2 * t + P.c) - q0 * sps;
+    const int wrap = (r0 + 1 == sps) ? 1 : 0;
+    const int r1 = wrap ? 0 : r0 + 1;
+    const bool any_wrap = (sps & 1) != 0 || (P.c & 1) != 0;
+    const double *Gcum = scratch + MOD_OFF_GCUM(P.ntiles);
+    double Q0[JMAX], Q1[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int k0 = r0 + j * sps, k1 = r1 + j * sps;
+        Q0[j] = Gcum[k0 < P.ntaps ? k0 : P.ntaps - 1];
+        Q1[j] = Gcum[k1 < P.ntaps ? k1 : P.ntaps - 1];
+    }
+    const double sec_per_unit = 128.0 * P.inv_sps, sec_phi0 = 128.0 * P.phi0_turns;
+    const int l_top0p1 = (q0 - cq) + JMAX;
+    const int win = MOD_ROWS * sym_per_row + JMAX + 2;
+    int *s_pi = reinterpret_cast<int *>(s_amp + ((win + 1) & ~1));
+    const double T = scratch[0];
+    const double Th_a = T * hvec[0], Th_b = P.nh > 1 ? T * hvec[1] : 0.0;
+    const int lpart = JMAX - cq - P.dsh;
+
+    for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        auto kt = KA0;
+        asm volatile("" : "+s"(kt));
+        const auto &P = kt->P;
+        const auto &Q = kt->Q;
+        const int8_t *__restrict__ const symbols = kt->symbols;
+        const double *__restrict__ const hvec = kt->hvec;
+        double *__restrict__ const out = kt->out;
+        const uint64_t *Wq = reinterpret_cast<const uint64_t *>(kt->scratch + MOD_OFF_P + P.ntiles);
+        int tp = t;
+        asm volatile("" : "+v"(tp));
+        const int64_t tile_g = P.tile_lo + tile;
+        const int64_t tile_base = tile_g * tile_len;
+        const int64_t sym_base = tile_base / sps;
+        const int64_t mp1_lo = sym_base + cq - JMAX + 1;
+        const bool full_tile = tile_base >= P.out_origin && tile_base + tile_len <= P.out_hi;
+        wf_lds_barrier();
+        mod_stage_window(symbols, hvec, P, mp1_lo - 1, win, s_amp, s_pi, s_wtot, tp);
+        const uint64_t pair_t = Q.pair0 + (Q.dyn_index ? (*Q.dyn_index >> 1) : 0ull) + (uint64_t)(tile_base >> 1) + (uint64_t)tp;
+        const double W = (double)Wq[tile] * 0x1.0p-62 * P.sps_d;
+        const int ref_a = s_pi[lpart], ref_b = P.nh > 1 ? s_pi[win + 1 + lpart] : 0;
+#pragma unroll 2
+        for (int u = 0; u < MOD_ROWS; ++u) {
+            double ra, rb;
+            double2 e0, e1;
+            mod_pair_phase<JMAX>(Q0, Q1, &s_amp[l_top0p1 + u * sym_per_row], &s_pi[(q0 - cq) + u * sym_per_row], wrap, any_wrap, P.nh > 1 ? 2 : 1,
+                                 win + 1, ref_a, ref_b, W, Th_a, Th_b, P.sps_d, P.inv_sps, ra, rb);
+            wf_sincos_sectors_pos(s_cis, fma(ra, sec_per_unit, sec_phi0), &e0.y, &e0.x);   // (ra, rb in [0, sps), phi0 >= 0: the host checks)
+            wf_sincos_sectors_pos(s_cis, fma(rb, sec_per_unit, sec_phi0), &e1.y, &e1.x);
+            double g[4];
+            {
+                uint32_t k0 = (uint32_t)Q.seed, k1 = (uint32_t)(Q.seed >> 32);
+                asm volatile("" : "+s"(k0), "+s"(k1));
+                wf_gaussian_two_il<true, decltype(tb), false, 0>(pair_t + (uint64_t)(u * (P.rs / 2)), Q.stream_id, ((uint64_t)k1 << 32) | k0, Q.sigma, tb, g);
+            }
+            const double2 x0 = make_double2(fma(e0.x, Q.rot_re, fma(-e0.y, Q.rot_im, g[0])), fma(e0.x, Q.rot_im, fma(e0.y, Q.rot_re, g[1])));
+            const double2 x1 = make_double2(fma(e1.x, Q.rot_re, fma(-e1.y, Q.rot_im, g[2])), fma(e1.x, Q.rot_im, fma(e1.y, Q.rot_re, g[3])));
+            // the wave's 128 samples through its private LDS strip: every store instruction writes 64 consecutive samples (mod_main_kernel)
+            double2 *xw = s_xp + wave * (2 * WF_WAVE);
+            xw[2 * lane] = x0;
+            xw[2 * lane + 1] = x1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double2 xa = xw[lane], xb = xw[WF_WAVE + lane];
+            const int col = wave * (2 * WF_WAVE) + lane;
+            const int64_t na = tile_base + (int64_t)u * P.rs + col, nb = na + WF_WAVE;
+            double2 *o = reinterpret_cast<double2 *>(out);
+            if (full_tile) {
+                wf_store16_nt(o + (na - P.out_origin), xa);
+                wf_store16_nt(o + (nb - P.out_origin), xb);
+            } else {
+                if (na >= P.out_origin && na < P.out_hi) wf_store16_nt(o + (na - P.out_origin), xa);
+                if (nb >= P.out_origin && nb < P.out_hi) wf_store16_nt(o + (nb - P.out_origin), xb);
+            }
+            __builtin_amdgcn_wave_barrier();                    // (the strip is rewritten by the next row)
+        }
+    }
+}
+
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
 // Geometry shared by the one-shot entry point and the streaming link.
@@ -1720,6 +1843,49 @@ int wf_mod_chan_cpm_rows(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, con
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_templates, rot_re, rot_im, sigma, seed, stream_id, 0, nullptr, start0 + 4, 0, ncalls, 0,
                                    d_rows, stream, nfilt, nh, 3, 0, opts);
+}
+
+// Modulator + channel with the noisy samples stored (mod_chan_samples_kernel): d_out_ri[n] = sample n of the burst, n < (nsym + 1) sps.
+// Would it take this configuration?  (rows of exactly 512 samples, at most two modulation indices, a pulse of at most 9 symbols)
+int wf_mod_chan_samples_applies(int64_t nsym, int nh, int ntaps, int sps)
+{
+    mod_params P;
+    if (nh < 1 || nh > 2 || !mod_setup(P, nsym, nh, ntaps, sps, 0.0) || P.rs != 2 * MOD_THREADS) return 0;
+    return (ntaps + sps - 1) / sps <= 9;
+}
+
+// Returns 1 — not an error — when the configuration is outside the kernel (the caller runs modulator and channel separately).
+int wf_mod_chan_samples(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse, int ntaps,
+                        int sps, double phi0, double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id,
+                        uint64_t first_index, double *d_out_ri, void *stream)
+{
+    WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_out_ri, "wf_mod_chan_samples: NULL argument");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0, "wf_mod_chan_samples: d_out alignment");
+    if (!(phi0 >= 0.0) || (first_index & 1) || !wf_mod_chan_samples_applies(nsym, nh, ntaps, sps)) return 1;
+    mod_params P;
+    if (!mod_setup(P, nsym, nh, ntaps, sps, phi0)) return 1;
+    WF_HIP(hipSetDevice(ctx->device));
+    int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, nullptr, nullptr, stream);
+    if (rc) return rc;
+    mcb_params Q{};
+    Q.rot_re = rot_re; Q.rot_im = rot_im; Q.sigma = sigma;
+    Q.seed = seed; Q.stream_id = stream_id; Q.pair0 = first_index >> 1;
+    Q.dyn_index = nullptr;
+    const int J = (ntaps + sps - 1) / sps;
+    const int JM = J <= 4 ? 4 : 9;
+    const size_t win = (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2);
+    const size_t lds = ((win + 1) & ~(size_t)1) * sizeof(double) + (size_t)P.nh * (win + 1) * sizeof(int);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int64_t max_grid = (int64_t)cus * 4 * 4;              // (grid-stride over the tiles: a few rounds of resident workgroups)
+    const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
+    using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, double *, mod_params, mcb_params);
+    const kern_t k = JM == 4 ? mod_chan_samples_kernel<4> : mod_chan_samples_kernel<9>;
+    if (lds > 48 * 1024)
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(MOD_THREADS), lds, wf_stream(stream), d_symbols, d_h, d_pulse, ctx->d_mod_scratch, d_out_ri, P, Q);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
 }
 
 // Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total

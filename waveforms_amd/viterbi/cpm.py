@@ -211,3 +211,34 @@ class CPMTrellisDetector:
         lo = max(self.spec.D - 1 - self.i, 0)
         self.i += rows.shape[0]
         return dec[lo:].copy()
+
+    def detect_samples(self, received, templates, start0: int, sps: int, ncalls: int, warmup: int = 0) -> np.ndarray:
+        """The matched filters and the detector over the received SAMPLES (``wf_cpm_viterbi_detect_samples``: the filters
+        run inside the detector, no rows in HBM) — call k's window is ``received[start0 + k sps : start0 + k sps + sps + 1]``
+        against ``templates[k % nh]`` (complex128[nh][M^Lp][sps + 1], ``matched_filter_templates``).  Where that launch
+        does not serve the configuration (``self.samples_form`` says which path ran) the rows are made by
+        ``wf_cpm_mf_rows_c128`` and detected as :meth:`detect` does.  Returns what :meth:`detect` returns for those rows."""
+        from waveforms_amd import _hip, device as dev
+
+        r = np.ascontiguousarray(received, dtype=np.complex128).ravel()
+        t = np.ascontiguousarray(templates, dtype=np.complex128)
+        if self._ctx is None:
+            self._ctx = _hip.new_ctx()
+            self._d_rot = _hip.to_device(rotation_table(self.spec))
+            self._d_state = _hip.zeros(_hip.WF_CPM_STATE_BYTES // 8, "int64")
+        d_r, d_t = _hip.to_device(r), _hip.to_device(t)
+        out = _hip.zeros(int(ncalls) + 16, "uint8")
+        rc = _hip.lib().wf_cpm_viterbi_detect_samples(self._ctx, ctypes.byref(self._cfg), _hip.ptr(self._d_rot), _hip.ptr(d_t), int(t.shape[0]),
+                                                      int(t.shape[1]), int(t.shape[2]), _hip.ptr(d_r), int(r.size), int(start0), int(sps),
+                                                      int(ncalls), int(warmup), _hip.ptr(out), _hip.ptr(self._d_state), _hip.stream())
+        self.samples_form = rc == 0
+        if rc == 1:         # not this launch's configuration: rows, then the detector over them
+            return self.detect(_hip.to_host(dev.cpm_mf_rows(d_r, d_t, int(start0), int(sps), int(ncalls)), complex_pairs=True), warmup)
+        _hip.check(rc)
+        unproven = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
+        if unproven:
+            raise RuntimeError(f"{unproven} detector chunk(s) were left unproven (the repairs are switched off on this context)")
+        dec = _hip.to_host(out[:int(ncalls)])
+        lo = max(self.spec.D - 1 - self.i, 0)
+        self.i += int(ncalls)
+        return dec[lo:].copy()

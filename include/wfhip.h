@@ -73,7 +73,13 @@ typedef enum {
                                    * differs in wf_viterbi4_unmerged (an internal-consistency check; always 0) */
     WF_OPT_ITERATION_SERVER = 4,  /* wf_viterbi4_iteration_host: 0 persistent server, 1 one launch + synchronise per call */
     WF_OPT_MCB_TAIL_PERMILLE = 5, /* one-kernel front end: resident-slot-fulls of tail tiles x 1000; 0 = default, -1 = none */
-    WF_OPT_COUNT = 6
+    WF_OPT_PIPE_RESERVE_CUS = 6,  /* pipelined SOQPSK link (wf_link_config.fuse bit 5), a measured alternative that is NOT the default
+                                   * (profiles/r06_ab_prologue_ahead_cu_mask.log: 0.457 ms per block as shipped, 0.474 with -1, 0.50 with 8):
+                                   * N >= 1: each block's prologue (PRBS + precoder, carry kernels) on a stream of its own beside the
+                                   * previous block's front end, the front-end kernel on a stream whose CU mask leaves N compute units
+                                   * free; -1: the same without a mask; 0: front end and prologue on the caller's stream.  Set before
+                                   * the context's first pipelined block. */
+    WF_OPT_COUNT = 7
 } wf_option;
 int wf_ctx_set_option(wf_ctx *ctx, int key, int64_t value);
 int wf_ctx_get_option(wf_ctx *ctx, int key, int64_t *value);

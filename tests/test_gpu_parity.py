@@ -732,6 +732,42 @@ def test_link_pipelined_blocks_equal_sequential_blocks():
         assert per_block[0][-1][1] > 0
 
 
+@pytest.mark.parametrize("reserve", [-1, 8])
+def test_link_pipelined_with_the_prologue_ahead_equals_sequential_blocks(reserve, ctx_options):
+    """WF_OPT_PIPE_RESERVE_CUS (round 6, a measured alternative to the shipped form): each block's PRBS / precoder / carry
+    kernels on a stream of their own beside the previous block's front end, the front end on a stream of the library's
+    (CU-masked for N >= 1), two sets of modulator carries — the counts of the sequential link, block for block, from the
+    NULL stream and from a stream of the caller's, with resets and stage events in between."""
+    import torch
+
+    from waveforms_amd.link import SOQPSKLink
+
+    nsym = 300_001
+    with ctx_options(WF_OPT_PIPE_RESERVE_CUS=reserve):
+        for own in (False, True):
+            with torch.cuda.stream(torch.cuda.Stream() if own else torch.cuda.current_stream()):
+                seq = SOQPSKLink(nsym, 8, fuse=15, detector="PT", private_ctx=True)
+                pip = SOQPSKLink(nsym, 8, fuse=47, detector="PT", private_ctx=True)
+                assert pip.prologue_ahead and not seq.prologue_ahead
+                per_block = []
+                for link in (seq, pip):
+                    got = []
+                    for k in range(5):
+                        link.reset_counts()
+                        link.run_block(6.0, seed=3, stream_id=k, skip_bits=17 * k)
+                        got.append(link.result())
+                    link.reset_counts()
+                    for k in range(9):
+                        link.run_block(4.0 + (k % 3), seed=5, stream_id=100 + k, skip_bits=k, event_slot=0 if k == 8 else -1)
+                    got.append(link.result())
+                    ms = link.stage_ms(0)
+                    assert ms["fir"] > 0 and (ms["phase"] == 0 or link is seq)
+                    per_block.append(got)
+                assert per_block[0] == per_block[1]
+                torch.cuda.synchronize()
+                del seq, pip
+
+
 # ------------------------------------------------------------------ streaming (config 5)
 @pytest.mark.parametrize("detector,fuse,chunk", [("PT", 3, 1 << 16), ("PAM", 3, 1 << 15), ("PT", 1, 3 << 14),
                                                  ("PT", 7, 1 << 16), ("PAM", 7, 1 << 15), ("PT", 15, 1 << 16), ("PT", 15, 3 << 14),

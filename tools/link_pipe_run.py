@@ -22,7 +22,12 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     a = ap.parse_args()
     _hip.apply_option_args(a.opt)
-    link = CPMLink(a.nsym, 8, waveform=a.waveform, fuse=a.fuse, warmup=operating_point_warmup(a.waveform, a.ebn0))
+    if a.waveform == "soqpsk":
+        from waveforms_amd.link import SOQPSKLink, soqpsk_warmup_param
+
+        link = SOQPSKLink(a.nsym, 8, detector="PT", fuse=a.fuse, warmup=soqpsk_warmup_param(operating_point_warmup("soqpsk", a.ebn0)))
+    else:
+        link = CPMLink(a.nsym, 8, waveform=a.waveform, fuse=a.fuse, warmup=operating_point_warmup(a.waveform, a.ebn0))
     for _ in range(100):
         link.run_block(a.ebn0, seed=1, stream_id=1)
     torch.cuda.synchronize()

@@ -78,6 +78,10 @@ struct wf_ctx {
     // of the last block that used set s; wf_link_join / wf_ctx_check make the caller's stream wait for both.
     void *pipe_stream = nullptr;
     void *pipe_stream2 = nullptr;        // the CPM links alternate consecutive blocks' back ends between two side streams (wf_cpm_link_run)
+    // the pipelined SOQPSK link (wf_link_run): the NEXT block's prologue (PRBS + precoder, tile sums, tile scan) on pipe_pro while
+    // this block's front end runs on pipe_main, whose CU mask keeps a few compute units free for those small kernels
+    void *pipe_pro = nullptr, *pipe_main = nullptr;
+    hipEvent_t pipe_call = nullptr, pipe_pro_done = nullptr;
     hipEvent_t pipe_front = nullptr, pipe_done[2] = {nullptr, nullptr};
     bool pipe_done_valid[2] = {false, false};
     int pipe_set = 0;
@@ -133,12 +137,13 @@ struct wf_mcb_opts {
     const double *pam_factor = nullptr;
     bool cpm_paired = false;
     int runs_hint = 0;
+    int scratch_slot = -1;      // 0 / 1: which of two sets of carries in the context's scratch (stage 1 of one block beside stage 2 of another); -1: the one set
 };
 int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
                             const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
                             double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
                             int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps = 0,
-                            const wf_mcb_opts *opts = nullptr);
+                            const wf_mcb_opts *opts = nullptr, int stage = 3);   // stage 1: the carry kernels only, 2: the main kernel on carries a stage-1 call left (wf_mod_chan_bank_window)
 int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total,
                             const double *d_h, int nh, const double *d_pulse, int ntaps, int sps, double phi0,
                             int64_t tile_lo, int64_t ntiles, const uint64_t *d_q_in, uint64_t *d_q_out, int64_t q_out_tile,

@@ -61,6 +61,10 @@ extern "C" int wf_ctx_destroy(wf_ctx *c)
         if (c->pipe_done[k]) (void)hipEventDestroy(c->pipe_done[k]);
     if (c->pipe_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(c->pipe_stream));
     if (c->pipe_stream2) (void)hipStreamDestroy(static_cast<hipStream_t>(c->pipe_stream2));
+    if (c->pipe_pro) (void)hipStreamDestroy(static_cast<hipStream_t>(c->pipe_pro));
+    if (c->pipe_main) (void)hipStreamDestroy(static_cast<hipStream_t>(c->pipe_main));
+    if (c->pipe_call) (void)hipEventDestroy(c->pipe_call);
+    if (c->pipe_pro_done) (void)hipEventDestroy(c->pipe_pro_done);
     if (c->d_scan) (void)hipFree(c->d_scan);
     if (c->d_fsm_scratch) (void)hipFree(c->d_fsm_scratch);
     if (c->d_mod_scratch) (void)hipFree(c->d_mod_scratch);
@@ -89,6 +93,8 @@ extern "C" int wf_ctx_retire(wf_ctx *c)
     (void)wf_iter_server_stop(c);
     if (c->pipe_stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(c->pipe_stream));
     if (c->pipe_stream2) (void)hipStreamSynchronize(static_cast<hipStream_t>(c->pipe_stream2));
+    if (c->pipe_pro) (void)hipStreamSynchronize(static_cast<hipStream_t>(c->pipe_pro));
+    if (c->pipe_main) (void)hipStreamSynchronize(static_cast<hipStream_t>(c->pipe_main));
     return WF_OK;
 }
 
@@ -116,6 +122,7 @@ extern "C" int wf_ctx_set_option(wf_ctx *c, int key, int64_t value)
     case WF_OPT_CPM_CHUNK_CALLS: ok = value >= 0 && value <= 8192; break;
     case WF_OPT_DET_REPAIR: case WF_OPT_DET_FINAL_VERIFY: case WF_OPT_ITERATION_SERVER: ok = value == 0 || value == 1; break;
     case WF_OPT_MCB_TAIL_PERMILLE: ok = value >= -1 && value <= 16000; break;
+    case WF_OPT_PIPE_RESERVE_CUS: ok = value >= -1 && value <= 128; break;
     }
     WF_REQUIRE(ok, "wf_ctx_set_option: value %lld outside the range of option %d", (long long)value, key);
     c->opt[key] = value;

@@ -1590,14 +1590,20 @@ static bool mod_setup(mod_params &P, int64_t nsym, int nh, int ntaps, int sps, d
 }
 
 // The two carry kernels (tile sums, tile scan) into the context's scratch.
+// (slot 0 / 1: one of two sets of carries — a pipelined link computes the next block's while this block's main kernel reads its own)
+static double *mod_scratch_of(wf_ctx *ctx, const mod_params &P, int slot)
+{
+    const size_t words = (MOD_OFF_GCUM(P.ntiles) + (size_t)P.ntaps + 31) / 32 * 32;
+    return ctx->d_mod_scratch ? ctx->d_mod_scratch + (slot > 0 ? words : 0) : nullptr;
+}
 static int mod_launch_carries(wf_ctx *ctx, const mod_params &P, const int8_t *d_symbols, const double *d_h,
-                              const double *d_pulse, const uint64_t *d_q_in, uint64_t *d_q_out, void *stream)
+                              const double *d_pulse, const uint64_t *d_q_in, uint64_t *d_q_out, void *stream, int slot = -1)
 {
     hipStream_t s = wf_stream(stream);
-    const size_t words = MOD_OFF_GCUM(P.ntiles) + (size_t)P.ntaps;
-    int rc = wf_ctx_reserve_mod(ctx, words);
+    const size_t words = (MOD_OFF_GCUM(P.ntiles) + (size_t)P.ntaps + 31) / 32 * 32;
+    int rc = wf_ctx_reserve_mod(ctx, slot >= 0 ? 2 * words : words);
     if (rc) return rc;
-    double *scratch = ctx->d_mod_scratch;
+    double *scratch = mod_scratch_of(ctx, P, slot);
     hipLaunchKernelGGL(mod_tile_sums_kernel, dim3((unsigned)((P.ntiles + MOD_WAVES - 1) / MOD_WAVES)), dim3(MOD_THREADS),
                        0, s, d_symbols, d_h, P, scratch);
     WF_LAUNCH_CHECK();
@@ -1704,11 +1710,12 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     P.q_out_tile = q_out_tile;
     WF_HIP(hipSetDevice(ctx->device));
     if (stage & 1) {
-        int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, d_q_in, d_q_out, stream);
+        int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, d_q_in, d_q_out, stream, O.scratch_slot);
         if (rc) return rc;
     }
     if (!(stage & 2)) return WF_OK;
     WF_REQUIRE(ctx->d_mod_scratch != nullptr, "wf_mod_chan_bank: stage 2 without the carries of stage 1");
+    double *const scratch_main = mod_scratch_of(ctx, P, O.scratch_slot);
     mcb_params Q;
     Q.rot_re = rot_re; Q.rot_im = rot_im; Q.sigma = sigma;
     Q.seed = seed; Q.stream_id = stream_id; Q.pair0 = first_index >> 1;
@@ -1790,7 +1797,7 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
                             : (JM == 4 ? mod_chan_bank_kernel<4, 0> : mod_chan_bank_kernel<9, 0>);
     if (lds > 48 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(MOD_THREADS), lds, wf_stream(stream), d_symbols, d_h, d_pulse, ctx->d_mod_scratch, d_mf_taps,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(MOD_THREADS), lds, wf_stream(stream), d_symbols, d_h, d_pulse, scratch_main, d_mf_taps,
                        d_rows4, P, Q);
     WF_LAUNCH_CHECK();
     return WF_OK;
@@ -1799,11 +1806,12 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
 int wf_mod_chan_bank_packed(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh,
                             const double *d_pulse, int ntaps, int sps, double phi0, const double *d_mf_taps, double rot_re,
                             double rot_im, double sigma, uint64_t seed, uint64_t stream_id, uint64_t first_index,
-                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps, const wf_mcb_opts *opts)
+                            int64_t first, int64_t ncols, int pack_par0, double *d_rows4, void *stream, int mf_ntaps, const wf_mcb_opts *opts,
+                            int stage)
 {
     return wf_mod_chan_bank_window(ctx, d_symbols, 0, nsym, nsym, d_h, nh, d_pulse, ntaps, sps, phi0, 0, -1, nullptr, nullptr, -1,
                                    d_mf_taps, rot_re, rot_im, sigma, seed, stream_id, first_index, nullptr, first, 0, ncols,
-                                   pack_par0, d_rows4, stream, 0, 1, 3, mf_ntaps, opts);
+                                   pack_par0, d_rows4, stream, 0, 1, stage, mf_ntaps, opts);
 }
 
 // Would the one-kernel front end (SOQPSK form: 3 x (sps + 1) bank, detector-packed rows) take this configuration?

@@ -135,6 +135,25 @@ extern "C" int64_t wf_link_workspace_bytes(const wf_link_config *cfg)
     return link_pipelined(cfg) ? 2 * round_up(one, 256) : one;       // fuse bit 5: two sets of intermediates
 }
 
+// The stream a pipelined link's front-end kernel runs on: every compute unit but the first `reserve` (hipExtStreamCreateWithCUMask),
+// so that the small kernels of the NEXT block's prologue — which fit neither the registers (4 x 128 of a SIMD's 512) nor the LDS
+// (4 x 40 KB of a CU's 160) the front end leaves — and the previous block's detector always find a few CUs of their own.
+// (Such a stream has the default flags: it orders itself against the legacy NULL stream like any stream a caller creates.)
+static hipStream_t link_masked_stream(const wf_ctx *ctx, int reserve)
+{
+    hipStream_t s = nullptr;
+    if (reserve > 0 && reserve < ctx->cus) {
+        const int words = (ctx->cus + 31) / 32;
+        std::vector<uint32_t> mask((size_t)words, 0u);
+        for (int cu = reserve; cu < ctx->cus; ++cu) mask[(size_t)(cu / 32)] |= 1u << (cu % 32);
+        if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask.data()) == hipSuccess) return s;
+        (void)hipGetLastError();
+        s = nullptr;
+    }
+    if (hipStreamCreateWithFlags(&s, hipStreamDefault) != hipSuccess) return nullptr;
+    return s;
+}
+
 extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_workspace, int64_t workspace_bytes,
                            int64_t *d_counts, int64_t *h_compared, void *stream)
 {
@@ -148,6 +167,9 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
     WF_REQUIRE(L.npts >= cfg->mf_ntaps, "wf_link_run: burst shorter than the matched filter");
     char *w = static_cast<char *>(d_workspace);
     const bool piped = link_pipelined(cfg) && L.ncols > 0;
+    void *s_pro = stream, *s_main = stream;       // where the prologue / the front-end kernel go (a pipelined link: library streams)
+    bool ahead = false;
+    int slot = -1;
     if (piped) {
         const int64_t set_bytes = round_up((int64_t)L.total, 256);
         WF_REQUIRE(2 * set_bytes <= workspace_bytes, "wf_link_run: fuse bit 5 needs two sets of intermediates (%lld bytes)", (long long)(2 * set_bytes));
@@ -160,8 +182,40 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
             for (int k = 0; k < 2; ++k) WF_HIP(hipEventCreateWithFlags(&ctx->pipe_done[k], hipEventDisableTiming));
         }
         w += (int64_t)ctx->pipe_set * set_bytes;
-        // the set was last used two blocks ago: that block's detector and counter must be done with it
-        if (ctx->pipe_done_valid[ctx->pipe_set]) WF_HIP(hipStreamWaitEvent(wf_stream(stream), ctx->pipe_done[ctx->pipe_set], 0));
+        // Round 6: three library streams per pipelined link.  A block's PROLOGUE (PRBS + precoder, tile sums, tile scan: ~60 us of
+        // small kernels that used to sit between two front ends on the caller's stream) goes to pipe_pro and depends only on its
+        // set of intermediates being free — the host queues block k + 1 while block k's front end runs, so it runs BESIDE that front
+        // end; the front-end kernel goes to pipe_main (CU-masked: see link_masked_stream) behind its own prologue and the previous
+        // front end; detector + count to pipe_stream as before.  The carries live in one of two scratch sets (slot = the set).
+        // MEASURED AND NOT KEPT as the default (option WF_OPT_PIPE_RESERVE_CUS, 0 = off): the front ends then follow each other
+        // with 12 us between them, but each runs 404 - 475 us instead of 380 — what the detector and the prologue kernels take from
+        // it when they run beside it is what they cost between two front ends (the chip's work is conserved: the front end fills
+        // every SIMD's registers and every CU's LDS, nothing co-resides with it) — 0.457 ms per block as shipped, 0.474 without a
+        // mask, 0.50 with 8 CUs masked (profiles/r06_ab_prologue_ahead_cu_mask.log, r06_timeline_soqpsk_prologue_ahead.txt).
+        const int64_t rsv = ctx->opt[WF_OPT_PIPE_RESERVE_CUS];
+        ahead = rsv != 0;
+        if (ahead) {
+            if (!ctx->pipe_pro) {
+                hipStream_t sp;
+                WF_HIP(hipStreamCreateWithFlags(&sp, hipStreamDefault));       // (default flags: ordered behind what the caller queued on the NULL stream)
+                ctx->pipe_pro = sp;
+                ctx->pipe_main = link_masked_stream(ctx, rsv < 0 ? 0 : (int)rsv);
+                WF_REQUIRE(ctx->pipe_main != nullptr, "wf_link_run: could not create the front end's stream");
+                WF_HIP(hipEventCreateWithFlags(&ctx->pipe_call, hipEventDisableTiming));
+                WF_HIP(hipEventCreateWithFlags(&ctx->pipe_pro_done, hipEventDisableTiming));
+            }
+            s_pro = ctx->pipe_pro;
+            s_main = ctx->pipe_main;
+            slot = ctx->pipe_set;
+            if (stream) {          // a caller's own stream: what it queued there comes first (the NULL stream orders itself, and recording on it would wait for the front end in flight)
+                WF_HIP(hipEventRecord(ctx->pipe_call, wf_stream(stream)));
+                WF_HIP(hipStreamWaitEvent(wf_stream(s_pro), ctx->pipe_call, 0));
+            }
+            if (ctx->pipe_done_valid[ctx->pipe_set]) WF_HIP(hipStreamWaitEvent(wf_stream(s_pro), ctx->pipe_done[ctx->pipe_set], 0));
+        } else if (ctx->pipe_done_valid[ctx->pipe_set]) {
+            // the set was last used two blocks ago: that block's detector and counter must be done with it
+            WF_HIP(hipStreamWaitEvent(wf_stream(stream), ctx->pipe_done[ctx->pipe_set], 0));
+        }
     } else {
         const int rj = wf_link_join_internal(ctx, stream);      // (a context that ran pipelined blocks before: ordinary stream order from here on)
         if (rj) return rj;
@@ -197,39 +251,53 @@ extern "C" int wf_link_run(wf_ctx *ctx, const wf_link_config *cfg, void *d_works
         }
         ev = ctx->events + cfg->event_slot * (WF_LINK_STAGES + 1);
     }
-#define MARK(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(stream))); } while (0)
+#define MARKS(k, s) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(s))); } while (0)
+#define MARK(k) MARKS(k, stream)
     int rc;
-    MARK(0);
+    MARKS(0, s_pro);
     // PRBS + precoder: two launches when the burst fits the scan-free form (wf_soqpsk_prbs_encode), else the generic four
     rc = (cfg->fuse & 16) ? 1 : wf_soqpsk_prbs_encode(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, &next[0][0][0], &outp[0][0][0], bits,
-                                                       cfg->nsym, syms, stream, ev ? (void *)ev[1] : nullptr);
+                                                       cfg->nsym, syms, s_pro, ev ? (void *)ev[1] : nullptr);
     if (rc < 0) return rc;
     if (rc == 1) {
-        if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, cfg->nsym, nullptr, stream))) return rc;
-        MARK(1);
-        if ((rc = wf_fsm_encode(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, cfg->nsym, 0, 0, syms, nullptr, stream))) return rc;
+        if ((rc = wf_lfsr_generate(ctx, cfg->degree, cfg->mask, cfg->state, cfg->skip, bits, cfg->nsym, nullptr, s_pro))) return rc;
+        MARKS(1, s_pro);
+        if ((rc = wf_fsm_encode(ctx, &next[0][0][0], &outp[0][0][0], 2, 4, 1, bits, cfg->nsym, 0, 0, syms, nullptr, s_pro))) return rc;
     }
-    MARK(2);
+    if (!ahead) MARKS(2, s_pro);
     // fuse bit 3 (with bits 1 and 2 in effect): modulator, channel and bank in ONE kernel — the clean
     // baseband samples never exist in HBM.  Outside that kernel's envelope the bits below apply.
     bool fused_all = false;
     if (link_one_kernel(cfg) && L.ncols > 0) {
         wf_mcb_opts mo;
         mo.pam_factor = cfg->d_mf_factor;             // (a long bank handed over in factored form: two real filters + a 3 x 2 combination — checked)
+        mo.scratch_slot = slot;
         if ((rc = link_check_factor(ctx, cfg, stream))) return rc;
-        rc = wf_mod_chan_bank_packed(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_mf_taps,
-                                     cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, L.first, L.ncols, 0,
-                                     mf, stream, cfg->mf_ntaps, &mo);
-        if (rc < 0) return rc;
-        WF_REQUIRE(rc == 0, "wf_link_run: internal: the one-kernel front end refused a configuration wf_mod_chan_bank_applies accepted");
+        for (int stage = ahead ? 1 : 3; stage <= (ahead ? 2 : 3); ++stage) {
+            // (a pipelined link: the carry kernels with the prologue, the main kernel on the front end's stream behind them)
+            if (ahead && stage == 2) {
+                // stage events of such a block: "encode" = precoder + the two carry kernels (the prologue's tail), "fir" = the wait
+                // between the prologue's end and the main kernel's start (no kernel), "phase" = the main kernel
+                MARKS(2, s_pro);
+                WF_HIP(hipEventRecord(ctx->pipe_pro_done, wf_stream(s_pro)));
+                WF_HIP(hipStreamWaitEvent(wf_stream(s_main), ctx->pipe_pro_done, 0));
+                MARKS(3, s_main);
+            }
+            rc = wf_mod_chan_bank_packed(ctx, syms, cfg->nsym, cfg->d_h, 1, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cfg->d_mf_taps,
+                                         cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed, cfg->stream_id, 0, L.first, L.ncols, 0,
+                                         mf, stage == 1 ? s_pro : s_main, cfg->mf_ntaps, &mo, stage);
+            if (rc < 0) return rc;
+            WF_REQUIRE(rc == 0, "wf_link_run: internal: the one-kernel front end refused a configuration wf_mod_chan_bank_applies accepted");
+        }
         fused_all = true;
     }
     if (fused_all) {
-        MARK(3); MARK(4); MARK(5);            // the "fir" slot times the whole fused kernel
+        if (!ahead) MARKS(3, s_main);                                    // the "fir" slot times the whole fused kernel (the "phase" slot when the prologue runs ahead: above)
+        MARKS(4, s_main); MARKS(5, s_main);
         void *back = stream;                  // the stream the detector and the counter run on
         if (piped) {
             back = ctx->pipe_stream;
-            WF_HIP(hipEventRecord(ctx->pipe_front, wf_stream(stream)));
+            WF_HIP(hipEventRecord(ctx->pipe_front, wf_stream(s_main)));
             WF_HIP(hipStreamWaitEvent(wf_stream(back), ctx->pipe_front, 0));
         }
 #define MARKB(k) do { if (ev) WF_HIP(hipEventRecord(ev[k], wf_stream(back))); } while (0)

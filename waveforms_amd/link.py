@@ -139,7 +139,19 @@ class SOQPSKLink:
         """Per-stage HIP-event times (ms) of the last run that used ``event_slot``."""
         buf = (ctypes.c_float * len(self.STAGES))()
         _hip.check(_hip.lib().wf_link_stage_ms(self._ctx, event_slot, buf))
-        return dict(zip(self.STAGES, (float(v) for v in buf)))
+        d = dict(zip(self.STAGES, (float(v) for v in buf)))
+        if self.prologue_ahead:
+            # (wf_link_run, round 6: the prologue of such a block runs on its own stream beside the previous front end; the event
+            #  pair of the "fir" slot then brackets the WAIT between the prologue's end and the main kernel's start, and the main
+            #  kernel sits in the "phase" slot — reported here under the name every other form uses)
+            d["fir"], d["phase"] = d["phase"], 0.0
+        return d
+
+    @property
+    def prologue_ahead(self) -> bool:
+        """A pipelined link (``fuse`` bit 5 with the one-kernel front end) whose context runs each block's prologue ahead on its
+        own stream (``WF_OPT_PIPE_RESERVE_CUS`` other than 0: a measured alternative, not the default)."""
+        return bool(self.cfg.fuse & 32) and bool(self.layout()["one_kernel_front_end"]) and _hip.get_option(self._ctx, _hip.WF_OPT_PIPE_RESERVE_CUS) != 0
 
     def run_block(self, ebn0_db: float, seed: int = 1, stream_id: int = 0, skip_bits: int = 0,
                   event_slot: int = -1) -> None:

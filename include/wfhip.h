@@ -255,6 +255,12 @@ int wf_viterbi4_iteration_server_timing(wf_ctx *ctx, double *h_us4);
  * it (the next wf_viterbi4_iteration_host call needs nothing: one server, in order).  No-op without a server.
  * (Reference: the state is the detector object's own arrays, waveforms/viterbi/algorithm.py:36-42.) */
 int wf_viterbi4_iteration_quiesce(wf_ctx *ctx);
+/* The detector's public state arrays as the reference keeps them on every instance (waveforms/viterbi/algorithm.py:25-42:
+ * bi_history float64[8][length], metrics float64[4][length], path uint8[4][length]; :44 the call counter `i`), read from a
+ * device-resident state of wf_viterbi4_iteration / _host into host arrays of those shapes (row-major).  Quiesces the per-symbol
+ * server first; synchronous.  h_calls may be NULL. */
+int wf_viterbi4_state_read(wf_ctx *ctx, const void *d_state, int length, int64_t *h_calls, double *h_bi_history,
+                           double *h_metrics, uint8_t *h_path, void *stream);
 
 /* ---- K11: error counting ------------------------------------------------------
  * examples/soqpsk_detection.py:200-209: number of j < m with

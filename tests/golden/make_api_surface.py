@@ -1,7 +1,8 @@
 """tests/golden/api_surface.json: the public names of the reference package and the argument lists of its
 functions / methods, read from the reference's files with `ast` (nothing is imported or executed; the file
 holds names and defaults — an interface description, no code).  "constants" = every public module-level name
-that is assigned (numbers, tables, the named trellis instances).
+that is assigned (numbers, tables, the named trellis instances).  "attributes" (round 6) = per class, the public names its
+instances carry: every `self.<name> = ...` of `__init__` and every annotated field of the class body (dataclass fields).
 
     python3 tests/golden/make_api_surface.py
 """
@@ -42,10 +43,20 @@ for path in sorted(REF.rglob("*.py")):
             entry["functions"][node.name] = args_of(node)
         elif isinstance(node, ast.ClassDef) and not node.name.startswith("_"):
             methods = {}
+            attrs = []
             for sub in node.body:
                 if isinstance(sub, ast.FunctionDef) and (not sub.name.startswith("_") or sub.name in ("__init__", "__call__")):
                     methods[sub.name] = args_of(sub)
+                if isinstance(sub, ast.FunctionDef) and sub.name == "__init__":
+                    for st in ast.walk(sub):
+                        if isinstance(st, (ast.Assign, ast.AnnAssign, ast.AugAssign)):
+                            for t in (st.targets if isinstance(st, ast.Assign) else [st.target]):
+                                if isinstance(t, ast.Attribute) and isinstance(t.value, ast.Name) and t.value.id == "self" and not t.attr.startswith("_"):
+                                    attrs.append(t.attr)
+                if isinstance(sub, ast.AnnAssign) and isinstance(sub.target, ast.Name) and not sub.target.id.startswith("_"):
+                    attrs.append(sub.target.id)
             entry["classes"][node.name] = methods
+            entry.setdefault("attributes", {})[node.name] = sorted(set(attrs))
         elif isinstance(node, (ast.Assign, ast.AnnAssign)):
             targets = node.targets if isinstance(node, ast.Assign) else [node.target]
             for t in targets:

@@ -65,3 +65,18 @@ def test_module_surface_matches_reference(modname):
             if not inspect.isfunction(fn):
                 continue                             # generated (dataclass / NamedTuple) members
             _check_args(f"{modname}.{cname}.{mname}", want, fn, skip_self=True)
+        # the names an instance of the reference's class carries (self.<name> of __init__, dataclass fields): here as an
+        # attribute assigned by one of the class's own methods, a property, or a class-level name
+        want_attrs = entry.get("attributes", {}).get(cname, [])
+        if want_attrs:
+            have = set(dir(cls)) | set(getattr(cls, "__annotations__", {}))
+            try:
+                tree = ast.parse(inspect.getsource(cls).lstrip() if not inspect.getsource(cls).startswith("class") else inspect.getsource(cls))
+            except (OSError, TypeError, SyntaxError, IndentationError):
+                tree = None
+            if tree is not None:
+                for st in ast.walk(tree):
+                    if isinstance(st, ast.Attribute) and isinstance(st.value, ast.Name) and st.value.id == "self" and isinstance(st.ctx, ast.Store):
+                        have.add(st.attr)
+            missing = [a for a in want_attrs if a not in have]
+            assert not missing, f"{modname}.{cname}: instance attributes {missing} of the reference are missing"

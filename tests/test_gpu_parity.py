@@ -392,6 +392,34 @@ def test_detector_iteration_api(golden, length):
         assert det.i == 260
 
 
+@pytest.mark.parametrize("length", [1, 2, 5, 16])
+def test_detector_state_arrays_equal_the_reference(golden, length):
+    """The detector's public arrays (algorithm.py:25-42: bi_history f64[8, L], metrics f64[4, L], path u8[4, L]; a script may look
+    at them between calls): read back from the device state after k iteration() calls — shapes, dtypes and every value as the
+    reference's own arrays stood after the same k calls (tests/golden/make_detector_state_golden.py).  A detector driven
+    through the batch form has no window arrays: AttributeError."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detector_state")
+    for diff in (True, False):
+        det = SOQPSKTrellisDetector(length, differantial_encoding=diff)
+        for k in range(41):
+            if k in g["at"]:
+                tag = f"L{length}_diff{int(diff)}_k{k}"
+                for name in ("bi_history", "metrics", "path"):
+                    got, want = getattr(det, name), g[f"{tag}_{name}"]
+                    assert got.shape == want.shape and got.dtype == want.dtype, (tag, name, got.shape, got.dtype)
+                    assert np.array_equal(got, want), (tag, name)
+                    assert not got.flags.writeable
+            if k < 40:
+                det.iteration(g["triplets"][k])
+        assert det.i == 40
+    batch = SOQPSKTrellisDetector(2)
+    batch.detect(g["triplets"])
+    with pytest.raises(AttributeError):
+        batch.metrics
+
+
 def test_detector_iteration_fresh_detector_on_a_reused_address(golden):
     """A detector created right after another one is dropped gets the SAME device address for its state from
     the caching allocator; the persistent per-symbol server must start it from zeros, not continue the state it

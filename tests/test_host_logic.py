@@ -314,3 +314,17 @@ def test_long_bank_factorisation():
     assert factor_long_bank(np.ones((2, 9))) is None
     with pytest.raises(ValueError):
         pack_bank_factors(np.ones((3, 9)), np.ones((3, 2)))
+
+
+def test_fresh_detector_carries_the_reference_state_arrays(golden):
+    """waveforms/viterbi/algorithm.py:25-42: every detector instance has bi_history / metrics / path; before the first call
+    they are the reference's zeros (no device needed), read-only snapshots here."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+
+    g = golden("detector_state")
+    for length in (1, 2, 5, 16):
+        det = SOQPSKTrellisDetector(length, differantial_encoding=False)
+        for name in ("bi_history", "metrics", "path"):
+            got, want = getattr(det, name), g[f"L{length}_diff0_k0_{name}"]
+            assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want)
+        assert det.fsm.states == 4 and det.state_exp_term == [1j, -1, 1, -1j] and det.i == 0 and det.length == length

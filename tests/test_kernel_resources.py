@@ -69,12 +69,18 @@ HOT = {
     "cpm_repair_kernel<4, 2>": (168, 3),
     # ... its lane form (one lane = one chunk, the trellis's states in that lane's registers): one wave per SIMD; the
     # binary trellis fits two (and the LDS a front-end workgroup frees when it runs beside one)
-    "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false>": (256, 2),
-    "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, false>": (168, 3),
+    "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false, false>": (256, 2),
+    "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, false, false>": (168, 3),
+    # ... the ARTM lane form with the matched filters inside (round 6: samples in, 288 multiply-adds per call on scalar taps)
+    "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false, true>": (256, 2),
+    "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true, true>": (512, 1),
+    # ... and its front end: modulator + channel, noisy samples out
+    "mod_chan_samples_kernel<4>": (128, 4),
+    "mod_chan_samples_kernel<9>": (128, 4),
     # ... and the instantiation for launches outside a pipeline: accumulation registers claimed on purpose, ONE wave per SIMD
     # (wf_cpm_lanes.hip, SOLO: the dispatcher otherwise doubles waves up on some SIMDs while others stand empty)
-    "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true>": (512, 1),
-    "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, true>": (512, 1),
+    "cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true, false>": (512, 1),
+    "cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, true, false>": (512, 1),
     # ... its wide form (17 .. 64 states, lane = state, one wave per detector): issue-bound, wants every wave it can get
     "cpm_wide_kernel<4, 2>": (64, 8),
     "fir_kernel<9>": (96, 5),
@@ -117,27 +123,36 @@ def test_front_end_kernels_do_not_spill(table, name):
 def test_lane_detector_kernels_stay_out_of_scratch_and_spill_lanes_in_the_call_loop(table):
     """The lane form keeps a whole trellis per lane in registers: no scratch, no VGPR spills; the ARTM form's dozen scalar
     spills (lane masks of its compare / select pairs) stay below the ceiling and out of nested loops."""
-    for name, cap in (("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, false>", 0),
-                      ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, true>", 0)):
+    for name, cap in (("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false, false>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, false, false>", 0),
+                      ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true, false>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, true, false>", 0),
+                      # (the matched-filter form: the template pointers and ring words of its prologue in spill lanes, none read back in the call loop)
+                      ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false, true>", 32), ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true, true>", 32)):
         r = table[name]
-        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, r
+        # (the matched-filter form's frame reserves the register scavenger's emergency slot — 20 bytes nothing ever touches: no scratch instruction exists in the kernel)
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] <= (32 if name.endswith(", true>") else 0), r
         assert r["asm_scratch_load"] == 0 and r["asm_scratch_store"] == 0, r
         assert r["sgpr_spill_count"] <= cap, r
+        assert r.get("asm_v_readlane_in_nested_loop", 0) == 0, r
 
 
 def test_lane_detector_solo_instantiation_holds_a_simd_alone(table):
     """The instantiation for launches outside a pipeline claims accumulation registers so that the dispatcher cannot put two
     of its waves on one SIMD (wf_cpm_lanes.hip, SOLO); the plain one must stay small enough to slip in beside a front end."""
     for name in HOT:
-        if name.startswith("cpm_lane_kernel") and name.endswith(", true>"):
+        if name.startswith("cpm_lane_kernel") and (name.endswith(", true, false>") or name.endswith(", true, true>")):      # <spec, ring, DHI, SOLO, MF>
             r = table[name]
             assert kr.waves_per_simd(r["vgpr_count"], r.get("agpr_count", 0)) == 1, (name, r)
-            plain = table[name[: -len(", true>")] + ", false>"]
+            tail = name[name.rfind(", true, "):]
+            plain = table[name[: -len(tail)] + ", false, " + tail[len(", true, "):]]
             assert plain.get("agpr_count", 0) == 0 and kr.waves_per_simd(plain["vgpr_count"], 0) >= 2, plain
 
 
 def test_no_kernel_spills_vector_registers(table):
-    bad = {k: v["vgpr_spill_count"] for k, v in table.items() if v.get("vgpr_spill_count", 0)}
+    # (mod_tile_scan_kernel: ONE workgroup of 16 waves per launch, held to 64 registers on purpose — so that it finds room on a CU
+    #  beside the previous block's detector, whose lane waves hold 240 of a SIMD's 512 registers; at its natural 76 it waited
+    #  ~0.4 ms for one to retire, profiles/r06_timeline_multih_scan_blocked.txt — and parks 20 registers of its one-off tile batch in scratch)
+    allowed = {"mod_tile_scan_kernel": 24}
+    bad = {k: v["vgpr_spill_count"] for k, v in table.items() if v.get("vgpr_spill_count", 0) > allowed.get(k, 0)}
     assert not bad, bad
 
 
@@ -156,7 +171,9 @@ def test_no_spill_traffic_inside_nested_loops(table):
                 "mod_chan_bank_kernel<4, -2, 10>": 2, "mod_chan_bank_kernel<9, -2, 10>": 2,
                 # ... and the repair launches of the detectors (cold: only chunks that missed their warm-up reach them): the
                 # call loop sits inside the list and round loops, whose bookkeeping lives in spill lanes
-                "cpm_wide_repair_kernel<": 40, "cpm_quad_repair_kernel<": 16, "cpm_repair_kernel<4, 3>": 4, "vwin_fixup_kernel": 16}
+                "cpm_wide_repair_kernel<": 40, "cpm_quad_repair_kernel<": 16, "cpm_repair_kernel<4, 3>": 4, "vwin_fixup_kernel": 16,
+                # (... the 16-filter one also rebuilds its rows from the samples when the launch's lanes ran the matched filters: round 6)
+                "cpm_repair_kernel<4, 2>": 16}
     # ... and the stand-alone modulator's form for three or more modulation indices (no waveform of the reference has
     # them; modulate.py:91-92 allows it): its per-class staging loops carry the class bookkeeping in spill lanes.
     many_h = lambda k: k.startswith("mod_main_kernel<") and k.endswith(", true>")

@@ -85,6 +85,7 @@ SIGNATURES = {
     "wf_cpm_mf_rows_c128": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, _P, _P]),
     "wf_cpm_awgn_mf_rows_c128": (c_int, [_P, _P, c_int64, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64, _P, c_int, c_int,
                                          c_int, c_int64, c_int, c_int64, _P, _P]),
+    "wf_viterbi4_state_read": (c_int, [_P, _P, c_int, POINTER(c_int64), _P, _P, _P, _P]),
     "wf_cpm_detector_form": (c_int, [_P, _P, c_int64, c_int, POINTER(c_int)]),
     "wf_cpm_viterbi_detect": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
     "wf_cpm_viterbi_detect_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_int64, c_int, c_int64, c_int, _P, _P, _P]),

@@ -373,12 +373,12 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     double2 zz[MF ? NF : 1];
     // template column of the calls a loop trip runs first / second (uniform): local call k takes column (k + col0) % nh,
     // k = chunk CH - Weff + t and chunks start on even calls
-    lane_cdp tcol[2] = {nullptr, nullptr};
+    lane_cdp tcol0 = nullptr, tcol1 = nullptr;
     if constexpr (MF) {
         const int flip = SP::NH == 2 ? __builtin_amdgcn_readfirstlane((Weff + P.col0) & 1) : 0;
         const lane_cdp t0 = (lane_cdp)(uintptr_t)P.templ;
-        tcol[0] = t0 + (flip ? 2 * NF * 9 : 0);
-        tcol[1] = SP::NH == 2 ? t0 + (flip ? 0 : 2 * NF * 9) : t0;
+        tcol0 = t0 + (flip ? 2 * NF * 9 : 0);
+        tcol1 = SP::NH == 2 ? t0 + (flip ? 0 : 2 * NF * 9) : t0;
     }
     // pairs 4 ph .. 4 ph + 3 of the window in wx / wy against column tc: zz[p] and zz[15 - p] (groups ph and 3 - ph)
     auto mf_pairs = [&](auto phc, lane_cdp tc) __attribute__((always_inline)) {
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                     step(std::integral_constant<int, KV>{}, std::false_type{}, zreg, zreg,
                          [&](auto phc) __attribute__((always_inline)) {
                              if constexpr (decltype(phc)::value == 0) mf_window();
-                             mf_pairs(phc, tcol[UC & 1]);
+                             mf_pairs(phc, (UC & 1) ? tcol1 : tcol0);
                          },
                          emit, t >= t_ok, gp);
                 } else {

@@ -1463,6 +1463,37 @@ extern "C" int wf_viterbi4_iteration(wf_ctx *ctx, void *d_state, int length, int
     return WF_OK;
 }
 
+// The detector's public arrays (algorithm.py:25-42: every instance carries bi_history f64[8][length], metrics f64[4][length],
+// path u8[4][length]; a caller may look at them between iteration() calls): read from the device-resident state into host
+// arrays of exactly those shapes, after the per-symbol server's write-through has landed.  Synchronous.
+extern "C" int wf_viterbi4_state_read(wf_ctx *ctx, const void *d_state, int length, int64_t *h_calls, double *h_bi_history,
+                                      double *h_metrics, uint8_t *h_path, void *stream)
+{
+    WF_REQUIRE(ctx && d_state && h_bi_history && h_metrics && h_path, "wf_viterbi4_state_read: NULL argument");
+    WF_REQUIRE(length >= 1 && length <= VIT_MAX_LEN, "wf_viterbi4_state_read: length %d", length);
+    WF_HIP(hipSetDevice(ctx->device));
+    const int rq = wf_viterbi4_iteration_quiesce(ctx);
+    if (rq) return rq;
+    static_assert(sizeof(vit_state) % 8 == 0, "state block is whole words");
+    vit_state *h = new vit_state;
+    const hipError_t e1 = hipMemcpyAsync(h, d_state, sizeof(vit_state), hipMemcpyDeviceToHost, wf_stream(stream));
+    const hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(wf_stream(stream)) : e1;
+    if (e2 != hipSuccess) {
+        delete h;
+        WF_HIP(e2);
+    }
+    if (h_calls) *h_calls = (int64_t)h->i;
+    for (int b = 0; b < 8; ++b)
+        for (int j = 0; j < length; ++j) h_bi_history[b * length + j] = h->bi_history[b][j];
+    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < length; ++j) {
+            h_metrics[s * length + j] = h->metrics[s][j];
+            h_path[s * length + j] = h->path[s][j];
+        }
+    delete h;
+    return WF_OK;
+}
+
 // The per-symbol call as ONE host call with host operands (the drop-in loop of
 // examples/soqpsk_detection.py:189-198 calls the detector once per symbol): the three
 // matched-filter outputs and the 2 x length results travel through pinned host memory that the

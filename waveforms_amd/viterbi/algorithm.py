@@ -60,6 +60,44 @@ class SOQPSKTrellisDetector:
             _hip.free_ctx(self._ctx)
             self._ctx = None
 
+    # ------------------------------------------------------------------ the reference's public state arrays
+    # algorithm.py:25-42 gives every instance ``bi_history`` float64[branches_per_column, length], ``metrics``
+    # float64[states, length] and ``path`` uint8[states, length]; iteration() (:57-88) rewrites them on every call.  Here the
+    # state lives in HBM (one block per detector: wf_viterbi4_state_bytes), so the three names are properties that READ it —
+    # after the per-symbol server's write-through has landed (wf_viterbi4_state_read) — into fresh arrays of the reference's
+    # shapes and dtypes: a script that looks at ``det.metrics`` between calls sees what the reference's would hold.  They are
+    # snapshots (marked read-only: assigning into one would not reach the device).  A detector driven through the batch form
+    # detect() keeps a different, smaller carry (no window arrays exist): the properties then raise AttributeError.
+    def _state_arrays(self):
+        shape_b = (self.fsm.branches_per_column, int(self.length))
+        shape_s = (self.fsm.states, int(self.length))
+        if self._mode == "batch":
+            raise AttributeError("bi_history / metrics / path are the window arrays of the per-symbol API (iteration()); "
+                                 "this detector was driven through detect(), whose device carry holds no window")
+        if self._mode is None or self._d_state is None:          # no call made yet: the reference's initial zeros
+            out = (np.zeros(shape_b, dtype=np.float64), np.zeros(shape_s, dtype=np.float64), np.zeros(shape_s, dtype=np.uint8))
+        else:
+            from waveforms_amd import _hip
+
+            out = (np.empty(shape_b, dtype=np.float64), np.empty(shape_s, dtype=np.float64), np.empty(shape_s, dtype=np.uint8))
+            _hip.check(_hip.lib().wf_viterbi4_state_read(self._iter_ctx, self._d_state_ptr, int(self.length), None, out[0].ctypes.data,
+                                                         out[1].ctypes.data, out[2].ctypes.data, _hip.stream()))
+        for a in out:
+            a.setflags(write=False)
+        return out
+
+    @property
+    def bi_history(self) -> "NDArray[np.float64]":
+        return self._state_arrays()[0]
+
+    @property
+    def metrics(self) -> "NDArray[np.float64]":
+        return self._state_arrays()[1]
+
+    @property
+    def path(self) -> "NDArray[np.uint8]":
+        return self._state_arrays()[2]
+
     # ------------------------------------------------------------------ per-symbol API
     def _ensure_state(self):
         from waveforms_amd import _hip

@@ -83,6 +83,12 @@ typedef enum {
 } wf_option;
 int wf_ctx_set_option(wf_ctx *ctx, int key, int64_t value);
 int wf_ctx_get_option(wf_ctx *ctx, int key, int64_t *value);
+/* Two link options are promises about small device tables (wf_link_config.d_mf_factor; wf_cpm_link_config.fuse bit 6): the
+ * library checks each on a host copy the first time it sees the table's ADDRESS on a context and remembers the verdict.  Whoever
+ * frees or rewrites such a table calls this before the address can mean something else (the Python links do so when they are
+ * created): every promise is then checked again on its next use.  (Reference: its objects own their tables,
+ * examples/soqpsk_detection.py:134-173 builds them per run — nothing to invalidate there.) */
+int wf_ctx_forget_promises(wf_ctx *ctx);
 
 /* ---- K1: PRBS ------------------------------------------------------------
  * GLFSR.next_bit x n   (waveforms/glfsr/glfsr.py:6-19, pn.py:98-107).

@@ -201,3 +201,56 @@ def test_bench_pcmfm_at_2_db_prints_a_line():
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["ber"]["detector_chunks_unproven"] == 0 and line["steady_state"]["detector_chunks_unproven"] == 0
         assert line["ber"]["bit_errors"] > 0 and line["steady_state"]["bit_errors"] > 0
+
+
+def _survivor_permutation_rows(n, col0_first, amplitude=8.0, seed=5):
+    """Matched-filter rows under which no two survivors of the 4-state trellis ever share an ancestor: in each of the two trellis
+    sections ONE incoming branch of every end state is preferred by 2 x amplitude over the other, and the preferred branches
+    start in four different states (branch lists of waveforms/cpm/trellis/model.py:205-258; increments Re(state_exp_term *
+    mf), waveforms/viterbi/algorithm.py:57-63).  Metric differences between the states then travel along a permutation for
+    ever: a chunk warmed up from a fresh detector never meets the true trajectory bitwise — every repair changes its chunk's
+    end and hands on to the next chunk.  The first rows are random, so that the true metrics are not all equal."""
+    rng = np.random.default_rng(seed)
+    a = np.array([-1 - 1j, 1 - 1j, -1 + 1j]) * amplitude        # section 0: survivors 0 <- 2, 1 <- 1, 2 <- 0, 3 <- 3
+    b = np.array([-1 - 1j, 1 + 1j, -1 - 1j]) * amplitude        # section 1: survivors 0 <- 0, 1 <- 1, 2 <- 3, 3 <- 2
+    rows = np.empty((n, 3), dtype=np.complex128)
+    rows[0::2] = a if col0_first else b
+    rows[1::2] = b if col0_first else a
+    rows[:9] = rng.normal(size=(9, 3)) + 1j * rng.normal(size=(9, 3))
+    rows[9:] += 1e-3 * (rng.normal(size=(n - 9, 3)) + 1j * rng.normal(size=(n - 9, 3)))     # (no exact ties)
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("diff", [True, False])
+def test_soqpsk_batch_detector_cascades_through_every_chunk(oracle, ctx_options, diff):
+    """The cascade branch of the length-2 batch detector (viterbi_fixup_kernel: vit_rerun_chunk returns `changed`, the
+    chunk behind is listed for the next round, the carry of a stream is rewritten when the last chunk's end changes):
+    rows under which metrics never re-merge (above), so that EVERY repair hands on — hundreds of rounds, each reading
+    its predecessor's end while other chunks are being repaired in the same round.  Decisions == the sequential oracle
+    in one burst, in two bursts with the carry between them (the repaired chunk owns the first burst's last call), and
+    through the link-style packed rows' twin (the object API); every boundary proven once more behind the repairs."""
+    from waveforms.viterbi.algorithm import SOQPSKTrellisDetector
+    from waveforms_amd import _hip, device as dev
+
+    n = 40_001
+    seen_cascade = 0
+    for col0_first in (True, False):
+        rows = _survivor_permutation_rows(n, col0_first)
+        want_b, want_s = oracle.viterbi_detect(rows, 2, diff)
+        with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+            for k in (dev.viterbi_unmerged, dev.viterbi_repaired, dev.viterbi_cascaded):
+                k(reset=True)
+            b, s = dev.viterbi_detect(_hip.to_device(rows), differential=diff, warmup=16)
+            assert dev.viterbi_unmerged(reset=True) == 0
+            repaired, handed_on = dev.viterbi_repaired(reset=True), dev.viterbi_cascaded(reset=True)
+            assert np.array_equal(_hip.to_host(b), want_b) and np.array_equal(_hip.to_host(s), want_s), (col0_first, repaired, handed_on)
+            seen_cascade = max(seen_cascade, handed_on)
+            # the carry: two bursts, the first ending inside the permutation rows (its last chunk is repaired, and its end changes)
+            det = SOQPSKTrellisDetector(2, differantial_encoding=diff)
+            cut = 20_017
+            p0 = det.detect(rows[:cut], warmup=16)
+            p1 = det.detect(rows[cut:], warmup=16)
+            assert dev.viterbi_cascaded(reset=True, ctx=det._ctx) >= 0
+            assert np.array_equal(np.concatenate([p0[0], p1[0]]), want_b) and np.array_equal(np.concatenate([p0[1], p1[1]]), want_s)
+    assert seen_cascade > 500, f"the crafted rows were expected to make every repair hand on (saw {seen_cascade})"

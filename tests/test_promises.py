@@ -69,3 +69,27 @@ def test_soqpsk_link_refuses_a_factorisation_that_does_not_reproduce_the_bank(sp
     assert not plain.cfg.d_mf_factor
     plain.run_block(8.0, seed=1, stream_id=5)
     assert plain.result() == want
+
+
+def test_promise_verdicts_are_forgotten_on_request():
+    """The verdict of a promise is remembered per device ADDRESS (no host copy per block).  wf_ctx_forget_promises — what a new
+    link calls on its context, since an allocator may hand it the addresses of a dead link's tables — makes the next use check
+    again: templates rewritten in place are accepted from the cache until then, and refused after it."""
+    from waveforms_amd import _hip
+    from waveforms_amd.link import CPMLink
+
+    link = CPMLink(200_000, 8, waveform="multih", private_ctx=True)
+    assert link.cfg.fuse & 64
+    link.run_block(8.0, seed=1, stream_id=3)
+    link.result()
+    t = _hip.to_host(link._d_templates, complex_pairs=True).copy()
+    t[0, 1, 4] += 1e-9
+    link._d_templates.copy_(_hip.to_device(t))              # same address, other content
+    link.run_block(8.0, seed=1, stream_id=3)                # (remembered: not looked at again)
+    link.result()
+    _hip.check(_hip.lib().wf_ctx_forget_promises(link._ctx))
+    with pytest.raises(ValueError, match="bit 6"):
+        link.run_block(8.0, seed=1, stream_id=3)
+    other = CPMLink(200_000, 8, waveform="multih", private_ctx=True)      # a new link checks its own tables afresh, and they pair off
+    other.run_block(8.0, seed=1, stream_id=3)
+    other.result()

@@ -38,6 +38,7 @@ SIGNATURES = {
     "wf_ctx_check": (c_int, [_P, _P]),
     "wf_ctx_set_option": (c_int, [_P, c_int, c_int64]),
     "wf_ctx_get_option": (c_int, [_P, c_int, POINTER(c_int64)]),
+    "wf_ctx_forget_promises": (c_int, [_P]),
     "wf_lfsr_generate": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, _P, c_int64, POINTER(c_uint64), _P]),
     "wf_fsm_encode": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_int64, c_int, _P, POINTER(c_int), _P]),
     "wf_symbol_map": (c_int, [_P, c_int, _P, c_int64, c_int, c_int, c_int, _P, _P]),

@@ -165,7 +165,8 @@ int wf_mod_chan_samples(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, cons
                         int sps, double phi0, double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id,
                         uint64_t first_index, double *d_out_ri, void *stream);
 // A promise a caller makes about small device operands (<= 64 KB), checked on the HOST the first time this content is
-// seen on this context: `check(host copy, nbytes)` decides; the verdict is cached under a hash of (kind, bytes).
+// seen on this context: `check(host copy, nbytes)` decides; the verdict is cached under a hash of (kind, device ADDRESSES, sizes)
+// — wf_ctx_forget_promises drops the cache when tables are freed or rewritten (the links call it on creation).
 // Synchronises `stream` on a cache miss only.  Returns WF_OK, or WF_ERR_VALUE with `what` in the error text.
 int wf_promise_verified(wf_ctx *ctx, int kind, const void *const *d_ptrs, const size_t *nbytes, int nptrs, void *stream,
                         bool (*check)(const unsigned char *const *host, const size_t *nbytes, const void *arg), const void *arg, const char *what);

@@ -156,9 +156,12 @@ extern "C" int wf_ctx_check(wf_ctx *c, void *stream)
     return WF_OK;
 }
 
-// See wf_common.h.  Verified on first sight of (kind, pointers, sizes) on this context and again every 4096th use (an
-// allocator may hand the same address to another table later); never inside a stream capture (callers warm a context up
-// eagerly before they capture: an unverified promise inside a capture is refused).
+// See wf_common.h.  Verified on first sight of (kind, device pointers, sizes) on this context, never inside a stream capture
+// (callers warm a context up eagerly before they capture: an unverified promise inside a capture is refused).  The verdict is
+// remembered per ADDRESS, so whoever frees or rewrites such a table says so: wf_ctx_forget_promises (the Python links call it
+// when they are created — an allocator may hand a new link's tables the addresses of a dead one's; round-5 advice).  No
+// periodic re-check: it put a stream synchronisation into a pipelined link every 4096 blocks and closed no hole that the
+// explicit call leaves open.
 int wf_promise_verified(wf_ctx *c, int kind, const void *const *d_ptrs, const size_t *nbytes, int nptrs, void *stream,
                         bool (*check)(const unsigned char *const *host, const size_t *nbytes, const void *arg), const void *arg, const char *what)
 {
@@ -177,7 +180,10 @@ int wf_promise_verified(wf_ctx *c, int kind, const void *const *d_ptrs, const si
     }
     std::lock_guard<std::mutex> guard(c->promises_lock);
     auto it = c->promises.find(key);
-    if (it != c->promises.end() && (++it->second & 4095u) != 0) return WF_OK;
+    if (it != c->promises.end()) {
+        ++it->second;
+        return WF_OK;
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(wf_stream(stream), &cap);
     if (cap != hipStreamCaptureStatusNone) {
@@ -198,6 +204,14 @@ int wf_promise_verified(wf_ctx *c, int kind, const void *const *d_ptrs, const si
         return WF_ERR_VALUE;
     }
     c->promises[key] = 1;
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_forget_promises(wf_ctx *c)
+{
+    WF_REQUIRE(c != nullptr, "wf_ctx_forget_promises: ctx is NULL");
+    std::lock_guard<std::mutex> guard(c->promises_lock);
+    c->promises.clear();
     return WF_OK;
 }
 

@@ -970,6 +970,10 @@ __global__ __launch_bounds__(MOD_THREADS, CPMNF == 0 ? WF_MCB_WAVES : (CPMNF < 0
     typedef __attribute__((address_space(3))) wf_v2d *mcb_lds2;
     constexpr bool RINGPK = CPMNF == 0 && (SPS == 8 || JMAX <= 4);     // (the CPM and PAM forms, and the long-pulse forms at 10 / 20 samples per symbol, keep the index arithmetic: two more live registers spilled there)
     unsigned ring_pk_a = 0, ring_pk_b = 0;
+    // (two 16-bit LDS byte addresses per register: everything this workgroup has in LDS must end below 64 KB — the dynamic part
+    //  (window, ring, prefix counts of two index classes) plus a generous 12 KB for the static tables)
+    static_assert(!RINGPK || (((MOD_ROWS * CPR + JMAX + 2 + 1) & ~1) * 8 + RSLOTS * 16 + 2 * (MOD_ROWS * CPR + JMAX + 3) * 4 + 12 * 1024) < 65536,
+                  "packed ring addresses need the workgroup's LDS below 64 KB");
     if constexpr (RINGPK) {
         const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)s_ring;
         for (int par = 0; par < 2; ++par) {
@@ -1684,7 +1688,10 @@ int wf_mod_chan_bank_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_or
     WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_mf_taps && d_rows4, "wf_mod_chan_bank: NULL argument");
     if (cpm_nf != 0 && cpm_nf != 4 && cpm_nf != 16) return 1;
     if (cpm_nf && cpm_nh != 1 && cpm_nh != 2) return 1;
-    if (!(phi0 >= 0.0)) return 1;                      // (the kernel's sector split assumes a non-negative phase offset: wf_sincos_sectors_pos)
+    // (the kernel's sector split — wf_sincos_sectors_pos: index (int)y, remainder fract(y) — takes the phase offset to be at least ONE
+    //  sector, 2 pi / 128: the phase reduced mod sps can come out a rounding error below 0 at 10 / 20 samples per symbol, where 1 / sps
+    //  is inexact, and with no offset the argument would then be negative — truncation is not floor there.  Every caller passes pi / 4.)
+    if (!(phi0 * (128.0 / (2.0 * M_PI)) >= 1.0)) return 1;
     // SOQPSK bank: sps + 1 taps = the pulse-truncation form; any other odd length up to MCB_PAM_NT at 8 samples per
     // symbol = the long-bank (PAM) form on the matrix cores
     if (mf_ntaps <= 0) mf_ntaps = sps + 1;
@@ -1869,7 +1876,7 @@ int wf_mod_chan_samples(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, cons
 {
     WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_out_ri, "wf_mod_chan_samples: NULL argument");
     WF_REQUIRE((reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0, "wf_mod_chan_samples: d_out alignment");
-    if (!(phi0 >= 0.0) || (first_index & 1) || !wf_mod_chan_samples_applies(nsym, nh, ntaps, sps)) return 1;
+    if (!(phi0 * (128.0 / (2.0 * M_PI)) >= 1.0) || (first_index & 1) || !wf_mod_chan_samples_applies(nsym, nh, ntaps, sps)) return 1;   // (one sector of margin: wf_mod_chan_bank_window)
     mod_params P;
     if (!mod_setup(P, nsym, nh, ntaps, sps, phi0)) return 1;
     WF_HIP(hipSetDevice(ctx->device));

@@ -65,6 +65,7 @@ class SOQPSKLink:
         self.nsym, self.sps = int(nsym), int(sps)
         # a link that runs on its own stream next to other links needs its own scratch
         self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()
+        _hip.check(_hip.lib().wf_ctx_forget_promises(self._ctx))    # (this link's tables may sit where a dead link's did: every promise is checked afresh)
         self._owns_ctx = bool(private_ctx)
         pulse = freq_pulse_soqpsk_tg(sps) if pulse is None else np.asarray(pulse, dtype=np.float64)
         factors = None
@@ -435,6 +436,7 @@ class CPMLink:
             raise ValueError(f"unknown waveform {waveform!r}")
         self.nsym, self.sps, self.spec, self.waveform = int(nsym), int(sps), spec, waveform
         self._ctx = _hip.new_ctx() if private_ctx else _hip.ctx()
+        _hip.check(_hip.lib().wf_ctx_forget_promises(self._ctx))    # (this link's tables may sit where a dead link's did: every promise is checked afresh)
         self._owns_ctx = bool(private_ctx)
         self._d_h = _hip.to_device(spec.mod_index)
         self._d_pulse = _hip.to_device(np.asarray(pulse, dtype=np.float64))

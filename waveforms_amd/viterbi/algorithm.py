@@ -191,10 +191,18 @@ class SOQPSKTrellisDetector:
         if self._ctx is None:
             self._ctx = _hip.new_ctx()
         n = int(mf_rows.shape[0])
+        # the trellis as it stands NOW (iteration() follows a swap of det.fsm the same way; algorithm.py:62 reads self.fsm per call)
+        if self.fsm.trellis is not SOQPSKTrellis4x2DiffEncoded and self.fsm.trellis is not SOQPSKTrellis4x2:
+            raise ValueError("SOQPSKTrellisDetector serves the two 4-state, 2-column SOQPSK trellises (state_exp_term has four entries)")
+        self.differential = self.fsm.trellis is SOQPSKTrellis4x2DiffEncoded
+        # (repairs switched off — tests of the proof — is the one way this call can raise behind a launch: the carry is put back then)
+        keep = self._d_carry.clone() if _hip.get_option(self._ctx, _hip.WF_OPT_DET_REPAIR) else None
         out = (dev.viterbi_detect(mf_rows, self.differential, warmup, self._d_carry, ctx=self._ctx) if L == 2 else
                dev.viterbi_detect_window(mf_rows, L, self.differential, warmup, self._d_carry, ctx=self._ctx))
         unproven = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
         if unproven:        # only with the context's WF_OPT_DET_REPAIR option switched off (tests of the proof itself)
+            if keep is not None:
+                self._d_carry.copy_(keep)
             raise RuntimeError(f"{unproven} detector chunk(s) were left unproven (the repairs are switched off on this context)")
         self.i += n                         # like iteration(): one call per row, state carried
         return out

@@ -196,10 +196,14 @@ class CPMTrellisDetector:
         out = _hip.zeros(n + 16, "uint8")
         # (chunk-parallel; chunks that miss their warm-up are repaired on the device, cascading where needed: the
         #  decisions are the sequential detector's whatever `warmup` is — it only sets how many chunks get repaired)
+        # (repairs switched off — tests of the proof — is the one way this call can raise behind a launch: the carry is put back then)
+        keep = self._d_state.clone() if _hip.get_option(self._ctx, _hip.WF_OPT_DET_REPAIR) else None
         _hip.check(_hip.lib().wf_cpm_viterbi_detect(self._ctx, ctypes.byref(self._cfg), _hip.ptr(self._d_rot), _hip.ptr(rows), n, int(warmup),
                                                     _hip.ptr(out), _hip.ptr(self._d_state), _hip.stream()))
         unproven = dev.viterbi_unmerged(reset=True, ctx=self._ctx)
         if unproven:        # only with the context's WF_OPT_DET_REPAIR option switched off (tests of the proof itself)
+            if keep is not None:
+                self._d_state.copy_(keep)
             raise RuntimeError(f"{unproven} detector chunk(s) were left unproven (the repairs are switched off on this context)")
         return out[:n]
 

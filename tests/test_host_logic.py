@@ -288,7 +288,7 @@ def test_design_status_block_is_generated_from_committed_profiles():
     root = ROOT
     r = subprocess.run([sys.executable, str(root / "tools" / "gen_status.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert (root / "DESIGN.md").stat().st_size <= 25 * 1024
+    assert (root / "DESIGN.md").stat().st_size <= 32 * 1024
 
 
 def test_long_bank_factorisation():

@@ -46,10 +46,38 @@ def classify(op: str) -> str:
     return "full"
 
 
+PROBE_CLASS = {"full": ("v_fma_f64 (8 chains)", "v_mul_f64", "v_add_f64", "v_min_f64", "v_mul_lo_u32", "v_mad_u64_u32", "v_lshlrev_b64", "v_cmp_lt_f64",
+                        "v_cndmask_b32 (sgpr mask)", "v_add3_u32", "v_cvt_f64_u32"),
+               "fast": ("v_fma_f32 (8 chains)", "v_xor_b32", "v_add_u32", "v_bitop3_b32 (xor3)"),
+               "trans64": ("v_rsq_f64", "v_rcp_f64", "v_sqrt_f64"), "trans32": ("v_log_f32",)}
+
+
+def costs_from_newest_probe():
+    """Per-class issue cost = median of the event-time column of the newest profiles/r*_valu_probe.json over the class's named
+    instructions (tools/valu_probe.hip); the built-in figures when no probe record carries that column."""
+    import statistics
+
+    for path in sorted((ROOT / "profiles").glob("r*_valu_probe.json"), reverse=True):
+        try:
+            rows = {r["instruction"]: r for r in json.loads(path.read_text()) if r.get("waves_per_simd", 8) == 8}    # (the costs are those of a full SIMD: 8 waves)
+        except (OSError, ValueError, TypeError, KeyError):
+            continue
+        out = {}
+        for cls, names in PROBE_CLASS.items():
+            vals = [rows[n]["from_event_time"] for n in names if n in rows and "from_event_time" in rows[n]]
+            if vals:
+                out[cls] = round(statistics.median(vals), 2)
+        if len(out) == len(PROBE_CLASS):
+            return out, path.name
+    return dict(COST), "r02_valu_probe.json"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(ROOT / "profiles" / "r03_valu_mix.json"))
     a = ap.parse_args()
+    probe_cost, probe_name = costs_from_newest_probe()
+    COST.update(probe_cost)
     from waveforms_amd.csrc.build import FLAGS, SOURCES, _digest
 
     kernels, loopw = {}, {}
@@ -102,8 +130,8 @@ def main():
                       "avg_cycles_per_valu_loop": round(sum(COST[k] * v for k, v in lw.items()) / max(sum(lw.values()), 1e-9), 3)}
     doc = {"note": "static VALU class mix per kernel (hipcc -S of the in-tree sources; avg_cycles_per_valu_loop weights every instruction "
                    f"by {LOOP_WEIGHT} ** loop depth of its basic block, i.e. it is the mix of what the inner loops execute); issue cost per wave64 instruction per SIMD "
-                   f"by class: {COST} shader cycles (tools/valu_probe.hip on MI355X, profiles/r02_valu_probe.json)",
-           "build_digest": _digest(), "simds": 1024, "kernels": out}
+                   f"by class: {COST} shader cycles (tools/valu_probe.hip on MI355X, profiles/{probe_name})",
+           "probe": probe_name, "class_cost": dict(COST), "build_digest": _digest(), "simds": 1024, "kernels": out}
     Path(a.out).write_text(json.dumps(doc, indent=1) + "\n")
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["valu_static"])[:12]:
         print(f"{k[:60]:60s} {v}")

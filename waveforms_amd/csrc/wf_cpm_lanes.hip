@@ -181,6 +181,10 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
     static_assert(!MF || (!SP::PIPE && NF == 16 && M == 4 && SP::NCORR == 4 && R >= 2), "MF form: the 16-filter, 4-group trellis (ARTM)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
+#ifndef LANE_MF_PRIO
+#define LANE_MF_PRIO 0
+#endif
+    if constexpr (MF && !SOLO && LANE_MF_PRIO > 0) __builtin_amdgcn_s_setprio(LANE_MF_PRIO);   // (beside a front end: see the A/B at LANE_MF_PRIO's use in DESIGN)
     if constexpr (SOLO) {
         if constexpr (SP::M == 4) asm volatile("; accumulation registers claimed, never used: one lane wave per SIMD" ::: "a63");
         else asm volatile("; accumulation registers claimed, never used: one lane wave per SIMD" ::: "a127");

@@ -102,7 +102,7 @@ def detector_kernel_name(spec: "CPMDetectorSpec", ncalls: int = 10_000_000, warm
         k1 = spec.K[1] if len(spec.K) > 1 else spec.K[0]
         hi = "true" if spec.bits_per_symbol * (spec.D - 1) >= 32 else "false"
         solo = "false" if beside else "true"
-        return f"cpm_lane_kernel<lane_spec<{spec.M}, {spec.Lp}, {spec.NC}, {spec.p}, {len(spec.K)}, {spec.K[0]}, {k1}>, {info[1]}, {hi}, {solo}>"
+        return f"cpm_lane_kernel<lane_spec<{spec.M}, {spec.Lp}, {spec.NC}, {spec.p}, {len(spec.K)}, {spec.K[0]}, {k1}>, {info[1]}, {hi}, {solo}, false>"
     if info[0] == 3:
         return f"cpm_quad_kernel<{spec.M}, {spec.Lp}>"
     if info[0] == 2:

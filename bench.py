@@ -421,7 +421,7 @@ def main() -> None:
                              "viterbi": detector_kernel_name(links[0].spec, links[0].layout()["calls"], links[0].cfg.warmup, ctx=links[0]._ctx, info4=det_info),
                              "map": "symbol_map_kernel",
                              "modulate": "mod_main_kernel<4, true, false>"})
-        if samples_form:
+        if samples_form and link_form[1] == 1:
             # (the profiles time every kernel ALONE, where the lane form launches the instantiation that claims a SIMD's registers)
             k1 = links[0].spec.K[1] if len(links[0].spec.K) > 1 else links[0].spec.K[0]
             STAGE_KERNEL["viterbi"] = (f"cpm_lane_kernel<lane_spec<{links[0].spec.M}, {links[0].spec.Lp}, {links[0].spec.NC}, {links[0].spec.p}, "

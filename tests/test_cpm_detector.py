@@ -845,3 +845,39 @@ def test_gpu_detect_samples_carries_its_state(oracle, ctx_options):
         second = det.detect_samples(res["received"][SPS * k0:], T, 0, SPS, geo["ncalls"] - k0)
         assert det.samples_form
     assert np.array_equal(np.concatenate([first, second]), res["decisions"])
+
+
+@pytest.mark.gpu
+def test_gpu_samples_form_of_the_256_state_link_equals_rows_form(ctx_options):
+    """The full ARTM trellis (256 states, 64 matched filters: a row is 1 KB per symbol) with fuse bit 7: the front end stores the
+    noisy samples and every detector workgroup forms the filter outputs of a batch itself (quad form, the k-ascending chain of
+    wf_cpm_mf_rows_c128) — the same decisions and counts as the link that writes rows, at 10 dB and at 3 dB with a short
+    warm-up (repairs run from the samples too), chunk boundaries proven once more; and through the pipelined form."""
+    from waveforms_amd import device as dev
+    from waveforms_amd.link import CPMLink
+    from waveforms_amd.viterbi import cpm
+
+    nsym = 600_001
+    for ebn0, warm in ((10.0, 0), (3.0, 16), (None, 0)):
+        with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_CHUNK_CALLS=512):
+            a = CPMLink(nsym, SPS, waveform="multih", spec=cpm.ARTM_256, fuse=10, warmup=warm, private_ctx=True)
+            b = CPMLink(nsym, SPS, waveform="multih", spec=cpm.ARTM_256, fuse=10 | 128, warmup=warm, private_ctx=True)
+            fa, fb = _link_form(a), _link_form(b)
+            assert fa[0] == 0 and fb[0] == 2 and fb[1] == 3, (fa, fb)
+            for link in (a, b):
+                link.run_block(ebn0, seed=5, stream_id=3, skip_bits=11)
+            la, lb = a.layout(), b.layout()
+            da = a.workspace[la["off_decisions"]:la["off_decisions"] + la["calls"]].cpu().numpy()
+            db = b.workspace[lb["off_decisions"]:lb["off_decisions"] + lb["calls"]].cpu().numpy()
+            assert np.array_equal(da, db), (ebn0, warm, int(np.count_nonzero(da != db)))
+            assert a.result() == b.result()
+            if warm == 16:
+                assert dev.viterbi_repaired(reset=True, ctx=b._ctx) > 50
+            del a, b
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+        one = CPMLink(nsym, SPS, waveform="multih", spec=cpm.ARTM_256, fuse=10 | 128, private_ctx=True)
+        piped = CPMLink(nsym, SPS, waveform="multih", spec=cpm.ARTM_256, fuse=42 | 128, private_ctx=True)
+        for blk in range(3):
+            one.run_block(8.0, seed=2, stream_id=blk)
+            piped.run_block(8.0, seed=2, stream_id=blk)
+        assert one.result() == piped.result() and piped.result()[1] > 0

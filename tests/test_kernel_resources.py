@@ -126,7 +126,7 @@ def test_lane_detector_kernels_stay_out_of_scratch_and_spill_lanes_in_the_call_l
     for name, cap in (("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false, false>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, false, false>", 0),
                       ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true, false>", 16), ("cpm_lane_kernel<lane_spec<2, 2, 5, 10, 1, 7, 7>, 2, false, true, false>", 0),
                       # (the matched-filter form: the template pointers and ring words of its prologue in spill lanes, none read back in the call loop)
-                      ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false, true>", 32), ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true, true>", 32)):
+                      ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, false, true>", 40), ("cpm_lane_kernel<lane_spec<4, 2, 4, 16, 2, 4, 5>, 3, true, true, true>", 40)):
         r = table[name]
         # (the matched-filter form's frame reserves the register scavenger's emergency slot — 20 bytes nothing ever touches: no scratch instruction exists in the kernel)
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] <= (32 if name.endswith(", true>") else 0), r
@@ -151,7 +151,10 @@ def test_no_kernel_spills_vector_registers(table):
     # (mod_tile_scan_kernel: ONE workgroup of 16 waves per launch, held to 64 registers on purpose — so that it finds room on a CU
     #  beside the previous block's detector, whose lane waves hold 240 of a SIMD's 512 registers; at its natural 76 it waited
     #  ~0.4 ms for one to retire, profiles/r06_timeline_multih_scan_blocked.txt — and parks 20 registers of its one-off tile batch in scratch)
-    allowed = {"mod_tile_scan_kernel": 24}
+    # (cpm_quad_kernel: held to 64 registers = 8 workgroups per CU on purpose since its threads form the matched filters of a batch
+    #  themselves — at its natural 70 it ran 7 and the 256-state link 12.6 ms per block against 11.65, profiles/r06_ab_quad_waves.log —
+    #  and parks 2 registers; one scratch reload per batch)
+    allowed = {"mod_tile_scan_kernel": 24, "cpm_quad_kernel<2, 2>": 4, "cpm_quad_kernel<2, 3>": 4, "cpm_quad_kernel<4, 2>": 4, "cpm_quad_kernel<4, 3>": 4}
     bad = {k: v["vgpr_spill_count"] for k, v in table.items() if v.get("vgpr_spill_count", 0) > allowed.get(k, 0)}
     assert not bad, bad
 
@@ -171,14 +174,19 @@ def test_no_spill_traffic_inside_nested_loops(table):
                 "mod_chan_bank_kernel<4, -2, 10>": 2, "mod_chan_bank_kernel<9, -2, 10>": 2,
                 # ... and the repair launches of the detectors (cold: only chunks that missed their warm-up reach them): the
                 # call loop sits inside the list and round loops, whose bookkeeping lives in spill lanes
-                "cpm_wide_repair_kernel<": 40, "cpm_quad_repair_kernel<": 16, "cpm_repair_kernel<4, 3>": 4, "vwin_fixup_kernel": 16,
+                "cpm_wide_repair_kernel<": 40, "cpm_quad_repair_kernel<": 40, "cpm_repair_kernel<4, 3>": 4, "vwin_fixup_kernel": 16,
                 # (... the 16-filter one also rebuilds its rows from the samples when the launch's lanes ran the matched filters: round 6)
                 "cpm_repair_kernel<4, 2>": 16}
+    ceilings_with_vgpr_spills = {"cpm_quad_kernel<": (32, 4)}       # (see test_no_kernel_spills_vector_registers)
     # ... and the stand-alone modulator's form for three or more modulation indices (no waveform of the reference has
     # them; modulate.py:91-92 allows it): its per-class staging loops carry the class bookkeeping in spill lanes.
     many_h = lambda k: k.startswith("mod_main_kernel<") and k.endswith(", true>")
     bad = {}
     for k, v in table.items():
+        both = next((c for pre, c in ceilings_with_vgpr_spills.items() if k.startswith(pre)), None)
+        if both is not None:
+            assert v.get("sgpr_spill_count", 0) <= both[0] and v.get("vgpr_spill_count", 0) <= both[1], (k, v)
+            continue
         cap = 17 if many_h(k) else next((c for pre, c in ceilings.items() if k.startswith(pre)), None)
         if cap is not None:
             assert v.get("sgpr_spill_count", 0) <= cap and v.get("vgpr_spill_count", 0) == 0, (k, v)

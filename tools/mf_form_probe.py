@@ -33,9 +33,12 @@ def timed(link, ebn0, reps=6):
 
 def main():
     nsym = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+    states = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    from waveforms_amd.viterbi import cpm as _cpm
+    spec = {16: None, 64: _cpm.ARTM_64, 256: _cpm.ARTM_256}[states]
     for ebn0, warm in ((10.0, 48), (10.0, 0), (2.0, 16), (None, 48)):
-        a = CPMLink(nsym, 8, waveform="multih", fuse=10, warmup=warm, private_ctx=True)
-        b = CPMLink(nsym, 8, waveform="multih", fuse=10 | 128, warmup=warm, private_ctx=True)
+        a = CPMLink(nsym, 8, waveform="multih", spec=spec, fuse=10, warmup=warm, private_ctx=True)
+        b = CPMLink(nsym, 8, waveform="multih", spec=spec, fuse=10 | 128, warmup=warm, private_ctx=True)
         fa, fb = form(a), form(b)
         ta, sa = timed(a, ebn0)
         tb, sb = timed(b, ebn0)
@@ -52,15 +55,16 @@ def main():
         del a, b
     # pipelined (what bench.py runs): steady state over 200 blocks
     for fuse in (47, 47 | 128):
-        link = CPMLink(nsym, 8, waveform="multih", fuse=fuse, warmup=48, private_ctx=True)
+        link = CPMLink(nsym, 8, waveform="multih", spec=spec, fuse=fuse, warmup=48 if states == 16 else 0, private_ctx=True)
         for _ in range(5):
             link.run_block(10.0, seed=1, stream_id=2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(200):
+        nb = 200 if states == 16 else 40
+        for i in range(nb):
             link.run_block(10.0, seed=1, stream_id=2 + i)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 200 * 1e3
+        dt = (time.perf_counter() - t0) / nb * 1e3
         print(f"pipelined fuse {fuse}: form {form(link)} steady {dt:.4f} ms per block, result {link.result()}")
         del link
 

@@ -73,6 +73,7 @@ struct cpm_mf_source {
     const double *d_templates;
     int64_t nsamp;
     int col0;
+    int64_t start0 = 0;     // quad form only (the lane form is handed the pointer to its first window): window of call k starts at sample start0 + 8 k; samples outside [0, nsamp) count as zero
 };
 int wf_cpm_lanes_launch(const cpm_lane_plan &plan, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri,
                         int64_t ncalls, int warmup, int chunk_calls, int64_t nchunks, uint8_t *d_decisions, void *d_state, uint64_t *d_edge,
@@ -101,4 +102,4 @@ int wf_cpm_quad_applies(const wf_cpm_detector_config *det);
 int64_t wf_cpm_quad_chunk_calls(int64_t ncalls, int W, int cus, int64_t chunk_opt);
 int wf_cpm_quad_warmup(int warmup);
 int wf_cpm_quad_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
-                       int warmup, uint8_t *d_decisions, void *d_state, void *stream);
+                       int warmup, uint8_t *d_decisions, void *d_state, void *stream, const cpm_mf_source *mf = nullptr);   // mf: d_rows_ri are the noisy samples (64 filters of 9 taps formed per batch by the detector's own threads)

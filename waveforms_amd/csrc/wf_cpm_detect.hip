@@ -752,8 +752,8 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
                              const cpm_mf_source *mf, int edge_slot)
 {
     WF_REQUIRE(ctx && det && ncalls >= 0 && warmup >= 0, "wf_cpm_viterbi_detect: bad argument");
-    WF_REQUIRE(!mf || (!wf_cpm_quad_applies(det) && !wf_cpm_wide_applies(det) && ncalls >= det->Lp && ctx->opt[WF_OPT_CPM_FORM] != 1),
-               "wf_cpm_viterbi_detect: the matched-filter form is the lane form of a trellis of <= 16 states");
+    WF_REQUIRE(!mf || wf_cpm_quad_applies(det) || (!wf_cpm_wide_applies(det) && ncalls >= det->Lp && ctx->opt[WF_OPT_CPM_FORM] != 1),
+               "wf_cpm_viterbi_detect: the matched-filter form is the lane form of a trellis of <= 16 states, or the quad form");
     const bool quad = wf_cpm_quad_applies(det) != 0;               // 65 .. 256 states: wf_cpm_quad.hip
     const bool wide = quad || wf_cpm_wide_applies(det) != 0;       // 17 .. 64 states: wf_cpm_wide.hip
     cpm_vit_params P;
@@ -771,7 +771,7 @@ int wf_cpm_viterbi_detect_in(wf_ctx *ctx, const wf_cpm_detector_config *det, con
                    (reinterpret_cast<uintptr_t>(d_rot_cs) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_state) & 15) == 0,
                "wf_cpm_viterbi_detect: device pointers must be 16-byte aligned");
     WF_HIP(hipSetDevice(ctx->device));
-    if (quad) return wf_cpm_quad_detect(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream);
+    if (quad) return wf_cpm_quad_detect(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream, mf);
     if (wide) return wf_cpm_wide_detect(ctx, det, d_rot_cs, d_rows_ri, ncalls, warmup, d_decisions, d_state, stream);
     // Default warm-up.  A chunk that misses its warm-up is REPAIRED by the launches behind the first (cpm_repair_kernel),
     // so the default is sized for the typical merge depth of the trellis, not for its tail, and backed by a scan at
@@ -1226,8 +1226,16 @@ extern "C" int wf_cpm_link_layout(const wf_cpm_link_config *cfg, int64_t *info8)
 
 // fuse bit 7 (with bits 1 and 6): the front end stores the noisy SAMPLES and the detector's lanes run the matched filters —
 // where both kernels serve the configuration (16 paired templates, 8 samples per symbol, a burst the lane form takes)
+// ... and the 64-filter, 256-state design (quad form: the workgroup's own threads form the filter outputs of a batch, the plain
+// k-ascending chain — no promise about the templates needed, any start0)
+static bool cpm_link_samples_form_quad(const wf_cpm_link_config *cfg, const cpm_link_layout &L)
+{
+    return (cfg->fuse & 128) && (cfg->fuse & 2) && L.ncalls > 0 && wf_cpm_quad_applies(&cfg->det) && L.nfilt == 64 && L.ntm == 9 && cfg->sps == 8 &&
+           wf_mod_chan_samples_applies(cfg->nsym, cfg->det.nh, cfg->ntaps, cfg->sps);
+}
 static bool cpm_link_samples_form(wf_ctx *ctx, const wf_cpm_link_config *cfg, const cpm_link_layout &L)
 {
+    if (cpm_link_samples_form_quad(cfg, L)) return true;
     return (cfg->fuse & 128) && (cfg->fuse & 64) && (cfg->fuse & 2) && L.ncalls > 0 &&
            wf_mod_chan_samples_applies(cfg->nsym, cfg->det.nh, cfg->ntaps, cfg->sps) &&
            wf_cpm_samples_form_applies(ctx, &cfg->det, L.ncalls, cfg->warmup, cfg->sps, L.nfilt, L.ntm, L.start0);
@@ -1247,7 +1255,7 @@ extern "C" int wf_cpm_link_form(wf_ctx *ctx, const wf_cpm_link_config *cfg, int 
     wf_cpm_link_layout(cfg, i8);
     info4[0] = cpm_link_samples_form(ctx, cfg, L) ? 2 : (int)i8[5];
     info4[1] = d4[0]; info4[2] = d4[2]; info4[3] = d4[3];
-    if (info4[0] == 2) {
+    if (info4[0] == 2 && !cpm_link_samples_form_quad(cfg, L)) {
         info4[1] = 1;
         info4[2] = wf_cpm_samples_form_chunk(ctx, &cfg->det, L.ncalls, cfg->warmup, (cfg->fuse & 32) != 0);
     }
@@ -1267,7 +1275,10 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     char *w = static_cast<char *>(d_workspace);
     // fuse bit 5: the detector and the error count of a block on the context's side stream, beside the front end of the
     // next wf_cpm_link_run on this context (as wf_link_run does it: two sets of intermediates, used alternately)
-    const bool piped = (cfg->fuse & 32) != 0 && L.ncalls > 0;
+    // (the 256-state samples form runs its blocks one after the other: its front end is 3 % of a block, and whatever shares the chip with
+    //  the quad detector — 8 workgroups per CU, LDS-bound — slows it by more than it hides: 11.67 ms per block against 13.49 pipelined,
+    //  profiles/r06_bench_multih256_forms.log)
+    const bool piped = (cfg->fuse & 32) != 0 && L.ncalls > 0 && !cpm_link_samples_form_quad(cfg, L);
     if (piped) {
         const int64_t set_bytes = ((int64_t)L.total + 255) / 256 * 256;
         WF_REQUIRE(2 * set_bytes <= workspace_bytes, "wf_cpm_link_run: fuse bit 5 needs two sets of intermediates (%lld bytes)", (long long)(2 * set_bytes));
@@ -1323,8 +1334,9 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     // fuse bit 3 (with bit 1): modulator + channel + matched-filter rows in one kernel
     // (mod_chan_bank_kernel, wf_modulate.hip) — the baseband samples never reach HBM
     bool fused_all = false, samples_form = false;
+    const bool samples_quad = cpm_link_samples_form_quad(cfg, L);
     if (cpm_link_samples_form(ctx, cfg, L)) {
-        if ((rc = cpm_check_paired(ctx, cfg, L.nfilt, L.ntm, stream))) return rc;
+        if (!samples_quad && (rc = cpm_check_paired(ctx, cfg, L.nfilt, L.ntm, stream))) return rc;
         rc = wf_mod_chan_samples(ctx, syms, cfg->nsym, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, cos(-M_PI / 4), sin(-M_PI / 4),
                                  cfg->sigma, cfg->seed, cfg->stream_id, 0, sig, stream);
         if (rc < 0) return rc;
@@ -1377,7 +1389,10 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
     MARKB(6);
     // (rows sit inside the block's set of intermediates: what lies before them — symbols, the sample region — and behind
     //  them — the decisions, up to the end of the set — may be read by the lane form's row fetch, so no wave of it clamps)
-    if (samples_form) {
+    if (samples_form && samples_quad) {
+        const cpm_mf_source mf{cfg->d_templates, L.npts, 0, L.start0};
+        if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, sig, L.ncalls, cfg->warmup, dec, nullptr, back, 0, 0, piped, &mf, -1))) return rc;
+    } else if (samples_form) {
         // (the sample array sits inside the set too: bits and symbols before it, the — unused — row region and the decisions behind)
         const cpm_mf_source mf{cfg->d_templates, L.npts - L.start0, 0};
         if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, sig + 2 * L.start0, L.ncalls, cfg->warmup, dec, nullptr, back,

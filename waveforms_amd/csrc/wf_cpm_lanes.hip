@@ -135,6 +135,15 @@ __device__ __forceinline__ void lane_dma1(const void *src, unsigned lds)
                  : "memory");
 }
 
+// A 32-bit value widened to 64 bits INSIDE a cold branch of the call loop (the proof records written at a chunk's first and last
+// call): the value is made opaque where it is used, so the widening — a v_mov of zero per record word — cannot be speculated
+// out of the branch into every call (it was: ~70 moves per call, 6 % of the loop's vector instructions, for stores that run twice per chunk).
+__device__ __forceinline__ uint64_t lane_cold_u64(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return (uint64_t)v;
+}
+
 template <int N>
 __device__ __forceinline__ void lane_wait_vm()
 {
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                     lane_for<0, S>([&](auto sc) {
                         constexpr int s = decltype(sc)::value;
                         erec[3 * s] = (uint64_t)__double_as_longlong(m[s]);
-                        erec[3 * s + 1] = (uint64_t)(r8[s] >> 3);
+                        erec[3 * s + 1] = lane_cold_u64(r8[s] >> 3);
                         erec[3 * s + 2] = h[s];
                     });
                 }
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                     lane_for<0, S>([&](auto sc) {
                         constexpr int s = decltype(sc)::value;
                         erec[48 + 3 * s] = (uint64_t)__double_as_longlong(m[s]);
-                        erec[48 + 3 * s + 1] = (uint64_t)(r8[s] >> 3);
+                        erec[48 + 3 * s + 1] = lane_cold_u64(r8[s] >> 3);
                         erec[48 + 3 * s + 2] = h[s];
                     });
                     if (owns_last) {
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(64, 1) void cpm_lane_kernel(const double2 *__restri
                         lane_for<0, S>([&](auto sc) {
                             constexpr int s = decltype(sc)::value;
                             st[CPM_ST_STAGE + CPM_ST_M + s] = (uint64_t)__double_as_longlong(m[s]);
-                            st[CPM_ST_STAGE + CPM_ST_V + s] = (uint64_t)(r8[s] >> 3);
+                            st[CPM_ST_STAGE + CPM_ST_V + s] = lane_cold_u64(r8[s] >> 3);
                             st[CPM_ST_STAGE + CPM_ST_H + s] = h[s];
                         });
                     }

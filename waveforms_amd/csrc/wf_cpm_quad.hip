@@ -45,7 +45,16 @@ struct cpm_quad_params {
     int M, p, nh, K0, K1, Lp, NC, D, S, NF, msub;
     int CH, W;
     int64_t ncalls, nchunks;
-    int rows_off, xch_off, src_off, dec_off, min_off, cmp_off, team_bytes, rot_off;   // dynamic LDS layout (bytes)
+    int rows_off, xch_off, src_off, dec_off, min_off, cmp_off, team_bytes, rot_off, smp_off;   // dynamic LDS layout (bytes)
+    // round 6: the matched filters inside the detector — `rows` are the noisy samples: a batch's 8 QUAD_TB + 1 samples are fetched
+    // one per thread a batch ahead and staged in LDS, then thread s forms filter s % NF of call s / NF of the batch from the 9
+    // samples of that call's window (the k-ascending chain of cpm_mf_rows_kernel and cpm_oracle.c, bit for bit): 36 multiply-adds
+    // per thread and batch, one more workgroup barrier per batch, and 128 B per call from HBM where a row of 64 filter outputs is
+    // 1 KB.  The taps of a thread are the same for every batch (batches start on even calls) and are re-read through L1 in
+    // groups of three — held in registers they would halve the workgroups a CU holds.
+    const double *mf_templ;
+    int64_t mf_nsamp, mf_start0;
+    int mf_col0;
 };
 
 __device__ __forceinline__ double quad_min_raw(double a, double b)
@@ -159,6 +168,16 @@ __device__ __forceinline__ void cpm_quad_body(const double2 *__restrict__ rows, 
 
     auto fetch = [&](int b, double2 (&dst)[PL]) __attribute__((always_inline)) {
         const int64_t kb = k_first - P.W + (int64_t)b * QUAD_TB;          // local call of the batch's first row
+        if (P.mf_templ) {
+            // sample s of the batch's 8 QUAD_TB + 1 (threads beyond them fetch nothing); outside the burst: zero (wf_cpm_mf_rows_c128)
+            const int64_t idx = P.mf_start0 + 8 * kb + s;
+            const bool in = s <= 8 * QUAD_TB && idx >= 0 && idx < P.mf_nsamp;
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d v = {0.0, 0.0};
+            if (in) v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(rows + idx));
+            dst[0] = make_double2(v.x, v.y);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
             const int q = s + QUAD_T * i;
@@ -242,11 +261,16 @@ __device__ __forceinline__ void cpm_quad_body(const double2 *__restrict__ rows, 
     double2 pend[PL];
     const int nbatch = T / QUAD_TB;
     fetch(0, pend);
+    double2 *smpbuf = reinterpret_cast<double2 *>(tbase + P.smp_off);     // MF form: the batch's 8 QUAD_TB + 1 samples
     auto batch = [&](int b) __attribute__((always_inline)) {
+        if (P.mf_templ) {
+            if (s <= 8 * QUAD_TB) smpbuf[s] = pend[0];
+        } else {
 #pragma unroll
-        for (int i = 0; i < PL; ++i) {
-            const int q = s + QUAD_T * i;
-            if (q < PIECES) rowbuf[q] = pend[i];
+            for (int i = 0; i < PL; ++i) {
+                const int q = s + QUAD_T * i;
+                if (q < PIECES) rowbuf[q] = pend[i];
+            }
         }
         fetch(b + 1 < nbatch ? b + 1 : nbatch - 1, pend);                 // issued unconditionally
         const int t0 = b * QUAD_TB;
@@ -256,6 +280,27 @@ __device__ __forceinline__ void cpm_quad_body(const double2 *__restrict__ rows, 
             erec[3 * s + 2] = hist;
         }
         __syncthreads();                                                  // rows staged (and the previous batch consumed: its last call ended in a barrier)
+        if (P.mf_templ) {
+            // filter s % NF of call s / NF of the batch (NF = 64: one per thread; fewer filters: the first QUAD_TB NF threads)
+            if (s < PIECES) {
+                const int i = s / NF, f = s % NF;
+                const int64_t row = k_first - P.W + (int64_t)b * QUAD_TB + i;
+                const double2 *tp = reinterpret_cast<const double2 *>(P.mf_templ) + ((P.nh == 2 ? (int)((row + P.mf_col0) & 1) : 0) * NF + f) * 9;
+                const double2 *xs = smpbuf + 8 * i;
+                double zr = 0.0, zi = 0.0;
+#pragma unroll 1
+                for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                    for (int k = 3 * g; k < 3 * g + 3; ++k) {
+                        const double2 xv = xs[k], tk = tp[k];
+                        zr = fma(xv.x, tk.x, fma(xv.y, tk.y, zr));
+                        zi = fma(-xv.x, tk.y, fma(xv.y, tk.x, zi));              // (imaginary sample's term first in both sums: cpm_oracle.c)
+                    }
+                }
+                rowbuf[s] = make_double2(zr, zi);
+            }
+            __syncthreads();
+        }
         const bool emit = t0 >= P.W;
 #pragma unroll 1
         for (int tt = 0; tt < QUAD_TB; ++tt) step(tt, t0 + tt, emit);
@@ -332,7 +377,10 @@ __device__ __forceinline__ double *quad_stage_rot(const double2 *__restrict__ ro
 }
 
 template <int M_, int LP_>
-__global__ __launch_bounds__(QUAD_T) void cpm_quad_kernel(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
+#ifndef QUAD_MAIN_WAVES
+#define QUAD_MAIN_WAVES 8
+#endif
+__global__ __launch_bounds__(QUAD_T, QUAD_MAIN_WAVES) void cpm_quad_kernel(const double2 *__restrict__ rows, const double2 *__restrict__ rot_cs,
                                                          uint8_t *__restrict__ out, uint64_t *__restrict__ state,
                                                          uint64_t *__restrict__ edge, unsigned long long *__restrict__ unmerged,
                                                          cpm_quad_params P)
@@ -442,9 +490,13 @@ int64_t wf_cpm_quad_chunk_calls(int64_t ncalls, int W, int cus, int64_t chunk_op
 }
 
 int wf_cpm_quad_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_rows_ri, int64_t ncalls,
-                       int warmup, uint8_t *d_decisions, void *d_state, void *stream)
+                       int warmup, uint8_t *d_decisions, void *d_state, void *stream, const cpm_mf_source *mf)
 {
     cpm_quad_params P{};
+    P.mf_templ = mf ? mf->d_templates : nullptr;
+    P.mf_nsamp = mf ? mf->nsamp : 0;
+    P.mf_start0 = mf ? mf->start0 : 0;
+    P.mf_col0 = mf ? (mf->col0 & 1) : 0;
     WF_REQUIRE((det->M == 2 || det->M == 4) && det->Lp >= 2 && det->Lp <= 3 && (det->nh == 1 || det->nh == 2) && det->p >= 1 && det->p <= 64 &&
                    det->NC >= 1 && det->p % det->NC == 0 && det->D >= 1,
                "wf_cpm: unsupported detector (M %d Lp %d nh %d p %d NC %d D %d)", det->M, det->Lp, det->nh, det->p, det->NC, det->D);
@@ -466,7 +518,8 @@ int wf_cpm_quad_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const dou
     P.xch_off = pieces * 16;
     P.src_off = P.xch_off + 4 * QUAD_XS * 8;
     P.min_off = P.src_off + QUAD_T * 4 + QUAD_T * 8;
-    P.dec_off = P.min_off + 64;                                // (end of a team's block)
+    P.smp_off = P.min_off + 64;                                // MF form: 8 QUAD_TB + 1 samples (+ pad)
+    P.dec_off = P.smp_off + (mf ? (8 * QUAD_TB + 2) * 16 : 0);  // (end of a team's block)
     P.team_bytes = (P.dec_off + 15) / 16 * 16;
     P.rot_off = 2 * P.team_bytes;                              // (the first launch uses one team's worth; the layout is the repair's)
     P.cmp_off = P.rot_off + 2 * CPM_ROT_SIN * 8;

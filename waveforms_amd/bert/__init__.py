@@ -117,14 +117,19 @@ def gpu_block_runner(plan: SweepPlan, streams: int | None = None, fuse: int | No
     cpm = plan.waveform != "soqpsk"
     # (SOQPSK blocks under 2^23 symbols: three lanes again — 2^22-symbol blocks 0.0735 s against 0.0762 for one pipelined lane;
     #  1e7-symbol blocks, which the front-end kernel's launch shape is tuned for, are the fastest way to run the sweep)
-    one_pipelined = (not cpm and plan.nsym >= (1 << 23)) or (plan.waveform == "pcmfm" and plan.nsym >= 6_500_000)
-    n = max(1, int(streams)) if streams is not None else (1 if one_pipelined else 3)
+    # (round 6: ARTM's 16-state link with the matched filters inside the detector — fuse bit 7, blocks of >= 2^21 calls — pipelines
+    #  like PCM/FM's: one lane, 0.85 ms per 1e7-symbol block against 1.2 for three lanes of the rows form; the 256-state link in that
+    #  form runs its blocks one after the other on one lane: whatever shares the chip with its detector costs more than it hides)
+    artm16 = plan.waveform == "multih" and plan.states == 16 and plan.nsym >= 6_000_000
+    artm256 = plan.waveform == "multih" and plan.states == 256
+    one_pipelined = (not cpm and plan.nsym >= (1 << 23)) or (plan.waveform == "pcmfm" and plan.nsym >= 6_500_000) or artm16
+    n = max(1, int(streams)) if streams is not None else (1 if one_pipelined or artm256 else 3)
     if cpm:
         from waveforms_amd.viterbi.cpm import ARTM_64, ARTM_256
 
         big = {64: ARTM_64, 256: ARTM_256}.get(plan.states) if plan.waveform == "multih" else None
         links = [CPMLink(plan.nsym, plan.sps, waveform=plan.waveform, spec=big, pn_degree=plan.pn_degree, private_ctx=n > 1,
-                         warmup=plan.warmup, fuse=(42 if n == 1 and one_pipelined else 10) if fuse is None else fuse)
+                         warmup=plan.warmup, fuse=((42 if n == 1 and one_pipelined else 10) | (128 if plan.waveform == "multih" else 0)) if fuse is None else fuse)
                  for _ in range(n)]
         run_fn = _hip.lib().wf_cpm_link_run
     else:

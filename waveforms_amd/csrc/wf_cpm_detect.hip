@@ -1283,16 +1283,19 @@ extern "C" int wf_cpm_link_run(wf_ctx *ctx, const wf_cpm_link_config *cfg, void 
         const int64_t set_bytes = ((int64_t)L.total + 255) / 256 * 256;
         WF_REQUIRE(2 * set_bytes <= workspace_bytes, "wf_cpm_link_run: fuse bit 5 needs two sets of intermediates (%lld bytes)", (long long)(2 * set_bytes));
         WF_HIP(hipSetDevice(ctx->device));
+#ifndef WF_CPM_PIPE_PRIO
+#define WF_CPM_PIPE_PRIO 0      // (A/B aid: priority of the side streams, 0 = default; -1 = high: profiles/r06_ab_side_stream_priority.log)
+#endif
         if (!ctx->pipe_stream) {
             hipStream_t ps;
-            WF_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+            WF_HIP(hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, WF_CPM_PIPE_PRIO));
             ctx->pipe_stream = ps;
             WF_HIP(hipEventCreateWithFlags(&ctx->pipe_front, hipEventDisableTiming));
             for (int k = 0; k < 2; ++k) WF_HIP(hipEventCreateWithFlags(&ctx->pipe_done[k], hipEventDisableTiming));
         }
         if (!ctx->pipe_stream2) {
             hipStream_t ps;
-            WF_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+            WF_HIP(hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, WF_CPM_PIPE_PRIO));
             ctx->pipe_stream2 = ps;
         }
         w += (int64_t)ctx->pipe_set * set_bytes;

@@ -13,6 +13,13 @@ python3 tools/ber_sweep.py --waveform multih --states 256 --passes 1 --json-out 
 python3 tools/ber_sweep.py --waveform pcmfm --json-out $out/${tag}_ber_sweep_pcmfm.json > /dev/null
 echo SWEEPSDONE
 python3 tools/stream_bench.py --pipelined --chunk 8388608 > $out/${tag}_stream_soqpsk.json
+# BASELINE configs[4] names hipGraph replay: the stream's steady-state chunk replayed as ONE graph, and the two-stream chunk pipeline
+# captured as graphs of 2 / 4 / 8 interior chunks — beside the eager forms (round-5 verdict, item 2)
+python3 tools/stream_bench.py --chunk 8388608 > $out/${tag}_stream_soqpsk_eager.json
+python3 tools/stream_bench.py --graph --chunk 8388608 > $out/${tag}_stream_soqpsk_graph.json
+python3 tools/stream_bench.py --graph-pipelined 2 --chunk 8388608 > $out/${tag}_stream_soqpsk_graph_pipe2.json
+python3 tools/stream_bench.py --graph-pipelined 4 --chunk 8388608 > $out/${tag}_stream_soqpsk_graph_pipe4.json
+python3 tools/stream_bench.py --graph-pipelined 8 --chunk 8388608 > $out/${tag}_stream_soqpsk_graph_pipe8.json
 python3 tools/stream_bench.py --pipelined --chunk 8388608 --detector PAM > $out/${tag}_stream_pam.json
 python3 tools/stream_bench.py --pipelined --chunk 10485760 --waveform multih > $out/${tag}_stream_multih.json
 python3 tools/stream_bench.py --pipelined --chunk 10485760 --waveform pcmfm > $out/${tag}_stream_pcmfm.json

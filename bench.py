@@ -199,6 +199,10 @@ def cpu_baseline(sps: int, ebn0: float, nsym_port: int, nsym_loop: int, waveform
                 "sample": f"same {waveform} @{sps}sps chain, Eb/N0 {ebn0:.1f} dB, sequential C detector + numpy (the reference has no "
                           f"detector for this waveform: build-defined oracle), PCG64 noise: {o['sample']}"}
     return {"value": out["port"]["value"], "unit": "Msym/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+            # SURVEY 8(d) asks for two CPU variants: its "vectorised NumPy" one is this line's top level (the oracle's NumPy for the array
+            # stages with the two sequential loops — encoder, detector — compiled, on a bounded 2^21-symbol sample per core instead of
+            # N = 1e7: per-symbol cost is linear in N), its "faithful-loop" one is `faithful_loop` below
+            "survey_variant": "vectorised (NumPy array stages + compiled sequential loops), bounded sample", 
             "cores_note": f"min(cores this process may run on, 16 per GPU of the job) = {cores} of the host's {host_cores} cores, one process per core",
             "single_core": out["port"]["single_core"],
             "sample": "same SOQPSK-TG @%dsps chain, Eb/N0 %.1f dB, oracle C loops + numpy, PCG64 noise: %s"

@@ -19,11 +19,14 @@ cases = [("soqpsk PT", lambda w: SOQPSKLink(nsym, 8, warmup=w, fuse=47, private_
          ("soqpsk PAM", lambda w: SOQPSKLink(nsym, 8, warmup=w, fuse=47, private_ctx=True, detector="PAM"), 1, (-8.0, 2.0)),
          ("pcmfm", lambda w: CPMLink(nsym, 8, waveform="pcmfm", warmup=w, fuse=42, private_ctx=True), 1, (-8.0, 0.0, 2.0)),
          ("multih 16", lambda w: CPMLink(nsym, 8, waveform="multih", warmup=w, fuse=42, private_ctx=True), 2, (-8.0, 0.0, 4.0)),
+         # (round 6: the same two links with the matched filters inside the detector — fuse bit 7 — whose repairs rebuild their rows from the samples)
+         ("multih 16 samples", lambda w: CPMLink(nsym, 8, waveform="multih", warmup=w, fuse=42 | 128, private_ctx=True), 2, (-8.0, 0.0, 4.0, 10.0)),
+         ("multih 256 samples", lambda w: CPMLink(nsym, 8, waveform="multih", spec=cpm.ARTM_256, warmup=w, fuse=10 | 128, private_ctx=True), 2, (0.0,)),
          ("multih 64", lambda w: CPMLink(nsym, 8, waveform="multih", spec=cpm.ARTM_64, warmup=w, fuse=42, private_ctx=True), 2, (0.0,)),
          ("multih 256", lambda w: CPMLink(nsym, 8, waveform="multih", spec=cpm.ARTM_256, warmup=w, fuse=10, private_ctx=True), 2, (0.0,))]
 ok = True
 for name, make, bps, ebn0s in cases:
-    blocks = max(2, a.blocks // 10) if name.endswith("256") else a.blocks
+    blocks = max(2, a.blocks // 10) if "256" in name else a.blocks
     for ebn0 in ebn0s:
         res = {}
         for w in (2, 640):

@@ -79,7 +79,10 @@ typedef enum {
                                    * previous block's front end, the front-end kernel on a stream whose CU mask leaves N compute units
                                    * free; -1: the same without a mask; 0: front end and prologue on the caller's stream.  Set before
                                    * the context's first pipelined block. */
-    WF_OPT_COUNT = 7
+    WF_OPT_CPM_SAMPLES_MIN_CALLS = 7, /* wf_cpm_viterbi_detect_samples / wf_cpm_link_config.fuse bit 7, 16-state lane form: shortest burst (calls) that
+                                   * takes the samples form; 0 = the library's 6e6 (below it rows + the row form are faster: one lane per chunk leaves
+                                   * most of a short burst's chunks to warm-up), otherwise >= 4096 — tests run the form on bursts an oracle can follow */
+    WF_OPT_COUNT = 8
 } wf_option;
 int wf_ctx_set_option(wf_ctx *ctx, int key, int64_t value);
 int wf_ctx_get_option(wf_ctx *ctx, int key, int64_t *value);
@@ -482,7 +485,7 @@ int wf_cpm_viterbi_detect(wf_ctx *ctx, const wf_cpm_detector_config *det, const 
  * (checked on a host copy, WF_ERR_VALUE if not): each pair is formed from four real 9-tap sums, so the filter outputs equal
  * wf_cpm_mf_rows_c128's to rounding (another order of additions) and are bit for bit those of the link's paired one-kernel front
  * end (wf_cpm_link_config.fuse bit 6).  Serves the 16-filter, 16-state ARTM design at 8 samples per symbol, 9-tap templates,
- * start0 >= 0, on bursts the lane form of the detector takes (wf_cpm_detector_form info4[0] == 1): returns 1 — nothing launched,
+ * start0 >= 0, on bursts of at least 6e6 calls (shorter ones are faster through rows and the row form): returns 1 — nothing launched,
  * not an error — otherwise, and the caller runs wf_cpm_mf_rows_c128 + wf_cpm_viterbi_detect.  Call k takes template column k % nh.
  * Decisions, d_state, warm-up, proof and repair as wf_cpm_viterbi_detect (the repairs rebuild the rows they need from the samples). */
 int wf_cpm_viterbi_detect_samples(wf_ctx *ctx, const wf_cpm_detector_config *det, const double *d_rot_cs, const double *d_templates_ri,

@@ -728,7 +728,7 @@ def test_gpu_samples_form_link_equals_rows_form(ctx_options):
     nsym = 2_400_001
     if True:
         for ebn0, warm, chunk in ((None, 48, 0), (10.0, 48, 0), (10.0, 0, 0), (3.0, 16, 0), (6.0, 32, 80), (6.0, 32, 208)):
-            with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_CHUNK_CALLS=chunk):
+            with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_CHUNK_CALLS=chunk, WF_OPT_CPM_SAMPLES_MIN_CALLS=1 << 21):
                 a = CPMLink(nsym, SPS, waveform="multih", fuse=10, warmup=warm, private_ctx=True)
                 b = CPMLink(nsym, SPS, waveform="multih", fuse=10 | 128, warmup=warm, private_ctx=True)
                 assert a.paired_templates and b.paired_templates
@@ -751,7 +751,7 @@ def test_gpu_samples_form_link_equals_rows_form(ctx_options):
                     assert rep > 1000, rep
                 del a, b
     # the pipelined form bench.py times: consecutive blocks' detectors on two side streams, each with its own proof records
-    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_SAMPLES_MIN_CALLS=1 << 21):
         one = CPMLink(nsym, SPS, waveform="multih", fuse=10 | 128, warmup=48, private_ctx=True)
         piped = CPMLink(nsym, SPS, waveform="multih", fuse=42 | 128, warmup=48, private_ctx=True)
         assert _link_form(piped)[0] == 2
@@ -762,14 +762,18 @@ def test_gpu_samples_form_link_equals_rows_form(ctx_options):
 
 
 @pytest.mark.gpu
-def test_gpu_samples_front_end_stores_the_samples_the_paired_bank_saw():
+def test_gpu_samples_front_end_stores_the_samples_the_paired_bank_saw(ctx_options):
     """mod_chan_samples_kernel against the staged kernels: its samples equal wf_cpm_modulate_c128 + wf_awgn_c128 to 1e-11, and
     wf_cpm_mf_rows_c128 over them gives the rows of the one-kernel front end (both forms) to 1e-11."""
+    with ctx_options(WF_OPT_CPM_SAMPLES_MIN_CALLS=1 << 21):           # (the library's own floor is 6e6 calls)
+        _samples_front_end_body(2_200_000)
+
+
+def _samples_front_end_body(nsym):
     from waveforms_amd import _hip, device as dev
     from waveforms_amd.link import CPMLink
     from waveforms_amd.viterbi import cpm
 
-    nsym = 2_200_000
     rows_link = CPMLink(nsym, SPS, waveform="multih", fuse=10, private_ctx=True)
     samp_link = CPMLink(nsym, SPS, waveform="multih", fuse=10 | 128, private_ctx=True)
     staged = CPMLink(nsym, SPS, waveform="multih", fuse=0, private_ctx=True)
@@ -806,7 +810,7 @@ def test_gpu_detect_samples_equals_sequential_oracle(oracle, ebn0, ctx_options):
     sym, res = _noisy_rows(oracle, oracle.ARTM_16, pulse, nsym, ebn0, int(ebn0) + 21)
     geo = res["geometry"]
     T = matched_filter_templates(pulse, SPS, ARTM_16)
-    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_SAMPLES_MIN_CALLS=1 << 21):
         det = CPMTrellisDetector(ARTM_16)
         got = det.detect_samples(res["received"], T, geo["start0"], SPS, geo["ncalls"])
         assert det.samples_form and got.size == res["decisions"].size
@@ -838,7 +842,7 @@ def test_gpu_detect_samples_carries_its_state(oracle, ctx_options):
     geo = res["geometry"]
     assert geo["start0"] == 0
     T = matched_filter_templates(pulse, SPS, ARTM_16)
-    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1):
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_SAMPLES_MIN_CALLS=1 << 21):
         det = CPMTrellisDetector(ARTM_16)
         first = det.detect_samples(res["received"], T, 0, SPS, k0)
         assert det.samples_form
@@ -881,3 +885,37 @@ def test_gpu_samples_form_of_the_256_state_link_equals_rows_form(ctx_options):
             one.run_block(8.0, seed=2, stream_id=blk)
             piped.run_block(8.0, seed=2, stream_id=blk)
         assert one.result() == piped.result() and piped.result()[1] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_cpm_stream_in_the_samples_form_equals_one_shot(ctx_options):
+    """The streaming ARTM link with fuse bit 7: a chunk's noisy samples take its rows' place in the workspace and the detector
+    (state carried from chunk to chunk) runs the matched filters — decisions and counts of the one-shot link over the whole
+    stream, chunk by chunk and as the two-stream chunk pipeline; the last, short chunk falls back to rows (below the lane
+    form's reach), so both forms hand the same carries to each other."""
+    from waveforms_amd.link import CPMLink, CPMStream
+
+    chunk = 3 << 20
+    nsym = 2 * chunk + 1_200_000
+    with ctx_options(WF_OPT_DET_FINAL_VERIFY=1, WF_OPT_CPM_SAMPLES_MIN_CALLS=1 << 21):
+        one = CPMLink(nsym, SPS, waveform="multih", fuse=10 | 128)
+        st = CPMStream(nsym, chunk, SPS, waveform="multih", fuse=10 | 128)
+        rows_st = CPMStream(nsym, chunk, SPS, waveform="multih", fuse=10)
+        assert st.nchunks == 3 and _link_form(one)[0] == 2
+        for ebn0, sid in ((7.0, 3), (None, 0)):
+            one.reset_counts()
+            one.run_block(ebn0, seed=4, stream_id=sid)
+            want = one.result()
+            lo = one.layout()
+            want_dec = one.workspace[lo["off_decisions"]:lo["off_decisions"] + lo["calls"]].cpu().numpy()
+            st.reset()
+            got_dec = []
+            for c in range(st.nchunks):
+                st.run_chunk(c, ebn0, seed=4, stream_id=sid)
+                info = st.chunk_info(c)
+                got_dec.append(st.workspace[info["off_decisions"]:info["off_decisions"] + info["calls"]].cpu().numpy())
+            assert st.result() == want
+            assert np.array_equal(np.concatenate(got_dec), want_dec)
+            assert st.run_pipelined(ebn0, seed=4, stream_id=sid) == want
+            assert rows_st.run(ebn0, seed=4, stream_id=sid) == want
+            assert ebn0 is None or want[1] > 0

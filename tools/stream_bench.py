@@ -35,7 +35,8 @@ def main():
         from waveforms_amd.link import CPMStream, operating_point_warmup as opw
 
         wu = a.vit_warmup if a.vit_warmup >= 0 else opw(a.waveform, a.ebn0)
-        st = CPMStream(int(a.total), a.chunk, 8, waveform=a.waveform, pn_degree=a.pn_degree, warmup=wu)
+        # (ARTM: fuse bit 7 — the chunk's samples instead of its rows, the matched filters inside the detector; ignored for PCM/FM)
+        st = CPMStream(int(a.total), a.chunk, 8, waveform=a.waveform, pn_degree=a.pn_degree, warmup=wu, fuse=10 | 128)
         st.run_chunk(0, a.ebn0)
         torch.cuda.synchronize()
         go = st.run_pipelined if a.pipelined else st.run

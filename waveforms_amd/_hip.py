@@ -24,7 +24,7 @@ WF_ERR_VALUE, WF_ERR_KEY, WF_ERR_HIP, WF_ERR_DEVICE, WF_ERR_NOMEM = -1, -2, -3, 
 WF_CPM_STATE_BYTES, WF_CPM_STREAM_STATE_BYTES = 16384, 20480      # include/wfhip.h (tests/test_cabi.py compares)
 # wf_option (include/wfhip.h): per-context options set with wf_ctx_set_option
 (WF_OPT_CPM_FORM, WF_OPT_CPM_CHUNK_CALLS, WF_OPT_DET_REPAIR, WF_OPT_DET_FINAL_VERIFY, WF_OPT_ITERATION_SERVER,
- WF_OPT_MCB_TAIL_PERMILLE, WF_OPT_PIPE_RESERVE_CUS) = range(7)
+ WF_OPT_MCB_TAIL_PERMILLE, WF_OPT_PIPE_RESERVE_CUS, WF_OPT_CPM_SAMPLES_MIN_CALLS) = range(8)
 
 # name -> (restype, argtypes); must list every function include/wfhip.h declares
 # (tests/test_cabi.py parses the header and compares).

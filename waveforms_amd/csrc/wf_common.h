@@ -164,6 +164,10 @@ int wf_mod_chan_samples_applies(int64_t nsym, int nh, int ntaps, int sps);
 int wf_mod_chan_samples(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, const double *d_h, int nh, const double *d_pulse, int ntaps,
                         int sps, double phi0, double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id,
                         uint64_t first_index, double *d_out_ri, void *stream);
+int wf_mod_chan_samples_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total, const double *d_h, int nh,
+                               const double *d_pulse, int ntaps, int sps, double phi0, int64_t tile_lo, int64_t ntiles, const uint64_t *d_q_in,
+                               uint64_t *d_q_out, int64_t q_out_tile, double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id,
+                               uint64_t first_index, double *d_out_ri, int64_t out_origin, int64_t out_hi, void *stream);
 // A promise a caller makes about small device operands (<= 64 KB), checked on the HOST the first time this content is
 // seen on this context: `check(host copy, nbytes)` decides; the verdict is cached under a hash of (kind, device ADDRESSES, sizes)
 // — wf_ctx_forget_promises drops the cache when tables are freed or rewritten (the links call it on creation).

@@ -735,8 +735,10 @@ bool wf_cpm_samples_form_applies(wf_ctx *ctx, const wf_cpm_detector_config *det,
     if (wf_cpm_quad_applies(det) || wf_cpm_wide_applies(det) || ctx->opt[WF_OPT_CPM_FORM] == 1) return false;
     cpm_lane_plan lanes{};
     if (wf_cpm_lanes_plan(det, &lanes) != 0 || lanes.spec != 0) return false;
-    // one lane per chunk: below ~2e6 calls the chunks that fill the chip are mostly warm-up, and the row form on rows is the faster path
-    return ncalls >= ((int64_t)1 << 21);
+    // one lane per chunk: on short bursts the chunks that fill the chip are mostly warm-up, and the row form on rows is the faster path
+    // (1e9-symbol stream, same box: chunks of 2^22 calls 7.09 Gsym/s in this form against 7.35 on rows, chunks of 10 x 2^20 9.66 against 8.21)
+    const int64_t floor_calls = ctx->opt[WF_OPT_CPM_SAMPLES_MIN_CALLS] ? ctx->opt[WF_OPT_CPM_SAMPLES_MIN_CALLS] : 6000000;
+    return ncalls >= floor_calls;
 }
 
 // calls per chunk of such a launch (what wf_cpm_viterbi_detect_in will choose)
@@ -1539,7 +1541,24 @@ extern "C" int wf_cpm_link_stream_chunk_phase(wf_ctx *ctx, const wf_cpm_link_con
         // (the mappers are memoryless per symbol; a window starts on a symbol boundary, so the multi-h mapper's parity is 0)
         if ((rc = wf_symbol_map(ctx, cfg->mapper_kind, bits, S.nloc * bps, 0, 0, 0, syms, stream))) return rc;
     }
-    if (phases & 4) {
+    // fuse bit 7 (as in wf_cpm_link_run): the chunk's noisy samples instead of its rows — they take the rows' place in the workspace
+    // (128 B per call where a 16-filter row is 256) — and the matched filters inside the detector, where the chunk is one the lane
+    // form takes (the last, shorter chunk of a stream may fall back to rows: both forms carry the same detector state, and the
+    // modulator's tile window and phase carry are those of the rows form either way)
+    const bool samples_form = (cfg->fuse & 128) && (cfg->fuse & 64) && (cfg->fuse & 2) && S.L.start0 == 0 &&
+                              wf_mod_chan_samples_applies(cfg->nsym, cfg->det.nh, cfg->ntaps, cfg->sps) &&
+                              wf_cpm_samples_form_applies(ctx, &cfg->det, S.ncols, cfg->warmup, cfg->sps, S.L.nfilt, S.L.ntm, S.L.start0);
+    const int64_t smp_lo = 8 * S.k_lo;                                    // global index of the first sample the chunk's detector reads
+    int64_t smp_hi = 8 * (S.k_lo + S.ncols) + 8;                          // ... one past the last (the last window's ninth sample, + padding to a whole call)
+    if (smp_hi > S.L.npts) smp_hi = S.L.npts;
+    if ((phases & 4) && samples_form) {
+        if ((rc = cpm_check_paired(ctx, cfg, S.L.nfilt, S.L.ntm, stream))) return rc;
+        rc = wf_mod_chan_samples_window(ctx, syms, S.ws, S.nloc, S.N, cfg->d_h, cfg->det.nh, cfg->d_pulse, cfg->ntaps, cfg->sps, M_PI / 4, S.tile_lo,
+                                        S.ntiles, q_phase, q_phase, S.q_out_tile, cos(-M_PI / 4), sin(-M_PI / 4), cfg->sigma, cfg->seed,
+                                        cfg->stream_id, 0, rows, smp_lo, smp_hi, stream);
+        if (rc < 0) return rc;
+        WF_REQUIRE(rc == 0, "wf_cpm_link_stream_chunk: internal: the samples front end refused the window");
+    } else if (phases & 4) {
         wf_mcb_opts mo;
         mo.cpm_paired = (cfg->fuse & 64) != 0;
         if (mo.cpm_paired && (rc = cpm_check_paired(ctx, cfg, S.L.nfilt, S.L.ntm, stream))) return rc;
@@ -1552,8 +1571,13 @@ extern "C" int wf_cpm_link_stream_chunk_phase(wf_ctx *ctx, const wf_cpm_link_con
     }
     if (phases & 2) {
         // (the rows sit inside the chunk's workspace: symbols before them, decisions behind — see wf_cpm_link_run)
-        if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, S.ncols, cfg->warmup, dec, carry, stream, (int64_t)S.off_rows,
-                                           (int64_t)(S.total - S.off_rows) - S.ncols * S.L.nfilt * 16, phases != 7)))   // (issued in parts: chunks overlap on two streams)
+        if (samples_form) {
+            const cpm_mf_source mf{cfg->d_templates, smp_hi - smp_lo, (int)(S.k_lo & 1)};
+            if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, S.ncols, cfg->warmup, dec, carry, stream, (int64_t)S.off_rows,
+                                               (int64_t)(S.total - S.off_rows) - (smp_hi - smp_lo) * 16, phases != 7, &mf)))
+                return rc;
+        } else if ((rc = wf_cpm_viterbi_detect_in(ctx, &cfg->det, cfg->d_rot_cs, rows, S.ncols, cfg->warmup, dec, carry, stream, (int64_t)S.off_rows,
+                                                  (int64_t)(S.total - S.off_rows) - S.ncols * S.L.nfilt * 16, phases != 7)))   // (issued in parts: chunks overlap on two streams)
             return rc;
         // decision of call k is symbol k - D + 1; symbols [skip_head, ncalls - D] of the stream are compared
         const int64_t skip = cfg->skip_head > 0 ? cfg->skip_head : 0;

@@ -123,6 +123,7 @@ extern "C" int wf_ctx_set_option(wf_ctx *c, int key, int64_t value)
     case WF_OPT_DET_REPAIR: case WF_OPT_DET_FINAL_VERIFY: case WF_OPT_ITERATION_SERVER: ok = value == 0 || value == 1; break;
     case WF_OPT_MCB_TAIL_PERMILLE: ok = value >= -1 && value <= 16000; break;
     case WF_OPT_PIPE_RESERVE_CUS: ok = value >= -1 && value <= 128; break;
+    case WF_OPT_CPM_SAMPLES_MIN_CALLS: ok = value == 0 || (value >= 4096 && value <= ((int64_t)1 << 40)); break;
     }
     WF_REQUIRE(ok, "wf_ctx_set_option: value %lld outside the range of option %d", (long long)value, key);
     c->opt[key] = value;

@@ -1903,6 +1903,56 @@ int wf_mod_chan_samples(wf_ctx *ctx, const int8_t *d_symbols, int64_t nsym, cons
     return WF_OK;
 }
 
+// Window form of wf_mod_chan_samples (the streaming CPM link): tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total symbols,
+// d_symbols[0] = symbol sym_origin (nloc resident), phase carry of the first tile from *d_q_in (ignored for tile_lo == 0), carry of
+// local tile q_out_tile to *d_q_out; d_out_ri[0] is global sample out_origin and samples [out_origin, out_hi) are stored (the tiles may
+// cover more).  The noise of sample n is that of absolute index first_index + n whatever the window.
+int wf_mod_chan_samples_window(wf_ctx *ctx, const int8_t *d_symbols, int64_t sym_origin, int64_t nloc, int64_t nsym_total, const double *d_h, int nh,
+                               const double *d_pulse, int ntaps, int sps, double phi0, int64_t tile_lo, int64_t ntiles, const uint64_t *d_q_in,
+                               uint64_t *d_q_out, int64_t q_out_tile, double rot_re, double rot_im, double sigma, uint64_t seed, uint64_t stream_id,
+                               uint64_t first_index, double *d_out_ri, int64_t out_origin, int64_t out_hi, void *stream)
+{
+    WF_REQUIRE(ctx && d_symbols && d_h && d_pulse && d_out_ri, "wf_mod_chan_samples_window: NULL argument");
+    WF_REQUIRE((reinterpret_cast<uintptr_t>(d_out_ri) & 15) == 0, "wf_mod_chan_samples_window: d_out alignment");
+    if (!(phi0 * (128.0 / (2.0 * M_PI)) >= 1.0) || (first_index & 1) || !wf_mod_chan_samples_applies(nsym_total, nh, ntaps, sps)) return 1;
+    mod_params P;
+    if (!mod_setup(P, nsym_total, nh, ntaps, sps, phi0)) return 1;
+    const int64_t tile_len = (int64_t)MOD_ROWS * P.rs;
+    WF_REQUIRE(tile_lo >= 0 && ntiles >= 1 && tile_lo + ntiles <= P.ntiles && out_origin >= tile_lo * tile_len && out_hi >= out_origin,
+               "wf_mod_chan_samples_window: bad tile window");
+    P.sym_origin = sym_origin;
+    P.nloc = nloc;
+    P.tile_lo = tile_lo;
+    P.ntiles = ntiles;
+    P.out_origin = out_origin;
+    const int64_t hi = (tile_lo + ntiles) * tile_len;
+    P.out_hi = out_hi < hi ? out_hi : hi;
+    if (P.out_hi > P.out_len) P.out_hi = P.out_len;
+    P.q_out_tile = q_out_tile;
+    WF_HIP(hipSetDevice(ctx->device));
+    int rc = mod_launch_carries(ctx, P, d_symbols, d_h, d_pulse, d_q_in, d_q_out, stream);
+    if (rc) return rc;
+    mcb_params Q{};
+    Q.rot_re = rot_re; Q.rot_im = rot_im; Q.sigma = sigma;
+    Q.seed = seed; Q.stream_id = stream_id; Q.pair0 = first_index >> 1;
+    Q.dyn_index = nullptr;
+    const int J = (ntaps + sps - 1) / sps;
+    const int JM = J <= 4 ? 4 : 9;
+    const size_t win = (size_t)(MOD_ROWS * (P.rs / sps) + JM + 2);
+    const size_t lds = ((win + 1) & ~(size_t)1) * sizeof(double) + (size_t)P.nh * (win + 1) * sizeof(int);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int64_t max_grid = (int64_t)cus * 4 * 4;
+    const int grid = (int)(P.ntiles < max_grid ? P.ntiles : max_grid);
+    using kern_t = void (*)(const int8_t *, const double *, const double *, const double *, double *, mod_params, mcb_params);
+    const kern_t k = JM == 4 ? mod_chan_samples_kernel<4> : mod_chan_samples_kernel<9>;
+    if (lds > 48 * 1024)
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(MOD_THREADS), lds, wf_stream(stream), d_symbols, d_h, d_pulse, ctx->d_mod_scratch, d_out_ri, P, Q);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+}
+
 // Streaming form (internal): modulate the tiles [tile_lo, tile_lo + ntiles) of a burst of nsym_total
 // symbols.  d_symbols[0] is global symbol sym_origin (nloc resident), d_out_ri[0] is global sample
 // out_origin.  The phase carry of the window's first tile comes from *d_q_in (ignored when tile_lo == 0)

@@ -616,10 +616,10 @@ static int viterbi_launch(wf_ctx *ctx, const double *d_mf_ri, int64_t ncalls, in
     // walks ch + 48 dependent steps, so smaller is faster, and the warm-up re-reads 48 / ch of the
     // rows.  (1e7 calls: ch = 160, 0.112 ms; at 128 the 306 workgroups took 0.134 ms.)  Very long
     // bursts cap at 512 (decision strips in LDS) and take several rounds.
-#ifndef VIT_LANE_SLOTS
-#define VIT_LANE_SLOTS 65536     // lanes the burst is cut for: 256 workgroups x 256 lanes (A/B aid: profiles/r06_ab_viterbi_slots.log)
+#ifndef VIT_CHUNK_LANES
+#define VIT_CHUNK_LANES 65536    // lanes the burst is cut for: 256 workgroups x 256 lanes (A/B aid: profiles/r06_ab_viterbi_chunk_lanes.log)
 #endif
-    int ch = (int)((ncalls + VIT_LANE_SLOTS - 1) / VIT_LANE_SLOTS);
+    int ch = (int)((ncalls + VIT_CHUNK_LANES - 1) / VIT_CHUNK_LANES);
     ch = (ch + 15) / 16 * 16;
     if (ch < 32) ch = 32;
     if (ch > 512) ch = 512;

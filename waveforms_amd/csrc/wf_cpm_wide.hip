@@ -498,10 +498,13 @@ int64_t wf_cpm_wide_chunk_calls(int64_t ncalls, int W, int cus, int64_t chunk_op
     return ch;
 }
 
-// Default warm-up: 160 calls (chunks that miss it are repaired by the launches behind the first); a multiple of two batches.
+// Default warm-up: 64 calls (chunks that miss it are repaired by the launches behind the first); a multiple of two batches.
+// 1e7 calls are 7813 chunks of 1280, so the warm-up is a tenth of the work: ARTM 64 states, same box, steady state per block —
+// 160 calls 3.02 - 3.03 ms (0.15 repairs per block at 0 dB); 96: 2.86 - 2.88 (33 at 0 dB); 64: 2.78 at 10 dB, 2.83 at 6 dB
+// (55 repairs per block), 2.85 at 0 dB (450); 48: 2.76 / 2.80 / 2.88 (1544) — profiles/r06_ab_big_trellis_warmup.log.
 int wf_cpm_wide_warmup(int warmup)
 {
-    int W = warmup ? warmup : 160;
+    int W = warmup ? warmup : 64;
     W = (W + 2 * WIDE_TB - 1) / (2 * WIDE_TB) * (2 * WIDE_TB);
     return W > 4096 ? 4096 : W;
 }

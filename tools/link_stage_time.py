@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=-1)
     ap.add_argument("--label", default="")
     ap.add_argument("--detector", default="PT", choices=["PT", "PAM"])
+    ap.add_argument("--sps", type=int, default=8)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="wf_ctx options, e.g. cpm_chunk_calls=320")
     a = ap.parse_args()
     import torch
@@ -28,10 +29,10 @@ def main():
     from waveforms_amd.link import CPMLink, SOQPSKLink, operating_point_warmup, soqpsk_warmup_param
 
     if a.waveform == "soqpsk":
-        link = SOQPSKLink(a.nsym, 8, pn_degree=23, warmup=soqpsk_warmup_param(operating_point_warmup("soqpsk", 10.0)), fuse=15 if a.fuse < 0 else a.fuse,
+        link = SOQPSKLink(a.nsym, a.sps, pn_degree=23, warmup=soqpsk_warmup_param(operating_point_warmup("soqpsk", 10.0)), fuse=15 if a.fuse < 0 else a.fuse,
                           detector=a.detector)
     else:
-        link = CPMLink(a.nsym, 8, waveform=a.waveform, warmup=operating_point_warmup(a.waveform, 10.0), fuse=10 if a.fuse < 0 else a.fuse)
+        link = CPMLink(a.nsym, a.sps, waveform=a.waveform, warmup=operating_point_warmup(a.waveform, 10.0), fuse=10 if a.fuse < 0 else a.fuse)
     acc = {}
     for k in range(a.steps + 3):
         link.run_block(10.0, seed=1, stream_id=k, event_slot=0)

@@ -1,5 +1,6 @@
 """Soak of the cascading repairs at scale: the same trial blocks through every link with a chunk warm-up of TWO rows (most chunks
-miss it; at low Eb/N0 a repair moves the chunk's end and the next chunk follows) and with a long one (nothing to repair): error
+miss it; at low Eb/N0 a repair moves the chunk's end and the next chunk follows), with the library's default and with a long one
+(nothing to repair): error
 counts must be identical, nothing unproven.  repair_soak.py does the same at the operating points' own warm-ups.
     python tools/cascade_soak.py [--blocks 20]"""
 import argparse, json, sys
@@ -29,7 +30,7 @@ for name, make, bps, ebn0s in cases:
     blocks = max(2, a.blocks // 10) if "256" in name else a.blocks
     for ebn0 in ebn0s:
         res = {}
-        for w in (2, 640):
+        for w in (2, 0, 640):                      # (0: the library's default warm-up)
             link = make(w)
             dev.viterbi_repaired(reset=True, ctx=link._ctx); dev.viterbi_cascaded(reset=True, ctx=link._ctx)
             for b in range(blocks):
@@ -38,7 +39,8 @@ for name, make, bps, ebn0s in cases:
             res[w] = (r, dev.viterbi_repaired(reset=True, ctx=link._ctx), dev.viterbi_cascaded(reset=True, ctx=link._ctx))
             del link
         row = {"link": name, "ebn0_db": ebn0, "blocks": blocks, "counts_warmup_2": res[2][0], "repaired": res[2][1], "handed_on": res[2][2],
-               "counts_warmup_640": res[640][0], "repaired_640": res[640][1], "identical": res[2][0] == res[640][0]}
+               "counts_default_warmup": res[0][0], "repaired_default": res[0][1],
+               "counts_warmup_640": res[640][0], "repaired_640": res[640][1], "identical": res[2][0] == res[640][0] == res[0][0]}
         ok = ok and row["identical"]
         print(json.dumps(row), flush=True)
 print("ALL IDENTICAL" if ok else "MISMATCH")
